@@ -1,0 +1,223 @@
+/*
+ * rewriting_hip.h -- C ABI of librewriting_hip.so, the MI355X (gfx950) kernels behind the
+ * rule-editing hot path of davidbau/rewriting.
+ *
+ * Boundary contract (level B3):
+ *   - every pointer is a DEVICE pointer to contiguous float32 unless stated otherwise;
+ *   - the CALLER owns and allocates every buffer (the Python host passes
+ *     torch.Tensor.data_ptr()); the library allocates nothing and keeps no global state;
+ *   - every entry point enqueues on the stream it is given (a hipStream_t passed as void*,
+ *     NULL = the default stream) and returns immediately: stream-ordered and re-entrant;
+ *   - return value 0 = success, otherwise a hipError_t (or RW_ERR_* below); the host
+ *     wrapper raises RuntimeError(rw_error_string(code)) -- the reference's ops surface
+ *     failures as RuntimeError through TORCH_CHECK
+ *     (utils/stylegan2/op/fused_bias_act.cpp:6-8, upfirdn2d.cpp:8-10);
+ *   - "nullable" pointers may be NULL, mirroring the reference's "empty tensor means
+ *     absent" convention (utils/stylegan2/op/fused_bias_act_kernel.cu:62-63).
+ *
+ * Each declaration cites the reference interface it replaces (paths relative to the
+ * reference repository root).
+ */
+#ifndef REWRITING_HIP_H
+#define REWRITING_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* rw_stream_t; /* hipStream_t */
+
+#define RW_ERR_BAD_ARGUMENT 10001
+#define RW_ERR_UNSUPPORTED  10002
+
+int rw_abi_version(void);
+const char* rw_error_string(int code);
+
+/* ---------------------------------------------------------------------------------------
+ * L1 native ops -- replace the two pybind entry points of utils/stylegan2/op/
+ * ------------------------------------------------------------------------------------- */
+
+/* fused_bias_act(input, bias, refer, act, grad, alpha, scale)
+ *   pybind: utils/stylegan2/op/fused_bias_act.cpp:11-20
+ *   kernel: utils/stylegan2/op/fused_bias_act_kernel.cu:18-49 (host wrapper :52-98)
+ * y[i] = act'(x[i] + b[(i / step_b) % size_b]) * scale, act*10+grad in {10,11,12,30,31,32}.
+ * b nullable (no bias), ref nullable (required for grad=1 of act=3). */
+int rw_fused_bias_act_f32(const float* x, const float* b, const float* ref, float* y,
+                          int64_t n, int64_t step_b, int64_t size_b,
+                          int act, int grad, float alpha, float scale, rw_stream_t stream);
+
+/* grad_bias = grad_input.sum(all dims but 1)   (utils/stylegan2/op/fused_act.py:32-39)
+ * g viewed as (outer, channels, inner); gb[c] = sum_{o,i} g[o][c][i]. */
+int rw_bias_grad_f32(const float* g, float* gb, int64_t outer, int64_t channels, int64_t inner,
+                     rw_stream_t stream);
+
+/* upfirdn2d(input[major,H,W,minor], kernel[kh,kw], up_x, up_y, down_x, down_y,
+ *           pad_x0, pad_x1, pad_y0, pad_y1) -> out[major,out_h,out_w,minor]
+ *   pybind: utils/stylegan2/op/upfirdn2d.cpp:12-22
+ *   kernel: utils/stylegan2/op/upfirdn2d_kernel.cu:52-137 (host wrapper :140-271)
+ * out_h = (in_h*up_y + pad_y0 + pad_y1 - kh + down_y) / down_y  (:167-168); the caller
+ * allocates y with that shape.  Any up/down/pad/kernel size (the reference compiles only
+ * six modes, :178-210). */
+int rw_upfirdn2d_f32(const float* x, const float* k, float* y,
+                     int major, int in_h, int in_w, int minor, int kh, int kw,
+                     int up_x, int up_y, int down_x, int down_y,
+                     int pad_x0, int pad_x1, int pad_y0, int pad_y1, rw_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Generator forward -- replaces the torch expressions of utils/stylegan2/models.py
+ * ------------------------------------------------------------------------------------- */
+
+/* PixelNormL: y = x * rsqrt(mean(x^2, dim=1) + eps)      (models.py:609-614) */
+int rw_pixel_norm_f32(const float* x, float* y, int batch, int dim, float eps, rw_stream_t stream);
+
+/* EqualLinear.forward (models.py:503-511): y[b][o] = sum_i x[b*x_stride + i] * (w[o][i]*w_scale)
+ * + bias[o]*b_scale, then, if act != 0, fused lrelu(alpha) * act_scale
+ * (op/fused_act.py:85-86).  x_stride lets the caller pass latent[:, index] un-copied
+ * (PickLatent, models.py:585-595). */
+int rw_equal_linear_f32(const float* x, const float* w, const float* bias, float* y,
+                        int batch, int in_dim, int out_dim, int64_t x_stride,
+                        float w_scale, float b_scale, int act, float alpha, float act_scale,
+                        rw_stream_t stream);
+
+/* AdjustLatent (models.py:570-583): out[b][l][:] = avg + psi*(w[b] - avg) for l < n_latent;
+ * avg nullable (no truncation). */
+int rw_adjust_latent_f32(const float* w, const float* avg, float* out, int batch, int n_latent,
+                         int dim, float psi, rw_stream_t stream);
+
+/* ApplyStyle (models.py:616-620): y[b][c][p] = style[b][c] * x[b][c][p].  This output is the
+ * rewriter's KEY (rewrite/ganrewrite.py:662-665). */
+int rw_style_mul_f32(const float* x, const float* style, float* y, int batch, int channels,
+                     int64_t hw, rw_stream_t stream);
+
+/* wsq[o][i] = sum_{ky,kx} (w_scale * W[o][i][ky][kx])^2   -- first half of the demodulation
+ * factor of DemodulatedConv2dF.forward (models.py:320-328), cached per weight version. */
+int rw_weight_sqsum_f32(const float* w, float* wsq, int out_ch, int in_ch, int taps, float w_scale,
+                        rw_stream_t stream);
+
+/* demod[b][o] = rsqrt(sum_i style[b][i]^2 * wsq[o][i] + eps)      (models.py:326-327) */
+int rw_demod_f32(const float* wsq, const float* style, float* demod, int batch, int out_ch,
+                 int in_ch, float eps, rw_stream_t stream);
+
+/* Repack a conv weight W[o][i][3][3] for the implicit-GEMM kernels:
+ *   mode 0 (stride-1 conv, models.py:318-319):       wp[tap][i][o] = W[o][i][tap]
+ *   mode 1 (stride-2 transposed conv, models.py:315-316), grouped by output parity
+ *          phase (py,px): wp = [phase(0,0): 4 taps][phase(0,1): 2][phase(1,0): 2][phase(1,1): 1],
+ *          each tap a contiguous [i][o] slab.  The scale 1/sqrt(9*Cin) is NOT folded in. */
+int rw_pack_conv_weight_f32(const float* w, float* wp, int out_ch, int in_ch, int mode,
+                            rw_stream_t stream);
+
+/* Epilogue description shared by the two conv entry points.  y = acc * w_scale, then
+ *   if demod: y *= demod[b][o]                                   (models.py:328)
+ *   if noise: y += noise_w[0] * noise[b][pixel]                  (NoiseInjectionF :539-546)
+ *   if act:   y = lrelu(y + bias[o], 0.2) * sqrt(2)              (FusedLeakyReLUF :622-626)
+ * noise/bias/act are only legal for the stride-1 conv (for up layers the blur sits between). */
+typedef struct rw_conv_epilogue {
+  const float* style;    /* nullable: multiply the input by style[b][i] while loading (ApplyStyle fused) */
+  const float* demod;    /* nullable */
+  const float* noise;    /* nullable, (batch, out_h*out_w) */
+  const float* noise_w;  /* device scalar, required iff noise */
+  const float* bias;     /* nullable, (out_ch) */
+  int act;               /* 0 / 1 */
+} rw_conv_epilogue;
+
+/* F.conv2d(x, scale*W, padding=1) [* demod]           (DemodulatedConv2dF, models.py:318-329)
+ * x (B,Cin,H,W) -> y (B,Cout,H,W), wp from rw_pack_conv_weight_f32 mode 0.  impl: 0 = MFMA
+ * implicit GEMM (v_mfma_f32_32x32x2_f32, exact fp32), 1 = direct VALU kernel (cross-check). */
+int rw_conv3x3_f32(const float* x, const float* wp, float* y, int batch, int in_ch, int out_ch,
+                   int h, int w, float w_scale, const rw_conv_epilogue* ep, int impl,
+                   rw_stream_t stream);
+
+/* F.conv_transpose2d(x, scale*W^T, stride=2, padding=0) [* demod]     (models.py:315-316,328)
+ * x (B,Cin,H,W) -> y (B,Cout,2H+1,2W+1), wp from rw_pack_conv_weight_f32 mode 1. */
+int rw_conv_transpose3x3s2_f32(const float* x, const float* wp, float* y, int batch, int in_ch,
+                               int out_ch, int h, int w, float w_scale, const rw_conv_epilogue* ep,
+                               int impl, rw_stream_t stream);
+
+/* NoiseInjectionF (models.py:535-546): y[b][c][p] = x[b][c][p] + noise_w[0] * noise[b][p] */
+int rw_noise_add_f32(const float* x, const float* noise, const float* noise_w, float* y,
+                     int batch, int channels, int64_t hw, rw_stream_t stream);
+
+/* BlurF(pad=(1,1)) -> NoiseInjectionF -> FusedLeakyReLUF in one pass for upsampling layers
+ * (models.py:277-281,481-485,539-546,622-626): x (B,C,2H+1,2W+1) -> y (B,C,2H,2W);
+ * k4 = the 4x4 FIR buffer (already multiplied by 4). */
+int rw_blur_noise_act_f32(const float* x, const float* k4, const float* noise, const float* noise_w,
+                          const float* bias, float* y, int batch, int channels, int out_h, int out_w,
+                          rw_stream_t stream);
+
+/* ToRGBF (models.py:628-655): y[b][c][p] = sum_i (W[c][i]*style[b][i]*w_scale) x[b][i][p]
+ * + bias[c] + skip[b][c][p]; out channels = 3, skip nullable. */
+int rw_to_rgb_f32(const float* x, const float* w, const float* style, const float* bias,
+                  const float* skip, float* y, int batch, int in_ch, int64_t hw, float w_scale,
+                  rw_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Key statistics -- replaces RunningSecondMoment.add (utils/runningstats.py:1086-1097,
+ * progress_addbmm :1181-1190) and RunningVariance.add's reductions (:763-788)
+ * ------------------------------------------------------------------------------------- */
+
+/* mom2 (C,C) += a^T a on fp32 MFMA.
+ *   layout 0: a is (rows, C) row-major, as the reference passes it
+ *             (rewrite/ganrewrite.py:90-93);
+ *   layout 1: a is (batch, C, hw) NCHW, rows = batch*hw -- the key map as the generator
+ *             produced it (no permute copy).
+ * workspace: >= rw_second_moment_workspace_bytes(C, rows) bytes of device scratch. */
+int64_t rw_second_moment_workspace_bytes(int channels, int64_t rows);
+int rw_second_moment_f32(const float* a, float* mom2, int64_t rows, int channels, int64_t hw,
+                         int layout, void* workspace, rw_stream_t stream);
+
+/* per-channel sum and sum of squares over rows (same layouts); sums (2,C) are OVERWRITTEN. */
+int rw_channel_sums_f32(const float* a, float* sums, int64_t rows, int channels, int64_t hw,
+                        int layout, int square_input, rw_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * The rank-constrained solve -- replaces the body of ProgressiveGanRewriter.insert
+ * (rewrite/ganrewrite.py:254-298) for a stride-1 SeqStyleGAN2 layer: forward of
+ * target_model, L1 loss, backward to dconv.weight, torch.optim.Adam step, projection.
+ * Arithmetic: SURVEY.md section 10.
+ * ------------------------------------------------------------------------------------- */
+
+typedef struct rw_solve_problem {
+  /* shapes */
+  int out_ch, in_ch, h, w, rank;
+  /* constants of the layer / goal (device) */
+  const float* key;      /* (in_ch, h, w)   goal_in.fmap  = adain output crop            */
+  const float* style;    /* (in_ch)         goal_in.style                               */
+  const float* val;      /* (out_ch, h, w)  goal_out.fmap                               */
+  const float* bias;     /* (out_ch)        activate.bias                               */
+  const float* noise;    /* (h*w)           RandomState(0).randn(1,h*w)  (quirk Q1)     */
+  const float* noise_w;  /* device scalar   noise.weight                                */
+  const float* context;  /* (rank, in_ch)   orthonormal rows                            */
+  const float* ortho;    /* (out_ch,in_ch,9) W0 - P(W0), nullable when !low_rank_insert  */
+  /* state (device, updated in place) */
+  float* weight;         /* (out_ch,in_ch,3,3) dconv.weight[0]                          */
+  float* exp_avg;        /* Adam m */
+  float* exp_avg_sq;     /* Adam v */
+  /* per-step tables (device, length niter), computed on the host in double like torch.optim.Adam */
+  const float* step_size;   /* lr / (1 - beta1^t)      */
+  const float* bc2_sqrt;    /* sqrt(1 - beta2^t)       */
+  int32_t* step_counter;    /* device int: index of the NEXT step; incremented by the library */
+  float* losses;            /* (niter) l1 loss of every step, written by the library        */
+  /* scratch (device) */
+  float* conv;           /* (ksplit, out_ch, P16)  partial conv sums                      */
+  float* wsq;            /* (ksplit, out_ch)                                              */
+  float* gd;             /* (out_ch, P16)  g_pre*demod, zero padded to P16 = ceil16(h*w)  */
+  float* c2;             /* (out_ch)       s^2 * demod^3 * sum_p g_pre*conv                */
+  float* grad;           /* (out_ch,in_ch,9) only for low_rank_gradient, else nullable     */
+  int ksplit;
+  float beta1, beta2, eps, w_scale;
+  int low_rank_gradient;
+} rw_solve_problem;
+
+int rw_solve_ksplit(int out_ch, int in_ch, int h, int w);
+/* one iteration `it` (loss, gradient, Adam); project != 0 also applies W <- ortho + P(W) */
+int rw_solve_step_f32(const rw_solve_problem* p, int project, rw_stream_t stream);
+/* W <- W - P(W) + amount*P(1)  (zero(), ganrewrite.py:190-195) and ortho = W - P(W) helpers */
+int rw_project_weight_f32(const float* w, const float* context, const float* base, float* out,
+                          int out_ch, int in_ch, int taps, int rank, float scale_w, rw_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REWRITING_HIP_H */

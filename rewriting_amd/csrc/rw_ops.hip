@@ -1,0 +1,538 @@
+// Streaming (HBM-bound) kernels of the StyleGANv2 sequential generator for gfx950:
+// fused bias+leaky-ReLU, upfirdn2d, pixel-norm, equalised linear, style multiply,
+// demodulation factors, weight repacking, noise injection, blur+noise+activation, ToRGB.
+//
+// All of these are bandwidth-bound (arithmetic intensity <= ~2 FLOP/B): the rules that
+// matter are coalesced 16-byte accesses along W (NCHW => W is the fast axis), one pass over
+// each feature map, and >> 256 workgroups.  Nothing here is reshaped into a GEMM.
+#include "rw_common.h"
+
+extern "C" int rw_abi_version(void) { return 1; }
+
+extern "C" const char* rw_error_string(int code) {
+  if (code == 0) return "success";
+  if (code == RW_ERR_BAD_ARGUMENT) return "rewriting_hip: bad argument";
+  if (code == RW_ERR_UNSUPPORTED) return "rewriting_hip: unsupported configuration";
+  return hipGetErrorString((hipError_t)code);
+}
+
+// ---------------------------------------------------------------------------------------
+// fused_bias_act   (reference: utils/stylegan2/op/fused_bias_act_kernel.cu:18-49)
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float rw_bias_act_one(float x, float ref, int code, float alpha, float scale) {
+  float y;
+  switch (code) {
+    default:
+    case 10: y = x; break;
+    case 11: y = x; break;
+    case 12: y = 0.0f; break;
+    case 30: y = (x > 0.0f) ? x : x * alpha; break;
+    case 31: y = (ref > 0.0f) ? x : x * alpha; break;
+    case 32: y = 0.0f; break;
+  }
+  return y * scale;
+}
+
+template <bool VEC4>
+__global__ void __launch_bounds__(256) fused_bias_act_kernel(
+    const float* __restrict__ x, const float* __restrict__ b, const float* __restrict__ ref,
+    float* __restrict__ y, int64_t n, int64_t step_b, int64_t size_b, int code, float alpha,
+    float scale) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  if (VEC4) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+      float4 v = reinterpret_cast<const float4*>(x)[i];
+      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ref) r = reinterpret_cast<const float4*>(ref)[i];
+      if (b) {  // step_b % 4 == 0: the four lanes of the vector share one bias entry
+        const float bv = b[((i << 2) / step_b) % size_b];
+        v.x += bv; v.y += bv; v.z += bv; v.w += bv;
+      }
+      float4 o;
+      o.x = rw_bias_act_one(v.x, r.x, code, alpha, scale);
+      o.y = rw_bias_act_one(v.y, r.y, code, alpha, scale);
+      o.z = rw_bias_act_one(v.z, r.z, code, alpha, scale);
+      o.w = rw_bias_act_one(v.w, r.w, code, alpha, scale);
+      reinterpret_cast<float4*>(y)[i] = o;
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+      float v = x[i];
+      if (b) v += b[(i / step_b) % size_b];
+      const float r = ref ? ref[i] : 0.0f;
+      y[i] = rw_bias_act_one(v, r, code, alpha, scale);
+    }
+  }
+}
+
+extern "C" int rw_fused_bias_act_f32(const float* x, const float* b, const float* ref, float* y,
+                                     int64_t n, int64_t step_b, int64_t size_b, int act, int grad,
+                                     float alpha, float scale, rw_stream_t stream) {
+  if (n == 0) return 0;
+  RW_CHECK_ARG(x && y && n > 0);
+  RW_CHECK_ARG(!b || (step_b > 0 && size_b > 0));
+  const int code = act * 10 + grad;
+  const bool aligned = (((uintptr_t)x | (uintptr_t)y | (uintptr_t)ref) & 15) == 0;
+  const bool vec = aligned && (n % 4 == 0) && (!b || step_b % 4 == 0);
+  if (vec) {
+    hipLaunchKernelGGL(fused_bias_act_kernel<true>, dim3(rw_stream_grid(n / 4, 256)), dim3(256), 0,
+                       rw_s(stream), x, b, ref, y, n, step_b, size_b, code, alpha, scale);
+  } else {
+    hipLaunchKernelGGL(fused_bias_act_kernel<false>, dim3(rw_stream_grid(n, 256)), dim3(256), 0,
+                       rw_s(stream), x, b, ref, y, n, step_b, size_b, code, alpha, scale);
+  }
+  return RW_LAUNCH_RESULT();
+}
+
+// grad_bias[c] = sum_{outer, inner} g[o][c][i]        (op/fused_act.py:32-39)
+__global__ void __launch_bounds__(256) bias_grad_kernel(const float* __restrict__ g,
+                                                        float* __restrict__ gb, int64_t outer,
+                                                        int64_t channels, int64_t inner) {
+  __shared__ float red[4];
+  const int64_t c = blockIdx.x;
+  float acc = 0.f;
+  for (int64_t o = 0; o < outer; ++o) {
+    const float* row = g + (o * channels + c) * inner;
+    for (int64_t i = threadIdx.x; i < inner; i += 256) acc += row[i];
+  }
+  acc = rw_block_sum_256(acc, red);
+  if (threadIdx.x == 0) gb[c] = acc;
+}
+
+extern "C" int rw_bias_grad_f32(const float* g, float* gb, int64_t outer, int64_t channels,
+                                int64_t inner, rw_stream_t stream) {
+  RW_CHECK_ARG(g && gb && outer > 0 && channels > 0 && inner > 0);
+  hipLaunchKernelGGL(bias_grad_kernel, dim3((unsigned)channels), dim3(256), 0, rw_s(stream), g, gb,
+                     outer, channels, inner);
+  return RW_LAUNCH_RESULT();
+}
+
+// ---------------------------------------------------------------------------------------
+// upfirdn2d   (reference: utils/stylegan2/op/upfirdn2d_kernel.cu:52-137)
+// One thread per output sample; taps that land on inserted zeros or padding are skipped, and
+// the kernel is applied FLIPPED (:71-81).  minor == 1 for every NCHW caller, so consecutive
+// threads walk W: coalesced stores, L1-served overlapping loads.
+// ---------------------------------------------------------------------------------------
+struct UpfirdnParams {
+  int major, in_h, in_w, minor, kh, kw, up_x, up_y, down_x, down_y, px0, py0, out_h, out_w;
+};
+
+__global__ void __launch_bounds__(256) upfirdn2d_kernel(const float* __restrict__ x,
+                                                        const float* __restrict__ k,
+                                                        float* __restrict__ y, UpfirdnParams p) {
+  __shared__ float sk[64];
+  for (int t = threadIdx.x; t < p.kh * p.kw; t += 256) {
+    const int ky = t / p.kw, kx = t - ky * p.kw;
+    sk[t] = k[(p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx)];
+  }
+  __syncthreads();
+  const int64_t total = (int64_t)p.major * p.out_h * p.out_w * p.minor;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+    int64_t r = idx;
+    const int mi = (int)(r % p.minor); r /= p.minor;
+    const int ox = (int)(r % p.out_w); r /= p.out_w;
+    const int oy = (int)(r % p.out_h); r /= p.out_h;
+    const int64_t ma = r;
+    const float* xm = x + ma * (int64_t)p.in_h * p.in_w * p.minor + mi;
+    float acc = 0.f;
+    for (int a = 0; a < p.kh; ++a) {
+      const int vy = oy * p.down_y + a - p.py0;     // position in the zero-inserted image
+      if (vy < 0 || vy % p.up_y) continue;
+      const int iy = vy / p.up_y;
+      if (iy >= p.in_h) continue;
+      for (int c = 0; c < p.kw; ++c) {
+        const int vx = ox * p.down_x + c - p.px0;
+        if (vx < 0 || vx % p.up_x) continue;
+        const int ix = vx / p.up_x;
+        if (ix >= p.in_w) continue;
+        acc += xm[((int64_t)iy * p.in_w + ix) * p.minor] * sk[a * p.kw + c];
+      }
+    }
+    y[idx] = acc;
+  }
+}
+
+extern "C" int rw_upfirdn2d_f32(const float* x, const float* k, float* y, int major, int in_h,
+                                int in_w, int minor, int kh, int kw, int up_x, int up_y,
+                                int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0,
+                                int pad_y1, rw_stream_t stream) {
+  RW_CHECK_ARG(x && k && y && major >= 0 && in_h > 0 && in_w > 0 && minor > 0);
+  RW_CHECK_ARG(kh > 0 && kw > 0 && kh * kw <= 64 && up_x > 0 && up_y > 0 && down_x > 0 && down_y > 0);
+  UpfirdnParams p;
+  p.major = major; p.in_h = in_h; p.in_w = in_w; p.minor = minor; p.kh = kh; p.kw = kw;
+  p.up_x = up_x; p.up_y = up_y; p.down_x = down_x; p.down_y = down_y; p.px0 = pad_x0; p.py0 = pad_y0;
+  p.out_h = (in_h * up_y + pad_y0 + pad_y1 - kh + down_y) / down_y;
+  p.out_w = (in_w * up_x + pad_x0 + pad_x1 - kw + down_x) / down_x;
+  if (p.out_h <= 0 || p.out_w <= 0 || major == 0) return 0;
+  const int64_t total = (int64_t)major * p.out_h * p.out_w * minor;
+  hipLaunchKernelGGL(upfirdn2d_kernel, dim3(rw_stream_grid(total, 256)), dim3(256), 0, rw_s(stream),
+                     x, k, y, p);
+  return RW_LAUNCH_RESULT();
+}
+
+// ---------------------------------------------------------------------------------------
+// Mapping network pieces
+// ---------------------------------------------------------------------------------------
+// PixelNormL (models.py:609-614): one wave per latent row.
+__global__ void __launch_bounds__(256) pixel_norm_kernel(const float* __restrict__ x,
+                                                         float* __restrict__ y, int batch, int dim,
+                                                         float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= batch) return;
+  const float* xr = x + (int64_t)row * dim;
+  float ss = 0.f;
+  for (int i = lane; i < dim; i += 64) { const float v = xr[i]; ss += v * v; }
+  ss = rw_wave_sum(ss);
+  const float r = rsqrtf(ss / (float)dim + eps);
+  for (int i = lane; i < dim; i += 64) y[(int64_t)row * dim + i] = xr[i] * r;
+}
+
+extern "C" int rw_pixel_norm_f32(const float* x, float* y, int batch, int dim, float eps,
+                                 rw_stream_t stream) {
+  RW_CHECK_ARG(x && y && batch > 0 && dim > 0);
+  hipLaunchKernelGGL(pixel_norm_kernel, dim3((batch + 3) / 4), dim3(256), 0, rw_s(stream), x, y,
+                     batch, dim, eps);
+  return RW_LAUNCH_RESULT();
+}
+
+// EqualLinear (models.py:503-511).  One wave per output feature: the weight row stays in
+// registers (scaled once, as the reference scales the weight before F.linear) while the
+// wave walks the batch; per-row dot products finish with a 64-lane butterfly.
+#define RW_LINEAR_MAX_PER_LANE 16  // in_dim <= 1024
+__global__ void __launch_bounds__(256) equal_linear_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+    float* __restrict__ y, int batch, int in_dim, int out_dim, int64_t x_stride, float w_scale,
+    float b_scale, int act, float alpha, float act_scale) {
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (o >= out_dim) return;
+  float wr[RW_LINEAR_MAX_PER_LANE];
+  const int per = (in_dim + 63) / 64;
+#pragma unroll
+  for (int j = 0; j < RW_LINEAR_MAX_PER_LANE; ++j) {
+    const int i = lane + j * 64;
+    wr[j] = (j < per && i < in_dim) ? w[(int64_t)o * in_dim + i] * w_scale : 0.f;
+  }
+  const float bv = bias ? bias[o] * b_scale : 0.f;
+  for (int b = 0; b < batch; ++b) {
+    const float* xr = x + (int64_t)b * x_stride;
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < RW_LINEAR_MAX_PER_LANE; ++j) {
+      const int i = lane + j * 64;
+      if (j < per && i < in_dim) acc += xr[i] * wr[j];
+    }
+    acc = rw_wave_sum(acc);
+    if (lane == 0) {
+      float v = acc + bv;
+      if (act) v = ((v > 0.f) ? v : v * alpha) * act_scale;
+      y[(int64_t)b * out_dim + o] = v;
+    }
+  }
+}
+
+extern "C" int rw_equal_linear_f32(const float* x, const float* w, const float* bias, float* y,
+                                   int batch, int in_dim, int out_dim, int64_t x_stride,
+                                   float w_scale, float b_scale, int act, float alpha,
+                                   float act_scale, rw_stream_t stream) {
+  RW_CHECK_ARG(x && w && y && batch > 0 && in_dim > 0 && out_dim > 0 && x_stride >= in_dim);
+  if (in_dim > 64 * RW_LINEAR_MAX_PER_LANE) return RW_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(equal_linear_kernel, dim3((out_dim + 3) / 4), dim3(256), 0, rw_s(stream), x, w,
+                     bias, y, batch, in_dim, out_dim, x_stride, w_scale, b_scale, act, alpha,
+                     act_scale);
+  return RW_LAUNCH_RESULT();
+}
+
+// AdjustLatent (models.py:570-583)
+__global__ void __launch_bounds__(256) adjust_latent_kernel(const float* __restrict__ w,
+                                                            const float* __restrict__ avg,
+                                                            float* __restrict__ out, int batch,
+                                                            int n_latent, int dim, float psi) {
+  const int64_t total = (int64_t)batch * n_latent * dim;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int d = (int)(idx % dim);
+    const int b = (int)(idx / ((int64_t)n_latent * dim));
+    float v = w[(int64_t)b * dim + d];
+    if (avg) { const float a = avg[d]; v = a + psi * (v - a); }
+    out[idx] = v;
+  }
+}
+
+extern "C" int rw_adjust_latent_f32(const float* w, const float* avg, float* out, int batch,
+                                    int n_latent, int dim, float psi, rw_stream_t stream) {
+  RW_CHECK_ARG(w && out && batch > 0 && n_latent > 0 && dim > 0);
+  const int64_t total = (int64_t)batch * n_latent * dim;
+  hipLaunchKernelGGL(adjust_latent_kernel, dim3(rw_stream_grid(total, 256)), dim3(256), 0,
+                     rw_s(stream), w, avg, out, batch, n_latent, dim, psi);
+  return RW_LAUNCH_RESULT();
+}
+
+// ---------------------------------------------------------------------------------------
+// ApplyStyle / NoiseInjection (per-row scalar broadcast over a contiguous row of hw floats)
+// ---------------------------------------------------------------------------------------
+// y[row][p] = x[row][p] * rowscale[row]                               (ApplyStyle)
+// y[b][c][p] = x[b][c][p] + nw * noise[b][p]   (rows = b*C + c)       (NoiseInjectionF)
+template <int MODE>  // 0 = style multiply, 1 = noise add
+__global__ void __launch_bounds__(256) row_broadcast_kernel(
+    const float* __restrict__ x, const float* __restrict__ aux, const float* __restrict__ nw_ptr,
+    float* __restrict__ y, int64_t rows, int channels, int64_t hw) {
+  const int64_t total = rows * hw;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const float nw = (MODE == 1) ? nw_ptr[0] : 0.f;
+  if ((hw & 3) == 0) {
+    const int64_t hw4 = hw >> 2, total4 = total >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
+      const int64_t row = i / hw4;
+      float4 v = reinterpret_cast<const float4*>(x)[i];
+      if (MODE == 0) {
+        const float s = aux[row];
+        v.x = s * v.x; v.y = s * v.y; v.z = s * v.z; v.w = s * v.w;
+      } else {
+        const int64_t b = row / channels;
+        const float4 nz = reinterpret_cast<const float4*>(aux)[b * hw4 + (i - row * hw4)];
+        v.x = v.x + nw * nz.x; v.y = v.y + nw * nz.y; v.z = v.z + nw * nz.z; v.w = v.w + nw * nz.w;
+      }
+      reinterpret_cast<float4*>(y)[i] = v;
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+      const int64_t row = i / hw;
+      if (MODE == 0) {
+        y[i] = aux[row] * x[i];
+      } else {
+        const int64_t b = row / channels;
+        y[i] = x[i] + nw * aux[b * hw + (i - row * hw)];
+      }
+    }
+  }
+}
+
+extern "C" int rw_style_mul_f32(const float* x, const float* style, float* y, int batch,
+                                int channels, int64_t hw, rw_stream_t stream) {
+  RW_CHECK_ARG(x && style && y && batch > 0 && channels > 0 && hw > 0);
+  const int64_t rows = (int64_t)batch * channels;
+  hipLaunchKernelGGL(row_broadcast_kernel<0>, dim3(rw_stream_grid(rows * hw / 4 + 1, 256)),
+                     dim3(256), 0, rw_s(stream), x, style, (const float*)nullptr, y, rows, channels, hw);
+  return RW_LAUNCH_RESULT();
+}
+
+extern "C" int rw_noise_add_f32(const float* x, const float* noise, const float* noise_w, float* y,
+                                int batch, int channels, int64_t hw, rw_stream_t stream) {
+  RW_CHECK_ARG(x && noise && noise_w && y && batch > 0 && channels > 0 && hw > 0);
+  const int64_t rows = (int64_t)batch * channels;
+  hipLaunchKernelGGL(row_broadcast_kernel<1>, dim3(rw_stream_grid(rows * hw / 4 + 1, 256)),
+                     dim3(256), 0, rw_s(stream), x, noise, noise_w, y, rows, channels, hw);
+  return RW_LAUNCH_RESULT();
+}
+
+// ---------------------------------------------------------------------------------------
+// Demodulation factors (DemodulatedConv2dF.forward, models.py:320-328)
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) weight_sqsum_kernel(const float* __restrict__ w,
+                                                           float* __restrict__ wsq, int64_t pairs,
+                                                           int taps, float w_scale) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < pairs;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float acc = 0.f;
+    for (int t = 0; t < taps; ++t) { const float v = w_scale * w[i * taps + t]; acc += v * v; }
+    wsq[i] = acc;
+  }
+}
+
+extern "C" int rw_weight_sqsum_f32(const float* w, float* wsq, int out_ch, int in_ch, int taps,
+                                   float w_scale, rw_stream_t stream) {
+  RW_CHECK_ARG(w && wsq && out_ch > 0 && in_ch > 0 && taps > 0);
+  const int64_t pairs = (int64_t)out_ch * in_ch;
+  hipLaunchKernelGGL(weight_sqsum_kernel, dim3(rw_stream_grid(pairs, 256)), dim3(256), 0,
+                     rw_s(stream), w, wsq, pairs, taps, w_scale);
+  return RW_LAUNCH_RESULT();
+}
+
+// one wave per (b, o): 64-lane butterfly for the per-channel reduction
+__global__ void __launch_bounds__(256) demod_kernel(const float* __restrict__ wsq,
+                                                    const float* __restrict__ style,
+                                                    float* __restrict__ demod, int batch, int out_ch,
+                                                    int in_ch, float eps) {
+  const int64_t idx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (idx >= (int64_t)batch * out_ch) return;
+  const int b = (int)(idx / out_ch), o = (int)(idx % out_ch);
+  float acc = 0.f;
+  for (int i = lane; i < in_ch; i += 64) {
+    const float s = style[(int64_t)b * in_ch + i];
+    acc += (s * s) * wsq[(int64_t)o * in_ch + i];
+  }
+  acc = rw_wave_sum(acc);
+  if (lane == 0) demod[idx] = rsqrtf(acc + eps);
+}
+
+extern "C" int rw_demod_f32(const float* wsq, const float* style, float* demod, int batch,
+                            int out_ch, int in_ch, float eps, rw_stream_t stream) {
+  RW_CHECK_ARG(wsq && style && demod && batch > 0 && out_ch > 0 && in_ch > 0);
+  const int64_t waves = (int64_t)batch * out_ch;
+  hipLaunchKernelGGL(demod_kernel, dim3((unsigned)rw_cdiv(waves, 4)), dim3(256), 0, rw_s(stream),
+                     wsq, style, demod, batch, out_ch, in_ch, eps);
+  return RW_LAUNCH_RESULT();
+}
+
+// ---------------------------------------------------------------------------------------
+// Weight repack for the implicit-GEMM convolutions: [o][i][tap] -> [slab][i][o]
+// ---------------------------------------------------------------------------------------
+__constant__ int rw_up_tap_order[9] = {0, 2, 6, 8, 1, 7, 3, 5, 4};
+
+__global__ void __launch_bounds__(256) pack_conv_weight_kernel(const float* __restrict__ w,
+                                                               float* __restrict__ wp, int out_ch,
+                                                               int in_ch, int mode) {
+  const int64_t total = (int64_t)9 * in_ch * out_ch;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int o = (int)(idx % out_ch);
+    const int i = (int)((idx / out_ch) % in_ch);
+    const int slab = (int)(idx / ((int64_t)out_ch * in_ch));
+    const int tap = mode == 0 ? slab : rw_up_tap_order[slab];
+    wp[idx] = w[((int64_t)o * in_ch + i) * 9 + tap];
+  }
+}
+
+extern "C" int rw_pack_conv_weight_f32(const float* w, float* wp, int out_ch, int in_ch, int mode,
+                                       rw_stream_t stream) {
+  RW_CHECK_ARG(w && wp && out_ch > 0 && in_ch > 0 && (mode == 0 || mode == 1));
+  const int64_t total = (int64_t)9 * in_ch * out_ch;
+  hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(rw_stream_grid(total, 256)), dim3(256), 0,
+                     rw_s(stream), w, wp, out_ch, in_ch, mode);
+  return RW_LAUNCH_RESULT();
+}
+
+// ---------------------------------------------------------------------------------------
+// Blur(pad 1,1) + noise + bias + leaky-ReLU for upsampling layers: one pass, 4 outputs/thread
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) blur_noise_act_kernel(
+    const float* __restrict__ x, const float* __restrict__ k4, const float* __restrict__ noise,
+    const float* __restrict__ nw_ptr, const float* __restrict__ bias, float* __restrict__ y,
+    int batch, int channels, int out_h, int out_w) {
+  __shared__ float kf[16];
+  if (threadIdx.x < 16) {
+    const int a = threadIdx.x >> 2, c = threadIdx.x & 3;
+    kf[threadIdx.x] = k4[(3 - a) * 4 + (3 - c)];     // flipped, as upfirdn2d applies it
+  }
+  __syncthreads();
+  const int in_h = out_h + 1, in_w = out_w + 1;
+  const int ow4 = out_w >> 2;                         // out_w is a multiple of 4 (>= 8)
+  const int64_t total = (int64_t)batch * channels * out_h * ow4;
+  const float nw = noise ? nw_ptr[0] : 0.f;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int xq = (int)(idx % ow4);
+    const int oy = (int)((idx / ow4) % out_h);
+    const int64_t bc = idx / ((int64_t)ow4 * out_h);
+    const int c = (int)(bc % channels);
+    const int64_t b = bc / channels;
+    const int ox = xq << 2;
+    const float* xp = x + bc * (int64_t)in_h * in_w;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int iy = oy + a - 1;
+      if (iy < 0 || iy >= in_h) continue;
+      float rowv[7];
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        const int ix = ox + j - 1;
+        rowv[j] = (ix >= 0 && ix < in_w) ? xp[(int64_t)iy * in_w + ix] : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) acc[q] += rowv[q + cc] * kf[a * 4 + cc];
+    }
+    float4 o;
+    float* op = &o.x;
+    float4 nz = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (noise) nz = *reinterpret_cast<const float4*>(noise + b * (int64_t)out_h * out_w + (int64_t)oy * out_w + ox);
+    const float* nzp = &nz.x;
+    const float bv = bias ? bias[c] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v = acc[q] + nw * nzp[q];
+      if (bias) { v += bv; v = ((v > 0.f) ? v : v * 0.2f) * 1.4142135623730951f; }
+      op[q] = v;
+    }
+    *reinterpret_cast<float4*>(y + (bc * out_h + oy) * (int64_t)out_w + ox) = o;
+  }
+}
+
+extern "C" int rw_blur_noise_act_f32(const float* x, const float* k4, const float* noise,
+                                     const float* noise_w, const float* bias, float* y, int batch,
+                                     int channels, int out_h, int out_w, rw_stream_t stream) {
+  RW_CHECK_ARG(x && k4 && y && batch > 0 && channels > 0 && out_h > 0 && out_w > 0);
+  RW_CHECK_ARG(!noise || noise_w);
+  if (out_w % 4) return RW_ERR_UNSUPPORTED;
+  const int64_t total = (int64_t)batch * channels * out_h * (out_w / 4);
+  hipLaunchKernelGGL(blur_noise_act_kernel, dim3(rw_stream_grid(total, 256)), dim3(256), 0,
+                     rw_s(stream), x, k4, noise, noise_w, bias, y, batch, channels, out_h, out_w);
+  return RW_LAUNCH_RESULT();
+}
+
+// ---------------------------------------------------------------------------------------
+// ToRGB (models.py:628-655): 1x1 modulated conv to 3 channels + bias + skip, AI ~1.3 FLOP/B.
+// Each thread owns 4 consecutive pixels (16-byte loads along W) and walks the input channels;
+// the 3 x C modulated weight row of this image lives in LDS.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) to_rgb_kernel(const float* __restrict__ x,
+                                                     const float* __restrict__ w,
+                                                     const float* __restrict__ style,
+                                                     const float* __restrict__ bias,
+                                                     const float* __restrict__ skip,
+                                                     float* __restrict__ y, int in_ch, int64_t hw,
+                                                     float w_scale) {
+  extern __shared__ float wm[];  // [3][in_ch]
+  const int b = blockIdx.y;
+  for (int t = threadIdx.x; t < 3 * in_ch; t += 256) {
+    const int i = t % in_ch;
+    wm[t] = w_scale * w[t] * style[(int64_t)b * in_ch + i];
+  }
+  __syncthreads();
+  const int64_t hw4 = hw >> 2;
+  const float* xb = x + (int64_t)b * in_ch * hw;
+  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < hw4; q += (int64_t)gridDim.x * 256) {
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
+    for (int i = 0; i < in_ch; ++i) {
+      const float4 v = reinterpret_cast<const float4*>(xb + (int64_t)i * hw)[q];
+      const float w0 = wm[i], w1 = wm[in_ch + i], w2 = wm[2 * in_ch + i];
+      a0.x += w0 * v.x; a0.y += w0 * v.y; a0.z += w0 * v.z; a0.w += w0 * v.w;
+      a1.x += w1 * v.x; a1.y += w1 * v.y; a1.z += w1 * v.z; a1.w += w1 * v.w;
+      a2.x += w2 * v.x; a2.y += w2 * v.y; a2.z += w2 * v.z; a2.w += w2 * v.w;
+    }
+    float4 acc[3] = {a0, a1, a2};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float bv = bias ? bias[c] : 0.f;
+      float4 o = acc[c];
+      o.x += bv; o.y += bv; o.z += bv; o.w += bv;
+      const int64_t off = ((int64_t)b * 3 + c) * hw4 + q;
+      if (skip) {
+        const float4 s = reinterpret_cast<const float4*>(skip)[off];
+        o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w;
+      }
+      reinterpret_cast<float4*>(y)[off] = o;
+    }
+  }
+}
+
+extern "C" int rw_to_rgb_f32(const float* x, const float* w, const float* style, const float* bias,
+                             const float* skip, float* y, int batch, int in_ch, int64_t hw,
+                             float w_scale, rw_stream_t stream) {
+  RW_CHECK_ARG(x && w && style && y && batch > 0 && in_ch > 0 && hw > 0);
+  if (hw % 4) return RW_ERR_UNSUPPORTED;
+  int gx = (int)rw_cdiv(hw / 4, 256);
+  const int cap = (256 * 8 + batch - 1) / batch;
+  if (gx > cap) gx = cap;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(to_rgb_kernel, dim3(gx, batch), dim3(256), 3 * in_ch * sizeof(float),
+                     rw_s(stream), x, w, style, bias, skip, y, in_ch, hw, w_scale);
+  return RW_LAUNCH_RESULT();
+}
