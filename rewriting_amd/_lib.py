@@ -1,0 +1,107 @@
+"""ctypes binding of librewriting_hip.so (C ABI declared in include/rewriting_hip.h).
+
+The library is prebuilt in-tree by ``__graft_entry__.build()`` /
+``rewriting_amd/csrc/build.sh`` (hipcc, gfx950); nothing is JIT-compiled at import, unlike
+the reference's ``torch.utils.cpp_extension.load`` (utils/stylegan2/op/fused_act.py:10-16).
+There is NO fallback: if the shared object is missing or a tensor is not on a HIP device the
+wrappers raise.
+"""
+import ctypes
+import os
+from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_uint,
+                    c_void_p)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'librewriting_hip.so')
+
+ABI_VERSION = 1
+
+
+class ConvEpilogue(Structure):
+    _fields_ = [('style', c_void_p), ('demod', c_void_p), ('noise', c_void_p),
+                ('noise_w', c_void_p), ('bias', c_void_p), ('act', c_int)]
+
+
+class SolveProblem(Structure):
+    _fields_ = [
+        ('out_ch', c_int), ('in_ch', c_int), ('h', c_int), ('w', c_int), ('rank', c_int),
+        ('key', c_void_p), ('style', c_void_p), ('val', c_void_p), ('bias', c_void_p),
+        ('noise', c_void_p), ('noise_w', c_void_p), ('context', c_void_p), ('ortho', c_void_p),
+        ('weight', c_void_p), ('exp_avg', c_void_p), ('exp_avg_sq', c_void_p),
+        ('step_size', c_void_p), ('bc2_sqrt', c_void_p), ('step_counter', c_void_p),
+        ('losses', c_void_p),
+        ('conv', c_void_p), ('wsq', c_void_p), ('gd', c_void_p), ('c2', c_void_p),
+        ('grad', c_void_p),
+        ('ksplit', c_int), ('beta1', c_float), ('beta2', c_float), ('eps', c_float),
+        ('w_scale', c_float), ('low_rank_gradient', c_int),
+    ]
+
+
+# name -> (restype, argtypes); must list EVERY symbol include/rewriting_hip.h declares
+# (tests/test_abi.py parses the header and checks this table and the .so against it).
+SIGNATURES = {
+    'rw_abi_version': (c_int, []),
+    'rw_error_string': (c_char_p, [c_int]),
+    'rw_fused_bias_act_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                      c_int64, c_int, c_int, c_float, c_float, c_void_p]),
+    'rw_bias_grad_f32': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
+    'rw_upfirdn2d_f32': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 14 + [c_void_p]),
+    'rw_pixel_norm_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    'rw_equal_linear_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                    c_int64, c_float, c_float, c_int, c_float, c_float, c_void_p]),
+    'rw_adjust_latent_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
+                                     c_void_p]),
+    'rw_style_mul_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
+    'rw_weight_sqsum_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
+    'rw_demod_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
+    'rw_pack_conv_weight_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'rw_conv3x3_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                               c_float, POINTER(ConvEpilogue), c_int, c_void_p]),
+    'rw_conv_transpose3x3s2_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                           c_int, c_float, POINTER(ConvEpilogue), c_int, c_void_p]),
+    'rw_noise_add_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64,
+                                 c_void_p]),
+    'rw_blur_noise_act_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_int, c_int, c_int, c_int, c_void_p]),
+    'rw_to_rgb_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                              c_int, c_int64, c_float, c_void_p]),
+    'rw_second_moment_workspace_bytes': (c_int64, [c_int, c_int64]),
+    'rw_second_moment_f32': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_int, c_void_p,
+                                     c_void_p]),
+    'rw_channel_sums_f32': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_int, c_int,
+                                    c_void_p]),
+    'rw_solve_ksplit': (c_int, [c_int, c_int, c_int, c_int]),
+    'rw_solve_step_f32': (c_int, [POINTER(SolveProblem), c_int, c_void_p]),
+    'rw_project_weight_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                      c_int, c_float, c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Returns the loaded CDLL; raises RuntimeError (never falls back) if it is unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise RuntimeError(
+            'rewriting_amd: %s is missing -- build it with `python -c "import __graft_entry__ as g; '
+            'g.build()"` or rewriting_amd/csrc/build.sh (hipcc --offload-arch=gfx950). There is no '
+            'CPU or PyTorch fallback for the HIP kernels.' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.rw_abi_version() != ABI_VERSION:
+        raise RuntimeError('rewriting_amd: %s has ABI %d, expected %d (rebuild it)'
+                           % (LIB_PATH, lib.rw_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(code):
+    if code != 0:
+        msg = load().rw_error_string(code)
+        raise RuntimeError('librewriting_hip: %s (code %d)' % (msg.decode() if msg else '?', code))

@@ -1,0 +1,383 @@
+// The rank-constrained projected-gradient solve of ProgressiveGanRewriter.insert
+// (rewrite/ganrewrite.py:254-298) for a stride-1 SeqStyleGAN2 layer, as four kernels per
+// iteration (arithmetic: SURVEY.md section 10):
+//
+//   K1 solve_fwd      conv[o][p] = sum_k W[o][k] xcol[k][p]  (split-K fp32 MFMA GEMM, K = 9*Cin)
+//                     + partial sums of the demodulation norm   sum_k (s W[o][k] sigma_i)^2
+//   K2 solve_mid      demod, noise, bias, leaky-ReLU, L1 loss, dL/dpre, per-channel sum g*conv
+//   K3 solve_bwd_adam dW = s * gd xcol^T - c2 * W * sigma^2  (fp32 MFMA GEMM, K = pixels) with the
+//                     torch.optim.Adam update applied in the epilogue: the gradient never
+//                     touches HBM; W, m, v are each read and written exactly once per step
+//   K4 solve_project  W <- W_orth + P(W)  (every piter-th step; also the low-rank-gradient path)
+//
+// The per-iteration scalars (lr/(1-b1^t), sqrt(1-b2^t)) come from device tables indexed by a
+// device-side step counter, so ten iterations can be captured in one HIP graph and replayed
+// with no host synchronisation; losses are written to a device array.
+#include "rw_common.h"
+
+#define SV_KC 16
+#define SV_BM 64        // out channels per workgroup (both GEMMs)
+#define SV_BN 64        // pixels per workgroup in K1
+#define SV_BNK 128      // weight columns per workgroup in K3
+
+static inline int sv_pp(int p) { return (int)rw_cdiv(p, 64) * 64; }
+
+extern "C" int rw_solve_ksplit(int out_ch, int in_ch, int h, int w) {
+  const int blocks = (out_ch / SV_BM) * (int)rw_cdiv((int64_t)h * w, SV_BN);
+  const int chunks = 9 * in_ch / SV_KC;
+  int ks = (int)rw_cdiv(512, blocks > 0 ? blocks : 1);
+  if (ks > 32) ks = 32;
+  if (ks > chunks) ks = chunks;
+  if (ks < 1) ks = 1;
+  return ks;
+}
+
+// ---------------------------------------------------------------------------------------
+// K1
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) solve_fwd_kernel(const rw_solve_problem p, int pp) {
+  __shared__ __attribute__((aligned(16))) float As[2][SV_KC][SV_BM + 4];
+  __shared__ float Bs[2][SV_KC][SV_BN];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+  const int frow = lane >> 5, fcol = lane & 31;
+  const int o0 = blockIdx.x * SV_BM;
+  const int n0 = blockIdx.y * SV_BN;
+  const int ks = blockIdx.z;
+  const int P = p.h * p.w;
+  const int K = 9 * p.in_ch;
+  const int chunks = K / SV_KC;
+  const int cbeg = (int)((int64_t)chunks * ks / p.ksplit), cend = (int)((int64_t)chunks * (ks + 1) / p.ksplit);
+
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) p.step_counter[0] += 1;
+
+  // A staging: thread -> (row = tid>>2, 4 consecutive k); B staging: thread -> pixel tid&63, 4 k rows
+  const int arow = tid >> 2, apart = (tid & 3) * 4;
+  const int bn = tid & 63, bk0 = tid >> 6;
+  const int pix = n0 + bn;
+  const bool pix_ok = pix < P;
+  const int py = pix_ok ? pix / p.w : 0, px = pix_ok ? pix - py * p.w : 0;
+
+  float4 areg;
+  float breg[4];
+  float wsq_acc = 0.f;
+  auto fetch = [&](int c) {
+    const int k0 = c * SV_KC;
+    areg = *reinterpret_cast<const float4*>(p.weight + (int64_t)(o0 + arow) * K + k0 + apart);
+    const float* av = &areg.x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = (k0 + apart + e) / 9;
+      const float t = p.w_scale * av[e] * p.style[i];
+      wsq_acc += t * t;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + bk0 + 4 * j;
+      const int i = k / 9, tap = k - 9 * i;
+      const int iy = py + tap / 3 - 1, ix = px + tap % 3 - 1;
+      float v = 0.f;
+      if (pix_ok && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w) v = p.key[((int64_t)i * p.h + iy) * p.w + ix];
+      breg[j] = v;
+    }
+  };
+  auto stash = [&](int buf) {
+    As[buf][apart + 0][arow] = areg.x; As[buf][apart + 1][arow] = areg.y;
+    As[buf][apart + 2][arow] = areg.z; As[buf][apart + 3][arow] = areg.w;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Bs[buf][bk0 + 4 * j][bn] = breg[j];
+  };
+
+  rw_f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  if (cbeg < cend) { fetch(cbeg); stash(0); }
+  __syncthreads();
+  for (int c = cbeg; c < cend; ++c) {
+    const int buf = (c - cbeg) & 1;
+    if (c + 1 < cend) fetch(c + 1);
+#pragma unroll
+    for (int kp = 0; kp < SV_KC / 2; ++kp) {
+      const float af = As[buf][2 * kp + frow][wm0 + fcol];
+      const float bf = Bs[buf][2 * kp + frow][wn0 + fcol];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc, 0, 0, 0);
+    }
+    if (c + 1 < cend) stash(buf ^ 1);
+    __syncthreads();
+  }
+  float* cpart = p.conv + (int64_t)ks * p.out_ch * pp;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int o = o0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * frow;
+    const int n = n0 + wn0 + fcol;
+    cpart[(int64_t)o * pp + n] = acc[r];
+  }
+  if (blockIdx.y == 0) {   // demodulation partial: 4 adjacent lanes share an out channel
+    wsq_acc += __shfl_xor(wsq_acc, 1, 64);
+    wsq_acc += __shfl_xor(wsq_acc, 2, 64);
+    if ((tid & 3) == 0) p.wsq[(int64_t)ks * p.out_ch + o0 + arow] = wsq_acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// K2: one workgroup per out channel
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) solve_mid_kernel(const rw_solve_problem p, int pp, float* lpart) {
+  __shared__ float red[4];
+  const int o = blockIdx.x, tid = threadIdx.x;
+  const int P = p.h * p.w;
+  float wsq = 0.f;
+  for (int s = 0; s < p.ksplit; ++s) wsq += p.wsq[(int64_t)s * p.out_ch + o];
+  const float demod = rsqrtf(wsq + 1e-8f);
+  const float nw = p.noise_w[0], bv = p.bias[o];
+  const float inv_numel = 1.0f / ((float)p.out_ch * (float)P);
+  float lsum = 0.f, tsum = 0.f;
+  for (int n = tid; n < pp; n += 256) {
+    float gdv = 0.f;
+    if (n < P) {
+      float conv = 0.f;
+      for (int s = 0; s < p.ksplit; ++s) conv += p.conv[((int64_t)s * p.out_ch + o) * pp + n];
+      conv *= p.w_scale;
+      const float pre = conv * demod + nw * p.noise[n] + bv;
+      const float out = 1.4142135623730951f * ((pre > 0.f) ? pre : 0.2f * pre);
+      const float diff = out - p.val[(int64_t)o * P + n];
+      lsum += fabsf(diff);
+      const float sgn = (diff > 0.f) ? 1.f : ((diff < 0.f) ? -1.f : 0.f);
+      const float g_out = sgn * inv_numel;                      // l1_loss backward, mean reduction
+      const float g_pre = ((pre > 0.f) ? g_out : g_out * 0.2f) * 1.4142135623730951f;  // kernel case 31
+      gdv = g_pre * demod;
+      tsum += g_pre * conv;
+    }
+    p.gd[(int64_t)o * pp + n] = gdv;
+  }
+  lsum = rw_block_sum_256(lsum, red);
+  tsum = rw_block_sum_256(tsum, red);
+  if (tid == 0) {
+    lpart[o] = lsum * inv_numel;
+    p.c2[o] = p.w_scale * p.w_scale * demod * demod * demod * tsum;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Adam, as torch.optim.Adam's single-tensor path computes it (rewrite/ganrewrite.py:277,287)
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void adam_update(float g, float& w, float& m, float& v, float b1,
+                                            float b2, float eps, float step_size, float bc2s) {
+  m = m + (g - m) * (1.0f - b1);               // exp_avg.lerp_(grad, 1 - beta1)
+  v = v * b2 + ((1.0f - b2) * g) * g;          // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1-beta2)
+  const float denom = sqrtf(v) / bc2s + eps;   // (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps)
+  w = w + (-step_size * m) / denom;            // param.addcdiv_(exp_avg, denom, value=-step_size)
+}
+
+// ---------------------------------------------------------------------------------------
+// K3
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) solve_bwd_adam_kernel(const rw_solve_problem p, int pp,
+                                                             const float* lpart) {
+  __shared__ __attribute__((aligned(16))) float As[2][SV_KC][SV_BM + 4];
+  __shared__ float Bs[2][SV_KC][SV_BNK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 64;     // wave tile 32 (o) x 64 (k)
+  const int frow = lane >> 5, fcol = lane & 31;
+  const int o0 = blockIdx.x * SV_BM;
+  const int k0 = blockIdx.y * SV_BNK;
+  const int P = p.h * p.w;
+  const int K = 9 * p.in_ch;
+  const int it = p.step_counter[0];
+
+  if (blockIdx.x == 0 && blockIdx.y == 0 && wave == 0) {   // deterministic loss reduction
+    float l = 0.f;
+    for (int o = lane; o < p.out_ch; o += 64) l += lpart[o];
+    l = rw_wave_sum(l);
+    if (lane == 0) p.losses[it] = l;
+  }
+
+  const int arow = tid >> 2, apart = (tid & 3) * 4;
+  const int bcol = tid & 127, bp0 = tid >> 7;
+  const int kmine = k0 + bcol;
+  const int ci = kmine / 9, ctap = kmine - 9 * ci;
+  const int cdy = ctap / 3 - 1, cdx = ctap % 3 - 1;
+  const float* kch = p.key + (int64_t)ci * p.h * p.w;
+
+  float4 areg;
+  float breg[8];
+  auto fetch = [&](int c) {
+    const int p0 = c * SV_KC;
+    areg = *reinterpret_cast<const float4*>(p.gd + (int64_t)(o0 + arow) * pp + p0 + apart);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int n = p0 + bp0 + 2 * j;
+      float v = 0.f;
+      if (n < P) {
+        const int y = n / p.w, x = n - y * p.w;
+        const int iy = y + cdy, ix = x + cdx;
+        if (iy >= 0 && iy < p.h && ix >= 0 && ix < p.w) v = kch[iy * p.w + ix];
+      }
+      breg[j] = v;
+    }
+  };
+  auto stash = [&](int buf) {
+    As[buf][apart + 0][arow] = areg.x; As[buf][apart + 1][arow] = areg.y;
+    As[buf][apart + 2][arow] = areg.z; As[buf][apart + 3][arow] = areg.w;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) Bs[buf][bp0 + 2 * j][bcol] = breg[j];
+  };
+
+  rw_f32x16 acc[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+  const int chunks = (P + SV_KC - 1) / SV_KC;
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  for (int c = 0; c < chunks; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < chunks) fetch(c + 1);
+#pragma unroll
+    for (int kp = 0; kp < SV_KC / 2; ++kp) {
+      const float af = As[buf][2 * kp + frow][wm0 + fcol];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const float bf = Bs[buf][2 * kp + frow][wn0 + 32 * b + fcol];
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[b], 0, 0, 0);
+      }
+    }
+    if (c + 1 < chunks) stash(buf ^ 1);
+    __syncthreads();
+  }
+
+  const float step_size = p.step_size[it], bc2s = p.bc2_sqrt[it];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int k = k0 + wn0 + 32 * b + fcol;
+    const int i = k / 9;
+    const float sg = p.style[i];
+    const float sig2 = sg * sg;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = o0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * frow;
+      const int64_t idx = (int64_t)o * K + k;
+      float wv = p.weight[idx];
+      const float g = p.w_scale * acc[b][r] - p.c2[o] * wv * sig2;
+      if (p.low_rank_gradient) {
+        p.grad[idx] = g;
+      } else {
+        float m = p.exp_avg[idx], v = p.exp_avg_sq[idx];
+        adam_update(g, wv, m, v, p.beta1, p.beta2, p.eps, step_size, bc2s);
+        p.weight[idx] = wv; p.exp_avg[idx] = m; p.exp_avg_sq[idx] = v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// K4 and rw_project_weight: P(W)[o][i][t] = sum_r (sum_j W[o][j][t] d[r][j]) d[r][i]
+// (projected_conv, rewrite/ganrewrite.py:806-813).  One workgroup per out channel; W[o] is held
+// in LDS, each rank costs `taps` block reductions.
+//   MODE 0: out = (base ? base : 0) + P(src)                    (projection / ortho / zero())
+//   MODE 1: g = P(grad); Adam(g) on weight                       (low_rank_gradient=True)
+// ---------------------------------------------------------------------------------------
+#define SV_MAX_TAPS 9
+template <int MODE>
+__global__ void __launch_bounds__(256) project_kernel(const float* __restrict__ src,
+                                                      const float* __restrict__ ctx,
+                                                      const float* __restrict__ base,
+                                                      float* __restrict__ out, int in_ch, int taps,
+                                                      int rank, rw_solve_problem p) {
+  extern __shared__ float lds[];            // [in_ch*taps] source row, [in_ch*taps] projection
+  __shared__ float red[4];
+  __shared__ float cosv[SV_MAX_TAPS];
+  const int o = blockIdx.x, tid = threadIdx.x;
+  const int rowlen = in_ch * taps;
+  float* srow = lds;
+  float* prow = lds + rowlen;
+  const float* s = src + (int64_t)o * rowlen;
+  for (int e = tid; e < rowlen; e += 256) { srow[e] = s[e]; prow[e] = 0.f; }
+  __syncthreads();
+  for (int r = 0; r < rank; ++r) {
+    const float* d = ctx + (int64_t)r * in_ch;
+    float part[SV_MAX_TAPS];
+#pragma unroll
+    for (int t = 0; t < SV_MAX_TAPS; ++t) part[t] = 0.f;
+    for (int i = tid; i < in_ch; i += 256) {
+      const float dv = d[i];
+#pragma unroll
+      for (int t = 0; t < SV_MAX_TAPS; ++t)
+        if (t < taps) part[t] += srow[i * taps + t] * dv;
+    }
+#pragma unroll
+    for (int t = 0; t < SV_MAX_TAPS; ++t) {
+      if (t < taps) {
+        const float v = rw_block_sum_256(part[t], red);
+        if (tid == 0) cosv[t] = v;
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < in_ch; i += 256) {
+      const float dv = d[i];
+      for (int t = 0; t < taps; ++t) prow[i * taps + t] += cosv[t] * dv;
+    }
+    __syncthreads();
+  }
+  if (MODE == 0) {
+    const float* b = base ? base + (int64_t)o * rowlen : nullptr;
+    for (int e = tid; e < rowlen; e += 256) out[(int64_t)o * rowlen + e] = (b ? b[e] : 0.f) + prow[e];
+  } else {
+    const int it = p.step_counter[0];
+    const float step_size = p.step_size[it], bc2s = p.bc2_sqrt[it];
+    for (int e = tid; e < rowlen; e += 256) {
+      const int64_t idx = (int64_t)o * rowlen + e;
+      float wv = p.weight[idx], m = p.exp_avg[idx], v = p.exp_avg_sq[idx];
+      adam_update(prow[e], wv, m, v, p.beta1, p.beta2, p.eps, step_size, bc2s);
+      p.weight[idx] = wv; p.exp_avg[idx] = m; p.exp_avg_sq[idx] = v;
+    }
+  }
+}
+
+extern "C" int rw_project_weight_f32(const float* w, const float* context, const float* base,
+                                     float* out, int out_ch, int in_ch, int taps, int rank,
+                                     float scale_w, rw_stream_t stream) {
+  (void)scale_w;
+  RW_CHECK_ARG(w && context && out && out_ch > 0 && in_ch > 0 && taps > 0 && taps <= SV_MAX_TAPS && rank > 0);
+  const size_t lds = 2 * (size_t)in_ch * taps * sizeof(float);
+  if (lds > 64 * 1024) return RW_ERR_UNSUPPORTED;
+  rw_solve_problem dummy = {};
+  hipLaunchKernelGGL(project_kernel<0>, dim3(out_ch), dim3(256), lds, rw_s(stream), w, context, base,
+                     out, in_ch, taps, rank, dummy);
+  return RW_LAUNCH_RESULT();
+}
+
+extern "C" int rw_solve_step_f32(const rw_solve_problem* pr, int project, rw_stream_t stream) {
+  RW_CHECK_ARG(pr);
+  const rw_solve_problem& p = *pr;
+  RW_CHECK_ARG(p.key && p.style && p.val && p.bias && p.noise && p.noise_w && p.weight && p.exp_avg &&
+               p.exp_avg_sq && p.step_size && p.bc2_sqrt && p.step_counter && p.losses && p.conv &&
+               p.wsq && p.gd && p.c2);
+  RW_CHECK_ARG(p.out_ch > 0 && p.in_ch > 0 && p.h > 0 && p.w > 0 && p.ksplit > 0);
+  RW_CHECK_ARG(!(project || p.low_rank_gradient) || (p.context && p.rank > 0));
+  RW_CHECK_ARG(!project || p.ortho);
+  RW_CHECK_ARG(!p.low_rank_gradient || p.grad);
+  if (p.out_ch % SV_BM || p.in_ch % SV_KC || (9 * p.in_ch) % SV_BNK) return RW_ERR_UNSUPPORTED;
+  hipStream_t s = rw_s(stream);
+  const int P = p.h * p.w;
+  const int pp = sv_pp(P);
+  float* lpart = p.c2 + p.out_ch;   // c2 is allocated with 2*out_ch floats: [c2 | per-channel loss]
+  hipLaunchKernelGGL(solve_fwd_kernel, dim3(p.out_ch / SV_BM, pp / SV_BN, p.ksplit), dim3(256), 0, s, p, pp);
+  hipLaunchKernelGGL(solve_mid_kernel, dim3(p.out_ch), dim3(256), 0, s, p, pp, lpart);
+  hipLaunchKernelGGL(solve_bwd_adam_kernel, dim3(p.out_ch / SV_BM, 9 * p.in_ch / SV_BNK), dim3(256), 0,
+                     s, p, pp, (const float*)lpart);
+  const size_t lds = 2 * (size_t)p.in_ch * 9 * sizeof(float);
+  if (p.low_rank_gradient) {
+    if (lds > 64 * 1024) return RW_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(project_kernel<1>, dim3(p.out_ch), dim3(256), lds, s, (const float*)p.grad,
+                       p.context, (const float*)nullptr, (float*)nullptr, p.in_ch, 9, p.rank, p);
+  }
+  if (project) {
+    if (lds > 64 * 1024) return RW_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(project_kernel<0>, dim3(p.out_ch), dim3(256), lds, s, (const float*)p.weight,
+                       p.context, p.ortho, p.weight, p.in_ch, 9, p.rank, p);
+  }
+  return RW_LAUNCH_RESULT();
+}

@@ -1,0 +1,305 @@
+"""Tensor-level wrappers over the C ABI (include/rewriting_hip.h).
+
+PyTorch is used here for device memory and streams only: every wrapper allocates its output
+with torch, passes ``data_ptr()`` and ``torch.cuda.current_stream().cuda_stream`` to the
+library and returns the torch tensor -- the ownership rule of SURVEY.md section 8b.  Inputs
+must be float32 tensors on a HIP device; anything else raises (no CPU path).
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+from ._lib import ConvEpilogue, SolveProblem, check
+
+SQRT2 = 2 ** 0.5
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t, name='tensor'):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError('%s must be a torch.Tensor' % name)
+    if not t.is_cuda:
+        raise RuntimeError('rewriting_amd: %s is on %s; the HIP kernels need a GPU tensor '
+                           '(there is no CPU fallback)' % (name, t.device))
+    if t.dtype != torch.float32:
+        raise RuntimeError('rewriting_amd: %s must be float32, got %s' % (name, t.dtype))
+    return t.detach().contiguous()
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _opt(t, name):
+    return None if t is None else _dev(t, name)
+
+
+def lib():
+    return _lib.load()
+
+
+def on_device(t):
+    """True when ``t`` lives on a HIP device, i.e. when the kernels (and only the kernels) must
+    be used for it.  Host code branches on this, never on try/except around a kernel call."""
+    return bool(t.is_cuda)
+
+
+# ------------------------------------------------------------------ L1 native ops
+def fused_bias_act(x, b, ref, act, grad, alpha, scale):
+    """fused.fused_bias_act(input, bias, refer, act, grad, alpha, scale)
+    (utils/stylegan2/op/fused_bias_act.cpp:11-20); empty tensor = absent."""
+    x = _dev(x, 'input')
+    b = _dev(b, 'bias') if b is not None and b.numel() else None
+    ref = _dev(ref, 'refer') if ref is not None and ref.numel() else None
+    y = torch.empty_like(x)
+    step_b = 1
+    for d in x.shape[2:]:
+        step_b *= d
+    size_b = b.numel() if b is not None else 1
+    check(lib().rw_fused_bias_act_f32(_p(x), _p(b), _p(ref), _p(y), x.numel(), step_b, size_b,
+                                      int(act), int(grad), float(alpha), float(scale), _stream()))
+    return y
+
+
+def bias_grad(g):
+    g = _dev(g, 'grad')
+    outer = g.shape[0]
+    channels = g.shape[1] if g.ndim > 1 else 1
+    inner = 1
+    for d in g.shape[2:]:
+        inner *= d
+    gb = torch.empty(channels, device=g.device, dtype=g.dtype)
+    check(lib().rw_bias_grad_f32(_p(g), _p(gb), outer, channels, inner, _stream()))
+    return gb
+
+
+def upfirdn2d_major(x, k, up_x, up_y, down_x, down_y, px0, px1, py0, py1):
+    """upfirdn2d_op.upfirdn2d on (major, H, W, minor) (utils/stylegan2/op/upfirdn2d.cpp:12-22)."""
+    x = _dev(x, 'input')
+    k = _dev(k, 'kernel')
+    major, in_h, in_w, minor = x.shape
+    kh, kw = k.shape
+    out_h = (in_h * up_y + py0 + py1 - kh + down_y) // down_y
+    out_w = (in_w * up_x + px0 + px1 - kw + down_x) // down_x
+    y = torch.empty(major, max(out_h, 0), max(out_w, 0), minor, device=x.device, dtype=x.dtype)
+    if y.numel():
+        check(lib().rw_upfirdn2d_f32(_p(x), _p(k), _p(y), major, in_h, in_w, minor, kh, kw,
+                                     up_x, up_y, down_x, down_y, px0, px1, py0, py1, _stream()))
+    return y
+
+
+# ------------------------------------------------------------------ generator pieces
+def pixel_norm(x, eps=1e-8):
+    x = _dev(x, 'latent')
+    y = torch.empty_like(x)
+    check(lib().rw_pixel_norm_f32(_p(x), _p(y), x.shape[0], x.shape[1], eps, _stream()))
+    return y
+
+
+def equal_linear(x, weight, bias, w_scale, b_scale, act=False, alpha=0.2, act_scale=SQRT2):
+    """x may be a strided row view (latent[:, index]): last dim contiguous."""
+    if not x.is_cuda:
+        _dev(x, 'input')
+    x = x.detach()
+    if x.dtype != torch.float32 or x.ndim != 2 or x.stride(1) != 1:
+        x = _dev(x.reshape(x.shape[0], -1), 'input')
+    weight = _dev(weight, 'weight')
+    bias = _opt(bias, 'bias')
+    batch, in_dim = x.shape
+    out_dim = weight.shape[0]
+    y = torch.empty(batch, out_dim, device=x.device, dtype=torch.float32)
+    x_stride = x.stride(0) if batch > 1 else in_dim
+    check(lib().rw_equal_linear_f32(_p(x), _p(weight), _p(bias), _p(y), batch, in_dim, out_dim,
+                                    max(x_stride, in_dim), float(w_scale), float(b_scale), int(bool(act)),
+                                    float(alpha), float(act_scale), _stream()))
+    return y
+
+
+def adjust_latent(w, avg, n_latent, psi):
+    w = _dev(w, 'latent')
+    avg = _opt(avg, 'latent_avg')
+    out = torch.empty(w.shape[0], n_latent, w.shape[1], device=w.device, dtype=w.dtype)
+    check(lib().rw_adjust_latent_f32(_p(w), _p(avg), _p(out), w.shape[0], n_latent, w.shape[1],
+                                     float(psi), _stream()))
+    return out
+
+
+def style_mul(x, style):
+    x = _dev(x, 'fmap')
+    style = _dev(style, 'style')
+    b, c, h, w = x.shape
+    y = torch.empty_like(x)
+    check(lib().rw_style_mul_f32(_p(x), _p(style), _p(y), b, c, h * w, _stream()))
+    return y
+
+
+def weight_sqsum(weight, w_scale):
+    weight = _dev(weight, 'weight')
+    o, i = weight.shape[-4], weight.shape[-3]
+    taps = weight.shape[-1] * weight.shape[-2]
+    wsq = torch.empty(o, i, device=weight.device, dtype=weight.dtype)
+    check(lib().rw_weight_sqsum_f32(_p(weight), _p(wsq), o, i, taps, float(w_scale), _stream()))
+    return wsq
+
+
+def demod(wsq, style, eps=1e-8):
+    wsq = _dev(wsq, 'wsq')
+    style = _dev(style, 'style')
+    b = style.shape[0]
+    o, i = wsq.shape
+    out = torch.empty(b, o, device=wsq.device, dtype=wsq.dtype)
+    check(lib().rw_demod_f32(_p(wsq), _p(style), _p(out), b, o, i, float(eps), _stream()))
+    return out
+
+
+def pack_conv_weight(weight, mode):
+    weight = _dev(weight, 'weight')
+    o, i = weight.shape[-4], weight.shape[-3]
+    wp = torch.empty(9, i, o, device=weight.device, dtype=weight.dtype)
+    check(lib().rw_pack_conv_weight_f32(_p(weight), _p(wp), o, i, int(mode), _stream()))
+    return wp
+
+
+def _epilogue(style=None, demod=None, noise=None, noise_w=None, bias=None, act=False):
+    keep = [_opt(style, 'style'), _opt(demod, 'demod'), _opt(noise, 'noise'),
+            _opt(noise_w, 'noise weight'), _opt(bias, 'bias')]
+    ep = ConvEpilogue(_p(keep[0]).value, _p(keep[1]).value, _p(keep[2]).value,
+                      _p(keep[3]).value, _p(keep[4]).value, int(bool(act)))
+    return ep, keep
+
+
+def conv3x3(x, wp, out_ch, w_scale, style=None, demod=None, noise=None, noise_w=None, bias=None,
+            act=False, impl=0):
+    x = _dev(x, 'fmap')
+    wp = _dev(wp, 'packed weight')
+    b, i, h, w = x.shape
+    y = torch.empty(b, out_ch, h, w, device=x.device, dtype=x.dtype)
+    ep, keep = _epilogue(style, demod, noise, noise_w, bias, act)
+    check(lib().rw_conv3x3_f32(_p(x), _p(wp), _p(y), b, i, out_ch, h, w, float(w_scale),
+                               ctypes.byref(ep), int(impl), _stream()))
+    return y
+
+
+def conv_transpose3x3s2(x, wp, out_ch, w_scale, style=None, demod=None, impl=0):
+    x = _dev(x, 'fmap')
+    wp = _dev(wp, 'packed weight')
+    b, i, h, w = x.shape
+    y = torch.empty(b, out_ch, 2 * h + 1, 2 * w + 1, device=x.device, dtype=x.dtype)
+    ep, keep = _epilogue(style, demod)
+    check(lib().rw_conv_transpose3x3s2_f32(_p(x), _p(wp), _p(y), b, i, out_ch, h, w, float(w_scale),
+                                           ctypes.byref(ep), int(impl), _stream()))
+    return y
+
+
+def noise_add(x, noise, noise_w):
+    x = _dev(x, 'fmap')
+    noise = _dev(noise, 'noise')
+    noise_w = _dev(noise_w, 'noise weight')
+    b, c, h, w = x.shape
+    y = torch.empty_like(x)
+    check(lib().rw_noise_add_f32(_p(x), _p(noise), _p(noise_w), _p(y), b, c, h * w, _stream()))
+    return y
+
+
+def blur_noise_act(x, k4, noise, noise_w, bias):
+    x = _dev(x, 'fmap')
+    k4 = _dev(k4, 'blur kernel')
+    noise = _opt(noise, 'noise')
+    noise_w = _opt(noise_w, 'noise weight')
+    bias = _opt(bias, 'bias')
+    b, c, ih, iw = x.shape
+    y = torch.empty(b, c, ih - 1, iw - 1, device=x.device, dtype=x.dtype)
+    check(lib().rw_blur_noise_act_f32(_p(x), _p(k4), _p(noise), _p(noise_w), _p(bias), _p(y), b, c,
+                                      ih - 1, iw - 1, _stream()))
+    return y
+
+
+def to_rgb(x, weight, style, bias, skip, w_scale):
+    x = _dev(x, 'fmap')
+    weight = _dev(weight, 'rgb weight')
+    style = _dev(style, 'style')
+    bias = _opt(bias, 'bias')
+    skip = _opt(skip, 'skip')
+    b, c, h, w = x.shape
+    y = torch.empty(b, 3, h, w, device=x.device, dtype=x.dtype)
+    check(lib().rw_to_rgb_f32(_p(x), _p(weight), _p(style), _p(bias), _p(skip), _p(y), b, c, h * w,
+                              float(w_scale), _stream()))
+    return y
+
+
+# ------------------------------------------------------------------ statistics
+_workspaces = {}
+
+
+def _workspace(nbytes, device):
+    key = (device.index, 'ws')
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def second_moment_accumulate(mom2, a, nchw=False):
+    """mom2 (C,C) += a^T a.  a: (rows, C) row-major, or (B, C, H, W) when nchw."""
+    a = _dev(a, 'sample')
+    if not (mom2.is_cuda and mom2.dtype == torch.float32 and mom2.is_contiguous()):
+        raise RuntimeError('mom2 must be a contiguous float32 GPU tensor')
+    if nchw:
+        b, c, h, w = a.shape
+        rows, hw, layout = b * h * w, h * w, 1
+        if hw % 16:
+            a = a.permute(0, 2, 3, 1).reshape(-1, c).contiguous()
+            rows, hw, layout = a.shape[0], 0, 0
+    else:
+        rows, c = a.shape
+        hw, layout = 0, 0
+    nbytes = lib().rw_second_moment_workspace_bytes(c, rows)
+    ws = _workspace(nbytes, a.device)
+    check(lib().rw_second_moment_f32(_p(a), _p(mom2), rows, c, hw, layout, _p(ws), _stream()))
+    return mom2
+
+
+def channel_sums(a, nchw=False, square_input=False):
+    a = _dev(a, 'sample')
+    if nchw:
+        b, c, h, w = a.shape
+        rows, hw, layout = b * h * w, h * w, 1
+    else:
+        rows, c = a.shape
+        hw, layout = 0, 0
+    sums = torch.empty(2, c, device=a.device, dtype=a.dtype)
+    check(lib().rw_channel_sums_f32(_p(a), _p(sums), rows, c, hw, layout, int(bool(square_input)),
+                                    _stream()))
+    return sums
+
+
+# ------------------------------------------------------------------ solve
+def project_weight(w, context, base=None, out=None):
+    """out = base + P(w), P = projected_conv (rewrite/ganrewrite.py:806-813).  w (..., O, I, kh, kw)."""
+    wc = _dev(w, 'weight')
+    context = _dev(context, 'context')
+    base = _opt(base, 'base')
+    o, i = wc.shape[-4], wc.shape[-3]
+    taps = wc.shape[-1] * wc.shape[-2]
+    if out is None:
+        out = torch.empty_like(wc)
+    check(lib().rw_project_weight_f32(_p(wc), _p(context), _p(base), _p(out), o, i, taps,
+                                      context.shape[0], 1.0, _stream()))
+    return out
+
+
+def solve_ksplit(out_ch, in_ch, h, w):
+    return lib().rw_solve_ksplit(out_ch, in_ch, h, w)
+
+
+def solve_step(problem, project):
+    check(lib().rw_solve_step_f32(ctypes.byref(problem), int(bool(project)), _stream()))
+
+
+__all__ = [n for n in dir() if not n.startswith('_')] + ['SolveProblem', 'ConvEpilogue']

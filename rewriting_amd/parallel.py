@@ -1,0 +1,84 @@
+"""Multi-GPU pieces of the hot path: one process per GPU, torch.distributed over RCCL/xGMI.
+
+The reference has no distributed code on this path; what shards
+naturally is (section 8e):
+
+* the key-statistics sweep -- whole batches of 10 consecutive seeds are dealt round-robin to
+  ranks (every seed keeps its reference noise row), each rank accumulates its own C x C sums,
+  and ONE sum all-reduce of (mom2, count) makes every rank hold the same ``C``.  The message
+  is 1 MiB at C=512: latency-bound on xGMI, so a plain ``all_reduce`` is the right collective.
+  The reduction is done in float64 so the result does not depend on the ring order;
+* per-seed generator passes (sample sets): seed i -> rank i mod world, no collective;
+* the solve does not shard (2001 sequential steps on 9.4 MB of state): replicas only.
+
+Backend "nccl" IS RCCL on ROCm; CPU tests use "gloo" with world_size 2.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialises torch.distributed from RANK / WORLD_SIZE / MASTER_* if a launcher set them.
+    Returns (rank, world, local_rank)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard():
+    """(rank, world) for ``tally.tally_second_moment(shard=...)``; None when single-process."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist.get_rank(), dist.get_world_size()
+    return None
+
+
+def batches_for_rank(n_batches, rank, world):
+    return list(range(rank, n_batches, world))
+
+
+def allreduce_second_moment(r2mom):
+    """In place: every rank ends with the global (mom2, count)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return r2mom
+    backend = dist.get_backend()
+    if r2mom.mom2 is None:
+        raise RuntimeError('rank %d received no batches; use at least world_size batches' % dist.get_rank())
+    dev = r2mom.mom2.device
+    if backend == 'nccl' and not r2mom.mom2.is_cuda:
+        dev = torch.device('cuda', torch.cuda.current_device())
+    if backend == 'gloo':
+        dev = torch.device('cpu')
+    packed = torch.cat([r2mom.mom2.to(dev, torch.float64).reshape(-1),
+                        torch.tensor([float(r2mom.count)], dtype=torch.float64, device=dev)])
+    dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+    r2mom.mom2 = packed[:-1].reshape(r2mom.mom2.shape).to(r2mom.mom2.dtype).to(r2mom.mom2.device)
+    r2mom.count = int(round(packed[-1].item()))
+    return r2mom
+
+
+def gather_images(local_images, seeds_total):
+    """all_gather of per-rank image batches produced with seed i -> rank i mod world; returns the
+    images in seed order on every rank (optional: ranks normally write their own files)."""
+    if shard() is None:
+        return local_images
+    rank, world = shard()
+    parts = [torch.empty_like(local_images) for _ in range(world)]
+    dist.all_gather(parts, local_images.contiguous())
+    out = torch.empty((seeds_total,) + tuple(local_images.shape[1:]), dtype=local_images.dtype,
+                      device=local_images.device)
+    for r, part in enumerate(parts):
+        idx = torch.arange(r, seeds_total, world, device=out.device)
+        out[idx] = part[:idx.numel()]
+    return out

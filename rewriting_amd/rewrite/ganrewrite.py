@@ -1,0 +1,627 @@
+"""Rewriting a layer of a generator as a rank-constrained associative-memory update.
+
+Drop-in for rewrite/ganrewrite.py: ``ProgressiveGanRewriter`` (:24) and its StyleGAN
+subclasses (:658, :732, :742) keep their constructor arguments, attributes and methods
+(level B1), so ``rewriteapp.GanRewriteApp`` and the ``metrics/`` drivers
+call them unchanged.  Underneath:
+
+* the three sub-models (context | target | rendering) are ``nethook.subsequence`` views sharing
+  the parameters of a private deep copy of the model, as in the reference (:47-58);
+* the key statistics sweep feeds the NCHW key map straight into the fp32-MFMA second-moment
+  kernel, optionally sharded over ranks with one RCCL all-reduce (``parallel``);
+* ``insert`` on a stride-1 SeqStyleGAN2 layer runs the fused HIP solver (four kernels per
+  iteration, ten iterations per HIP graph, no host synchronisation unless the caller's
+  ``update_callback`` asks for one); any other target (ProgGAN's plain ``nn.Conv2d``, CPU
+  tensors) takes the autograd path the reference describes, on torch ops;
+* the tiny dense factorizations (fp64 ``eigh`` for ZCA, ``svd``/``qr`` of the ~100 x 512 key
+  matrix) run in LAPACK on the host, as in the reference's CPU configuration.
+"""
+import copy
+import json
+import math
+import os
+import random
+import time
+import warnings
+from collections import OrderedDict
+
+import torch
+
+from ..utils import nethook, pbar, renormalize, tally
+from .. import hip, parallel
+
+# Debug globals the reference's notebooks peek at (rewrite/ganrewrite.py:13-14); kept assigned.
+(all_obs, all_weight, all_CinvK, all_kCinvK, e_val, e_vec, kbasis, row_dirs, q) = (None,) * 9
+
+
+class ProgressiveGanRewriter(object):
+    def __init__(self, model, zds, layernum, cachedir=None,
+                 low_rank_insert=True,       # restrict the update to the context subspace
+                 low_rank_gradient=False,    # also project every gradient
+                 use_linear_insert=False,    # optimise Lambda with W = W0 + Lambda D
+                 tight_paste=True,           # optimise over the pasted crop, not the whole map
+                 alpha_area=True,            # composite with the painted area, not its bounding box
+                 key_method='zca'):          # or 'svd', 'mean', 'gandissect'
+        self.firstlayer, self.lastlayer = self.maplayers(layernum)
+        self.cachedir = cachedir
+        self.tight_paste = tight_paste
+        self.alpha_area = alpha_area
+        self.key_method = key_method
+        self.unit_rq = None
+        self.unit_rs = None
+        self.cad_rq = None
+        self.low_rank_insert = low_rank_insert
+        self.low_rank_gradient = low_rank_gradient
+        self.use_linear_insert = use_linear_insert
+        self.device = next(model.parameters()).device
+        self.zds = zds
+        self.model = copy.deepcopy(model)
+        self.context_model = nethook.subsequence(
+            self.model, upto_layer=self.firstlayer, share_weights=True)
+        self.target_model = nethook.subsequence(
+            self.model, first_layer=self.firstlayer, last_layer=self.lastlayer, share_weights=True)
+        self.rendering_model = nethook.subsequence(
+            self.model, after_layer=self.lastlayer, share_weights=True)
+        with torch.no_grad():
+            k = self.context_model(self.get_z(0))
+            v = self.target_model(k)
+            x = self.rendering_model(v)
+        self.k_shape = self.context_acts(k).shape
+        self.v_shape = self.target_acts(v).shape
+        self.x_shape = self.rendered_image(x).shape
+        self.c_matrix = self.collect_2nd_moment().to(self.device)
+        self.zca_matrix = zca_from_cov(self.c_matrix)
+
+    # ---- model plumbing -------------------------------------------------------------------
+    def maplayers(self, layernum):
+        return 'layer%d.conv' % layernum, 'layer%d.conv' % layernum
+
+    def model_state_dict(self):
+        parts = [m.state_dict() for m in (self.context_model, self.target_model, self.rendering_model)]
+        merged = {}
+        for part in parts:
+            merged.update(part)
+        assert len(merged) == sum(len(p) for p in parts)
+        return merged
+
+    def context_acts(self, context_out):
+        return context_out
+
+    def target_acts(self, target_out):
+        return target_out
+
+    def rendered_image(self, rendered_out):
+        return rendered_out
+
+    def detach(self, v):
+        return v.detach()
+
+    def merge_target_output(self, target_out, new_acts, crop_bounds):
+        return new_acts
+
+    def get_z(self, imgnum):
+        return self.zds[imgnum][0][None].to(self.device)
+
+    def sample_image_from_latent(self, z):
+        return self.rendering_model(self.target_model(self.context_model(z)))
+
+    def target_weights(self):
+        for name, param in self.target_model.named_parameters():
+            if 'weight' in name:
+                return param
+        raise ValueError('target model has no weight')
+
+    def rf(self, fn):
+        return None if self.cachedir is None else os.path.join(self.cachedir, fn)
+
+    def _kernels(self):
+        """True when this rewriter's tensors live on a HIP device (kernels mandatory)."""
+        return hip.on_device(next(self.model.parameters()))
+
+    # ---- key statistics -------------------------------------------------------------------
+    def collect_2nd_moment(self):
+        """Uncentred second moment C of the keys over the seed sweep (cached in r2m.npz)."""
+        with torch.no_grad(), pbar.quiet():
+            on_gpu = self._kernels()
+
+            def key_rows(zbatch):
+                acts = self.context_acts(self.context_model(zbatch.to(self.device)))
+                if on_gpu:
+                    return acts          # NCHW straight into the MFMA kernel
+                return acts.permute(0, 2, 3, 1).reshape(-1, acts.shape[1])
+            r2m = tally.tally_second_moment(key_rows, self.zds, cachefile=self.rf('r2m.npz'),
+                                            shard=parallel.shard(), nchw=on_gpu)
+            return r2m.moment()
+
+    def square_scales_for_units(self):
+        if self.unit_rs is None:
+            with pbar.quiet(), torch.no_grad():
+                on_gpu = self._kernels()
+
+                def squared_units(zbatch):
+                    acts = self.context_acts(self.context_model(zbatch.to(self.device))).detach()
+                    if on_gpu:
+                        return acts
+                    return acts.permute(0, 2, 3, 1).reshape(-1, acts.shape[1]).pow(2)
+                self.unit_rs = tally.tally_mean(squared_units, self.zds, cachefile=self.rf('unit_rs.npz'),
+                                                nchw=on_gpu, square_input=on_gpu).mean()
+        return self.unit_rs
+
+    def covariance_adjusted_query_key(self, k):
+        """C^-1 k by least squares (the reference's torch.lstsq, :101-105)."""
+        c = self.c_matrix.double().cpu()
+        rhs = (k[:, None] if k.dim() == 1 else k.permute(1, 0)).double().cpu()
+        sol = torch.linalg.lstsq(c, rhs).solution.to(k.dtype).to(k.device)
+        return sol[:, 0] if k.dim() == 1 else sol.permute(1, 0)
+
+    def covariance_adjusted_key(self, k, kout):
+        return self.covariance_adjusted_query_key(k)
+
+    def zca_whitened_query_key(self, k):
+        if k.dim() == 1:
+            return torch.mm(self.zca_matrix, k[:, None])[:, 0]
+        return torch.mm(self.zca_matrix, k.permute(1, 0)).permute(1, 0)
+
+    # ---- requests -------------------------------------------------------------------------
+    def apply_edit(self, request, rank=1, niter=2001, piter=10, lr=0.05, update_callback=None,
+                   single_key=-1):
+        """Applies an edit request as saved by the UI: {'object': [imgnum, mask], 'paste': [...],
+        'key': [[imgnum, mask], ...]}."""
+        o_imgnum, o_mask = request['object']
+        p_imgnum, p_mask = request['paste']
+        key_examples = request.get('key', [(p_imgnum, p_mask)])
+        if single_key >= 0:
+            print('Using only key', single_key, 'out of a total', len(key_examples))
+            key_examples = [key_examples[single_key]]
+        obj_acts, _, obj_area, _ = self.object_from_selection(o_imgnum, o_mask)
+        goal_in, goal_out, _, _ = self.paste_from_selection(p_imgnum, p_mask, obj_acts, obj_area)
+        mkey = self.multi_key_from_selection(key_examples, rank=rank)
+        return self.insert(goal_in, goal_out, mkey, update_callback=update_callback,
+                           niter=niter, piter=piter, lr=lr)
+
+    def apply_erase(self, request, rank=1, drank=30, niter=2001, piter=10, lr=0.05,
+                    update_callback=None):
+        p_imgnum, p_mask = request['paste']
+        key_examples = request.get('key', [(p_imgnum, p_mask)])
+        goal_in, goal_out = self.erase_from_selection(p_imgnum, p_mask, key_examples, drank)
+        mkey = self.multi_key_from_selection(key_examples, rank=rank)
+        self.insert(goal_in, goal_out, mkey, update_callback=update_callback,
+                    niter=niter, piter=piter, lr=lr)
+
+    def apply_overfit(self, request, niter=20001, lr=0.01, update_callback=None):
+        raise NotImplementedError(
+            'apply_overfit trains every weight against a VGG16 perceptual loss '
+            '(rewrite/ganrewrite.py:171-181,300-331); torchvision weights are unavailable and the '
+            'path is outside the rule-editing hot path (SURVEY.md section 8a row d5)')
+
+    def zero(self, context, amount=0.0):
+        """W <- W - P(W) + amount * P(1)   (:190-195)"""
+        weight = self.target_weights()
+        with torch.no_grad():
+            pw = projected_conv(weight, context)
+            weight[...] = weight - pw
+            if amount != 0.0:
+                weight[...] = weight + amount * projected_conv(torch.ones_like(weight), context)
+        _weights_changed()
+
+    # ---- the solve ------------------------------------------------------------------------
+    def insert(self, key, val, context=None, update_callback=None, niter=2001, piter=10, lr=0.05,
+               return_timing=False):
+        if self.use_linear_insert:
+            return self.linear_insert(key, val, context, update_callback=update_callback,
+                                      niter=niter, lr=lr, return_timing=return_timing)
+        sync = (lambda: torch.cuda.synchronize()) if self.device.type == 'cuda' else (lambda: None)
+        if return_timing:
+            sync()
+            started = time.time()
+        key, val = self.detach(key), self.detach(val)
+        self._run_insert(key, val, context, update_callback, niter, piter, lr)
+        if return_timing:
+            sync()
+            return (time.time() - started) * 1000
+
+    def _run_insert(self, key, val, context, update_callback, niter, piter, lr):
+        """Projected-gradient Adam through torch autograd (targets made of torch ops)."""
+        weight = self.target_weights()
+        constrained = self.low_rank_insert or self.low_rank_gradient
+        if constrained:
+            with torch.no_grad():
+                ortho = weight - projected_conv(weight, context)
+        optimizer = torch.optim.Adam([weight], lr=lr)
+        goal = self.target_acts(val)
+        for it in range(niter):
+            with torch.enable_grad():
+                loss = torch.nn.functional.l1_loss(goal, self.target_acts(self.target_model(key)))
+                optimizer.zero_grad()
+                loss.backward()
+                if self.low_rank_gradient:
+                    weight.grad[...] = projected_conv(weight.grad, context)
+                optimizer.step()
+                if update_callback is not None:
+                    update_callback(it, loss)
+                if self.low_rank_insert and (it % piter == 0 or it == niter - 1):
+                    with torch.no_grad():
+                        weight[...] = ortho + projected_conv(weight, context)
+        _weights_changed()
+
+    def linear_insert(self, key, val, context=None, update_callback=None, niter=2001, lr=0.05,
+                      return_timing=False):
+        raise NotImplementedError(
+            'linear_insert (rewrite/ganrewrite.py:201-252) is a "next" row (SURVEY.md section 8f.4)')
+
+    def all_weights_insert(self, *args, **kwargs):
+        raise NotImplementedError('see apply_overfit')
+
+    # ---- context direction ----------------------------------------------------------------
+    def _key_observations(self, imgnum_mask_pairs):
+        """[(rows (H*W, C), context output, mask weights (H*W, 1))] for every key example."""
+        observed = []
+        for imgnum, mask in imgnum_mask_pairs:
+            k_outs = self.context_model(self.get_z(imgnum))
+            k_acts = self.context_acts(k_outs)
+            area = renormalize.from_url(mask, target='pt', size=self.k_shape[2:])[0]
+            observed.append((k_acts.permute(0, 2, 3, 1).reshape(-1, k_acts.shape[1]), k_outs,
+                             area.reshape(-1)[:, None].to(k_acts.device)))
+        return observed
+
+    def multi_key_from_selection(self, imgnum_mask_pairs, rank=1, key_method=None):
+        """Orthonormal rows (rank, C) spanning the context subspace d.  'zca' (:339-374): whiten
+        the selected keys with Z = C^-1/2, take the top right-singular vectors, whiten again,
+        orthogonalise, and orient each along the mean selected key."""
+        global all_obs, all_weight, row_dirs, q
+        key_method = key_method or self.key_method
+        with torch.no_grad():
+            if key_method == 'zca':
+                observed = self._key_observations(imgnum_mask_pairs)
+                sel = [(w > 0).nonzero()[:, 0] for _, _, w in observed]
+                all_obs = torch.cat([obs[s] for (obs, _, _), s in zip(observed, sel)])
+                all_weight = torch.cat([w[w > 0] for _, _, w in observed])
+                all_zca_k = torch.cat([(w * self.zca_whitened_query_key(obs))[s]
+                                       for (obs, _, w), s in zip(observed, sel)])
+                zk = all_zca_k.cpu()
+                zca = self.zca_matrix.cpu()
+                _, _, vh = torch.linalg.svd(zk, full_matrices=False)
+                top = vh.t()[:, :rank]
+                row_dirs = torch.mm(zca, top).t()
+                qmat, _ = torch.linalg.qr(row_dirs.t())
+                signs = (qmat * zk.sum(0)[:, None]).sum(0).sign()
+                q = qmat * signs[None, :]
+                return q.t().contiguous().to(self.device)
+            if key_method == 'gandissect':
+                raise NotImplementedError(
+                    "key_method='gandissect' needs RunningQuantile (SURVEY.md section 8f.4)")
+            assert key_method in ['svd', 'mean']
+            gathered = []
+            for imgnum, mask in imgnum_mask_pairs:
+                k_outs = self.context_model(self.get_z(imgnum))
+                k_acts = self.context_acts(k_outs)
+                area = renormalize.from_url(mask, target='pt', size=self.k_shape[2:])[0]
+                weighted = (k_acts[0] * area[None].to(self.device)).permute(1, 2, 0).reshape(
+                    -1, k_acts.shape[1])
+                gathered.append((weighted[weighted.norm(2, dim=1) > 0], k_outs))
+            all_k = torch.cat([self.covariance_adjusted_key(nk, ko) for nk, ko in gathered])
+            just_avg = all_k.mean(0)
+            if key_method == 'mean':
+                assert rank == 1
+                return just_avg[None, :] / just_avg.norm()
+            u, _, _ = torch.linalg.svd(all_k.permute(1, 0).cpu(), full_matrices=True)
+            u = u.to(self.device)
+            if (just_avg * u[:, 0]).sum() < 0:
+                u[:, 0] = -u[:, 0]
+            assert u.shape[1] >= rank
+            return u.permute(1, 0)[:rank].contiguous()
+
+    def query_key_from_selection(self, imgnum, mask):
+        area = renormalize.from_url(mask, target='pt', size=self.k_shape[2:])[0]
+        with torch.no_grad():
+            k_acts = self.context_acts(self.context_model(self.get_z(imgnum)))
+            mean = (k_acts[0] * area[None].to(self.device)).sum(2).sum(1) / (1e-10 + area.sum())
+        k = self.covariance_adjusted_query_key(mean)
+        return k / (1e-10 + k.norm(2))
+
+    def is_empty_mask(self, mask):
+        return renormalize.from_url(mask, target='pt')[0].sum() == 0.0
+
+    # ---- goals ----------------------------------------------------------------------------
+    def object_from_selection(self, imgnum, mask):
+        """The value patch to copy: activations of the target layer under the mask's bounding box."""
+        area = renormalize.from_url(mask, target='pt', size=self.v_shape[2:])[0]
+        with torch.no_grad():
+            v_output = self.target_model(self.context_model(self.get_z(imgnum)))
+            v_acts = self.target_acts(v_output)
+        t, l, b, r = positive_bounding_box(area)
+        return v_acts[:, :, t:b, l:r], v_output, area[t:b, l:r], (t, l, b, r)
+
+    def paste_from_selection(self, imgnum, mask, obj_acts, obj_area):
+        area = renormalize.from_url(mask, target='pt', size=self.v_shape[2:])[0]
+        source_outputs = self.context_model(self.get_z(imgnum))
+        source_acts = self.context_acts(source_outputs)
+        unchanged_outputs = self.target_model(source_outputs)
+        unchanged_acts = self.target_acts(unchanged_outputs)
+        target_acts, bounds = paste_clip_at_center(
+            unchanged_acts, obj_acts, centered_location(area), obj_area if self.alpha_area else None)
+        full_target_acts = target_acts
+        source_bounds = target_bounds = None
+        if self.tight_paste:
+            source_acts, target_acts, source_bounds, target_bounds = crop_clip_to_bounds(
+                source_acts, target_acts, bounds)
+        goal_in = self.merge_target_output(source_outputs, source_acts, source_bounds)
+        goal_out = self.merge_target_output(unchanged_outputs, target_acts, target_bounds)
+        viz_out = self.merge_target_output(unchanged_outputs, full_target_acts, None)
+        return goal_in, goal_out, viz_out, bounds
+
+    def normdissect_units(self, imgnum_mask_pairs, rank):
+        """Units whose squared activation, relative to its sweep mean, is largest under the masks."""
+        with torch.no_grad():
+            observed = self._key_observations(imgnum_mask_pairs)
+            obs = torch.cat([o for o, _, _ in observed])
+            wts = torch.cat([w for _, _, w in observed])
+            scale = self.square_scales_for_units().to(obs.device)
+            score = ((obs.pow(2) / scale[None, :]) * wts).sum(0) / wts.sum()
+            return score.sort(descending=True)[1][:rank]
+
+    def erase_from_selection(self, imgnum, mask, context_mask_pairs, rank):
+        k_area = renormalize.from_url(mask, target='pt', size=self.k_shape[2:])[0]
+        area = renormalize.from_url(mask, target='pt', size=self.v_shape[2:])[0]
+        source_outputs = self.context_model(self.get_z(imgnum))
+        source_acts = self.context_acts(source_outputs)
+        unchanged_outputs = self.target_model(source_outputs)
+        without = source_acts.clone()
+        without[:, self.normdissect_units(context_mask_pairs, rank)] = 0.0
+        erased_out = self.target_model(self.merge_target_output(source_outputs, without, None))
+        target_acts = self.target_acts(erased_out)
+        source_bounds = target_bounds = None
+        if self.tight_paste:
+            source_bounds = positive_bounding_box(k_area)
+            target_bounds = positive_bounding_box(area)
+        goal_in = self.merge_target_output(source_outputs, source_acts, source_bounds)
+        goal_out = self.merge_target_output(unchanged_outputs, target_acts, target_bounds)
+        return goal_in, goal_out
+
+    def rgb_from_selection(self, imgnum, mask):
+        area = renormalize.from_url(mask, target='pt', size=self.x_shape[2:])[0]
+        with torch.no_grad():
+            x_output = self.model(self.get_z(imgnum))
+        t, l, b, r = positive_bounding_box(area)
+        return x_output[:, :, t:b, l:r], x_output, area[t:b, l:r], (t, l, b, r)
+
+    def rgbpaste_from_selection(self, imgnum, mask, obj_rgb, obj_area):
+        with torch.no_grad():
+            area = renormalize.from_url(mask, target='pt', size=self.x_shape[2:])[0]
+            source_z = self.get_z(imgnum)
+            changed, bounds = paste_clip_at_center(
+                self.model(source_z), obj_rgb, centered_location(area), obj_area)
+        return source_z, changed, bounds
+
+    # ---- UI conveniences ------------------------------------------------------------------
+    def quantiles_for_units(self):
+        raise NotImplementedError('RunningQuantile is a "next" row (SURVEY.md section 8f.2)')
+
+    quantiles_for_covariance_adjusted_directions = quantiles_for_units
+
+    def ranking_for_key(self, key, k=12):
+        raise NotImplementedError('ranking_for_key needs RunningTopK/RunningQuantile '
+                                  '(SURVEY.md section 8f.2)')
+
+    def _overlay(self):
+        try:
+            from ..utils import imgviz      # optional: visualisation is outside the hot path
+            return imgviz
+        except ImportError:
+            raise NotImplementedError('heat-map / mask overlays need utils.imgviz (visualisation is '
+                                      'outside the hot path); plain rendering works')
+
+    def render_object(self, target_output, obj_area=None, box=None):
+        with torch.no_grad():
+            imgdata = self.rendered_image(self.rendering_model(target_output))
+        if box is None:
+            return renormalize.as_image(imgdata[0])
+        t, l, b, r = box
+        lowres = torch.zeros(self.v_shape[2:])
+        lowres[t:b, l:r] = 1
+        iv = self._overlay().ImageVisualizer(imgdata.shape[2:])
+        return iv.masked_image(imgdata, activations=lowres, level=0.0, border_color=[255, 0, 0],
+                               thickness=3)
+
+    def render_image(self, imgnum, key=None, level=None, mask=None, **kwargs):
+        with torch.no_grad():
+            z = self.get_z(imgnum)
+            imgdata = self.rendered_image(self.sample_image_from_latent(z))
+        if key is not None and level is not None:
+            with torch.no_grad():
+                acts = self.context_acts(self.context_model(z))
+            heatmap = (acts * key.to(self.device)[None, :, None, None]).sum(dim=1)[0]
+            iv = self._overlay().ImageVisualizer(imgdata.shape[2:])
+            return iv.masked_image(imgdata, heatmap, level=level, **kwargs)
+        if mask is not None:
+            iv = self._overlay().ImageVisualizer(imgdata.shape[2:])
+            return iv.masked_image(imgdata, mask=mask, **kwargs)
+        return renormalize.as_image(imgdata[0])
+
+    def render_image_batch(self, imgnums, key=None, level=None, **kwargs):
+        if key is not None and level is not None:
+            return [self.render_image(n, key=key, level=level, **kwargs) for n in imgnums]
+        results = []
+        for i in range(0, len(imgnums), 3):
+            with torch.no_grad():
+                zb = torch.cat([self.get_z(n) for n in imgnums[i:i + 3]])
+                batch = self.rendered_image(self.sample_image_from_latent(zb))
+            results.extend(renormalize.as_image(img) for img in batch)
+        return results
+
+
+class SeqStyleGanRewriter(ProgressiveGanRewriter):
+    """Rewrites ``layerN.sconv.mconv.dconv`` of a SeqStyleGAN2; the key is the style-modulated
+    input of that convolution, the value the output of ``layerN.sconv.activate`` (:658-729)."""
+
+    def __init__(self, model, zds, layernum, **kwargs):
+        super().__init__(model, zds, layernum, **kwargs)
+
+    def maplayers(self, layernum):
+        return 'layer%d.sconv.mconv.dconv' % layernum, 'layer%d.sconv.activate' % layernum
+
+    def detach(self, v):
+        if isinstance(v, dict):
+            return type(v)({k: d.detach() for k, d in v.items()})
+        return v.detach()
+
+    def context_acts(self, context_out):
+        return context_out.fmap
+
+    def target_acts(self, target_out):
+        return target_out.fmap
+
+    def merge_target_output(self, target_out, new_acts, crop_bounds):
+        merged = type(target_out)({k: d.detach() for k, d in target_out.items()})
+        if crop_bounds is not None:
+            t, l, b, r = crop_bounds
+            merged.output = merged.output[:, :, t:b, l:r]
+        merged.fmap = new_acts
+        return merged
+
+    def sample_image_patch(self, z, act_crop_size, seed=(None, None), act=False, size=None):
+        out = self.context_model(z)
+        fmap, img = out['fmap'], out['output']
+        assert act_crop_size <= fmap.size(2)
+        if seed[0] is not None:
+            xi, yi = seed
+        else:
+            xi = random.randint(0, fmap.shape[2] - act_crop_size)
+            yi = random.randint(0, fmap.shape[3] - act_crop_size)
+        xf, yf = xi + act_crop_size, yi + act_crop_size
+        ratio = 1 if fmap.shape[2:] == img.shape[2:] else 2
+        out['output'] = img[:, :, ratio * xi:ratio * xf, ratio * yi:ratio * yf]
+        out['fmap'] = fmap[:, :, xi:xf, yi:yf]
+        result = self.rendering_model(self.target_model(out))
+        if not act:
+            return result
+        top = out['fmap'].max(3)[0].max(2)[0].max(1)[1].item()
+        iv = self._overlay().ImageVisualizer((size, size))
+        return result, iv.heatmap(out['fmap'][0, top], mode='nearest')
+
+    # ---- fused HIP solve ------------------------------------------------------------------
+    def _hip_solvable(self, key):
+        from ..utils.stylegan2 import models as sg
+        mods = list(self.target_model.modules())
+        leaves = [m for m in mods if len(list(m.children())) == 0]
+        if len(leaves) != 3 or not self._kernels():
+            return None
+        dconv, noise, act = leaves
+        if not (isinstance(dconv, sg.DemodulatedConv2dF) and isinstance(noise, sg.NoiseInjectionF)
+                and isinstance(act, sg.FusedLeakyReLUF)):
+            return None
+        if dconv.upsample or not dconv.demodulate or key.fmap.shape[0] != 1:
+            return None
+        if any('forward' in m.__dict__ for m in mods):
+            return None                       # someone hooked the target: keep module semantics
+        return dconv, noise, act
+
+    def _run_insert(self, key, val, context, update_callback, niter, piter, lr):
+        parts = self._hip_solvable(key) if isinstance(key, dict) else None
+        if parts is None:
+            if self._kernels():
+                raise NotImplementedError(
+                    'the fused HIP solver covers stride-1 SeqStyleGAN2 layers (even layernum, batch-1 '
+                    'goal); the kernels have no autograd path for other targets yet')
+            return super()._run_insert(key, val, context, update_callback, niter, piter, lr)
+        from . import hipsolve
+        dconv, noise, act = parts
+        hipsolve.run(dconv.weight, key.fmap, key.style, val.fmap, act.bias, noise.weight, context,
+                     niter=niter, piter=piter, lr=lr,
+                     low_rank_insert=self.low_rank_insert, low_rank_gradient=self.low_rank_gradient,
+                     update_callback=update_callback)
+        _weights_changed()
+
+
+class SeqTinyStyleGanRewriter(SeqStyleGanRewriter):
+    def maplayers(self, layernum):
+        name = 'layer%d.sconv.mconv.dconv' % layernum
+        return name, name
+
+
+class SeqPreStyleGanRewriter(SeqStyleGanRewriter):
+    def maplayers(self, layernum):
+        return 'layer%d.sconv.mconv.adain' % layernum, 'layer%d.sconv.activate' % layernum
+
+    def covariance_adjusted_key(self, k, kout):
+        assert 'adain' in self.firstlayer
+        assert kout.style.shape[0] == 1
+        cs = (self.c_matrix * kout.style[0][None, :]).double().cpu()
+        rhs = (k[:, None] if k.dim() == 1 else k.permute(1, 0)).double().cpu()
+        sol = torch.linalg.lstsq(cs, rhs).solution.to(k.dtype).to(k.device)
+        return sol[:, 0] if k.dim() == 1 else sol.permute(1, 0)
+
+
+# ------------------------------------------------------------------------------------------
+# utilities
+# ------------------------------------------------------------------------------------------
+
+def _weights_changed():
+    from ..utils.stylegan2 import models as sg
+    sg.bump_weight_epoch()
+
+
+def positive_bounding_box(data):
+    """(top, left, bottom, right) of the positive entries of a 2-d map; zeros if none."""
+    pos = data > 0
+    if pos.sum() == 0:
+        return 0, 0, 0, 0
+    cols = pos.any(0).nonzero()
+    rows = pos.any(1).nonzero()
+    return rows.min().item(), cols.min().item(), rows.max().item() + 1, cols.max().item() + 1
+
+
+def centered_location(data):
+    t, l, b, r = positive_bounding_box(data)
+    return (t + b) // 2, (l + r) // 2
+
+
+def paste_clip_at_center(source, clip, center, area=None):
+    """Copy of ``source`` with ``clip`` pasted (alpha-blended by ``area``) centred at ``center``,
+    shifted to stay inside; returns (target, (t, l, b, r))."""
+    target = source.clone()
+    t, l = (max(0, min(extent - size, c - size // 2))
+            for size, c, extent in zip(clip.shape[2:], center, source.shape[2:]))
+    b, r = t + clip.shape[2], l + clip.shape[3]
+    if area is None:
+        target[:, :, t:b, l:r] = clip
+    else:
+        a = area[None, None, :, :].to(target.device)
+        target[:, :, t:b, l:r] = (1 - a) * target[:, :, t:b, l:r] + a * clip
+    return target, (t, l, b, r)
+
+
+def crop_clip_to_bounds(source, target, bounds):
+    """Crop key (source) and value (target) maps to the paste bounds, rounding outwards to the
+    key grid when the value map has twice its resolution."""
+    t, l, b, r = bounds
+    vr, hr = [ts // ss for ts, ss in zip(target.shape[2:], source.shape[2:])]
+    st, sl, sb, sr = t // vr, l // hr, -(-b // vr), -(-r // hr)
+    tt, tl, tb, tr = st * vr, sl * hr, sb * vr, sr * hr
+    return (source[:, :, st:sb, sl:sr], target[:, :, tt:tb, tl:tr],
+            (st, sl, sb, sr), (tt, tl, tb, tr))
+
+
+def projected_conv(weight, direction):
+    """P(W)[.., o, i, y, x] = sum_d (sum_j W[.., o, j, y, x] d[d, j]) d[d, i]   (:806-813)"""
+    if hip.on_device(weight) and weight.dtype == torch.float32 and weight.dim() in (4, 5) \
+            and weight.shape[-1] * weight.shape[-2] <= 9:
+        return hip.project_weight(weight, direction).view(weight.shape)
+    if weight.dim() == 5:
+        cos = torch.einsum('goiyx,di->godyx', weight, direction)
+        return torch.einsum('godyx,di->goiyx', cos, direction)
+    cos = torch.einsum('oiyx,di->odyx', weight, direction)
+    return torch.einsum('odyx,di->oiyx', cos, direction)
+
+
+def rank_one_conv(weight, direction):
+    cos = (weight * direction[None, :, None, None]).sum(1, keepdim=True)
+    return cos * direction[None, :, None, None]
+
+
+def zca_from_cov(cov):
+    """Z = V diag(1/sqrt(lambda)) V^T in float64 -> cov.dtype (:821-826).  LAPACK on the host;
+    the reference's symeig read the upper triangle."""
+    evals, evecs = torch.linalg.eigh(cov.double().cpu(), UPLO='U')
+    zca = evecs @ torch.diag(evals.sqrt().clamp(1e-20).reciprocal()) @ evecs.t()
+    return zca.to(cov.dtype).to(cov.device)

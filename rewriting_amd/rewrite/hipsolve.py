@@ -1,0 +1,125 @@
+"""Driver of the fused HIP solver (``rw_solve_step_f32``) behind ``SeqStyleGanRewriter.insert``.
+
+Reference loop: rewrite/ganrewrite.py:271-294 -- 2001 iterations of {L1 loss through
+dconv+demod, noise, bias+lrelu; backward to W; Adam; optional callback; projection when
+``it % piter == 0 or it == niter-1``}.  Here an iteration is three kernels (+ one projection
+kernel), the Adam bias corrections come from per-step tables computed on the host in double
+precision exactly as torch.optim.Adam computes them, and blocks of ``piter`` iterations are
+captured once in a HIP graph and replayed, so the host never synchronises unless the caller's
+``update_callback`` reads a loss.
+"""
+import ctypes
+import math
+import os
+
+import torch
+
+from .. import hip
+from ..utils.stylegan2.models import reference_noise
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else 0
+
+
+class Solver:
+    def __init__(self, weight, key, style, val, bias, noise_w, context, niter, piter, lr,
+                 low_rank_insert, low_rank_gradient):
+        dev = weight.device
+        self.weight = weight                       # (1,O,I,3,3) parameter, updated in place
+        w = weight.detach()
+        assert w.is_contiguous() and w.dtype == torch.float32
+        _, O, I, kh, kw = w.shape
+        assert (kh, kw) == (3, 3)
+        _, _, h, wd = key.shape
+        self.niter, self.piter = niter, piter
+        self.low_rank_insert, self.low_rank_gradient = low_rank_insert, low_rank_gradient
+        f32 = dict(device=dev, dtype=torch.float32)
+        self.key = key.detach().reshape(I, h, wd).contiguous().float()
+        self.style = style.detach().reshape(I).contiguous().float()
+        self.val = val.detach().reshape(O, h, wd).contiguous().float()
+        self.bias = bias.detach().contiguous().float()
+        self.noise = reference_noise(1, h * wd, dev).reshape(-1).contiguous()
+        self.noise_w = noise_w.detach().reshape(1).contiguous().float()
+        constrained = low_rank_insert or low_rank_gradient
+        self.context = context.detach().contiguous().float().to(dev) if constrained else None
+        self.ortho = None
+        if constrained:
+            self.ortho = (w - hip.project_weight(w, self.context).view(w.shape)).contiguous()
+        self.exp_avg = torch.zeros_like(w)
+        self.exp_avg_sq = torch.zeros_like(w)
+        steps = range(1, niter + 1)                # torch.optim.Adam: python doubles, then fp32 use
+        self.step_size = torch.tensor([lr / (1 - 0.9 ** t) for t in steps], **f32)
+        self.bc2_sqrt = torch.tensor([math.sqrt(1 - 0.999 ** t) for t in steps], **f32)
+        self.counter = torch.full((1,), -1, device=dev, dtype=torch.int32)
+        self.losses = torch.zeros(niter, **f32)
+        ks = hip.solve_ksplit(O, I, h, wd)
+        pp = -(-(h * wd) // 64) * 64
+        self.conv = torch.empty(ks, O, pp, **f32)
+        self.wsq = torch.empty(ks, O, **f32)
+        self.gd = torch.empty(O, pp, **f32)
+        self.c2 = torch.empty(2 * O, **f32)
+        self.grad = torch.empty_like(w) if low_rank_gradient else None
+        p = hip.SolveProblem()
+        p.out_ch, p.in_ch, p.h, p.w = O, I, h, wd
+        p.rank = self.context.shape[0] if constrained else 0
+        p.key, p.style, p.val, p.bias = _ptr(self.key), _ptr(self.style), _ptr(self.val), _ptr(self.bias)
+        p.noise, p.noise_w = _ptr(self.noise), _ptr(self.noise_w)
+        p.context, p.ortho = _ptr(self.context), _ptr(self.ortho)
+        p.weight, p.exp_avg, p.exp_avg_sq = _ptr(w), _ptr(self.exp_avg), _ptr(self.exp_avg_sq)
+        p.step_size, p.bc2_sqrt = _ptr(self.step_size), _ptr(self.bc2_sqrt)
+        p.step_counter, p.losses = _ptr(self.counter), _ptr(self.losses)
+        p.conv, p.wsq, p.gd, p.c2, p.grad = (_ptr(self.conv), _ptr(self.wsq), _ptr(self.gd),
+                                             _ptr(self.c2), _ptr(self.grad))
+        p.ksplit = ks
+        p.beta1, p.beta2, p.eps = 0.9, 0.999, 1e-8
+        p.w_scale = 1 / math.sqrt(I * 9)
+        p.low_rank_gradient = int(low_rank_gradient)
+        self.problem = p
+        self._w = w
+
+    def projects(self, it):
+        return self.low_rank_insert and (it % self.piter == 0 or it == self.niter - 1)
+
+    def step(self, it, project=None):
+        hip.solve_step(self.problem, self.projects(it) if project is None else project)
+
+    def project_now(self):
+        hip.project_weight(self._w, self.context, base=self.ortho, out=self._w)
+
+    def run(self, update_callback=None):
+        niter, piter = self.niter, self.piter
+        if update_callback is not None:
+            # reference order: step, callback (sees the stepped, not yet projected weight), projection
+            for it in range(niter):
+                self.step(it, project=False)
+                update_callback(it, self.losses[it])
+                if self.projects(it):
+                    self.project_now()
+            return
+        use_graph = os.environ.get('RW_SOLVE_GRAPH', '1') != '0' and niter >= 3 * piter + 1 and piter > 1
+        if not use_graph:
+            for it in range(niter):
+                self.step(it)
+            return
+        self.step(0)                                # eager first step: loads every code object
+        blocks = (niter - 1) // piter
+        # iterations 1..piter: the projection falls on the last one of the block
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for j in range(1, piter + 1):
+                self.step(j, project=self.low_rank_insert and j == piter)
+        # the capture itself did not execute; replay once per block
+        for _ in range(blocks):
+            graph.replay()
+        for it in range(1 + blocks * piter, niter):
+            self.step(it)
+
+
+def run(weight, key, style, val, bias, noise_w, context, niter=2001, piter=10, lr=0.05,
+        low_rank_insert=True, low_rank_gradient=False, update_callback=None):
+    solver = Solver(weight, key, style, val, bias, noise_w, context, niter, piter, lr,
+                    low_rank_insert, low_rank_gradient)
+    solver.run(update_callback)
+    return solver

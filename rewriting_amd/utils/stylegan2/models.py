@@ -1,0 +1,633 @@
+"""Sequential StyleGANv2 generator on MI355X kernels.
+
+Drop-in for utils/stylegan2/models.py: the same class names, constructor arguments, child-module
+names and state-dict keys (level B2), so ``nethook.subsequence``,
+``InstrumentedModel`` and ``ganrewrite.SeqStyleGanRewriter`` split and hook it exactly as they
+split the reference.  Every non-leaf is an ``nn.Sequential``; data flows as ``DataBag`` dicts.
+
+What differs is underneath: every leaf calls a hand-written gfx950 kernel through the C ABI
+(``rewriting_amd.hip``), and a ``StyledConvSeq`` whose children are all present and un-hooked
+runs as ONE fused block (style multiply folded into the implicit-GEMM gather; demodulation,
+noise, bias and leaky-ReLU in its epilogue) -- invisible at the module boundaries the
+rewriter observes, because any hook or split turns the fusion off for that block.
+"""
+import math
+import os
+import re
+import warnings
+from collections import OrderedDict
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import op
+from ... import hip
+
+# ------------------------------------------------------------------------------------------
+# helpers
+# ------------------------------------------------------------------------------------------
+
+_weight_epoch = [0]
+
+
+def bump_weight_epoch():
+    """Called by code that rewrites parameters through raw device pointers (the HIP solver),
+    which torch's version counters cannot see; invalidates every derived-weight cache."""
+    _weight_epoch[0] += 1
+
+
+class _DerivedWeights:
+    """Cache of tensors derived from a parameter (repacked weights, squared sums), keyed on the
+    parameter's storage, torch version counter and the package-wide epoch."""
+
+    def __init__(self):
+        self.store = {}
+
+    def get(self, name, param, make):
+        key = (param.data_ptr(), param._version, _weight_epoch[0], str(param.device))
+        hit = self.store.get(name)
+        if hit is None or hit[0] != key:
+            hit = (key, make())
+            self.store[name] = hit
+        return hit[1]
+
+
+_noise_streams = {}
+
+
+def reference_noise(batch, hw, device):
+    """The reference regenerates ``np.random.RandomState(0).randn(batch, H*W)`` on the host for
+    every noise layer of every call (utils/stylegan2/models.py:542-545; quirk Q1).  That is a
+    fixed stream prefix, so it is generated once and kept on the device."""
+    need = batch * hw
+    key = str(device)
+    stream = _noise_streams.get(key)
+    if stream is None or stream.numel() < need:
+        n = max(need, 1 << 16)
+        host = np.random.RandomState(0).randn(n).astype('float32')
+        stream = torch.from_numpy(host).to(device)
+        _noise_streams[key] = stream
+    return stream[:need].view(batch, hw)
+
+
+def make_kernel(k):
+    k = torch.tensor(k, dtype=torch.float32)
+    if k.ndim == 1:
+        k = torch.outer(k, k)
+    return k / k.sum()
+
+
+def _unhooked(*modules):
+    """nethook hooks a layer by planting a ``forward`` attribute on the instance
+    (utils/nethook.py:197-201)."""
+    return all('forward' not in m.__dict__ for m in modules)
+
+
+def fusion_enabled():
+    return os.environ.get('RW_FUSE', '1') != '0'
+
+
+def conv_impl():
+    return 1 if os.environ.get('RW_CONV_IMPL', 'mfma') == 'direct' else 0
+
+
+class DataBag(dict):
+    """dict with attribute access, carrying latent / style / fmap / output / noise through the
+    sequential generator (reference: utils/stylegan2/models.py:204-230)."""
+
+    def __init__(self, rep=None, **kwargs):
+        super().__init__()
+        self.update(rep, **kwargs)
+
+    def __getattr__(self, name):
+        try:
+            return self[name]
+        except KeyError:
+            raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        self[name] = value
+
+    def __delattr__(self, name):
+        try:
+            del self[name]
+        except KeyError:
+            raise AttributeError(name)
+
+    def update(self, rep=None, **kwargs):
+        if rep is not None:
+            super().update(rep)
+        super().update(kwargs)
+
+
+# ------------------------------------------------------------------------------------------
+# leaves
+# ------------------------------------------------------------------------------------------
+
+class InputLatent(nn.Module):
+    def forward(self, z):
+        return DataBag(latent=z)
+
+
+class ReturnOutput(nn.Module):
+    def forward(self, d):
+        return d.output
+
+
+class PixelNormL(nn.Module):
+    def forward(self, d):
+        return DataBag(d, latent=hip.pixel_norm(d.latent))
+
+
+class EqualLinear(nn.Linear):
+    """Equalised-learning-rate linear layer (reference: models.py:487-517)."""
+
+    def __init__(self, in_dim, out_dim, bias=True, bias_init=0, lr_mul=1, activation=None):
+        self.bias_init = bias_init
+        self.lr_mul = lr_mul
+        self.scale = (1 / math.sqrt(in_dim)) * lr_mul
+        super().__init__(in_dim, out_dim, bias)
+        self.activation = activation
+
+    def reset_parameters(self):
+        nn.init.normal_(self.weight, std=1.0 / self.lr_mul)
+        if self.bias is not None:
+            nn.init.constant_(self.bias, self.bias_init)
+
+    def forward(self, input):
+        return hip.equal_linear(input, self.weight, self.bias, self.scale, self.lr_mul,
+                                act=bool(self.activation))
+
+    def __repr__(self):
+        return '%s(%d, %d)' % (type(self).__name__, self.weight.shape[1], self.weight.shape[0])
+
+
+class EqualLinearL(EqualLinear):
+    def forward(self, d):
+        return DataBag(d, latent=super().forward(d.latent))
+
+
+class EqualLinearS(EqualLinear):
+    def forward(self, d):
+        return DataBag(d, style=super().forward(d.style))
+
+
+class AdjustLatent(nn.Module):
+    """Truncation toward ``latent_avg`` and broadcast to one row per layer (models.py:570-583).
+    As in the reference the buffer starts as a 0-d placeholder and truncation only applies once
+    it has been given a real vector."""
+
+    def __init__(self, n_latent, truncation=1.0):
+        super().__init__()
+        self.n_latent = n_latent
+        self.truncation = truncation
+        self.register_buffer('latent_avg', torch.tensor(0.0))
+
+    def forward(self, d):
+        truncate = self.truncation != 1.0 and self.latent_avg.ndim > 0
+        lat = hip.adjust_latent(d.latent, self.latent_avg if truncate else None, self.n_latent,
+                                self.truncation)
+        return DataBag(d, latent=lat)
+
+
+class PickLatent(nn.Module):
+    def __init__(self, index):
+        super().__init__()
+        self.index = index
+
+    def __repr__(self):
+        return '%s(%d)' % (type(self).__name__, self.index)
+
+    def forward(self, d):
+        return DataBag(d, style=d.latent[:, self.index])
+
+
+class NoiseBuffers(nn.Module):
+    def __init__(self, replace_input=False):
+        super().__init__()
+        self.replace_input = replace_input
+
+    def forward(self, d):
+        for name, buf in self.named_buffers(recurse=False):
+            if name.startswith('noise_') and (self.replace_input or name not in d):
+                d[name] = buf
+        return d
+
+
+class FixedNoiseBuffers(NoiseBuffers):
+    """Per-layer fixed noise images noise_0.. (models.py:342-352).  Present in the state dict for
+    checkpoint compatibility; NoiseInjectionF never reads them (quirk Q1)."""
+
+    def __init__(self, num_layers, seed, replace_input=False):
+        super().__init__(replace_input=replace_input)
+        self.num_layers = num_layers
+        rng = np.random.RandomState(seed)
+        for idx in range(num_layers):
+            res = 2 ** ((idx + 5) // 2)
+            self.register_buffer('noise_%d' % idx,
+                                 torch.from_numpy(rng.randn(1, 1, res, res).astype('float32')))
+
+
+class ConstantInputF(nn.Module):
+    def __init__(self, channel, size=4):
+        super().__init__()
+        self.input = nn.Parameter(torch.randn(1, channel, size, size))
+
+    def forward(self, d):
+        return DataBag(d, fmap=self.input.detach().repeat(d.latent.shape[0], 1, 1, 1))
+
+
+class ApplyStyle(nn.Module):
+    """fmap * style -- its output is the rewriter's key (rewrite/ganrewrite.py:662-665)."""
+
+    def forward(self, d):
+        return DataBag(d, fmap=hip.style_mul(d.fmap, d.style))
+
+
+class DemodulatedConv2dF(nn.Module):
+    """The plain linear convolution the rewriter edits, followed by the demodulation factor
+    (models.py:291-329).  Stride 1: 3x3 conv, pad 1.  upsample: stride-2 transposed conv to
+    (2H+1, 2W+1)."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, demodulate=True, upsample=False):
+        super().__init__()
+        if kernel_size != 3:
+            raise NotImplementedError('the gfx950 kernels implement 3x3 styled convolutions')
+        self.kernel_size = kernel_size
+        self.in_channel = in_channel
+        self.out_channel = out_channel
+        self.scale = 1 / math.sqrt(in_channel * kernel_size ** 2)
+        self.padding = kernel_size // 2
+        self.demodulate = demodulate
+        self.upsample = upsample
+        self.weight = nn.Parameter(torch.randn(1, out_channel, in_channel, kernel_size, kernel_size))
+        self._derived = _DerivedWeights()
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state['_derived'] = _DerivedWeights()       # caches are not copied or pickled
+        return state
+
+    def __repr__(self):
+        return '%s(%d, %d, %d, upsample=%s)' % (type(self).__name__, self.in_channel,
+                                                self.out_channel, self.kernel_size, self.upsample)
+
+    def packed_weight(self):
+        return self._derived.get('packed', self.weight,
+                                 lambda: hip.pack_conv_weight(self.weight, 1 if self.upsample else 0))
+
+    def squared_sums(self):
+        return self._derived.get('wsq', self.weight, lambda: hip.weight_sqsum(self.weight, self.scale))
+
+    def demod_factors(self, style):
+        return hip.demod(self.squared_sums(), style) if self.demodulate else None
+
+    def run(self, fmap, style, style_on_load, **epilogue):
+        demod = self.demod_factors(style)
+        load_style = style if style_on_load else None
+        if self.upsample:
+            return hip.conv_transpose3x3s2(fmap, self.packed_weight(), self.out_channel, self.scale,
+                                           style=load_style, demod=demod, impl=conv_impl())
+        return hip.conv3x3(fmap, self.packed_weight(), self.out_channel, self.scale,
+                           style=load_style, demod=demod, impl=conv_impl(), **epilogue)
+
+    def forward(self, d):
+        return DataBag(d, fmap=self.run(d.fmap, d.style, style_on_load=False))
+
+
+class Blur(nn.Module):
+    def __init__(self, kernel, pad, upsample_factor=1):
+        super().__init__()
+        k = make_kernel(kernel)
+        if upsample_factor > 1:
+            k = k * (upsample_factor ** 2)
+        self.register_buffer('kernel', k)
+        self.pad = pad
+
+    def forward(self, input):
+        return op.upfirdn2d(input, self.kernel, pad=self.pad)
+
+
+class BlurF(Blur):
+    def forward(self, d):
+        return DataBag(d, fmap=super().forward(d.fmap))
+
+
+class Upsample(nn.Module):
+    def __init__(self, kernel, factor=2):
+        super().__init__()
+        self.factor = factor
+        self.register_buffer('kernel', make_kernel(kernel) * (factor ** 2))
+        p = self.kernel.shape[0] - factor
+        self.pad = ((p + 1) // 2 + factor - 1, p // 2)
+
+    def forward(self, input):
+        return op.upfirdn2d(input, self.kernel, up=self.factor, down=1, pad=self.pad)
+
+
+class UpsampleF(Upsample):
+    def forward(self, d):
+        return DataBag(d, fmap=super().forward(d.fmap))
+
+
+class UpsampleO(Upsample):
+    def __init__(self, kernel=[1, 3, 3, 1], factor=2):
+        super().__init__(kernel, factor)
+
+    def forward(self, d):
+        return DataBag(d, output=super().forward(d.output))
+
+
+class NoiseInjectionF(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(1))
+
+    def noise_for(self, d, batch, height, width, device):
+        noise = d.get('noise', None)
+        if noise is None:
+            return reference_noise(batch, height * width, device)
+        return noise.reshape(batch, height * width)
+
+    def forward(self, d):
+        b, _, h, w = d.fmap.shape
+        return DataBag(d, fmap=hip.noise_add(d.fmap, self.noise_for(d, b, h, w, d.fmap.device),
+                                             self.weight))
+
+
+class FusedLeakyReLUF(op.FusedLeakyReLU):
+    def forward(self, d):
+        return DataBag(d, fmap=super().forward(d.fmap))
+
+
+class ModulatedConv2d(nn.Module):
+    """Style-modulated convolution taking (input, style) tensors (models.py:354-425).  3x3 uses
+    the styled implicit-GEMM kernels (style folded into the gather, demodulation in the
+    epilogue: the same arithmetic as modulating the weights first); 1x1 without demodulation is
+    the ToRGB projection."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, style_dim, demodulate=True,
+                 upsample=False, blur_kernel=[1, 3, 3, 1]):
+        super().__init__()
+        self.eps = 1e-8
+        self.kernel_size = kernel_size
+        self.in_channel = in_channel
+        self.out_channel = out_channel
+        self.upsample = upsample
+        if upsample:
+            factor = 2
+            p = (len(blur_kernel) - factor) - (kernel_size - 1)
+            self.blur = Blur(blur_kernel, pad=((p + 1) // 2 + factor - 1, p // 2 + 1),
+                             upsample_factor=factor)
+        self.scale = 1 / math.sqrt(in_channel * kernel_size ** 2)
+        self.padding = kernel_size // 2
+        self.weight = nn.Parameter(torch.randn(1, out_channel, in_channel, kernel_size, kernel_size))
+        self.modulation = EqualLinear(style_dim, in_channel, bias_init=1)
+        self.demodulate = demodulate
+        self._derived = _DerivedWeights()
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state['_derived'] = _DerivedWeights()
+        return state
+
+    def __repr__(self):
+        return '%s(%d, %d, %d, upsample=%s, downsample=False)' % (
+            type(self).__name__, self.in_channel, self.out_channel, self.kernel_size, self.upsample)
+
+    def forward(self, input, style):
+        style = self.modulation(style)
+        if self.kernel_size == 1:
+            if self.demodulate or self.upsample or self.out_channel != 3:
+                raise NotImplementedError('1x1 modulated conv is implemented for ToRGB only')
+            return hip.to_rgb(input, self.weight.view(3, self.in_channel), style, None, None, self.scale)
+        if self.kernel_size != 3:
+            raise NotImplementedError('kernel_size %d' % self.kernel_size)
+        wp = self._derived.get('packed', self.weight,
+                               lambda: hip.pack_conv_weight(self.weight, 1 if self.upsample else 0))
+        demod = None
+        if self.demodulate:
+            wsq = self._derived.get('wsq', self.weight, lambda: hip.weight_sqsum(self.weight, self.scale))
+            demod = hip.demod(wsq, style)
+        if self.upsample:
+            out = hip.conv_transpose3x3s2(input, wp, self.out_channel, self.scale, style=style,
+                                          demod=demod, impl=conv_impl())
+            return self.blur(out)
+        return hip.conv3x3(input, wp, self.out_channel, self.scale, style=style, demod=demod,
+                           impl=conv_impl())
+
+
+class ModulatedConv2dF(ModulatedConv2d):
+    def forward(self, d):
+        return DataBag(d, fmap=super().forward(d.fmap, d.style))
+
+
+class ToRGBF(nn.Module):
+    """Modulated 1x1 projection to RGB + bias + running skip image (models.py:628-655)."""
+
+    def __init__(self, in_channel, style_dim, upsample=True, blur_kernel=[1, 3, 3, 1], skip=False):
+        super().__init__()
+        if upsample:
+            self.upsample = Upsample(blur_kernel)
+        self.conv = ModulatedConv2d(in_channel, 3, 1, style_dim, demodulate=False)
+        self.bias = nn.Parameter(torch.zeros(1, 3, 1, 1))
+        self.skip = skip
+
+    def forward(self, d):
+        skip = d.output if self.skip else None
+        if skip is not None and tuple(skip.shape[2:]) != tuple(d.fmap.shape[2:]):
+            up = self.upsample if hasattr(self, 'upsample') else Upsample([1, 3, 3, 1]).to(skip.device)
+            skip = up(skip)
+        conv = self.conv
+        style = conv.modulation(d.style)
+        out = hip.to_rgb(d.fmap, conv.weight.view(3, conv.in_channel), style, self.bias.view(3), skip,
+                         conv.scale)
+        return DataBag(d, output=out)
+
+
+# ------------------------------------------------------------------------------------------
+# containers
+# ------------------------------------------------------------------------------------------
+
+class ModulatedConv2dSeq(nn.Sequential):
+    """modulation -> adain -> dconv [-> blur], explicitly separated so that the learned linear
+    convolution can be rewritten as an associative memory (models.py:259-289)."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, style_dim, demodulate=True,
+                 upsample=False, blur_kernel=[1, 3, 3, 1]):
+        self.eps = 1e-8
+        self.kernel_size = kernel_size
+        self.in_channel = in_channel
+        self.out_channel = out_channel
+        self.upsample = upsample
+        steps = [
+            ('modulation', EqualLinearS(style_dim, in_channel, bias_init=1)),
+            ('adain', ApplyStyle()),
+            ('dconv', DemodulatedConv2dF(in_channel, out_channel, kernel_size,
+                                         demodulate=demodulate, upsample=upsample)),
+        ]
+        if upsample:
+            factor = 2
+            p = (len(blur_kernel) - factor) - (kernel_size - 1)
+            steps.append(('blur', BlurF(blur_kernel, pad=((p + 1) // 2 + factor - 1, p // 2 + 1),
+                                        upsample_factor=factor)))
+        super().__init__(OrderedDict(steps))
+
+
+class StyledConvSeq(nn.Sequential):
+    """mconv -> noise -> activate (models.py:232-257).  When nothing inside is hooked the block
+    runs fused; otherwise child by child, so hooks and splits observe reference semantics."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, style_dim, upsample=False,
+                 blur_kernel=[1, 3, 3, 1], demodulate=True, mconv=None):
+        assert mconv in [None, 'seq', 'fast']
+        conv_cls = ModulatedConv2dSeq if mconv == 'seq' else ModulatedConv2dF
+        super().__init__(OrderedDict([
+            ('mconv', conv_cls(in_channel, out_channel, kernel_size, style_dim, upsample=upsample,
+                               blur_kernel=blur_kernel, demodulate=demodulate)),
+            ('noise', NoiseInjectionF()),
+            ('activate', FusedLeakyReLUF(out_channel)),
+        ]))
+
+    def _fusable(self):
+        if not fusion_enabled() or set(self._modules) != {'mconv', 'noise', 'activate'}:
+            return False
+        mconv = self.mconv
+        if not isinstance(mconv, ModulatedConv2dSeq):
+            return False
+        want = {'modulation', 'adain', 'dconv'} | ({'blur'} if mconv.upsample else set())
+        if set(mconv._modules) != want:
+            return False
+        return _unhooked(mconv, self.noise, self.activate, *mconv._modules.values())
+
+    def forward(self, d):
+        if not self._fusable():
+            return super().forward(d)
+        mconv, act = self.mconv, self.activate
+        style = mconv.modulation(DataBag(style=d.style)).style
+        fmap = d.fmap
+        b = fmap.shape[0]
+        dconv = mconv.dconv
+        if act.negative_slope != 0.2 or abs(act.scale - 2 ** 0.5) > 1e-12:
+            return super().forward(d)
+        if mconv.upsample:
+            h, w = 2 * fmap.shape[2], 2 * fmap.shape[3]
+            noise = self.noise.noise_for(d, b, h, w, fmap.device)
+            wide = dconv.run(fmap, style, style_on_load=True)
+            out = hip.blur_noise_act(wide, mconv.blur.kernel, noise, self.noise.weight, act.bias)
+        else:
+            h, w = fmap.shape[2:]
+            noise = self.noise.noise_for(d, b, h, w, fmap.device)
+            out = dconv.run(fmap, style, style_on_load=True, noise=noise,
+                            noise_w=self.noise.weight, bias=act.bias, act=True)
+        return DataBag(d, style=style, fmap=out)
+
+
+class SeqStyleGAN2(nn.Sequential):
+    """The whole generator as named sequential steps (models.py:31-141): bag_in, style, latents,
+    noises, input, layer2, to_rgb1, then per resolution up_rgbK, layer(2j+1), layer(2j+2),
+    to_rgbK, and output."""
+
+    def __init__(self, size, style_dim, n_mlp, channel_multiplier=2, blur_kernel=[1, 3, 3, 1],
+                 lr_mlp=0.01, truncation=1.0, mconv=None, bag_input=False, bag_output=False):
+        self.size = size
+        self.style_dim = style_dim
+        self.mconv = mconv
+        self.bag_input = bag_input
+        self.bag_output = bag_output
+        cm = channel_multiplier
+        self.channels = {4: 512, 8: 512, 16: 512, 32: 512, 64: 256 * cm, 128: 128 * cm,
+                         256: 64 * cm, 512: 32 * cm, 1024: 16 * cm}
+        self.log_size = int(math.log(size, 2))
+        self.num_layers = (self.log_size - 2) * 2 + 1
+        self.n_latent = self.log_size * 2 - 2
+
+        def styled(cin, cout, upsample=False):
+            return StyledConvSeq(cin, cout, 3, style_dim, upsample=upsample,
+                                 blur_kernel=blur_kernel, mconv=mconv)
+
+        def picked(index, name, module):
+            return nn.Sequential(OrderedDict([('lat%d' % index, PickLatent(index)), (name, module)]))
+
+        mapping = [PixelNormL()] + [
+            EqualLinearL(style_dim, style_dim, lr_mul=lr_mlp, activation='fused_lrelu')
+            for _ in range(n_mlp)]
+        c4 = self.channels[4]
+        steps = [] if bag_input else [('bag_in', InputLatent())]
+        steps += [
+            ('style', nn.Sequential(*mapping)),
+            ('latents', AdjustLatent(self.n_latent, truncation)),
+            ('noises', FixedNoiseBuffers(self.num_layers, 1, replace_input=False)),
+            ('input', ConstantInputF(c4)),
+            ('layer2', picked(0, 'conv', styled(c4, c4))),
+            ('to_rgb1', picked(1, 'rgb', ToRGBF(c4, style_dim, upsample=False))),
+        ]
+        cin, lat = c4, 1
+        for level in range(3, self.log_size + 1):
+            cout = self.channels[2 ** level]
+            steps += [
+                ('up_rgb%d' % (level - 2), UpsampleO()),
+                ('layer%d' % (lat + 2), picked(lat, 'sconv', styled(cin, cout, upsample=True))),
+                ('layer%d' % (lat + 3), picked(lat + 1, 'sconv', styled(cout, cout))),
+                ('to_rgb%d' % (level - 1),
+                 picked(lat + 2, 'rgb', ToRGBF(cout, style_dim, skip=True, upsample=False))),
+            ]
+            cin, lat = cout, lat + 2
+        if not bag_output:
+            steps.append(('output', ReturnOutput()))
+        super().__init__(OrderedDict(steps))
+
+    def bag_from_z(self, z):
+        return InputLatent()(z)
+
+    def output_from_bag(self, bag):
+        return ReturnOutput()(bag)
+
+    def load_state_dict(self, data, latent_avg=None, **kwargs):
+        """Accepts this class's own keys, or a rosinality/stylegan2-pytorch generator
+        checkpoint (``{'g_ema': ..., 'latent_avg': ...}`` or its ``g_ema`` dict), renaming
+        keys the way the reference does (models.py:149-202)."""
+        try:
+            return super().load_state_dict(data, **kwargs)
+        except Exception:
+            pass
+        if len(data) < 10 and 'g_ema' in data and 'latent_avg' in data:
+            latent_avg = data['latent_avg']
+            data = data['g_ema']
+        converted = convert_rosinality_keys(data, seq=(self.mconv == 'seq'))
+        current = self.state_dict()
+        if latent_avg is not None:
+            converted['latents.latent_avg'] = latent_avg
+        elif 'latents.latent_avg' not in converted:
+            if self.latents.truncation != 1.0:
+                warnings.warn('Need to provide latent_avg to use truncation.')
+            converted['latents.latent_avg'] = current['latents.latent_avg']
+        for key in current:
+            if key.startswith('noises') and key not in converted:
+                converted[key] = current[key]
+        return super().load_state_dict(converted, **kwargs)
+
+
+_ROSINALITY_RULES = [
+    (r'^conv1\.conv\.', lambda m: 'layer2.conv.mconv.'),
+    (r'^conv1\.', lambda m: 'layer2.conv.'),
+    (r'^convs\.(\d+)\.conv', lambda m: 'layer%d.sconv.mconv' % (int(m.group(1)) + 3)),
+    (r'^convs\.(\d+)\.', lambda m: 'layer%d.sconv.' % (int(m.group(1)) + 3)),
+    (r'^to_rgb1\.(conv\.|bias$)', lambda m: 'to_rgb1.rgb.%s' % m.group(1)),
+    (r'^to_rgbs\.(\d+)\.upsample\.', lambda m: 'up_rgb%d.' % (int(m.group(1)) + 1)),
+    (r'^to_rgbs\.(\d+)\.', lambda m: 'to_rgb%d.rgb.' % (int(m.group(1)) + 2)),
+]
+
+
+def convert_rosinality_keys(data, seq=True):
+    out = {}
+    for key, value in data.items():
+        for pattern, repl in _ROSINALITY_RULES:
+            key = re.sub(pattern, repl, key)
+        if seq:
+            key = re.sub(r'mconv\.weight$', 'mconv.dconv.weight', key)
+        else:
+            key = re.sub(r'mconv\.dconv\.weight$', 'mconv.weight', key)
+        out[key] = value
+    return out

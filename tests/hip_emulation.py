@@ -1,0 +1,232 @@
+"""TEST INFRASTRUCTURE -- a torch-CPU stand-in for the tensor-level kernel wrappers of
+``rewriting_amd.hip``, so that the HOST logic above the C ABI (module tree, fusion switch,
+rewriter orchestration, solver driver) can be exercised by the CPU test-suite against the
+golden fixtures.  It lives under tests/ and is installed by the ``emulated_hip`` fixture only;
+the product package never imports it and has no CPU path for these ops.
+
+Each function mirrors the *interface* of the wrapper it replaces and computes the result with
+plain torch ops (delegating to oracle/restatement.py where that has the op already).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from oracle import restatement as R
+
+SQRT2 = 2 ** 0.5
+
+
+def fused_bias_act(x, b, ref, act, grad, alpha, scale):
+    b = b if (b is not None and b.numel()) else None
+    ref = ref if (ref is not None and ref.numel()) else None
+    return R.fused_bias_act(x.detach(), None if b is None else b.detach(), ref, act, grad, alpha, scale)
+
+
+def bias_grad(g):
+    dims = [0] + list(range(2, g.ndim))
+    return g.sum(dims)
+
+
+def upfirdn2d_major(x, k, up_x, up_y, down_x, down_y, px0, px1, py0, py1):
+    return R.upfirdn2d_major(x.detach(), k.detach(), up_x, up_y, down_x, down_y, px0, px1, py0, py1)
+
+
+def pixel_norm(x, eps=1e-8):
+    x = x.detach()
+    return x * torch.rsqrt(torch.mean(x ** 2, dim=1, keepdim=True) + eps)
+
+
+def equal_linear(x, weight, bias, w_scale, b_scale, act=False, alpha=0.2, act_scale=SQRT2):
+    out = F.linear(x.detach(), weight.detach() * w_scale)
+    if bias is not None:
+        out = out + bias.detach() * b_scale
+    if act:
+        out = F.leaky_relu(out, alpha) * act_scale
+    return out
+
+
+def adjust_latent(w, avg, n_latent, psi):
+    w = w.detach()
+    if avg is not None:
+        w = avg + psi * (w - avg)
+    return w.unsqueeze(1).repeat(1, n_latent, 1)
+
+
+def style_mul(x, style):
+    return style.detach()[:, :, None, None] * x.detach()
+
+
+def weight_sqsum(weight, w_scale):
+    w = weight.detach().reshape(weight.shape[-4], weight.shape[-3], -1)
+    return ((w * w_scale) ** 2).sum(-1)
+
+
+def demod(wsq, style, eps=1e-8):
+    return torch.rsqrt((style.detach() ** 2) @ wsq.t() + eps)
+
+
+_UP_ORDER = [0, 2, 6, 8, 1, 7, 3, 5, 4]
+
+
+def pack_conv_weight(weight, mode):
+    w = weight.detach().reshape(weight.shape[-4], weight.shape[-3], 9)   # [o][i][tap]
+    wp = w.permute(2, 1, 0).contiguous()                                   # [tap][i][o]
+    if mode == 1:
+        wp = wp[_UP_ORDER].contiguous()
+    return wp
+
+
+def _unpack(wp, mode):
+    if mode == 1:
+        inv = [0] * 9
+        for slab, tap in enumerate(_UP_ORDER):
+            inv[tap] = slab
+        wp = wp[inv]
+    o, i = wp.shape[2], wp.shape[1]
+    return wp.permute(2, 1, 0).reshape(o, i, 3, 3)
+
+
+def conv3x3(x, wp, out_ch, w_scale, style=None, demod=None, noise=None, noise_w=None, bias=None,
+            act=False, impl=0):
+    x = x.detach()
+    if style is not None:
+        x = x * style.detach()[:, :, None, None]
+    y = F.conv2d(x, _unpack(wp, 0), padding=1) * w_scale
+    if demod is not None:
+        y = y * demod[:, :, None, None]
+    b, _, h, w = y.shape
+    if noise is not None:
+        y = y + noise_w.detach().reshape(1) * noise.reshape(b, 1, h, w)
+    if act:
+        y = F.leaky_relu(y + bias.detach().view(1, -1, 1, 1), 0.2) * SQRT2
+    return y
+
+
+def conv_transpose3x3s2(x, wp, out_ch, w_scale, style=None, demod=None, impl=0):
+    x = x.detach()
+    if style is not None:
+        x = x * style.detach()[:, :, None, None]
+    w = _unpack(wp, 1)                                   # [o][i][3][3]
+    y = F.conv_transpose2d(x, w.transpose(0, 1), stride=2) * w_scale
+    if demod is not None:
+        y = y * demod[:, :, None, None]
+    return y
+
+
+def noise_add(x, noise, noise_w):
+    b, c, h, w = x.shape
+    return x.detach() + noise_w.detach().reshape(1) * noise.reshape(b, 1, h, w)
+
+
+def blur_noise_act(x, k4, noise, noise_w, bias):
+    y = R.upfirdn2d(x.detach(), k4, pad=(1, 1))
+    b, c, h, w = y.shape
+    if noise is not None:
+        y = y + noise_w.detach().reshape(1) * noise.reshape(b, 1, h, w)
+    if bias is not None:
+        y = F.leaky_relu(y + bias.detach().view(1, -1, 1, 1), 0.2) * SQRT2
+    return y
+
+
+def to_rgb(x, weight, style, bias, skip, w_scale):
+    wm = (w_scale * weight.detach()[None] * style.detach()[:, None, :])      # (B,3,C)
+    y = torch.einsum('bci,bihw->bchw', wm, x.detach())
+    if bias is not None:
+        y = y + bias.detach().view(1, 3, 1, 1)
+    if skip is not None:
+        y = y + skip
+    return y
+
+
+def second_moment_accumulate(mom2, a, nchw=False):
+    a = a.detach()
+    if nchw:
+        a = a.permute(0, 2, 3, 1).reshape(-1, a.shape[1])
+    mom2 += a.t() @ a
+    return mom2
+
+
+def channel_sums(a, nchw=False, square_input=False):
+    a = a.detach()
+    if nchw:
+        a = a.permute(0, 2, 3, 1).reshape(-1, a.shape[1])
+    if square_input:
+        a = a * a
+    return torch.stack([a.sum(0), (a * a).sum(0)])
+
+
+def project_weight(w, context, base=None, out=None):
+    res = R.projected_conv(w.detach(), context.detach())
+    if base is not None:
+        res = res + base
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res
+
+
+def solve_ksplit(out_ch, in_ch, h, w):
+    return 2
+
+
+_solvers = {}
+
+
+def register_solver(solver):
+    import ctypes
+    _solvers[ctypes.addressof(solver.problem)] = solver
+
+
+def solve_step(problem, project):
+    """One iteration of the solve in torch, on the driver's own tensors."""
+    import ctypes
+    s = _solvers[ctypes.addressof(problem)]
+    it = int(s.counter.item()) + 1
+    s.counter.fill_(it)
+    W = s._w[0]
+    O, I = W.shape[:2]
+    sc = 1 / math.sqrt(I * 9)
+    h, wd = s.key.shape[1:]
+    xcol = F.unfold(s.key[None], (3, 3), padding=1)[0]
+    conv = (sc * W.reshape(O, -1)) @ xcol
+    sig2 = (s.style ** 2).view(1, I, 1, 1)
+    dm = torch.rsqrt(((sc * W) ** 2 * sig2).sum([1, 2, 3]) + 1e-8)
+    pre = conv * dm[:, None] + s.noise_w * s.noise[None, :] + s.bias[:, None]
+    out = SQRT2 * torch.where(pre > 0, pre, 0.2 * pre)
+    diff = out - s.val.reshape(O, -1)
+    s.losses[it] = diff.abs().mean()
+    g_out = torch.sign(diff) / diff.numel()
+    g_pre = torch.where(pre > 0, g_out, g_out * 0.2) * SQRT2
+    dW = sc * ((g_pre * dm[:, None]) @ xcol.t()).view(O, I, 3, 3)
+    dW = dW - (sc * sc) * W * sig2 * (dm ** 3 * (g_pre * conv).sum(1)).view(O, 1, 1, 1)
+    if s.low_rank_gradient:
+        dW = R.projected_conv(dW, s.context)
+    m, v = s.exp_avg[0], s.exp_avg_sq[0]
+    m += (dW - m) * (1 - 0.9)
+    v.mul_(0.999).add_((1 - 0.999) * dW * dW)
+    W += (-s.step_size[it] * m) / (v.sqrt() / s.bc2_sqrt[it] + 1e-8)
+    if project:
+        W.copy_(s.ortho[0] + R.projected_conv(W, s.context))
+
+
+def install(monkeypatch):
+    """Replaces the kernel wrappers of rewriting_amd.hip and makes host code take the
+    'tensors live on the device' branches."""
+    from rewriting_amd import hip
+    from rewriting_amd.rewrite import hipsolve
+    names = ['fused_bias_act', 'bias_grad', 'upfirdn2d_major', 'pixel_norm', 'equal_linear',
+             'adjust_latent', 'style_mul', 'weight_sqsum', 'demod', 'pack_conv_weight', 'conv3x3',
+             'conv_transpose3x3s2', 'noise_add', 'blur_noise_act', 'to_rgb',
+             'second_moment_accumulate', 'channel_sums', 'project_weight', 'solve_ksplit',
+             'solve_step']
+    for n in names:
+        monkeypatch.setattr(hip, n, globals()[n])
+    monkeypatch.setattr(hip, 'on_device', lambda t: True)
+    orig_init = hipsolve.Solver.__init__
+
+    def init(self, *a, **k):
+        orig_init(self, *a, **k)
+        register_solver(self)
+    monkeypatch.setattr(hipsolve.Solver, '__init__', init)
+    monkeypatch.setenv('RW_SOLVE_GRAPH', '0')

@@ -1,0 +1,183 @@
+"""Pins the travelling oracle (oracle/restatement.py, oracle/native_ops.c) against fixtures
+produced by the reference's own files (oracle/make_golden.py), and -- when /root/reference is
+present -- against the reference executed live."""
+import json
+import math
+
+import numpy
+import pytest
+import torch
+
+from oracle import native, reference_shim, restatement as R
+from tests.conftest import (build_stylegan, golden_meta, load_golden, load_mask_request,
+                            oracle_state_dict, subsample)
+
+STAGE_ALIASES = [('.sconv.mconv.', '.sconv.'), ('.conv.mconv.', '.conv.')]
+
+
+def test_native_ops_c_and_torch_restatements_match_reference_spec():
+    g = load_golden('ops')
+    ncase = len([k for k in g.files if k.startswith('upfirdn/') and k.endswith('/x')])
+    assert ncase >= 7
+    for ci in range(ncase):
+        x, k, y = (torch.from_numpy(g['upfirdn/%d/%s' % (ci, n)]) for n in 'xky')
+        up, down, p0, p1 = [int(v) for v in g['upfirdn/%d/cfg' % ci]]
+        got = R.upfirdn2d(x, k, up=up, down=down, pad=(p0, p1))
+        assert got.shape == y.shape
+        assert (got - y).abs().max() < 1e-5
+        b, c, h, w = x.shape
+        gotc = native.upfirdn2d(x.reshape(-1, h, w, 1).numpy(), k.numpy(), up, up, down, down, p0, p1, p0, p1)
+        assert numpy.abs(gotc.reshape(y.shape) - y.numpy()).max() < 1e-5
+    x, b, y = (torch.from_numpy(g['lrelu/' + n]) for n in ('x', 'b', 'y'))
+    assert torch.equal(R.fused_leaky_relu(x, b), y)
+    assert numpy.array_equal(native.fused_bias_act(x.numpy(), b.numpy(), None, 3, 0, 0.2, 2 ** 0.5), y.numpy())
+    go = torch.from_numpy(g['lrelu/go'])
+    gx, gb = R.fused_leaky_relu_backward(go, y)
+    # the golden went through torch autograd ((g*scale)*slope); the kernel order is (g*slope)*scale
+    assert (gx - torch.from_numpy(g['lrelu/gx'])).abs().max() < 1e-6
+    assert (gb - torch.from_numpy(g['lrelu/gb'])).abs().max() < 1e-5
+    assert numpy.abs(native.fused_bias_act(go.numpy(), None, y.numpy(), 3, 1, 0.2, 2 ** 0.5)
+                     - g['lrelu/gx']).max() < 1e-6
+    assert numpy.array_equal(native.fused_bias_act(go.numpy(), None, y.numpy(), 3, 1, 0.2, 2 ** 0.5), gx.numpy())
+    x2, b2 = torch.from_numpy(g['lrelu2/x']), torch.from_numpy(g['lrelu2/b'])
+    assert torch.equal(R.fused_leaky_relu(x2, b2), torch.from_numpy(g['lrelu2/y']))
+
+
+def test_upfirdn2d_adjoint_identity():
+    """<A x, y> == <x, A^T y> for the adjoint algebra of op/upfirdn2d.py:100-115."""
+    rs = numpy.random.RandomState(3)
+    for up, down, pad, shape in [(1, 1, (1, 1), (1, 2, 9, 9)), (2, 1, (2, 1), (1, 2, 6, 6)),
+                                 (1, 2, (2, 1), (1, 1, 12, 12))]:
+        k = R.make_kernel([1, 3, 3, 1]) * up * up
+        k[0, 2] += 0.05
+        x = torch.from_numpy(rs.randn(*shape).astype('float32'))
+        y = R.upfirdn2d(x, k, up=up, down=down, pad=pad)
+        gy = torch.from_numpy(rs.randn(*y.shape).astype('float32'))
+        gx = R.upfirdn2d_backward(gy, k, up, down, pad, x.shape)
+        assert abs((y * gy).sum().item() - (x * gx).sum().item()) < 1e-3
+
+
+@pytest.mark.parametrize('name', ['gen_s32_t05', 'gen_s64_cm1'])
+def test_generator_restatement_matches_reference_golden(name):
+    g = load_golden(name)
+    meta = golden_meta(g)
+    model = build_stylegan(meta['size'], meta['truncation'], meta['channel_multiplier'])
+    sd = oracle_state_dict(model)
+    col = {}
+    img = R.generator_forward(sd, torch.from_numpy(g['z']), meta['size'],
+                              truncation=meta['truncation'], collect=col)
+    assert (img - torch.from_numpy(g['image'])).abs().max() < 2e-5
+    checked = 0
+    for key in g.files:
+        if not key.startswith('stage/') or not key.endswith('/sub'):
+            continue
+        lname = key[len('stage/'):-len('/sub')]
+        short = lname
+        for a, b in STAGE_ALIASES:
+            short = short.replace(a, b)
+        if short.endswith('.modulation') and not short.startswith('to_rgb'):
+            short = short[:-len('modulation')] + 'style'
+        if short == 'style.8':
+            short = 'style'
+        if short not in col:
+            continue
+        want = torch.from_numpy(g[key])
+        got = subsample(col[short])
+        assert got.shape == want.shape, lname
+        assert (got - want).abs().max() < 3e-5 * max(1.0, want.abs().max().item()), lname
+        checked += 1
+    assert checked >= 40, checked
+
+
+def _rewriter_pieces(g, meta):
+    model = build_stylegan(meta['size'], meta['truncation'])
+    sd = oracle_state_dict(model)
+    zs = torch.from_numpy(numpy.random.RandomState(1).standard_normal(meta['nseeds'] * 512)
+                          .reshape(meta['nseeds'], 512)).float()
+    return sd, zs
+
+
+def test_rewriter_restatement_matches_reference_golden_horsehat():
+    g = load_golden('rw_s64_l8_horsehat')
+    meta = golden_meta(g)
+    sd, zs = _rewriter_pieces(g, meta)
+    size, layer, trunc = meta['size'], meta['layernum'], meta['truncation']
+    req = load_mask_request(meta['mask'], meta['nseeds'])
+    # key statistics: batches of 10 in order (quirk Q1: noise row = position in the batch)
+    keys = (R.context_forward(sd, zs[i:i + 10], size, layer, trunc)[0] for i in range(0, len(zs), 10))
+    C, mom2, count = R.second_moment(keys)
+    assert count == meta['nseeds'] * 32 * 32
+    assert abs(C.double().norm().item() / float(g['c_matrix_norm']) - 1) < 1e-5
+    assert (C[::4, ::4] - torch.from_numpy(g['c_matrix'])).abs().max() < 1e-4 * C.abs().max()
+    Z = R.zca_from_cov(C)
+    assert abs(Z.double().norm().item() / float(g['zca_norm']) - 1) < 1e-3
+    # context direction from the golden-consistent Z
+    obs, wts = [], []
+    for imgnum, mask in req['key']:
+        k, _, _ = R.context_forward(sd, zs[imgnum][None], size, layer, trunc)
+        obs.append(k.permute(0, 2, 3, 1).reshape(-1, k.shape[1]))
+        wts.append(R.mask_from_url(mask, (32, 32)).reshape(-1)[:, None])
+    mkey, zk = R.multi_key_zca(obs, wts, Z, 1)
+    want = torch.from_numpy(g['mkey'])
+    assert zk.shape[0] == int(g['n_sel'])
+    assert (mkey - want).abs().max() < 2e-3, (mkey - want).abs().max()
+    # goal
+    o_img, o_mask = req['object']
+    p_img, p_mask = req['paste']
+    ko, so, _ = R.context_forward(sd, zs[o_img][None], size, layer, trunc)
+    vo = R.target_forward(sd, layer, ko, so)
+    area = R.mask_from_url(o_mask, (32, 32))
+    t, l, b, r = R.positive_bounding_box(area)
+    assert [t, l, b, r] == list(g['obj_bounds'])
+    kp, sp, _ = R.context_forward(sd, zs[p_img][None], size, layer, trunc)
+    vp = R.target_forward(sd, layer, kp, sp)
+    parea = R.mask_from_url(p_mask, (32, 32))
+    tgt, bounds = R.paste_clip_at_center(vp, vo[:, :, t:b, l:r], R.centered_location(parea), area[t:b, l:r])
+    assert list(bounds) == list(g['paste_bounds'])
+    ck, cv, _, _ = R.crop_clip_to_bounds(kp, tgt, bounds)
+    assert (ck - torch.from_numpy(g['goal_in_fmap'])).abs().max() < 1e-4
+    assert (cv - torch.from_numpy(g['goal_out_fmap'])).abs().max() < 1e-4
+    # the solve, explicit arithmetic vs the reference's autograd + torch.optim.Adam
+    W0 = sd['layer%d.sconv.mconv.dconv.weight' % layer]
+    _, losses, snaps = R.insert_explicit(
+        W0, torch.from_numpy(g['goal_in_fmap']), torch.from_numpy(g['goal_in_style']),
+        torch.from_numpy(g['goal_out_fmap']), sd['layer%d.sconv.activate.bias' % layer],
+        sd['layer%d.sconv.noise.weight' % layer], want, niter=101, snapshots=(1, 10, 11, 100, 101))
+    for n in (1, 10, 11, 100, 101):
+        dW = (snaps[n] - W0)[0]
+        ref_norm = float(g['dW_%d_norm' % n])
+        cos = torch.einsum('oiyx,di->odyx', dW, want)
+        rel = (cos - torch.from_numpy(g['dW_%d_cos' % n])).norm() / ref_norm
+        assert abs(dW.double().norm().item() / ref_norm - 1) < 1e-4, n
+        assert rel < 1e-4, (n, rel.item())
+        assert (subsample(dW, 8192) - torch.from_numpy(g['dW_%d_sub' % n])).norm() / \
+            torch.from_numpy(g['dW_%d_sub' % n]).norm() < 2e-4, n
+    assert numpy.abs(numpy.array(losses) - g['losses']).max() < 1e-5
+
+
+def test_proggan_restatement_matches_reference_golden():
+    from rewriting_amd.utils import proggan
+    from rewriting_amd import synthetic
+    g = load_golden('pg64_l6_spire2tree')
+    meta = golden_meta(g)
+    model = proggan.ProgressiveGenerator(resolution=meta['resolution'])
+    synthetic.randomize_(model, seed=0, kind='proggan')
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    z = torch.from_numpy(g['z0'])[None]
+    img = R.proggan_forward(sd, z)
+    assert (img - torch.from_numpy(g['image'])).abs().max() < 1e-4
+
+
+@pytest.mark.skipif(not reference_shim.available(), reason='/root/reference not present')
+def test_restatement_against_live_reference():
+    ref = reference_shim.load()
+    from rewriting_amd import synthetic
+    g = ref.models.SeqStyleGAN2(16, 512, 8, truncation=0.7, mconv='seq')
+    synthetic.randomize_(g, seed=3)
+    g.eval()
+    z = ref.zdataset.standard_z_sample(2, 512, seed=5)
+    with torch.no_grad():
+        want = g(z)
+    sd = {k: v.detach().clone() for k, v in g.state_dict().items()}
+    got = R.generator_forward(sd, z, 16, truncation=0.7)
+    assert (got - want).abs().max() < 1e-5
