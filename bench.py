@@ -1,0 +1,280 @@
+"""Benchmark of the rule-editing hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--batch B]
+
+Default workload = BASELINE.json's metric: images/sec of the StyleGANv2-1024 sequential
+generator forward (SeqStyleGAN2 size 1024, mconv='seq', truncation 0.5, synthetic seeded
+weights, z = standard_z_sample seed 1), one "step" = one forward pass over a batch of B seeds per
+GPU with inputs resident in HBM.  For N>1 launch with torch.distributed.run (one rank per GPU,
+RCCL): seeds are partitioned rank-wise (no data-path collective, weak scaling); the timed region
+is bracketed by barrier + synchronize and the MAX over ranks is reported.
+
+Rank 0 prints ONE JSON line with `roofline` (the conv_mfma_kernel family: algorithmic conv
+FLOPs of its launches / their HIP-event time, against the 157.3 TFLOP/s fp32-MFMA peak) and
+`cpu_baseline` (the oracle restatement timed on the host cores on a bounded sample; N=1 only).
+
+Other workloads (parity-test configurations of BASELINE.json, not the headline line):
+  ffhq256   StyleGANv2-256 forward, batch 64         (configs[1])
+  edit      horse->hat rank-1 edit at layer 8 of the 256 model: 1000-seed key statistics +
+            2001-step solve, seconds per edit       (configs[2])
+  sweep     key-statistics sweep only (seeds/s), sharded over ranks with one all-reduce (configs[3])
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+HBM_PEAK_GBS = 8000.0
+
+
+def conv_flops(model_size, channel_multiplier=2):
+    """2*MACs of every 3x3 styled conv per image."""
+    ch = {4: 512, 8: 512, 16: 512, 32: 512, 64: 256 * channel_multiplier, 128: 128 * channel_multiplier,
+          256: 64 * channel_multiplier, 512: 32 * channel_multiplier, 1024: 16 * channel_multiplier}
+    total = 2 * 9 * 512 * 512 * 16                           # layer2 at 4x4
+    cin, res = 512, 4
+    while res < model_size:
+        cout = ch[res * 2]
+        total += 2 * 9 * cin * cout * res * res              # stride-2 transposed conv (input res)
+        res *= 2
+        total += 2 * 9 * cout * cout * res * res             # stride-1 conv
+        cin = cout
+    return total
+
+
+class ConvTimer:
+    """HIP events around every implicit-GEMM conv launch, on the stream they are launched on
+    (torch's current stream).  Installed for the timed region only."""
+
+    def __init__(self):
+        self.events = []
+        self.flops = 0.0
+        self.launches = 0
+
+    def install(self):
+        from rewriting_amd import hip
+        self._orig = (hip.conv3x3, hip.conv_transpose3x3s2)
+        timer = self
+
+        def wrap(fn, kernels_per_call):
+            def inner(x, wp, out_ch, w_scale, *a, **k):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                y = fn(x, wp, out_ch, w_scale, *a, **k)
+                e.record()
+                b, i, h, w = x.shape
+                timer.events.append((s, e))
+                timer.flops += 2.0 * 9 * i * out_ch * h * w * b
+                timer.launches += kernels_per_call
+                return y
+            return inner
+        hip.conv3x3 = wrap(self._orig[0], 1)
+        hip.conv_transpose3x3s2 = wrap(self._orig[1], 4)
+
+    def remove(self):
+        from rewriting_amd import hip
+        hip.conv3x3, hip.conv_transpose3x3s2 = self._orig
+
+    def result(self):
+        ms = sum(s.elapsed_time(e) for s, e in self.events)
+        achieved = self.flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        return dict(bound='mfma', achieved=round(achieved, 2), peak=FP32_MFMA_PEAK_TFLOPS,
+                    unit='TFLOP/s', frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
+                    kernel='conv_mfma_kernel', launches=self.launches,
+                    avg_launch_us=round(ms * 1e3 / max(self.launches, 1), 2),
+                    flops_per_launch=round(self.flops / max(self.launches, 1)))
+
+
+def build_generator(size, device):
+    from rewriting_amd import synthetic
+    from rewriting_amd.utils.stylegan2 import models
+    g = models.SeqStyleGAN2(size, 512, 8, truncation=0.5, mconv='seq')
+    synthetic.randomize_(g, seed=0)
+    return g.eval().to(device)
+
+
+def cpu_baseline_forward(size, seconds=12.0, max_images=16):
+    """The oracle (a port: oracle/restatement.py on torch-CPU kernels) on the host cores."""
+    from rewriting_amd import synthetic
+    from rewriting_amd.utils import zdataset
+    from rewriting_amd.utils.stylegan2 import models
+    from oracle import restatement as R
+    g = models.SeqStyleGAN2(size, 512, 8, truncation=0.5, mconv='seq')
+    synthetic.randomize_(g, seed=0)
+    sd = {k: v.detach() for k, v in g.state_dict().items()}
+    z = zdataset.standard_z_sample(max_images, 512, seed=1)
+    with torch.no_grad():
+        R.generator_forward(sd, z[:1], size, truncation=0.5)        # warm-up
+        t0 = time.perf_counter()
+        n = 0
+        while n < max_images and time.perf_counter() - t0 < seconds:
+            R.generator_forward(sd, z[n:n + 1], size, truncation=0.5)
+            n += 1
+        dt = time.perf_counter() - t0
+    return dict(value=round(n / dt, 4), unit='images/sec', cores=torch.get_num_threads(), kind='port',
+                sample='%d images of the stylegan2-%d forward at batch 1 through oracle/restatement.py '
+                       '(torch CPU kernels), %.1f s' % (n, size, dt))
+
+
+def timed(fn, steps, warmup, world):
+    import torch.distributed as dist
+    for _ in range(warmup):
+        fn()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    return dt
+
+
+def run_forward(args, rank, world, device, size, batch, name):
+    from rewriting_amd.utils import zdataset
+    g = build_generator(size, device)
+    # seed i -> rank i mod world; every rank holds its own `batch` seeds, resident in HBM
+    zall = zdataset.standard_z_sample(batch * world, 512, seed=1)
+    z = zall[rank::world].contiguous().to(device)
+
+    def step():
+        with torch.no_grad():
+            g(z)
+    timed(step, 1, args.warmup, world)                      # warm-up incl. weight repack caches
+    timer = ConvTimer()
+    timer.install()
+    dt = timed(step, args.steps, 0, world)
+    timer.remove()
+    images = batch * world * args.steps
+    out = dict(metric='images/sec StyleGANv2-%d fwd' % size, value=round(images / dt, 2), unit='images/sec',
+               n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3),
+               higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+               config=dict(workload=name, batch_per_gpu=batch, truncation=0.5, mconv='seq',
+                           weights='synthetic seed 0', parallelism='seeds partitioned per rank, no collective',
+                           conv_gflop_per_image=round(conv_flops(size) / 1e9, 2)))
+    out['roofline'] = timer.result()
+    out['roofline']['hbm_algorithmic_gbs'] = round(
+        {256: 276.3e6, 1024: 1217.7e6}.get(size, 0) * batch * world * args.steps / dt / 1e9, 1)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline_forward(size)
+    return out
+
+
+def run_edit(args, rank, world, device):
+    from rewriting_amd.rewrite import ganrewrite
+    from rewriting_amd.utils import zdataset
+    g = build_generator(256, device)
+    zds = zdataset.z_dataset_for_model(g, size=1000)
+    with open(os.path.join(ROOT, 'tests', 'golden', 'masks', 'recorded_horse_hat.json')) as f:
+        req = json.load(f)
+    times = dict(stats=[], solve=[], total=[])
+
+    def step():
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        gw = ganrewrite.SeqStyleGanRewriter(g, zds, 8)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        gw.apply_edit(req, rank=1, niter=2001, piter=10, lr=0.05)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        times['stats'].append(t1 - t0)
+        times['solve'].append(t2 - t1)
+        times['total'].append(t2 - t0)
+    dt = timed(step, args.steps, args.warmup, world)
+    n = args.steps
+    med = lambda v: sorted(v[-n:])[n // 2]
+    solve_bytes = 7 * 512 * 512 * 9 * 4 * 2001
+    return dict(metric='wall-clock per rank-1 edit (1000-seed key collect + 2001-step solve)',
+                value=round(dt / n, 4), unit='s', n_gpus=world, steps=n, warmup=args.warmup,
+                ms_per_step=round(dt / n * 1e3, 2), higher_is_better=False, scaling='weak',
+                vs_baseline=None, dtype='f32', data='synthetic',
+                config=dict(workload='stylegan2-256 layer 8 horse->hat edit (recorded_horse_hat.json)',
+                            key_collect_s=round(med(times['stats']), 4), edit_s=round(med(times['solve']), 4),
+                            replicas=world),
+                roofline=dict(bound='hbm', achieved=round(solve_bytes / med(times['solve']) / 1e9, 1),
+                              peak=HBM_PEAK_GBS, unit='GB/s',
+                              frac=round(solve_bytes / med(times['solve']) / 1e9 / HBM_PEAK_GBS, 4), traffic=None,
+                              note='solve: 7 x |W| x 4 B per step algorithmic (SURVEY.md 8d); latency-bound'))
+
+
+def run_sweep(args, rank, world, device):
+    from rewriting_amd import parallel
+    from rewriting_amd.utils import tally, zdataset, nethook
+    g = build_generator(args.size, device)
+    layer = args.layer
+    ctx = nethook.subsequence(g, upto_layer='layer%d.sconv.mconv.dconv' % layer, share_weights=True)
+    nseeds = args.seeds
+    zds = zdataset.z_dataset_for_model(g, size=nseeds)
+
+    def step():
+        with torch.no_grad():
+            r = tally.tally_second_moment(lambda zb: ctx(zb.to(device)).fmap, zds, shard=parallel.shard(),
+                                          nchw=True)
+        return r
+    dt = timed(step, args.steps, args.warmup, world)
+    return dict(metric='key-statistics sweep seeds/sec (layer %d of stylegan2-%d)' % (layer, args.size),
+                value=round(nseeds * args.steps / dt, 1), unit='seeds/sec', n_gpus=world, steps=args.steps,
+                warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 2), higher_is_better=True,
+                scaling='strong', vs_baseline=None, dtype='f32', data='synthetic',
+                config=dict(workload='%d-seed second-moment sweep, batches of 10 dealt round-robin, '
+                                     'one all-reduce' % nseeds))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--workload', default='ffhq1024', choices=['ffhq1024', 'ffhq256', 'edit', 'sweep'])
+    ap.add_argument('--batch', type=int, default=None)
+    ap.add_argument('--size', type=int, default=1024)
+    ap.add_argument('--layer', type=int, default=8)
+    ap.add_argument('--seeds', type=int, default=1000)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    from rewriting_amd import parallel
+    rank, world, local = parallel.init_from_env()
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d '
+                         '--master-addr 127.0.0.1 bench.py --gpus %d ...' % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (the HIP kernels have no CPU path)')
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+    if args.workload == 'ffhq1024':
+        out = run_forward(args, rank, world, device, 1024, args.batch or 8,
+                          'stylegan2-1024 generator forward (FFHQ-1024 architecture)')
+    elif args.workload == 'ffhq256':
+        out = run_forward(args, rank, world, device, 256, args.batch or 64,
+                          'stylegan2-256 generator forward, 64-seed batch (FFHQ-256 architecture)')
+    elif args.workload == 'edit':
+        out = run_edit(args, rank, world, device)
+    else:
+        out = run_sweep(args, rank, world, device)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,54 @@
+"""world_size-2 gloo test of the sharded key-statistics sweep: batches dealt round-robin, one
+all-reduce of (mom2, count); every rank must end with the single-process statistic."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from rewriting_amd import parallel
+    from rewriting_amd.utils import tally
+    r, w, _ = parallel.init_from_env(backend='gloo')
+    assert (r, w) == (rank, world) and parallel.shard() == (rank, world)
+    torch.manual_seed(0)
+    data = torch.randn(57, 6)
+    seen = []
+
+    def compute(batch):
+        seen.append(int(batch.shape[0]))
+        return batch * 2.0
+    stat = tally.tally_second_moment(compute, data, shard=parallel.shard())
+    torch.save(dict(mom2=stat.mom2, count=stat.count, seen=seen), os.path.join(out, 'r%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_second_moment_matches_single_process(tmp_path):
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    torch.manual_seed(0)
+    data = torch.randn(57, 6) * 2.0
+    want = data.t() @ data
+    got = [torch.load(str(tmp_path / ('r%d.pt' % r))) for r in range(2)]
+    assert got[0]['seen'] == [10, 10, 10] and got[1]['seen'] == [10, 10, 7]     # batches 0,2,4 | 1,3,5
+    for g in got:
+        assert g['count'] == 57
+        assert torch.allclose(g['mom2'], want, rtol=1e-5, atol=1e-4)
+    assert torch.equal(got[0]['mom2'], got[1]['mom2'])
+
+
+def test_batches_for_rank_partition():
+    from rewriting_amd import parallel
+    all_b = sorted(sum((parallel.batches_for_rank(13, r, 4) for r in range(4)), []))
+    assert all_b == list(range(13))

@@ -1,0 +1,238 @@
+"""GPU parity tests proper: every kernel, called through the C ABI, against the oracle
+(oracle/restatement.py, oracle/native_ops.c) and the reference-generated golden fixtures.
+Tolerances: fp32 throughout; streaming ops are compared at 1e-6 (bit-level where the
+arithmetic order is identical), contractions at 1e-5 relative (reduction order differs from
+MKL-DNN), as written at each assert."""
+import math
+import os
+
+import numpy
+import pytest
+import torch
+
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def cuda(a):
+    return torch.as_tensor(a).to(DEV)
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def test_library_loaded_is_the_in_tree_so():
+    from rewriting_amd import _lib
+    assert _lib.load().rw_abi_version() == _lib.ABI_VERSION
+    maps = open('/proc/self/maps').read()
+    assert 'librewriting_hip.so' in maps
+
+
+def test_fused_bias_act_and_upfirdn2d_match_golden_and_c_oracle():
+    from rewriting_amd import hip
+    from rewriting_amd.utils.stylegan2 import op
+    from oracle import native
+    g = load_golden('ops')
+    ncase = len([k for k in g.files if k.startswith('upfirdn/') and k.endswith('/x')])
+    for ci in range(ncase):
+        x, k, y = (cuda(g['upfirdn/%d/%s' % (ci, n)]) for n in 'xky')
+        up, down, p0, p1 = [int(v) for v in g['upfirdn/%d/cfg' % ci]]
+        got = op.upfirdn2d(x, k, up=up, down=down, pad=(p0, p1))
+        assert got.shape == y.shape, ci
+        assert (got - y).abs().max().item() < 1e-5, ci
+    x, b, y = (cuda(g['lrelu/' + n]) for n in ('x', 'b', 'y'))
+    xx, bb = x.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    out = op.fused_leaky_relu(xx, bb)
+    assert torch.equal(out.detach(), y)                      # identical arithmetic order: bit-exact
+    out.backward(cuda(g['lrelu/go']))
+    assert (xx.grad - cuda(g['lrelu/gx'])).abs().max().item() < 1e-6
+    assert (bb.grad - cuda(g['lrelu/gb'])).abs().max().item() < 1e-5
+    want = native.fused_bias_act(g['lrelu/go'], None, g['lrelu/y'], 3, 1, 0.2, 2 ** 0.5)
+    assert numpy.array_equal(xx.grad.cpu().numpy(), want)     # bit-exact vs the C statement of the .cu
+    assert torch.equal(op.fused_leaky_relu(cuda(g['lrelu2/x']), cuda(g['lrelu2/b'])), cuda(g['lrelu2/y']))
+    # unaligned / odd sizes take the scalar path
+    rs = numpy.random.RandomState(0)
+    for shape in [(1, 3, 5, 7), (2, 5, 1, 1), (3, 7), (1, 4, 16, 16)]:
+        xs = rs.randn(*shape).astype('float32')
+        bs = rs.randn(shape[1]).astype('float32')
+        got = hip.fused_bias_act(cuda(xs), cuda(bs), None, 3, 0, 0.2, 2 ** 0.5).cpu().numpy()
+        assert numpy.array_equal(got, native.fused_bias_act(xs, bs, None, 3, 0, 0.2, 2 ** 0.5)), shape
+    assert hip.fused_bias_act(torch.empty(0, 3, device=DEV), cuda(bs[:3]), None, 3, 0, 0.2, 1.0).numel() == 0
+
+
+def test_upfirdn2d_random_configs_against_c_oracle_and_autograd():
+    from rewriting_amd import hip
+    from rewriting_amd.utils.stylegan2 import op
+    from oracle import native, restatement as R
+    rs = numpy.random.RandomState(11)
+    for trial in range(12):
+        up, down = int(rs.randint(1, 3)), int(rs.randint(1, 3))
+        kh, kw = int(rs.randint(1, 5)), int(rs.randint(1, 5))
+        pads = [int(v) for v in rs.randint(-1, 4, size=4)]
+        major, h, w, minor = int(rs.randint(1, 4)), int(rs.randint(3, 12)), int(rs.randint(3, 12)), int(rs.randint(1, 3))
+        x = rs.randn(major, h, w, minor).astype('float32')
+        k = rs.randn(kh, kw).astype('float32')
+        want = native.upfirdn2d(x, k, up, up, down, down, *pads)
+        if want.size == 0:
+            continue
+        got = hip.upfirdn2d_major(cuda(x), cuda(k), up, up, down, down, *pads).cpu().numpy()
+        assert got.shape == want.shape
+        assert numpy.abs(got - want).max() < 1e-5, (trial, up, down, kh, kw, pads)
+    k = R.make_kernel([1, 3, 3, 1]) * 4
+    x = torch.randn(2, 3, 8, 8, device=DEV, requires_grad=True)
+    y = op.upfirdn2d(x, k.to(DEV), up=2, pad=(2, 1))
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    want = R.upfirdn2d_backward(gy.cpu(), k, 2, 1, (2, 1), x.shape)
+    assert (x.grad.cpu() - want).abs().max().item() < 1e-5
+
+
+def test_mapping_network_pieces():
+    from rewriting_amd import hip
+    from oracle import restatement as R
+    torch.manual_seed(0)
+    z = torch.randn(5, 512)
+    assert (hip.pixel_norm(z.to(DEV)).cpu() - z * torch.rsqrt((z ** 2).mean(1, keepdim=True) + 1e-8)).abs().max() < 1e-6
+    w, b = torch.randn(512, 512) * 100, torch.randn(512) * 10
+    got = hip.equal_linear(z.to(DEV), w.to(DEV), b.to(DEV), 0.01 / math.sqrt(512), 0.01, act=True).cpu()
+    want = R.equal_linear(z, w, b, lr_mul=0.01, activation=True)
+    assert rel(got, want) < 1e-6
+    lat = torch.randn(3, 14, 512)
+    got = hip.equal_linear(lat.to(DEV)[:, 5], w.to(DEV), b.to(DEV), 1 / math.sqrt(512), 1.0).cpu()   # strided rows
+    assert rel(got, R.equal_linear(lat[:, 5], w, b)) < 1e-6
+    avg = torch.randn(512)
+    got = hip.adjust_latent(z.to(DEV), avg.to(DEV), 6, 0.5).cpu()
+    assert torch.allclose(got, (avg + 0.5 * (z - avg)).unsqueeze(1).repeat(1, 6, 1), atol=1e-6)
+    assert torch.equal(hip.adjust_latent(z.to(DEV), None, 2, 1.0).cpu(), z.unsqueeze(1).repeat(1, 2, 1))
+
+
+CONV_CASES = [  # (batch, cin, cout, h, w)
+    (2, 512, 512, 4, 4), (3, 512, 512, 8, 8), (1, 512, 512, 32, 32), (2, 512, 256, 16, 16),
+    (1, 256, 128, 8, 12), (2, 128, 64, 16, 16), (1, 64, 32, 32, 32), (1, 32, 32, 20, 36),
+    (5, 16, 32, 3, 5), (1, 48, 96, 7, 9),
+]
+
+
+def _conv_inputs(b, i, o, h, w, seed=0):
+    rs = numpy.random.RandomState(seed)
+    x = torch.from_numpy(rs.randn(b, i, h, w).astype('float32'))
+    wt = torch.from_numpy(rs.randn(1, o, i, 3, 3).astype('float32'))
+    style = torch.from_numpy((1 + 0.5 * rs.randn(b, i)).astype('float32'))
+    return x, wt, style
+
+
+@pytest.mark.parametrize('impl', [0, 1])
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_demodulated_conv_matches_oracle(case, impl):
+    """conv2d(x, s*W, pad 1) * demod vs the oracle (DemodulatedConv2dF, models.py:313-329);
+    asymmetric random weights, so transposed fragments or swapped taps cannot pass."""
+    from rewriting_amd import hip
+    from oracle import restatement as R
+    b, i, o, h, w = case
+    x, wt, style = _conv_inputs(*case)
+    s = 1 / math.sqrt(i * 9)
+    key = style[:, :, None, None] * x
+    want = R.demod_conv(key, style, wt, upsample=False)
+    wp = hip.pack_conv_weight(wt.to(DEV), 0)
+    dm = hip.demod(hip.weight_sqsum(wt.to(DEV), s), style.to(DEV))
+    want_dm = torch.rsqrt(((s * wt * style.view(b, 1, i, 1, 1)) ** 2).sum([2, 3, 4]) + 1e-8)
+    assert rel(dm, want_dm) < 1e-6
+    got = hip.conv3x3(hip.style_mul(x.to(DEV), style.to(DEV)), wp, o, s, demod=dm, impl=impl)
+    assert rel(got, want) < 1e-5, rel(got, want)
+    assert (got.cpu() - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())
+    fused = hip.conv3x3(x.to(DEV), wp, o, s, style=style.to(DEV), demod=dm, impl=impl)   # style on load
+    assert rel(fused, want) < 1e-5
+
+
+@pytest.mark.parametrize('impl', [0, 1])
+@pytest.mark.parametrize('case', CONV_CASES[:8])
+def test_transposed_conv_matches_oracle(case, impl):
+    from rewriting_amd import hip
+    from oracle import restatement as R
+    b, i, o, h, w = case
+    x, wt, style = _conv_inputs(*case, seed=1)
+    s = 1 / math.sqrt(i * 9)
+    want = R.demod_conv(style[:, :, None, None] * x, style, wt, upsample=True)
+    wp = hip.pack_conv_weight(wt.to(DEV), 1)
+    dm = hip.demod(hip.weight_sqsum(wt.to(DEV), s), style.to(DEV))
+    got = hip.conv_transpose3x3s2(x.to(DEV), wp, o, s, style=style.to(DEV), demod=dm, impl=impl)
+    assert got.shape == want.shape
+    assert rel(got, want) < 1e-5, rel(got, want)
+
+
+def test_fused_epilogues_and_streaming_blocks():
+    from rewriting_amd import hip
+    from oracle import restatement as R
+    b, i, o, h, w = 2, 128, 64, 16, 16
+    x, wt, style = _conv_inputs(b, i, o, h, w, seed=2)
+    s = 1 / math.sqrt(i * 9)
+    rs = numpy.random.RandomState(5)
+    bias = torch.from_numpy(rs.randn(o).astype('float32'))
+    nw = torch.tensor([0.37])
+    noise = R.noise_rows(b, h * w)
+    conv = R.demod_conv(style[:, :, None, None] * x, style, wt, upsample=False)
+    want = R.fused_leaky_relu(conv + nw * noise.view(b, 1, h, w), bias)
+    wp = hip.pack_conv_weight(wt.to(DEV), 0)
+    dm = hip.demod(hip.weight_sqsum(wt.to(DEV), s), style.to(DEV))
+    got = hip.conv3x3(x.to(DEV), wp, o, s, style=style.to(DEV), demod=dm, noise=noise.to(DEV),
+                      noise_w=nw.to(DEV), bias=bias.to(DEV), act=True)
+    assert rel(got, want) < 1e-5
+    # noise add alone, blur+noise+act, ToRGB
+    assert rel(hip.noise_add(conv.to(DEV), noise.to(DEV), nw.to(DEV)), conv + nw * noise.view(b, 1, h, w)) < 1e-7
+    k4 = R.make_kernel([1, 3, 3, 1]) * 4
+    wide = torch.from_numpy(rs.randn(b, o, 2 * h + 1, 2 * w + 1).astype('float32'))
+    n2 = R.noise_rows(b, 4 * h * w)
+    want = R.fused_leaky_relu(R.upfirdn2d(wide, k4, pad=(1, 1)) + nw * n2.view(b, 1, 2 * h, 2 * w), bias)
+    got = hip.blur_noise_act(wide.to(DEV), k4.to(DEV), n2.to(DEV), nw.to(DEV), bias.to(DEV))
+    assert rel(got, want) < 1e-6
+    wrgb = torch.from_numpy(rs.randn(3, i).astype('float32'))
+    brgb = torch.from_numpy(rs.randn(3).astype('float32'))
+    skip = torch.from_numpy(rs.randn(b, 3, h, w).astype('float32'))
+    wm = (1 / math.sqrt(i)) * wrgb[None] * style[:, None, :]
+    want = torch.einsum('bci,bihw->bchw', wm, x) + brgb.view(1, 3, 1, 1) + skip
+    got = hip.to_rgb(x.to(DEV), wrgb.to(DEV), style.to(DEV), brgb.to(DEV), skip.to(DEV), 1 / math.sqrt(i))
+    assert rel(got, want) < 1e-6
+
+
+@pytest.mark.parametrize('channels,batch,h,w', [(512, 10, 32, 32), (512, 3, 4, 4), (128, 2, 64, 64),
+                                                (64, 4, 16, 16), (32, 2, 32, 32), (96, 2, 8, 8)])
+def test_second_moment_and_channel_sums(channels, batch, h, w):
+    from rewriting_amd import hip
+    from rewriting_amd.utils import runningstats
+    rs = numpy.random.RandomState(channels + h)
+    acts = torch.from_numpy((rs.randn(batch, channels, h, w) + 0.3).astype('float32'))
+    rows = acts.permute(0, 2, 3, 1).reshape(-1, channels)
+    want = (rows.double().t() @ rows.double())
+    r1, r2 = runningstats.RunningSecondMoment(), runningstats.RunningSecondMoment()
+    for _ in range(2):                      # accumulate twice: += semantics
+        r1.add_nchw(acts.to(DEV))
+        r2.add(rows.to(DEV))
+    assert r1.count == r2.count == 2 * rows.shape[0]
+    for r in (r1, r2):
+        assert rel(r.mom2, 2 * want) < 2e-6
+        assert (r.mom2 - r.mom2.t()).abs().max().item() == 0.0          # mirrored exactly
+    assert rel(r1.moment(), want / rows.shape[0]) < 2e-6
+    sums = hip.channel_sums(acts.to(DEV), nchw=True, square_input=True).cpu().double()
+    sq = rows.double() ** 2
+    assert rel(sums[0], sq.sum(0)) < 1e-6 and rel(sums[1], (sq ** 2).sum(0)) < 1e-6
+    sums2 = hip.channel_sums(rows.to(DEV)).cpu().double()
+    assert rel(sums2[0], rows.double().sum(0)) < 1e-5 and rel(sums2[1], sq.sum(0)) < 1e-6
+
+
+def test_projection_kernel():
+    from rewriting_amd import hip
+    from oracle import restatement as R
+    rs = numpy.random.RandomState(3)
+    for o, i, r in [(512, 512, 1), (64, 128, 3), (32, 48, 5)]:
+        w = torch.from_numpy(rs.randn(1, o, i, 3, 3).astype('float32'))
+        d = torch.linalg.qr(torch.from_numpy(rs.randn(i, r).astype('float32')))[0].t().contiguous()
+        want = R.projected_conv(w, d)
+        assert rel(hip.project_weight(w.to(DEV), d.to(DEV)), want) < 1e-5
+        base = torch.from_numpy(rs.randn(1, o, i, 3, 3).astype('float32'))
+        wd = w.to(DEV).clone()
+        hip.project_weight(wd, d.to(DEV), base=base.to(DEV), out=wd)       # in place
+        assert rel(wd, base + want) < 1e-5
