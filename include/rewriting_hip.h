@@ -208,6 +208,7 @@ typedef struct rw_solve_problem {
   int ksplit;
   float beta1, beta2, eps, w_scale;
   int low_rank_gradient;
+  float one_minus_beta1, one_minus_beta2;   /* (1 - beta) evaluated in double on the host */
 } rw_solve_problem;
 
 int rw_solve_ksplit(int out_ch, int in_ch, int h, int w);

@@ -34,6 +34,7 @@ class SolveProblem(Structure):
         ('grad', c_void_p),
         ('ksplit', c_int), ('beta1', c_float), ('beta2', c_float), ('eps', c_float),
         ('w_scale', c_float), ('low_rank_gradient', c_int),
+        ('one_minus_beta1', c_float), ('one_minus_beta2', c_float),
     ]
 
 

@@ -161,10 +161,12 @@ __global__ void __launch_bounds__(256) solve_mid_kernel(const rw_solve_problem p
 // ---------------------------------------------------------------------------------------
 // Adam, as torch.optim.Adam's single-tensor path computes it (rewrite/ganrewrite.py:277,287)
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void adam_update(float g, float& w, float& m, float& v, float b1,
-                                            float b2, float eps, float step_size, float bc2s) {
-  m = m + (g - m) * (1.0f - b1);               // exp_avg.lerp_(grad, 1 - beta1)
-  v = v * b2 + ((1.0f - b2) * g) * g;          // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1-beta2)
+// omb1 / omb2 are (1 - beta) evaluated in DOUBLE on the host and rounded once, as torch passes them
+// (1.0f - 0.999f differs from float(1 - 0.999) by 1.3e-5 relative).
+__device__ __forceinline__ void adam_update(float g, float& w, float& m, float& v, float omb1,
+                                            float b2, float omb2, float eps, float step_size, float bc2s) {
+  m = m + (g - m) * omb1;                      // exp_avg.lerp_(grad, 1 - beta1)
+  v = v * b2 + (omb2 * g) * g;                 // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1-beta2)
   const float denom = sqrtf(v) / bc2s + eps;   // (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps)
   w = w + (-step_size * m) / denom;            // param.addcdiv_(exp_avg, denom, value=-step_size)
 }
@@ -195,7 +197,8 @@ __global__ void __launch_bounds__(256) solve_bwd_adam_kernel(const rw_solve_prob
   const int arow = tid >> 2, apart = (tid & 3) * 4;
   const int bcol = tid & 127, bp0 = tid >> 7;
   const int kmine = k0 + bcol;
-  const int ci = kmine / 9, ctap = kmine - 9 * ci;
+  const bool col_ok = kmine < K;
+  const int ci = col_ok ? kmine / 9 : 0, ctap = col_ok ? kmine - 9 * ci : 0;
   const int cdy = ctap / 3 - 1, cdx = ctap % 3 - 1;
   const float* kch = p.key + (int64_t)ci * p.h * p.w;
 
@@ -208,7 +211,7 @@ __global__ void __launch_bounds__(256) solve_bwd_adam_kernel(const rw_solve_prob
     for (int j = 0; j < 8; ++j) {
       const int n = p0 + bp0 + 2 * j;
       float v = 0.f;
-      if (n < P) {
+      if (n < P && col_ok) {
         const int y = n / p.w, x = n - y * p.w;
         const int iy = y + cdy, ix = x + cdx;
         if (iy >= 0 && iy < p.h && ix >= 0 && ix < p.w) v = kch[iy * p.w + ix];
@@ -252,6 +255,7 @@ __global__ void __launch_bounds__(256) solve_bwd_adam_kernel(const rw_solve_prob
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
     const int k = k0 + wn0 + 32 * b + fcol;
+    if (k >= K) continue;
     const int i = k / 9;
     const float sg = p.style[i];
     const float sig2 = sg * sg;
@@ -265,7 +269,7 @@ __global__ void __launch_bounds__(256) solve_bwd_adam_kernel(const rw_solve_prob
         p.grad[idx] = g;
       } else {
         float m = p.exp_avg[idx], v = p.exp_avg_sq[idx];
-        adam_update(g, wv, m, v, p.beta1, p.beta2, p.eps, step_size, bc2s);
+        adam_update(g, wv, m, v, p.one_minus_beta1, p.beta2, p.one_minus_beta2, p.eps, step_size, bc2s);
         p.weight[idx] = wv; p.exp_avg[idx] = m; p.exp_avg_sq[idx] = v;
       }
     }
@@ -330,7 +334,7 @@ __global__ void __launch_bounds__(256) project_kernel(const float* __restrict__ 
     for (int e = tid; e < rowlen; e += 256) {
       const int64_t idx = (int64_t)o * rowlen + e;
       float wv = p.weight[idx], m = p.exp_avg[idx], v = p.exp_avg_sq[idx];
-      adam_update(prow[e], wv, m, v, p.beta1, p.beta2, p.eps, step_size, bc2s);
+      adam_update(prow[e], wv, m, v, p.one_minus_beta1, p.beta2, p.one_minus_beta2, p.eps, step_size, bc2s);
       p.weight[idx] = wv; p.exp_avg[idx] = m; p.exp_avg_sq[idx] = v;
     }
   }
@@ -359,14 +363,14 @@ extern "C" int rw_solve_step_f32(const rw_solve_problem* pr, int project, rw_str
   RW_CHECK_ARG(!(project || p.low_rank_gradient) || (p.context && p.rank > 0));
   RW_CHECK_ARG(!project || p.ortho);
   RW_CHECK_ARG(!p.low_rank_gradient || p.grad);
-  if (p.out_ch % SV_BM || p.in_ch % SV_KC || (9 * p.in_ch) % SV_BNK) return RW_ERR_UNSUPPORTED;
+  if (p.out_ch % SV_BM || p.in_ch % SV_KC) return RW_ERR_UNSUPPORTED;
   hipStream_t s = rw_s(stream);
   const int P = p.h * p.w;
   const int pp = sv_pp(P);
   float* lpart = p.c2 + p.out_ch;   // c2 is allocated with 2*out_ch floats: [c2 | per-channel loss]
   hipLaunchKernelGGL(solve_fwd_kernel, dim3(p.out_ch / SV_BM, pp / SV_BN, p.ksplit), dim3(256), 0, s, p, pp);
   hipLaunchKernelGGL(solve_mid_kernel, dim3(p.out_ch), dim3(256), 0, s, p, pp, lpart);
-  hipLaunchKernelGGL(solve_bwd_adam_kernel, dim3(p.out_ch / SV_BM, 9 * p.in_ch / SV_BNK), dim3(256), 0,
+  hipLaunchKernelGGL(solve_bwd_adam_kernel, dim3(p.out_ch / SV_BM, (unsigned)rw_cdiv(9 * p.in_ch, SV_BNK)), dim3(256), 0,
                      s, p, pp, (const float*)lpart);
   const size_t lds = 2 * (size_t)p.in_ch * 9 * sizeof(float);
   if (p.low_rank_gradient) {

@@ -73,6 +73,7 @@ class Solver:
                                              _ptr(self.c2), _ptr(self.grad))
         p.ksplit = ks
         p.beta1, p.beta2, p.eps = 0.9, 0.999, 1e-8
+        p.one_minus_beta1, p.one_minus_beta2 = 1 - 0.9, 1 - 0.999     # python doubles, rounded once
         p.w_scale = 1 / math.sqrt(I * 9)
         p.low_rank_gradient = int(low_rank_gradient)
         self.problem = p

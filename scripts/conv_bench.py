@@ -1,0 +1,56 @@
+"""Per-layer throughput of the implicit-GEMM conv kernels on the layer shapes of the 256^2 and
+1024^2 generators (GPU only).  Prints a table and writes gpurun_out/conv_bench.json."""
+import json
+import math
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from rewriting_amd import hip          # noqa: E402
+
+LAYERS = [  # (name, cin, cout, input res, upsample)
+    ('layer4', 512, 512, 8, False), ('layer6', 512, 512, 16, False), ('layer7', 512, 512, 16, True),
+    ('layer8', 512, 512, 32, False), ('layer9', 512, 512, 32, True), ('layer10', 512, 512, 64, False),
+    ('layer11', 512, 256, 64, True), ('layer12', 256, 256, 128, False), ('layer13', 256, 128, 128, True),
+    ('layer14', 128, 128, 256, False), ('layer15', 128, 64, 256, True), ('layer16', 64, 64, 512, False),
+    ('layer17', 64, 32, 512, True), ('layer18', 32, 32, 1024, False),
+]
+
+
+def main(batch=int(os.environ.get('RW_BATCH', '8')), iters=5):
+    dev = 'cuda'
+    rows = []
+    for name, cin, cout, res, up in LAYERS:
+        x = torch.randn(batch, cin, res, res, device=dev)
+        w = torch.randn(1, cout, cin, 3, 3, device=dev)
+        style = 1 + 0.3 * torch.randn(batch, cin, device=dev)
+        wp = hip.pack_conv_weight(w, 1 if up else 0)
+        dm = hip.demod(hip.weight_sqsum(w, 1.0), style)
+        fn = (lambda: hip.conv_transpose3x3s2(x, wp, cout, 1.0, style=style, demod=dm)) if up else \
+             (lambda: hip.conv3x3(x, wp, cout, 1.0, style=style, demod=dm))
+        fn()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(iters):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        ms = s.elapsed_time(e) / iters
+        flops = 2.0 * 9 * cin * cout * res * res * batch
+        out_res = 2 * res + 1 if up else res
+        bytes_io = 4.0 * batch * (cin * res * res + cout * out_res * out_res)
+        rows.append(dict(layer=name, cin=cin, cout=cout, res=res, up=up, ms=round(ms, 4),
+                         tflops=round(flops / ms / 1e9, 2), io_gbs=round(bytes_io / ms / 1e6, 1)))
+        print(rows[-1])
+        del x, w
+    os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+    with open(os.path.join(ROOT, 'gpurun_out', 'conv_bench.json'), 'w') as f:
+        json.dump(dict(batch=batch, rows=rows), f, indent=1)
+
+
+if __name__ == '__main__':
+    main()

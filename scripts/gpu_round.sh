@@ -19,8 +19,8 @@ for wl in ffhq256 edit; do
   echo "bench $wl exit $?" | tee -a "$OUT/summary.txt"; cat "$OUT/bench_$wl.json" | tee -a "$OUT/summary.txt"; tail -3 "$OUT/bench_$wl.err" | tee -a "$OUT/summary.txt"
 done
 echo "== rocprofv3 kernel-trace stats" | tee -a "$OUT/summary.txt"
-( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/prof" -o bench -- python "$OLDPWD/bench.py" --steps 5 --warmup 1 --no-cpu-baseline > "$OLDPWD/$OUT/prof_bench.log" 2>&1 ); echo "rocprof exit $?" | tee -a "$OUT/summary.txt"
-find "$OUT/prof" -name "*stats*" | head -5 | tee -a "$OUT/summary.txt"
+( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/prof" -o bench -- python "$OLDPWD/bench.py" --steps 5 --warmup 1 --no-cpu-baseline > "$OLDPWD/$OUT/prof_bench.log" 2>&1 ); echo "rocprof exit $?" | tee -a "$OUT/summary.txt"
+find "$OUT/prof" -name "*.csv" | head -8 | tee -a "$OUT/summary.txt"
 F=$(find "$OUT/prof" -name "*kernel_stats*.csv" | head -1)
 [ -n "$F" ] && head -25 "$F" | tee -a "$OUT/summary.txt"
 # keep only the small summaries (traces can be large)
