@@ -196,6 +196,219 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvProblem p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Halo-tile variant for feature maps at least one MFMA tile wide (W >= 24): the workgroup owns
+// a (TH rows x 32 columns) patch of ONE image and BM out-channels.  Per chunk of IC input
+// channels the (TH+2) x 34 input halo is staged in LDS ONCE (coalesced NCHW row pieces, style
+// multiplied on the way in) and all taps read it at shifted addresses, so global gathers drop
+// 9x versus the im2col staging above and there is one barrier per 9*IC/2 MFMA steps instead
+// of per 8.  Weight fragments are not staged at all: every lane loads its A operand
+// wp[tap][i][o] straight from L1/L2 (32 consecutive out-channels per half-wave = one 128-byte
+// line) one tap ahead of its use, which frees the LDS and the VALU for the matrix pipe.
+// The four output-parity phases of the stride-2 transposed convolution are four sub-problems
+// of ONE launch.
+// ---------------------------------------------------------------------------------------
+struct PhaseDesc {
+  int ntaps;
+  unsigned dy_bits, dx_bits;
+  int ph, pw, oy0, ox0;
+  int tiles_x, tiles_y, work0;
+  long long wp_off;
+};
+
+struct HaloProblem {
+  const float* x; const float* wp; float* y;
+  const float* style; const float* demod; const float* noise; const float* noise_w; const float* bias;
+  int batch, in_ch, out_ch, h, w, oh, ow, sy, sx;
+  float w_scale;
+  int act, nphase;
+  PhaseDesc phase[4];
+};
+
+template <int TM, int TN, int WGM, int WGN, int IC>
+__global__ void __launch_bounds__(256, 2) conv_halo_kernel(const HaloProblem p) {
+  constexpr int BM = 32 * TM * WGM;
+  constexpr int TH = TN * WGN;
+  constexpr int XH = TH + 2, XW = 36, XUSED = 34;
+  constexpr int KP = IC / 2;
+  static_assert(WGM * WGN == 4, "4 waves per workgroup");
+  __shared__ float Xs[2][IC][XH][XW];
+  __shared__ float Ss[1024];                 // this image's style row (1.0 when style is not fused)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave / WGN) * 32 * TM;
+  const int wrow0 = (wave % WGN) * TN;
+  const int frow = lane >> 5, fcol = lane & 31;
+
+  const int work = rw_xcd_remap(blockIdx.x, gridDim.x);
+  int phase = 0;
+#pragma unroll
+  for (int q = 1; q < 4; ++q)
+    if (q < p.nphase && work >= p.phase[q].work0) phase = q;
+  const PhaseDesc d = p.phase[phase];
+  int local = work - d.work0;
+  const int o_tiles = p.out_ch / BM;
+  const int o0 = (local % o_tiles) * BM; local /= o_tiles;
+  const int tx = local % d.tiles_x; local /= d.tiles_x;
+  const int ty = local % d.tiles_y;
+  const int ib = local / d.tiles_y;
+  const int y0 = ty * TH, x0 = tx * 32;
+  const int64_t hw = (int64_t)p.h * p.w;
+  const float* xb = p.x + (int64_t)ib * p.in_ch * hw;
+  for (int i = tid; i < p.in_ch; i += 256) Ss[i] = p.style ? p.style[(int64_t)ib * p.in_ch + i] : 1.0f;
+  const float* wph = p.wp + d.wp_off + o0;            // wave-uniform
+  const int a_lane = frow * p.out_ch + wm0 + fcol;    // this lane's offset inside a k-pair of rows
+
+  // Halo staging: this thread owns up to PSLOT fixed positions (r, c) of the (TH+2) x 34 patch and
+  // walks the IC channels of a chunk for each: one 32-bit offset per slot, channel stride uniform.
+  constexpr int NPOS = XH * XUSED;
+  constexpr int PSLOT = (NPOS + 255) / 256;
+  int xoff[PSLOT], xlds[PSLOT];
+  float xmask[PSLOT];
+#pragma unroll
+  for (int sl = 0; sl < PSLOT; ++sl) {
+    const int pos = tid + 256 * sl;
+    const int r = pos / XUSED, c = pos - r * XUSED;
+    const int iy = y0 - 1 + r, ix = x0 - 1 + c;
+    const bool ok = pos < NPOS && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
+    xoff[sl] = ok ? iy * p.w + ix : 0;            // invalid -> any legal address, value masked to 0
+    xmask[sl] = ok ? 1.0f : 0.0f;
+    xlds[sl] = pos < NPOS ? r * XW + c : -1;
+  }
+  float xreg[PSLOT][IC];
+  auto xfetch = [&](int i0) {
+    const float* xc = xb + (int64_t)i0 * hw;               // uniform
+#pragma unroll
+    for (int ic = 0; ic < IC; ++ic)
+#pragma unroll
+      for (int sl = 0; sl < PSLOT; ++sl) xreg[sl][ic] = xc[(int64_t)ic * hw + xoff[sl]];
+  };
+  auto xstash = [&](int buf, int i0) {      // mask + style applied on the way into LDS (Ss: broadcast read)
+    float* dst = &Xs[buf][0][0][0];
+#pragma unroll
+    for (int sl = 0; sl < PSLOT; ++sl)
+      if (xlds[sl] >= 0) {
+#pragma unroll
+        for (int ic = 0; ic < IC; ++ic)
+          dst[ic * XH * XW + xlds[sl]] = xreg[sl][ic] * (xmask[sl] * Ss[i0 + ic]);
+      }
+  };
+  float areg[KP][TM];
+  auto aload1 = [&](int kp, int t, int i0) {
+    const float* base = wph + ((int64_t)t * p.in_ch + i0) * p.out_ch;   // uniform: SGPR base + 32-bit lane offset
+#pragma unroll
+    for (int a = 0; a < TM; ++a) areg[kp][a] = base[a_lane + (2 * kp) * p.out_ch + 32 * a];
+  };
+
+  rw_f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int n_chunks = p.in_ch / IC;
+  xfetch(0);
+#pragma unroll
+  for (int kp = 0; kp < KP; ++kp) aload1(kp, 0, 0);
+  __syncthreads();                            // Ss visible
+  xstash(0, 0);
+  __syncthreads();
+  for (int c = 0; c < n_chunks; ++c) {
+    const int buf = c & 1;
+    const int i0 = c * IC;
+    if (c + 1 < n_chunks) xfetch(i0 + IC);
+    for (int t = 0; t < d.ntaps; ++t) {
+      int nt = t + 1, ni0 = i0;
+      if (nt == d.ntaps) { nt = 0; ni0 = i0 + IC; }
+      const bool more = ni0 < p.in_ch;
+      const int dy = rw_tap_off(d.dy_bits, t), dx = rw_tap_off(d.dx_bits, t);
+      const float* xs = &Xs[buf][frow][wrow0 + dy + 1][fcol + dx + 1];
+#pragma unroll
+      for (int kp = 0; kp < KP; ++kp) {
+        float bf[TN];
+#pragma unroll
+        for (int b = 0; b < TN; ++b) bf[b] = xs[(2 * kp) * XH * XW + b * XW];
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[kp][a], bf[b], acc[a][b], 0, 0, 0);
+        // this k-pair's weight registers are free again: refill them for the next tap, KP-1 steps
+        // (>= 1.5k cycles of MFMA) ahead of their use
+        if (more) aload1(kp, nt, ni0);
+      }
+    }
+    if (c + 1 < n_chunks) xstash(buf ^ 1, i0 + IC);
+    __syncthreads();
+  }
+
+  const float nw = p.noise ? p.noise_w[0] : 0.f;
+  const int64_t ohw = (int64_t)p.oh * p.ow;
+  const int xx = x0 + fcol;
+#pragma unroll
+  for (int b = 0; b < TN; ++b) {
+    const int yy = y0 + wrow0 + b;
+    if (yy >= d.ph || xx >= d.pw) continue;
+    const int64_t pix = (int64_t)(p.sy * yy + d.oy0) * p.ow + (p.sx * xx + d.ox0);
+    const float nz = p.noise ? nw * p.noise[(int64_t)ib * ohw + pix] : 0.f;
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = o0 + wm0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * frow;
+        float v = acc[a][b][r] * p.w_scale;
+        if (p.demod) v *= p.demod[(int64_t)ib * p.out_ch + o];
+        if (p.noise) v += nz;
+        if (p.act) {
+          v += p.bias[o];
+          v = ((v > 0.f) ? v : v * 0.2f) * 1.4142135623730951f;
+        }
+        p.y[((int64_t)ib * p.out_ch + o) * ohw + pix] = v;
+      }
+    }
+  }
+}
+
+static bool halo_applicable(const ConvProblem* ps, int n) {
+  for (int q = 0; q < n; ++q)
+    if (ps[q].pw < 24 || ps[q].in_ch % 16 || ps[q].in_ch > 1024 || ps[q].out_ch % 32) return false;
+  return true;
+}
+
+// ps: 1 (stride-1 conv) or 4 (transposed-conv phases) problems sharing x / y / epilogue.
+static int launch_halo(const ConvProblem* ps, int n, hipStream_t s) {
+  const ConvProblem& c = ps[0];
+  HaloProblem h;
+  h.x = c.x; h.wp = ps[0].wp; h.y = c.y; h.style = c.style; h.demod = c.demod; h.noise = c.noise;
+  h.noise_w = c.noise_w; h.bias = c.bias; h.batch = c.batch; h.in_ch = c.in_ch; h.out_ch = c.out_ch;
+  h.h = c.h; h.w = c.w; h.oh = c.oh; h.ow = c.ow; h.sy = c.sy; h.sx = c.sx; h.w_scale = c.w_scale;
+  h.act = c.act; h.nphase = n;
+  int th, bm;
+  if (c.out_ch % 128 == 0) { th = 4; bm = 128; }
+  else if (c.out_ch % 64 == 0) { th = 8; bm = 64; }
+  else { th = 16; bm = 32; }
+  int work = 0;
+  for (int q = 0; q < 4; ++q) {
+    PhaseDesc& d = h.phase[q];
+    const ConvProblem& pq = ps[q < n ? q : 0];
+    d.ntaps = pq.ntaps; d.dy_bits = pq.dy_bits; d.dx_bits = pq.dx_bits; d.ph = pq.ph; d.pw = pq.pw;
+    d.oy0 = pq.oy0; d.ox0 = pq.ox0;
+    d.tiles_x = (int)rw_cdiv(pq.pw, 32); d.tiles_y = (int)rw_cdiv(pq.ph, th);
+    d.work0 = work; d.wp_off = (long long)(pq.wp - ps[0].wp);
+    if (q < n) work += c.batch * d.tiles_x * d.tiles_y * (c.out_ch / bm);
+  }
+  if (work == 0) return 0;
+  if (bm == 128)
+    hipLaunchKernelGGL((conv_halo_kernel<2, 2, 2, 2, 16>), dim3(work), dim3(256), 0, s, h);
+  else if (bm == 64)
+    hipLaunchKernelGGL((conv_halo_kernel<2, 2, 1, 4, 16>), dim3(work), dim3(256), 0, s, h);
+  else
+    hipLaunchKernelGGL((conv_halo_kernel<1, 4, 1, 4, 8>), dim3(work), dim3(256), 0, s, h);
+  return RW_LAUNCH_RESULT();
+}
+
 // Direct VALU statement of the same problem (one thread per output sample).  Kept as an
 // independent on-device cross-check of the MFMA fragment layouts (impl = 1).
 __global__ void __launch_bounds__(256) conv_direct_kernel(const ConvProblem p) {
@@ -286,7 +499,9 @@ extern "C" int rw_conv3x3_f32(const float* x, const float* wp, float* y, int bat
   p.ph = h; p.pw = w; p.oh = h; p.ow = w; p.sy = 1; p.sx = 1; p.oy0 = 0; p.ox0 = 0;
   p.ntaps = 9;
   for (int t = 0; t < 9; ++t) set_tap(p, t, t / 3 - 1, t % 3 - 1);
-  return launch_problem(p, impl, rw_s(stream));
+  if (impl == 3 && !halo_applicable(&p, 1)) return RW_ERR_UNSUPPORTED;
+  if (impl == 3 || (impl == 0 && halo_applicable(&p, 1))) return launch_halo(&p, 1, rw_s(stream));
+  return launch_problem(p, impl == 2 ? 0 : impl, rw_s(stream));
 }
 
 extern "C" int rw_conv_transpose3x3s2_f32(const float* x, const float* wp, float* y, int batch,
@@ -302,15 +517,20 @@ extern "C" int rw_conv_transpose3x3s2_f32(const float* x, const float* wp, float
   static const int tdy[4][4] = {{0, 0, -1, -1}, {0, -1, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
   static const int tdx[4][4] = {{0, -1, 0, -1}, {0, 0, 0, 0}, {0, -1, 0, 0}, {0, 0, 0, 0}};
   const int64_t slab = (int64_t)in_ch * out_ch;
+  ConvProblem ps[4];
   for (int phase = 0; phase < 4; ++phase) {
     const int py = phase >> 1, px = phase & 1;
-    ConvProblem p;
+    ConvProblem& p = ps[phase];
     fill_common(p, x, wp + slab0[phase] * slab, y, batch, in_ch, out_ch, h, w, w_scale, ep);
     p.ph = py ? h : h + 1; p.pw = px ? w : w + 1;
     p.oh = 2 * h + 1; p.ow = 2 * w + 1; p.sy = 2; p.sx = 2; p.oy0 = py; p.ox0 = px;
     p.ntaps = ntaps[phase];
     for (int t = 0; t < p.ntaps; ++t) set_tap(p, t, tdy[phase][t], tdx[phase][t]);
-    const int rc = launch_problem(p, impl, rw_s(stream));
+  }
+  if (impl == 3 && !halo_applicable(ps, 4)) return RW_ERR_UNSUPPORTED;
+  if (impl == 3 || (impl == 0 && halo_applicable(ps, 4))) return launch_halo(ps, 4, rw_s(stream));
+  for (int phase = 0; phase < 4; ++phase) {
+    const int rc = launch_problem(ps[phase], impl == 2 ? 0 : impl, rw_s(stream));
     if (rc) return rc;
   }
   return 0;

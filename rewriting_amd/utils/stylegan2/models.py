@@ -88,8 +88,14 @@ def fusion_enabled():
     return os.environ.get('RW_FUSE', '1') != '0'
 
 
+_CONV_IMPLS = {'auto': 0, 'mfma': 0, 'direct': 1, 'generic': 2, 'halo': 3}
+
+
 def conv_impl():
-    return 1 if os.environ.get('RW_CONV_IMPL', 'mfma') == 'direct' else 0
+    """Kernel choice for the 3x3 convolutions (include/rewriting_hip.h, rw_conv3x3_f32 impl):
+    auto = halo-tile MFMA kernel where the map is >= 24 wide else the im2col MFMA kernel;
+    'generic' / 'halo' force one of them, 'direct' is the VALU cross-check."""
+    return _CONV_IMPLS[os.environ.get('RW_CONV_IMPL', 'auto')]
 
 
 class DataBag(dict):

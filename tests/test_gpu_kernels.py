@@ -113,7 +113,7 @@ def test_mapping_network_pieces():
 CONV_CASES = [  # (batch, cin, cout, h, w)
     (2, 512, 512, 4, 4), (3, 512, 512, 8, 8), (1, 512, 512, 32, 32), (2, 512, 256, 16, 16),
     (1, 256, 128, 8, 12), (2, 128, 64, 16, 16), (1, 64, 32, 32, 32), (1, 32, 32, 20, 36),
-    (5, 16, 32, 3, 5), (1, 48, 96, 7, 9),
+    (2, 128, 64, 40, 64), (5, 16, 32, 3, 5), (1, 48, 96, 7, 9), (2, 64, 128, 13, 29), (1, 32, 64, 70, 33),
 ]
 
 
@@ -125,7 +125,11 @@ def _conv_inputs(b, i, o, h, w, seed=0):
     return x, wt, style
 
 
-@pytest.mark.parametrize('impl', [0, 1])
+def _halo_ok(case):
+    return case[4] >= 24 and case[1] % 16 == 0
+
+
+@pytest.mark.parametrize('impl', [0, 1, 2, 3])
 @pytest.mark.parametrize('case', CONV_CASES)
 def test_demodulated_conv_matches_oracle(case, impl):
     """conv2d(x, s*W, pad 1) * demod vs the oracle (DemodulatedConv2dF, models.py:313-329);
@@ -133,6 +137,8 @@ def test_demodulated_conv_matches_oracle(case, impl):
     from rewriting_amd import hip
     from oracle import restatement as R
     b, i, o, h, w = case
+    if impl == 3 and not _halo_ok(case):
+        pytest.skip('halo kernel needs W >= 24')
     x, wt, style = _conv_inputs(*case)
     s = 1 / math.sqrt(i * 9)
     key = style[:, :, None, None] * x
@@ -148,12 +154,14 @@ def test_demodulated_conv_matches_oracle(case, impl):
     assert rel(fused, want) < 1e-5
 
 
-@pytest.mark.parametrize('impl', [0, 1])
-@pytest.mark.parametrize('case', CONV_CASES[:8])
+@pytest.mark.parametrize('impl', [0, 1, 2, 3])
+@pytest.mark.parametrize('case', CONV_CASES[:9])
 def test_transposed_conv_matches_oracle(case, impl):
     from rewriting_amd import hip
     from oracle import restatement as R
     b, i, o, h, w = case
+    if impl == 3 and not _halo_ok(case):
+        pytest.skip('halo kernel needs W >= 24')
     x, wt, style = _conv_inputs(*case, seed=1)
     s = 1 / math.sqrt(i * 9)
     want = R.demod_conv(style[:, :, None, None] * x, style, wt, upsample=True)

@@ -25,7 +25,7 @@ def rel(a, b):
 
 
 @pytest.mark.parametrize('fuse', ['1', '0'])
-@pytest.mark.parametrize('impl', ['mfma', 'direct'])
+@pytest.mark.parametrize('impl', ['auto', 'generic', 'direct'])
 @pytest.mark.parametrize('name', ['gen_s32_t05', 'gen_s64_cm1'])
 def test_generator_matches_reference_golden(monkeypatch, name, impl, fuse):
     monkeypatch.setenv('RW_FUSE', fuse)
@@ -139,7 +139,17 @@ def test_rewriter_edit_matches_reference_golden(tmp_path):
         report[niter] = r
         assert r < 1e-4, (niter, r)                                  # north_star: 1e-4 relative
         assert (dW - ganrewrite.projected_conv(dW[None], mkey)[0]).norm() / dW.norm() < 1e-4
-    # 10 / 100 (un-projected states) and 101 through the callback path and the graph path
+    # 10 / 100 (un-projected states) and 101 through the callback path and the graph path.
+    # At >= 100 steps the reference's own fp32 trajectory has left the exact (fp64) one by ~4e-4
+    # (L1 sign gradients + Adam amplify rounding chaotically; profiles/r01_solve_divergence_301.json),
+    # so the bar there is the EXACT arithmetic: the oracle's explicit update in float64.
+    from oracle import restatement as R
+    sd_w = W0.cpu()
+    _, _, exact = R.insert_explicit(
+        sd_w, torch.from_numpy(g['goal_in_fmap']), torch.from_numpy(g['goal_in_style']),
+        torch.from_numpy(g['goal_out_fmap']), gw.target_model.layer8.sconv.activate.bias.detach().cpu(),
+        gw.target_model.layer8.sconv.noise.weight.detach().cpu(), torch.from_numpy(g['mkey']),
+        niter=101, snapshots=(10, 100, 101), dtype=torch.float64)
     for use_cb in (True, False):
         gwn = _make_rewriter(meta, cachedir=str(tmp_path / 'cache'))
         snaps, losses = {}, []
@@ -153,12 +163,16 @@ def test_rewriter_edit_matches_reference_golden(tmp_path):
         assert t_ms > 0
         snaps[101] = gwn.target_weights().detach().clone()
         for n, W in snaps.items():
-            dW = (W - W0)[0]
-            r1 = abs(dW.double().norm().item() / float(g['dW_%d_norm' % n]) - 1)
-            r2 = ((subsample(dW, 8192) - torch.from_numpy(g['dW_%d_sub' % n])).norm()
-                  / torch.from_numpy(g['dW_%d_sub' % n]).norm()).item()
-            report['%s%d' % ('cb' if use_cb else 'graph', n)] = r2
-            assert r1 < 1e-4 and r2 < 2e-4, (use_cb, n, r1, r2)
+            dW = (W - W0)[0].cpu()
+            ex = (exact[n].float() - sd_w)[0]
+            gsub = torch.from_numpy(g['dW_%d_sub' % n])
+            r_exact = rel(dW, ex)
+            r_gold = ((subsample(dW, 8192) - gsub).norm() / gsub.norm()).item()
+            gold_self = ((subsample(ex, 8192) - gsub).norm() / gsub.norm()).item()
+            tag = '%s%d' % ('cb' if use_cb else 'graph', n)
+            report[tag] = dict(gpu_vs_exact=r_exact, gpu_vs_golden=r_gold, golden_vs_exact=gold_self)
+            assert r_exact < 1e-4, (tag, r_exact)                       # north_star bar, exact arithmetic
+            assert r_gold < 3 * gold_self + 2e-4, (tag, r_gold, gold_self)
         if use_cb:
             got = torch.stack(losses).cpu().numpy()
             assert numpy.abs(got - g['losses'])[:20].max() < 1e-5
