@@ -371,6 +371,238 @@ __global__ void __launch_bounds__(256, 2) conv_halo_kernel(const HaloProblem p) 
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Stride-2 transposed convolution, all four output-parity phases in ONE workgroup.
+// The workgroup owns BM out-channels and a (TH x 32) patch of the (H+1) x (W+1) grid of 2x2
+// output quads.  Per chunk of IC input channels the (TH+1) x 33 input halo (rows y-1..y,
+// columns x-1..x) is staged once; the four distinct input shifts {0,-1}^2 are read from LDS once
+// per k-pair and feed the nine weight slabs (4+2+2+1 taps of the four phases), so each wave keeps
+// four accumulator sets (one per phase) and the epilogue writes COMPLETE output rows: even rows
+// as aligned 8-byte (px=0, px=1) pairs, i.e. 256 contiguous bytes per half-wave.
+// Quads y < H, x < W are tiled exactly; output row 2H and column 2W (the "+1" of 2H+1) are a
+// strip of H+W+1 quads computed by conv_up_edge_kernel.
+// ---------------------------------------------------------------------------------------
+struct UpProblem {
+  const float* x; const float* wp; float* y;
+  const float* style; const float* demod;
+  int batch, in_ch, out_ch, h, w;
+  int tiles_x, tiles_y;
+  float w_scale;
+};
+
+template <int WGM, int WGN, int IC>
+__global__ void __launch_bounds__(256, 2) conv_up_halo_kernel(const UpProblem p) {
+  constexpr int TN = 2;                       // rows of quads per wave
+  constexpr int BM = 32 * WGM;
+  constexpr int TH = TN * WGN;
+  constexpr int XH = TH + 1, XW = 36, XUSED = 33;
+  constexpr int NPOS = XH * XUSED;
+  constexpr int PSLOT = (NPOS + 255) / 256;
+  constexpr int KP = IC / 2;
+  static_assert(WGM * WGN == 4, "4 waves per workgroup");
+  __shared__ float Xs[2][IC][XH][XW];
+  __shared__ float Ss[1024];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave / WGN) * 32;
+  const int wrow0 = (wave % WGN) * TN;
+  const int frow = lane >> 5, fcol = lane & 31;
+
+  int local = rw_xcd_remap(blockIdx.x, gridDim.x);
+  const int o_tiles = p.out_ch / BM;
+  const int o0 = (local % o_tiles) * BM; local /= o_tiles;
+  const int tx = local % p.tiles_x; local /= p.tiles_x;
+  const int ty = local % p.tiles_y;
+  const int ib = local / p.tiles_y;
+  const int y0 = ty * TH, x0 = tx * 32;
+  const int64_t hw = (int64_t)p.h * p.w;
+  const float* xb = p.x + (int64_t)ib * p.in_ch * hw;
+  for (int i = tid; i < p.in_ch; i += 256) Ss[i] = p.style ? p.style[(int64_t)ib * p.in_ch + i] : 1.0f;
+  const int64_t slab = (int64_t)p.in_ch * p.out_ch;
+  const float* wph = p.wp + o0;                                  // uniform
+  const int a_lane = frow * p.out_ch + wm0 + fcol;
+
+  int xoff[PSLOT], xlds[PSLOT];
+  float xmask[PSLOT];
+#pragma unroll
+  for (int sl = 0; sl < PSLOT; ++sl) {
+    const int pos = tid + 256 * sl;
+    const int r = pos / XUSED, c = pos - r * XUSED;
+    const int iy = y0 - 1 + r, ix = x0 - 1 + c;
+    const bool ok = pos < NPOS && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
+    xoff[sl] = ok ? iy * p.w + ix : 0;
+    xmask[sl] = ok ? 1.0f : 0.0f;
+    xlds[sl] = pos < NPOS ? r * XW + c : -1;
+  }
+  float xreg[PSLOT][IC];
+  auto xfetch = [&](int i0) {
+    const float* xc = xb + (int64_t)i0 * hw;
+#pragma unroll
+    for (int ic = 0; ic < IC; ++ic)
+#pragma unroll
+      for (int sl = 0; sl < PSLOT; ++sl) xreg[sl][ic] = xc[(int64_t)ic * hw + xoff[sl]];
+  };
+  auto xstash = [&](int buf, int i0) {
+    float* dst = &Xs[buf][0][0][0];
+#pragma unroll
+    for (int sl = 0; sl < PSLOT; ++sl)
+      if (xlds[sl] >= 0) {
+#pragma unroll
+        for (int ic = 0; ic < IC; ++ic)
+          dst[ic * XH * XW + xlds[sl]] = xreg[sl][ic] * (xmask[sl] * Ss[i0 + ic]);
+      }
+  };
+  // nine weight slabs (rw_pack_conv_weight_f32 mode 1 order) for one k-pair
+  float acur[9], anxt[9];
+  auto aload = [&](float (&dst)[9], int kp, int i0) {
+    const float* base = wph + (int64_t)(i0 + 2 * kp) * p.out_ch;
+#pragma unroll
+    for (int sb = 0; sb < 9; ++sb) dst[sb] = base[sb * slab + a_lane];
+  };
+
+  rw_f32x16 acc[4][TN];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[q][b][r] = 0.f;
+
+  const int n_chunks = p.in_ch / IC;
+  xfetch(0);
+  aload(acur, 0, 0);
+  __syncthreads();
+  xstash(0, 0);
+  __syncthreads();
+  for (int c = 0; c < n_chunks; ++c) {
+    const int buf = c & 1;
+    const int i0 = c * IC;
+    if (c + 1 < n_chunks) xfetch(i0 + IC);
+    // LDS row r holds input row y0-1+r, column c holds input column x0-1+c:
+    // shift (dy,dx) of quad (row, col) -> Xs[.][row + 1 + dy][col + 1 + dx]
+    const float* xs = &Xs[buf][frow][wrow0][fcol];
+#pragma unroll
+    for (int kp = 0; kp < KP; ++kp) {
+      int nkp = kp + 1, ni0 = i0;
+      if (nkp == KP) { nkp = 0; ni0 = i0 + IC; }
+      if (ni0 < p.in_ch) aload(anxt, nkp, ni0);
+      float b00[TN], b0m[TN], bm0[TN], bmm[TN];
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const float* q = xs + (2 * kp) * XH * XW + b * XW;
+        b00[b] = q[XW + 1]; b0m[b] = q[XW]; bm0[b] = q[1]; bmm[b] = q[0];
+      }
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[0], b00[b], acc[0][b], 0, 0, 0);
+        acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[1], b0m[b], acc[0][b], 0, 0, 0);
+        acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[2], bm0[b], acc[0][b], 0, 0, 0);
+        acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[3], bmm[b], acc[0][b], 0, 0, 0);
+        acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[4], b00[b], acc[1][b], 0, 0, 0);
+        acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[5], bm0[b], acc[1][b], 0, 0, 0);
+        acc[2][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[6], b00[b], acc[2][b], 0, 0, 0);
+        acc[2][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[7], b0m[b], acc[2][b], 0, 0, 0);
+        acc[3][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[8], b00[b], acc[3][b], 0, 0, 0);
+      }
+#pragma unroll
+      for (int sb = 0; sb < 9; ++sb) acur[sb] = anxt[sb];
+    }
+    if (c + 1 < n_chunks) xstash(buf ^ 1, i0 + IC);
+    __syncthreads();
+  }
+
+  const int oh = 2 * p.h + 1, ow = 2 * p.w + 1;
+  const int64_t ohw = (int64_t)oh * ow;
+  const int xx = x0 + fcol;
+#pragma unroll
+  for (int b = 0; b < TN; ++b) {
+    const int yy = y0 + wrow0 + b;
+    if (yy >= p.h || xx >= p.w) continue;       // the last output row / column come from the edge kernel
+    const bool odd_row = true, odd_col = true;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = o0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * frow;
+      float sc = p.w_scale;
+      if (p.demod) sc *= p.demod[(int64_t)ib * p.out_ch + o];
+      float* yo = p.y + ((int64_t)ib * p.out_ch + o) * ohw + (int64_t)(2 * yy) * ow + 2 * xx;
+      const float v00 = acc[0][b][r] * sc, v01 = acc[1][b][r] * sc;
+      const float v10 = acc[2][b][r] * sc, v11 = acc[3][b][r] * sc;
+      if (odd_col) {
+        *reinterpret_cast<float2*>(yo) = make_float2(v00, v01);        // (2yy*ow + 2xx) is even: 8-byte aligned
+      } else {
+        yo[0] = v00;
+      }
+      if (odd_row) {
+        yo[ow] = v10;
+        if (odd_col) yo[ow + 1] = v11;
+      }
+    }
+  }
+}
+
+// Output row 2H (quads y' = H: phases (0,0),(0,1), input row H-1 only) and output column 2W
+// (quads x' = W: phases (0,0),(1,0), input column W-1 only).  One thread per (image, out
+// channel, strip quad); ~1/(2*min(H,W)) of the layer's work.
+__global__ void __launch_bounds__(256) conv_up_edge_kernel(const UpProblem p) {
+  const int strip = p.w + 1 + p.h;
+  const int64_t total = (int64_t)p.batch * p.out_ch * strip;
+  const int64_t hw = (int64_t)p.h * p.w;
+  const int oh = 2 * p.h + 1, ow = 2 * p.w + 1;
+  const int64_t slab = (int64_t)p.in_ch * p.out_ch;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int e = (int)(idx % strip);
+    const int o = (int)((idx / strip) % p.out_ch);
+    const int ib = (int)(idx / ((int64_t)strip * p.out_ch));
+    const int yy = e <= p.w ? p.h : e - (p.w + 1);
+    const int xx = e <= p.w ? e : p.w;
+    const float* xb = p.x + (int64_t)ib * p.in_ch * hw;
+    const float* st = p.style ? p.style + (int64_t)ib * p.in_ch : nullptr;
+    // input samples for the four shifts (zero outside the image)
+    const bool r0 = yy < p.h, rm = yy >= 1, c0 = xx < p.w, cm = xx >= 1;
+    float a00 = 0.f, a01 = 0.f, a10 = 0.f;
+    for (int i = 0; i < p.in_ch; ++i) {
+      const float* xi = xb + (int64_t)i * hw;
+      const float sv = st ? st[i] : 1.0f;
+      const float x00 = (r0 && c0) ? xi[(int64_t)yy * p.w + xx] * sv : 0.f;
+      const float x0m = (r0 && cm) ? xi[(int64_t)yy * p.w + xx - 1] * sv : 0.f;
+      const float xm0 = (rm && c0) ? xi[(int64_t)(yy - 1) * p.w + xx] * sv : 0.f;
+      const float xmm = (rm && cm) ? xi[(int64_t)(yy - 1) * p.w + xx - 1] * sv : 0.f;
+      const float* w = p.wp + (int64_t)i * p.out_ch + o;
+      a00 += w[0] * x00 + w[slab] * x0m + w[2 * slab] * xm0 + w[3 * slab] * xmm;
+      a01 += w[4 * slab] * x00 + w[5 * slab] * xm0;
+      a10 += w[6 * slab] * x00 + w[7 * slab] * x0m;
+    }
+    float sc = p.w_scale;
+    if (p.demod) sc *= p.demod[(int64_t)ib * p.out_ch + o];
+    float* yo = p.y + ((int64_t)ib * p.out_ch + o) * (int64_t)oh * ow + (int64_t)(2 * yy) * ow + 2 * xx;
+    yo[0] = a00 * sc;
+    if (xx < p.w) yo[1] = a01 * sc;
+    if (yy < p.h) yo[ow] = a10 * sc;
+  }
+}
+
+static int launch_up_halo(const ConvProblem& c, const float* wp_all, hipStream_t s) {
+  UpProblem u;
+  u.x = c.x; u.wp = wp_all; u.y = c.y; u.style = c.style; u.demod = c.demod;
+  u.batch = c.batch; u.in_ch = c.in_ch; u.out_ch = c.out_ch; u.h = c.h; u.w = c.w; u.w_scale = c.w_scale;
+  u.tiles_x = (int)rw_cdiv(c.w, 32);
+  {
+    const int64_t total = (int64_t)c.batch * c.out_ch * (c.w + 1 + c.h);
+    hipLaunchKernelGGL(conv_up_edge_kernel, dim3(rw_stream_grid(total, 256) * 4), dim3(256), 0, s, u);
+  }
+  if (c.out_ch % 64 == 0) {
+    u.tiles_y = (int)rw_cdiv(c.h, 4);
+    const int work = c.batch * u.tiles_x * u.tiles_y * (c.out_ch / 64);
+    hipLaunchKernelGGL((conv_up_halo_kernel<2, 2, 16>), dim3(work), dim3(256), 0, s, u);
+  } else {
+    u.tiles_y = (int)rw_cdiv(c.h, 8);
+    const int work = c.batch * u.tiles_x * u.tiles_y * (c.out_ch / 32);
+    hipLaunchKernelGGL((conv_up_halo_kernel<1, 4, 16>), dim3(work), dim3(256), 0, s, u);
+  }
+  return RW_LAUNCH_RESULT();
+}
+
 static bool halo_applicable(const ConvProblem* ps, int n) {
   for (int q = 0; q < n; ++q)
     if (ps[q].pw < 24 || ps[q].in_ch % 16 || ps[q].in_ch > 1024 || ps[q].out_ch % 32) return false;
@@ -527,8 +759,9 @@ extern "C" int rw_conv_transpose3x3s2_f32(const float* x, const float* wp, float
     p.ntaps = ntaps[phase];
     for (int t = 0; t < p.ntaps; ++t) set_tap(p, t, tdy[phase][t], tdx[phase][t]);
   }
-  if (impl == 3 && !halo_applicable(ps, 4)) return RW_ERR_UNSUPPORTED;
-  if (impl == 3 || (impl == 0 && halo_applicable(ps, 4))) return launch_halo(ps, 4, rw_s(stream));
+  if ((impl == 3 || impl == 4) && !halo_applicable(ps, 4)) return RW_ERR_UNSUPPORTED;
+  if (impl == 4) return launch_halo(ps, 4, rw_s(stream));         // per-phase halo tiles (kept for A/B)
+  if (impl == 3 || (impl == 0 && halo_applicable(ps, 4))) return launch_up_halo(ps[0], wp, rw_s(stream));
   for (int phase = 0; phase < 4; ++phase) {
     const int rc = launch_problem(ps[phase], impl == 2 ? 0 : impl, rw_s(stream));
     if (rc) return rc;

@@ -202,6 +202,7 @@ extern "C" int rw_pixel_norm_f32(const float* x, float* y, int batch, int dim, f
 // registers (scaled once, as the reference scales the weight before F.linear) while the
 // wave walks the batch; per-row dot products finish with a 64-lane butterfly.
 #define RW_LINEAR_MAX_PER_LANE 16  // in_dim <= 1024
+#define RW_LINEAR_ROWS 4           // batch rows per wave pass (independent butterflies overlap)
 __global__ void __launch_bounds__(256) equal_linear_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
     float* __restrict__ y, int batch, int in_dim, int out_dim, int64_t x_stride, float w_scale,
@@ -217,19 +218,32 @@ __global__ void __launch_bounds__(256) equal_linear_kernel(
     wr[j] = (j < per && i < in_dim) ? w[(int64_t)o * in_dim + i] * w_scale : 0.f;
   }
   const float bv = bias ? bias[o] * b_scale : 0.f;
-  for (int b = 0; b < batch; ++b) {
-    const float* xr = x + (int64_t)b * x_stride;
-    float acc = 0.f;
+  for (int b0 = blockIdx.y * RW_LINEAR_ROWS; b0 < batch; b0 += gridDim.y * RW_LINEAR_ROWS) {
+    float acc[RW_LINEAR_ROWS];
 #pragma unroll
-    for (int j = 0; j < RW_LINEAR_MAX_PER_LANE; ++j) {
-      const int i = lane + j * 64;
-      if (j < per && i < in_dim) acc += xr[i] * wr[j];
+    for (int r = 0; r < RW_LINEAR_ROWS; ++r) {
+      acc[r] = 0.f;
+      const int b = b0 + r;
+      if (b < batch) {
+        const float* xr = x + (int64_t)b * x_stride;
+#pragma unroll
+        for (int j = 0; j < RW_LINEAR_MAX_PER_LANE; ++j) {
+          const int i = lane + j * 64;
+          if (j < per && i < in_dim) acc[r] += xr[i] * wr[j];
+        }
+      }
     }
-    acc = rw_wave_sum(acc);
-    if (lane == 0) {
-      float v = acc + bv;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+      for (int r = 0; r < RW_LINEAR_ROWS; ++r) acc[r] += __shfl_xor(acc[r], off, 64);
+    if (lane < RW_LINEAR_ROWS && b0 + lane < batch) {
+      float v = acc[0];
+#pragma unroll
+      for (int r = 1; r < RW_LINEAR_ROWS; ++r) v = (lane == r) ? acc[r] : v;
+      v += bv;
       if (act) v = ((v > 0.f) ? v : v * alpha) * act_scale;
-      y[(int64_t)b * out_dim + o] = v;
+      y[(int64_t)(b0 + lane) * out_dim + o] = v;
     }
   }
 }
@@ -240,7 +254,9 @@ extern "C" int rw_equal_linear_f32(const float* x, const float* w, const float* 
                                    float act_scale, rw_stream_t stream) {
   RW_CHECK_ARG(x && w && y && batch > 0 && in_dim > 0 && out_dim > 0 && x_stride >= in_dim);
   if (in_dim > 64 * RW_LINEAR_MAX_PER_LANE) return RW_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(equal_linear_kernel, dim3((out_dim + 3) / 4), dim3(256), 0, rw_s(stream), x, w,
+  int gy = (batch + RW_LINEAR_ROWS - 1) / RW_LINEAR_ROWS;
+  if (gy > 64) gy = 64;
+  hipLaunchKernelGGL(equal_linear_kernel, dim3((out_dim + 3) / 4, gy), dim3(256), 0, rw_s(stream), x, w,
                      bias, y, batch, in_dim, out_dim, x_stride, w_scale, b_scale, act, alpha,
                      act_scale);
   return RW_LAUNCH_RESULT();
@@ -408,60 +424,70 @@ extern "C" int rw_pack_conv_weight_f32(const float* w, float* wp, int out_ch, in
 }
 
 // ---------------------------------------------------------------------------------------
-// Blur(pad 1,1) + noise + bias + leaky-ReLU for upsampling layers: one pass, 4 outputs/thread
+// Blur(pad 1,1) + noise + bias + leaky-ReLU for upsampling layers: one pass
 // ---------------------------------------------------------------------------------------
+// Workgroup = 16 x 64 output tile of one (image, channel) plane: the 19 x 67 input patch is
+// staged in LDS with coalesced row loads (the odd row length 2W+1 rules out vector loads), each
+// thread then produces 4 vertically adjacent outputs from 7 x 4 LDS values.
+#define BL_TH 16
+#define BL_TW 64
 __global__ void __launch_bounds__(256) blur_noise_act_kernel(
     const float* __restrict__ x, const float* __restrict__ k4, const float* __restrict__ noise,
     const float* __restrict__ nw_ptr, const float* __restrict__ bias, float* __restrict__ y,
-    int batch, int channels, int out_h, int out_w) {
+    int batch, int channels, int out_h, int out_w, int tiles_x, int tiles_y) {
   __shared__ float kf[16];
-  if (threadIdx.x < 16) {
-    const int a = threadIdx.x >> 2, c = threadIdx.x & 3;
-    kf[threadIdx.x] = k4[(3 - a) * 4 + (3 - c)];     // flipped, as upfirdn2d applies it
+  __shared__ float tile[BL_TH + 3][BL_TW + 4];
+  const int tid = threadIdx.x;
+  if (tid < 16) {
+    const int a = tid >> 2, c = tid & 3;
+    kf[tid] = k4[(3 - a) * 4 + (3 - c)];     // flipped, as upfirdn2d applies it
+  }
+  int blk = blockIdx.x;
+  const int tx = blk % tiles_x; blk /= tiles_x;
+  const int ty = blk % tiles_y;
+  const int64_t bc = blk / tiles_y;
+  const int c = (int)(bc % channels);
+  const int64_t b = bc / channels;
+  const int in_h = out_h + 1, in_w = out_w + 1;
+  const int oy0 = ty * BL_TH, ox0 = tx * BL_TW;
+  const float* xp = x + bc * (int64_t)in_h * in_w;
+  // input patch rows oy0-1 .. oy0+BL_TH+1, cols ox0-1 .. ox0+BL_TW+1
+  for (int e = tid; e < (BL_TH + 3) * (BL_TW + 3); e += 256) {
+    const int r = e / (BL_TW + 3), cc = e - r * (BL_TW + 3);
+    const int iy = oy0 - 1 + r, ix = ox0 - 1 + cc;
+    tile[r][cc] = (iy >= 0 && iy < in_h && ix >= 0 && ix < in_w) ? xp[(int64_t)iy * in_w + ix] : 0.f;
   }
   __syncthreads();
-  const int in_h = out_h + 1, in_w = out_w + 1;
-  const int ow4 = out_w >> 2;                         // out_w is a multiple of 4 (>= 8)
-  const int64_t total = (int64_t)batch * channels * out_h * ow4;
-  const float nw = noise ? nw_ptr[0] : 0.f;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    const int xq = (int)(idx % ow4);
-    const int oy = (int)((idx / ow4) % out_h);
-    const int64_t bc = idx / ((int64_t)ow4 * out_h);
-    const int c = (int)(bc % channels);
-    const int64_t b = bc / channels;
-    const int ox = xq << 2;
-    const float* xp = x + bc * (int64_t)in_h * in_w;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  // thread = one output column x 4 consecutive rows: lanes walk x, so LDS reads are conflict-free
+  // and every global access of the wave is one contiguous 256-byte row piece
+  const int lx = tid & 63, ly = (tid >> 6) * 4;
+  const int ox = ox0 + lx;
+  if (ox >= out_w) return;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const int iy = oy + a - 1;
-      if (iy < 0 || iy >= in_h) continue;
-      float rowv[7];
+  for (int r = 0; r < 7; ++r) {
+    float rowv[4];
 #pragma unroll
-      for (int j = 0; j < 7; ++j) {
-        const int ix = ox + j - 1;
-        rowv[j] = (ix >= 0 && ix < in_w) ? xp[(int64_t)iy * in_w + ix] : 0.f;
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) acc[q] += rowv[q + cc] * kf[a * 4 + cc];
-    }
-    float4 o;
-    float* op = &o.x;
-    float4 nz = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (noise) nz = *reinterpret_cast<const float4*>(noise + b * (int64_t)out_h * out_w + (int64_t)oy * out_w + ox);
-    const float* nzp = &nz.x;
-    const float bv = bias ? bias[c] : 0.f;
+    for (int cc = 0; cc < 4; ++cc) rowv[cc] = tile[ly + r][lx + cc];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      float v = acc[q] + nw * nzp[q];
-      if (bias) { v += bv; v = ((v > 0.f) ? v : v * 0.2f) * 1.4142135623730951f; }
-      op[q] = v;
+      const int a = r - q;                    // tap row of output q
+      if (a >= 0 && a < 4) {
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) acc[q] += rowv[cc] * kf[a * 4 + cc];
+      }
     }
-    *reinterpret_cast<float4*>(y + (bc * out_h + oy) * (int64_t)out_w + ox) = o;
+  }
+  const float nw = noise ? nw_ptr[0] : 0.f;
+  const float bv = bias ? bias[c] : 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int oy = oy0 + ly + q;
+    if (oy >= out_h) break;
+    float v = acc[q];
+    if (noise) v += nw * noise[b * (int64_t)out_h * out_w + (int64_t)oy * out_w + ox];
+    if (bias) { v += bv; v = ((v > 0.f) ? v : v * 0.2f) * 1.4142135623730951f; }
+    y[(bc * out_h + oy) * (int64_t)out_w + ox] = v;
   }
 }
 
@@ -470,10 +496,11 @@ extern "C" int rw_blur_noise_act_f32(const float* x, const float* k4, const floa
                                      int channels, int out_h, int out_w, rw_stream_t stream) {
   RW_CHECK_ARG(x && k4 && y && batch > 0 && channels > 0 && out_h > 0 && out_w > 0);
   RW_CHECK_ARG(!noise || noise_w);
-  if (out_w % 4) return RW_ERR_UNSUPPORTED;
-  const int64_t total = (int64_t)batch * channels * out_h * (out_w / 4);
-  hipLaunchKernelGGL(blur_noise_act_kernel, dim3(rw_stream_grid(total, 256)), dim3(256), 0,
-                     rw_s(stream), x, k4, noise, noise_w, bias, y, batch, channels, out_h, out_w);
+  const int tiles_x = (int)rw_cdiv(out_w, BL_TW), tiles_y = (int)rw_cdiv(out_h, BL_TH);
+  const int64_t blocks = (int64_t)batch * channels * tiles_x * tiles_y;
+  if (blocks > 0x7fffffff) return RW_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(blur_noise_act_kernel, dim3((unsigned)blocks), dim3(256), 0, rw_s(stream), x, k4,
+                     noise, noise_w, bias, y, batch, channels, out_h, out_w, tiles_x, tiles_y);
   return RW_LAUNCH_RESULT();
 }
 

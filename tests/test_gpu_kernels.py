@@ -154,13 +154,13 @@ def test_demodulated_conv_matches_oracle(case, impl):
     assert rel(fused, want) < 1e-5
 
 
-@pytest.mark.parametrize('impl', [0, 1, 2, 3])
-@pytest.mark.parametrize('case', CONV_CASES[:9])
+@pytest.mark.parametrize('impl', [0, 1, 2, 3, 4])
+@pytest.mark.parametrize('case', CONV_CASES[:9] + CONV_CASES[11:])
 def test_transposed_conv_matches_oracle(case, impl):
     from rewriting_amd import hip
     from oracle import restatement as R
     b, i, o, h, w = case
-    if impl == 3 and not _halo_ok(case):
+    if impl in (3, 4) and not _halo_ok(case):
         pytest.skip('halo kernel needs W >= 24')
     x, wt, style = _conv_inputs(*case, seed=1)
     s = 1 / math.sqrt(i * 9)
@@ -197,6 +197,15 @@ def test_fused_epilogues_and_streaming_blocks():
     want = R.fused_leaky_relu(R.upfirdn2d(wide, k4, pad=(1, 1)) + nw * n2.view(b, 1, 2 * h, 2 * w), bias)
     got = hip.blur_noise_act(wide.to(DEV), k4.to(DEV), n2.to(DEV), nw.to(DEV), bias.to(DEV))
     assert rel(got, want) < 1e-6
+    for bb, cc, hh, ww in [(1, 3, 4, 4), (2, 5, 20, 72), (1, 2, 130, 136)]:      # partial tiles, asymmetric taps
+        kk = k4.clone()
+        kk[0, 1] += 0.03
+        wd = torch.from_numpy(rs.randn(bb, cc, hh + 1, ww + 1).astype('float32'))
+        bs = torch.from_numpy(rs.randn(cc).astype('float32'))
+        nn = R.noise_rows(bb, hh * ww)
+        want2 = R.fused_leaky_relu(R.upfirdn2d(wd, kk, pad=(1, 1)) + nw * nn.view(bb, 1, hh, ww), bs)
+        got2 = hip.blur_noise_act(wd.to(DEV), kk.to(DEV), nn.to(DEV), nw.to(DEV), bs.to(DEV))
+        assert rel(got2, want2) < 1e-6, (bb, cc, hh, ww)
     wrgb = torch.from_numpy(rs.randn(3, i).astype('float32'))
     brgb = torch.from_numpy(rs.randn(3).astype('float32'))
     skip = torch.from_numpy(rs.randn(b, 3, h, w).astype('float32'))
