@@ -27,6 +27,7 @@ struct ConvProblem {
   const float* style; const float* demod; const float* noise; const float* noise_w; const float* bias;
   int batch, in_ch, out_ch, h, w;   // input tensor
   int ph, pw;                       // positions per image in this problem
+  int yoff, xoff;                   // origin of the position grid: position = (yy + yoff, xx + xoff)
   int oh, ow;                       // output tensor
   int sy, sx, oy0, ox0;             // output pixel = (sy*yy + oy0, sx*xx + ox0)
   int ntaps;
@@ -36,6 +37,14 @@ struct ConvProblem {
 };
 
 #define RW_KC 16
+
+// Up to four problems that share x / y / out_ch (the parity phases of a transposed conv, or the
+// border strips of its halo variant) executed by ONE launch: workgroup -> problem by work0[].
+struct ConvBatch {
+  int n;
+  int work0[5];
+  ConvProblem p[4];
+};
 
 // Block id -> work item so that consecutive work items (the out-channel tiles of one pixel
 // tile, which share the gathered input) sit on ONE XCD's L2.  Bijective for any total.
@@ -47,7 +56,7 @@ __device__ __forceinline__ int rw_xcd_remap(int id, int total) {
 }
 
 template <int TM, int TN, int WGM, int WGN>
-__global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvProblem p) {
+__global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvBatch cb) {
   constexpr int BM = 32 * TM * WGM;
   constexpr int BN = 32 * TN * WGN;
   constexpr int B_ELEMS = RW_KC * BN / 256;
@@ -64,10 +73,16 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvProblem p) {
   const int wm0 = (wave / WGN) * 32 * TM;
   const int wn0 = (wave % WGN) * 32 * TN;
 
+  int work = rw_xcd_remap(blockIdx.x, gridDim.x);
+  int q = 0;
+#pragma unroll
+  for (int j = 1; j < 4; ++j)
+    if (j < cb.n && work >= cb.work0[j]) q = j;
+  work -= cb.work0[q];
+  const ConvProblem& p = cb.p[q];
   const int o_tiles = p.out_ch / BM;
   const int ppi = p.ph * p.pw;
   const int64_t n_total = (int64_t)p.batch * ppi;
-  const int work = rw_xcd_remap(blockIdx.x, gridDim.x);
   const int o0 = (work % o_tiles) * BM;
   const int64_t n0 = (int64_t)(work / o_tiles) * BN;
 
@@ -81,7 +96,8 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvProblem p) {
     gb = (int)(n_mine / ppi);
     const int r = (int)(n_mine - (int64_t)gb * ppi);
     gy = r / p.pw;
-    gx = r - gy * p.pw;
+    gx = r - gy * p.pw + p.xoff;
+    gy += p.yoff;
   }
   const int64_t hw = (int64_t)p.h * p.w;
   const float* xb = p.x + (int64_t)gb * p.in_ch * hw;
@@ -175,7 +191,8 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvProblem p) {
     if (n >= n_total) continue;
     const int ib = (int)(n / ppi);
     const int r0 = (int)(n - (int64_t)ib * ppi);
-    const int yy = r0 / p.pw, xx = r0 - yy * p.pw;
+    const int yq = r0 / p.pw;
+    const int yy = yq + p.yoff, xx = r0 - yq * p.pw + p.xoff;
     const int64_t pix = (int64_t)(p.sy * yy + p.oy0) * p.ow + (p.sx * xx + p.ox0);
     const float nz = p.noise ? nw * p.noise[(int64_t)ib * ohw + pix] : 0.f;
 #pragma unroll
@@ -183,6 +200,193 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvProblem p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int o = o0 + wm0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * frow;
+        float v = acc[a][b][r] * p.w_scale;
+        if (p.demod) v *= p.demod[(int64_t)ib * p.out_ch + o];
+        if (p.noise) v += nz;
+        if (p.act) {
+          v += p.bias[o];
+          v = ((v > 0.f) ? v : v * 0.2f) * 1.4142135623730951f;
+        }
+        p.y[((int64_t)ib * p.out_ch + o) * ohw + pix] = v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Split-K variant for LOW-RESOLUTION layers (4x4 .. 16x16 maps at small batch): there the
+// implicit GEMM has few output tiles (N = B*H*W is a few hundred) but a long K = 9*Cin = 4608,
+// so the tiling above leaves most of the 256 CUs idle behind a handful of long serial K loops.
+// Here a workgroup owns one small (32T x 32T) output tile and its FOUR WAVES SPLIT K: all
+// threads stage a chunk of 4*KW k-values, wave w multiplies k-slice w, and the four partial
+// tiles are summed through LDS (reusing the staging buffers) before wave 0 runs the epilogue.
+// ---------------------------------------------------------------------------------------
+template <int T, int KW>
+__global__ void __launch_bounds__(256) conv_mfma_ksplit_kernel(const ConvBatch cb) {
+  constexpr int BM = 32 * T, BN = 32 * T, KC = 4 * KW;
+  constexpr int B_ELEMS = KC * BN / 256;
+  constexpr int B_KSTEP = 256 / BN;
+  constexpr int A_VEC = KC * BM / 4 / 256;
+  static_assert(KC * BM / 4 % 256 == 0 && 2 * KC * (BM + BN) >= 2 * BM * BN, "tile/chunk shape");
+  __shared__ __attribute__((aligned(16))) float smem[2 * KC * BM + 2 * KC * BN];
+  float(*As)[KC][BM] = reinterpret_cast<float(*)[KC][BM]>(smem);
+  float(*Bs)[KC][BN] = reinterpret_cast<float(*)[KC][BN]>(smem + 2 * KC * BM);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int work = rw_xcd_remap(blockIdx.x, gridDim.x);
+  int q = 0;
+#pragma unroll
+  for (int j = 1; j < 4; ++j)
+    if (j < cb.n && work >= cb.work0[j]) q = j;
+  work -= cb.work0[q];
+  const ConvProblem& p = cb.p[q];
+  const int o_tiles = p.out_ch / BM;
+  const int ppi = p.ph * p.pw;
+  const int64_t n_total = (int64_t)p.batch * ppi;
+  const int o0 = (work % o_tiles) * BM;
+  const int64_t n0 = (int64_t)(work / o_tiles) * BN;
+
+  const int nl = tid % BN;
+  const int kk0 = tid / BN;
+  const int64_t n_mine = n0 + nl;
+  const bool n_ok = n_mine < n_total;
+  int gb = 0, gy = 0, gx = 0;
+  if (n_ok) {
+    gb = (int)(n_mine / ppi);
+    const int r = (int)(n_mine - (int64_t)gb * ppi);
+    gy = r / p.pw;
+    gx = r - gy * p.pw + p.xoff;
+    gy += p.yoff;
+  }
+  const int64_t hw = (int64_t)p.h * p.w;
+  const float* xb = p.x + (int64_t)gb * p.in_ch * hw;
+  const float* sb = p.style ? p.style + (int64_t)gb * p.in_ch : nullptr;
+  const int chunks_per_tap = p.in_ch / KC;
+  const int n_chunks = chunks_per_tap * p.ntaps;
+
+  float breg[B_ELEMS];
+  rw_f32x4 areg[A_VEC];
+  auto gather = [&](int c) {
+    const int t = c % p.ntaps;
+    const int i0 = (c / p.ntaps) * KC;
+    const int iy = gy + rw_tap_off(p.dy_bits, t), ix = gx + rw_tap_off(p.dx_bits, t);
+    const bool ok = n_ok && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
+    const float* src = xb + (int64_t)i0 * hw + (int64_t)(ok ? iy : 0) * p.w + (ok ? ix : 0);
+    const float m = ok ? 1.0f : 0.0f;
+#pragma unroll
+    for (int j = 0; j < B_ELEMS; ++j) {
+      const int kk = kk0 + j * B_KSTEP;
+      float v = src[(int64_t)kk * hw] * m;
+      if (sb) v *= sb[i0 + kk];
+      breg[j] = v;
+    }
+    const float* wrow = p.wp + ((int64_t)t * p.in_ch + i0) * p.out_ch + o0;
+#pragma unroll
+    for (int j = 0; j < A_VEC; ++j) {
+      const int qq = tid + j * 256;
+      const int kk = qq / (BM / 4), o4 = qq % (BM / 4);
+      areg[j] = *reinterpret_cast<const rw_f32x4*>(wrow + (int64_t)kk * p.out_ch + o4 * 4);
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < B_ELEMS; ++j) Bs[buf][kk0 + j * B_KSTEP][nl] = breg[j];
+#pragma unroll
+    for (int j = 0; j < A_VEC; ++j) {
+      const int qq = tid + j * 256;
+      const int kk = qq / (BM / 4), o4 = qq % (BM / 4);
+      *reinterpret_cast<rw_f32x4*>(&As[buf][kk][o4 * 4]) = areg[j];
+    }
+  };
+
+  rw_f32x16 acc[T][T];
+#pragma unroll
+  for (int a = 0; a < T; ++a)
+#pragma unroll
+    for (int b = 0; b < T; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  gather(0);
+  stash(0);
+  __syncthreads();
+  const int frow = lane >> 5, fcol = lane & 31;
+  for (int c = 0; c < n_chunks; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < n_chunks) gather(c + 1);
+#pragma unroll
+    for (int kp = 0; kp < KW / 2; ++kp) {
+      const int kr = wave * KW + 2 * kp + frow;
+      float af[T], bf[T];
+#pragma unroll
+      for (int a = 0; a < T; ++a) af[a] = As[buf][kr][32 * a + fcol];
+#pragma unroll
+      for (int b = 0; b < T; ++b) bf[b] = Bs[buf][kr][32 * b + fcol];
+#pragma unroll
+      for (int a = 0; a < T; ++a)
+#pragma unroll
+        for (int b = 0; b < T; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+    }
+    if (c + 1 < n_chunks) stash(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- cross-wave reduction tree through LDS: (2,3) -> (0,1), then 1 -> 0
+  float* red = smem;
+  auto slot = [&](int a, int b, int r) { return ((a * T + b) * 16 + r) * 64 + lane; };
+  if (wave >= 2) {
+#pragma unroll
+    for (int a = 0; a < T; ++a)
+#pragma unroll
+      for (int b = 0; b < T; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wave - 2) * BM * BN + slot(a, b, r)] = acc[a][b][r];
+  }
+  __syncthreads();
+  if (wave < 2) {
+#pragma unroll
+    for (int a = 0; a < T; ++a)
+#pragma unroll
+      for (int b = 0; b < T; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] += red[wave * BM * BN + slot(a, b, r)];
+  }
+  __syncthreads();
+  if (wave == 1) {
+#pragma unroll
+    for (int a = 0; a < T; ++a)
+#pragma unroll
+      for (int b = 0; b < T; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[slot(a, b, r)] = acc[a][b][r];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int a = 0; a < T; ++a)
+#pragma unroll
+    for (int b = 0; b < T; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] += red[slot(a, b, r)];
+
+  const float nw = p.noise ? p.noise_w[0] : 0.f;
+  const int64_t ohw = (int64_t)p.oh * p.ow;
+#pragma unroll
+  for (int b = 0; b < T; ++b) {
+    const int64_t n = n0 + 32 * b + fcol;
+    if (n >= n_total) continue;
+    const int ib = (int)(n / ppi);
+    const int r0 = (int)(n - (int64_t)ib * ppi);
+    const int yq = r0 / p.pw;
+    const int yy = yq + p.yoff, xx = r0 - yq * p.pw + p.xoff;
+    const int64_t pix = (int64_t)(p.sy * yy + p.oy0) * p.ow + (p.sx * xx + p.ox0);
+    const float nz = p.noise ? nw * p.noise[(int64_t)ib * ohw + pix] : 0.f;
+#pragma unroll
+    for (int a = 0; a < T; ++a) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = o0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * frow;
         float v = acc[a][b][r] * p.w_scale;
         if (p.demod) v *= p.demod[(int64_t)ib * p.out_ch + o];
         if (p.noise) v += nz;
@@ -380,7 +584,7 @@ __global__ void __launch_bounds__(256, 2) conv_halo_kernel(const HaloProblem p) 
 // four accumulator sets (one per phase) and the epilogue writes COMPLETE output rows: even rows
 // as aligned 8-byte (px=0, px=1) pairs, i.e. 256 contiguous bytes per half-wave.
 // Quads y < H, x < W are tiled exactly; output row 2H and column 2W (the "+1" of 2H+1) are a
-// strip of H+W+1 quads computed by conv_up_edge_kernel.
+// strip of H+W+1 quads computed by four strip problems of one batched im2col launch.
 // ---------------------------------------------------------------------------------------
 struct UpProblem {
   const float* x; const float* wp; float* y;
@@ -517,7 +721,7 @@ __global__ void __launch_bounds__(256, 2) conv_up_halo_kernel(const UpProblem p)
 #pragma unroll
   for (int b = 0; b < TN; ++b) {
     const int yy = y0 + wrow0 + b;
-    if (yy >= p.h || xx >= p.w) continue;       // the last output row / column come from the edge kernel
+    if (yy >= p.h || xx >= p.w) continue;       // the last output row / column come from the strip launch
     const bool odd_row = true, odd_col = true;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -540,57 +744,14 @@ __global__ void __launch_bounds__(256, 2) conv_up_halo_kernel(const UpProblem p)
   }
 }
 
-// Output row 2H (quads y' = H: phases (0,0),(0,1), input row H-1 only) and output column 2W
-// (quads x' = W: phases (0,0),(1,0), input column W-1 only).  One thread per (image, out
-// channel, strip quad); ~1/(2*min(H,W)) of the layer's work.
-__global__ void __launch_bounds__(256) conv_up_edge_kernel(const UpProblem p) {
-  const int strip = p.w + 1 + p.h;
-  const int64_t total = (int64_t)p.batch * p.out_ch * strip;
-  const int64_t hw = (int64_t)p.h * p.w;
-  const int oh = 2 * p.h + 1, ow = 2 * p.w + 1;
-  const int64_t slab = (int64_t)p.in_ch * p.out_ch;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    const int e = (int)(idx % strip);
-    const int o = (int)((idx / strip) % p.out_ch);
-    const int ib = (int)(idx / ((int64_t)strip * p.out_ch));
-    const int yy = e <= p.w ? p.h : e - (p.w + 1);
-    const int xx = e <= p.w ? e : p.w;
-    const float* xb = p.x + (int64_t)ib * p.in_ch * hw;
-    const float* st = p.style ? p.style + (int64_t)ib * p.in_ch : nullptr;
-    // input samples for the four shifts (zero outside the image)
-    const bool r0 = yy < p.h, rm = yy >= 1, c0 = xx < p.w, cm = xx >= 1;
-    float a00 = 0.f, a01 = 0.f, a10 = 0.f;
-    for (int i = 0; i < p.in_ch; ++i) {
-      const float* xi = xb + (int64_t)i * hw;
-      const float sv = st ? st[i] : 1.0f;
-      const float x00 = (r0 && c0) ? xi[(int64_t)yy * p.w + xx] * sv : 0.f;
-      const float x0m = (r0 && cm) ? xi[(int64_t)yy * p.w + xx - 1] * sv : 0.f;
-      const float xm0 = (rm && c0) ? xi[(int64_t)(yy - 1) * p.w + xx] * sv : 0.f;
-      const float xmm = (rm && cm) ? xi[(int64_t)(yy - 1) * p.w + xx - 1] * sv : 0.f;
-      const float* w = p.wp + (int64_t)i * p.out_ch + o;
-      a00 += w[0] * x00 + w[slab] * x0m + w[2 * slab] * xm0 + w[3 * slab] * xmm;
-      a01 += w[4 * slab] * x00 + w[5 * slab] * xm0;
-      a10 += w[6 * slab] * x00 + w[7 * slab] * x0m;
-    }
-    float sc = p.w_scale;
-    if (p.demod) sc *= p.demod[(int64_t)ib * p.out_ch + o];
-    float* yo = p.y + ((int64_t)ib * p.out_ch + o) * (int64_t)oh * ow + (int64_t)(2 * yy) * ow + 2 * xx;
-    yo[0] = a00 * sc;
-    if (xx < p.w) yo[1] = a01 * sc;
-    if (yy < p.h) yo[ow] = a10 * sc;
-  }
-}
+static int launch_batch(const ConvProblem* ps, int n, int impl, hipStream_t s);
 
-static int launch_up_halo(const ConvProblem& c, const float* wp_all, hipStream_t s) {
+static int launch_up_halo(const ConvProblem* ps, const float* wp_all, hipStream_t s) {
+  const ConvProblem& c = ps[0];
   UpProblem u;
   u.x = c.x; u.wp = wp_all; u.y = c.y; u.style = c.style; u.demod = c.demod;
   u.batch = c.batch; u.in_ch = c.in_ch; u.out_ch = c.out_ch; u.h = c.h; u.w = c.w; u.w_scale = c.w_scale;
   u.tiles_x = (int)rw_cdiv(c.w, 32);
-  {
-    const int64_t total = (int64_t)c.batch * c.out_ch * (c.w + 1 + c.h);
-    hipLaunchKernelGGL(conv_up_edge_kernel, dim3(rw_stream_grid(total, 256) * 4), dim3(256), 0, s, u);
-  }
   if (c.out_ch % 64 == 0) {
     u.tiles_y = (int)rw_cdiv(c.h, 4);
     const int work = c.batch * u.tiles_x * u.tiles_y * (c.out_ch / 64);
@@ -600,7 +761,14 @@ static int launch_up_halo(const ConvProblem& c, const float* wp_all, hipStream_t
     const int work = c.batch * u.tiles_x * u.tiles_y * (c.out_ch / 32);
     hipLaunchKernelGGL((conv_up_halo_kernel<1, 4, 16>), dim3(work), dim3(256), 0, s, u);
   }
-  return RW_LAUNCH_RESULT();
+  // Output row 2H and column 2W: quads y' = H (phases (0,0),(0,1)) and x' = W, y' < H (phases
+  // (0,0),(1,0)) as four strip problems of ONE batched im2col launch.
+  ConvProblem e[4] = {ps[0], ps[1], ps[0], ps[2]};
+  e[0].ph = 1; e[0].pw = c.w + 1; e[0].yoff = c.h;
+  e[1].ph = 1; e[1].pw = c.w;     e[1].yoff = c.h;
+  e[2].ph = c.h; e[2].pw = 1;     e[2].xoff = c.w;
+  e[3].ph = c.h; e[3].pw = 1;     e[3].xoff = c.w;
+  return launch_batch(e, 4, 0, s);
 }
 
 static bool halo_applicable(const ConvProblem* ps, int n) {
@@ -654,7 +822,8 @@ __global__ void __launch_bounds__(256) conv_direct_kernel(const ConvProblem p) {
     const int r0 = (int)(idx % ppi);
     const int o = (int)((idx / ppi) % p.out_ch);
     const int ib = (int)(idx / ((int64_t)ppi * p.out_ch));
-    const int yy = r0 / p.pw, xx = r0 - yy * p.pw;
+    const int yq = r0 / p.pw;
+    const int yy = yq + p.yoff, xx = r0 - yq * p.pw + p.xoff;
     float acc = 0.f;
     for (int t = 0; t < p.ntaps; ++t) {
       const int iy = yy + rw_tap_off(p.dy_bits, t), ix = xx + rw_tap_off(p.dx_bits, t);
@@ -679,25 +848,56 @@ __global__ void __launch_bounds__(256) conv_direct_kernel(const ConvProblem p) {
   }
 }
 
-static int launch_problem(const ConvProblem& p, int impl, hipStream_t s) {
-  const int64_t n_total = (int64_t)p.batch * p.ph * p.pw;
-  if (n_total == 0) return 0;
+static int64_t std_blocks(const ConvProblem& p, int bm, int bn) {
+  return rw_cdiv((int64_t)p.batch * p.ph * p.pw, bn) * (p.out_ch / bm);
+}
+
+// impl: 1 = direct VALU kernel, 5 = im2col MFMA without split-K, otherwise im2col MFMA with the
+// split-K variant chosen automatically for launches that would leave most CUs idle.
+static int launch_batch(const ConvProblem* ps, int n, int impl, hipStream_t s) {
   if (impl == 1) {
-    const int64_t total = n_total * p.out_ch;
-    hipLaunchKernelGGL(conv_direct_kernel, dim3(rw_stream_grid(total, 256) * 4), dim3(256), 0, s, p);
+    for (int q = 0; q < n; ++q) {
+      const int64_t total = (int64_t)ps[q].batch * ps[q].ph * ps[q].pw * ps[q].out_ch;
+      if (total == 0) continue;
+      hipLaunchKernelGGL(conv_direct_kernel, dim3(rw_stream_grid(total, 256) * 4), dim3(256), 0, s, ps[q]);
+    }
     return RW_LAUNCH_RESULT();
   }
-  if (p.in_ch % RW_KC || p.out_ch % 32) return RW_ERR_UNSUPPORTED;
-  if (p.out_ch % 128 == 0) {
-    const int64_t grid = rw_cdiv(n_total, 128) * (p.out_ch / 128);
-    hipLaunchKernelGGL((conv_mfma_kernel<2, 2, 2, 2>), dim3((unsigned)grid), dim3(256), 0, s, p);
-  } else if (p.out_ch % 64 == 0) {
-    const int64_t grid = rw_cdiv(n_total, 256) * (p.out_ch / 64);
-    hipLaunchKernelGGL((conv_mfma_kernel<2, 2, 1, 4>), dim3((unsigned)grid), dim3(256), 0, s, p);
-  } else {
-    const int64_t grid = rw_cdiv(n_total, 256) * (p.out_ch / 32);
-    hipLaunchKernelGGL((conv_mfma_kernel<1, 2, 1, 4>), dim3((unsigned)grid), dim3(256), 0, s, p);
+  const ConvProblem& c = ps[0];
+  if (c.in_ch % RW_KC || c.out_ch % 32) return RW_ERR_UNSUPPORTED;
+  int bm, bn;
+  if (c.out_ch % 128 == 0) { bm = 128; bn = 128; }
+  else if (c.out_ch % 64 == 0) { bm = 64; bn = 256; }
+  else { bm = 32; bn = 256; }
+  int64_t blocks = 0, blocks64 = 0;
+  for (int q = 0; q < n; ++q) {
+    blocks += std_blocks(ps[q], bm, bn);
+    if (c.out_ch % 64 == 0) blocks64 += std_blocks(ps[q], 64, 64);
   }
+  ConvBatch cb;
+  cb.n = n;
+  int ksplit = 0;   // 0 = off, 1 = 32x32 tiles (chunks of 64 k), 2 = 64x64 tiles (chunks of 32 k)
+  if (impl != 5 && blocks < 192) {
+    if (c.out_ch % 64 == 0 && c.in_ch % 32 == 0 && blocks64 >= 128) ksplit = 2;
+    else if (c.in_ch % 64 == 0) ksplit = 1;
+    else if (c.out_ch % 64 == 0 && c.in_ch % 32 == 0) ksplit = 2;
+  }
+  if (ksplit) { bm = bn = (ksplit == 2) ? 64 : 32; }
+  int64_t work = 0;
+  for (int q = 0; q < 4; ++q) {
+    cb.p[q] = ps[q < n ? q : 0];
+    cb.work0[q] = (int)work;
+    if (q < n) work += std_blocks(ps[q], bm, bn);
+  }
+  cb.work0[4] = (int)work;
+  if (work == 0) return 0;
+  if (work > 0x7fffffff) return RW_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)work), block(256);
+  if (ksplit == 2) hipLaunchKernelGGL((conv_mfma_ksplit_kernel<2, 8>), grid, block, 0, s, cb);
+  else if (ksplit == 1) hipLaunchKernelGGL((conv_mfma_ksplit_kernel<1, 16>), grid, block, 0, s, cb);
+  else if (bm == 128) hipLaunchKernelGGL((conv_mfma_kernel<2, 2, 2, 2>), grid, block, 0, s, cb);
+  else if (bm == 64) hipLaunchKernelGGL((conv_mfma_kernel<2, 2, 1, 4>), grid, block, 0, s, cb);
+  else hipLaunchKernelGGL((conv_mfma_kernel<1, 2, 1, 4>), grid, block, 0, s, cb);
   return RW_LAUNCH_RESULT();
 }
 
@@ -714,6 +914,7 @@ static void fill_common(ConvProblem& p, const float* x, const float* wp, float* 
   p.batch = batch; p.in_ch = in_ch; p.out_ch = out_ch; p.h = h; p.w = w;
   p.w_scale = w_scale;
   p.dy_bits = 0; p.dx_bits = 0;
+  p.yoff = 0; p.xoff = 0;
 }
 
 static void set_tap(ConvProblem& p, int t, int dy, int dx) {
@@ -733,7 +934,7 @@ extern "C" int rw_conv3x3_f32(const float* x, const float* wp, float* y, int bat
   for (int t = 0; t < 9; ++t) set_tap(p, t, t / 3 - 1, t % 3 - 1);
   if (impl == 3 && !halo_applicable(&p, 1)) return RW_ERR_UNSUPPORTED;
   if (impl == 3 || (impl == 0 && halo_applicable(&p, 1))) return launch_halo(&p, 1, rw_s(stream));
-  return launch_problem(p, impl == 2 ? 0 : impl, rw_s(stream));
+  return launch_batch(&p, 1, impl == 2 ? 0 : impl, rw_s(stream));
 }
 
 extern "C" int rw_conv_transpose3x3s2_f32(const float* x, const float* wp, float* y, int batch,
@@ -761,10 +962,6 @@ extern "C" int rw_conv_transpose3x3s2_f32(const float* x, const float* wp, float
   }
   if ((impl == 3 || impl == 4) && !halo_applicable(ps, 4)) return RW_ERR_UNSUPPORTED;
   if (impl == 4) return launch_halo(ps, 4, rw_s(stream));         // per-phase halo tiles (kept for A/B)
-  if (impl == 3 || (impl == 0 && halo_applicable(ps, 4))) return launch_up_halo(ps[0], wp, rw_s(stream));
-  for (int phase = 0; phase < 4; ++phase) {
-    const int rc = launch_problem(ps[phase], impl == 2 ? 0 : impl, rw_s(stream));
-    if (rc) return rc;
-  }
-  return 0;
+  if (impl == 3 || (impl == 0 && halo_applicable(ps, 4))) return launch_up_halo(ps, wp, rw_s(stream));
+  return launch_batch(ps, 4, impl == 2 ? 0 : impl, rw_s(stream));
 }

@@ -88,7 +88,7 @@ def fusion_enabled():
     return os.environ.get('RW_FUSE', '1') != '0'
 
 
-_CONV_IMPLS = {'auto': 0, 'mfma': 0, 'direct': 1, 'generic': 2, 'halo': 3}
+_CONV_IMPLS = {'auto': 0, 'mfma': 0, 'direct': 1, 'generic': 2, 'halo': 3, 'nosplitk': 5}
 
 
 def conv_impl():

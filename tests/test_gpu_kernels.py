@@ -114,6 +114,7 @@ CONV_CASES = [  # (batch, cin, cout, h, w)
     (2, 512, 512, 4, 4), (3, 512, 512, 8, 8), (1, 512, 512, 32, 32), (2, 512, 256, 16, 16),
     (1, 256, 128, 8, 12), (2, 128, 64, 16, 16), (1, 64, 32, 32, 32), (1, 32, 32, 20, 36),
     (2, 128, 64, 40, 64), (5, 16, 32, 3, 5), (1, 48, 96, 7, 9), (2, 64, 128, 13, 29), (1, 32, 64, 70, 33),
+    (1, 64, 64, 8, 8), (3, 128, 32, 4, 6), (16, 512, 512, 4, 4),
 ]
 
 
@@ -129,7 +130,7 @@ def _halo_ok(case):
     return case[4] >= 24 and case[1] % 16 == 0
 
 
-@pytest.mark.parametrize('impl', [0, 1, 2, 3])
+@pytest.mark.parametrize('impl', [0, 1, 2, 3, 5])
 @pytest.mark.parametrize('case', CONV_CASES)
 def test_demodulated_conv_matches_oracle(case, impl):
     """conv2d(x, s*W, pad 1) * demod vs the oracle (DemodulatedConv2dF, models.py:313-329);
@@ -154,7 +155,7 @@ def test_demodulated_conv_matches_oracle(case, impl):
     assert rel(fused, want) < 1e-5
 
 
-@pytest.mark.parametrize('impl', [0, 1, 2, 3, 4])
+@pytest.mark.parametrize('impl', [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize('case', CONV_CASES[:9] + CONV_CASES[11:])
 def test_transposed_conv_matches_oracle(case, impl):
     from rewriting_amd import hip
