@@ -51,47 +51,92 @@ def conv_flops(model_size, channel_multiplier=2):
     return total
 
 
+def conv_kernel_name(out_ch, in_ch, width, upsample):
+    """Which kernel rw_conv3x3_f32 / rw_conv_transpose3x3s2_f32 dispatch to (impl 0), mirroring
+    launch_halo / launch_up_halo / launch_batch in rewriting_amd/csrc/rw_conv.hip."""
+    halo = width >= 24 and in_ch % 16 == 0 and in_ch <= 1024 and out_ch % 32 == 0
+    if upsample:
+        if halo:
+            return 'conv_up_halo_kernel<2, 2, 16>' if out_ch % 64 == 0 else 'conv_up_halo_kernel<1, 4, 16>'
+        return 'conv_mfma(+ksplit)_kernel [4 phases]'
+    if halo:
+        if out_ch % 128 == 0:
+            return 'conv_halo_kernel<2, 2, 2, 2, 16>'
+        return 'conv_halo_kernel<2, 2, 1, 4, 16>' if out_ch % 64 == 0 else 'conv_halo_kernel<1, 4, 1, 4, 8>'
+    return 'conv_mfma(+ksplit)_kernel'
+
+
 class ConvTimer:
-    """HIP events around every implicit-GEMM conv launch, on the stream they are launched on
-    (torch's current stream).  Installed for the timed region only."""
+    """HIP events around every implicit-GEMM conv call, on the stream the kernels are launched on
+    (torch's current stream), attributed to the kernel the call dispatches to.  Installed for
+    the timed region only."""
 
     def __init__(self):
-        self.events = []
-        self.flops = 0.0
-        self.launches = 0
+        self.calls = []          # (kernel name, start event, end event, flops)
 
     def install(self):
         from rewriting_amd import hip
         self._orig = (hip.conv3x3, hip.conv_transpose3x3s2)
         timer = self
 
-        def wrap(fn, kernels_per_call):
+        def wrap(fn, upsample):
             def inner(x, wp, out_ch, w_scale, *a, **k):
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record()
                 y = fn(x, wp, out_ch, w_scale, *a, **k)
                 e.record()
                 b, i, h, w = x.shape
-                timer.events.append((s, e))
-                timer.flops += 2.0 * 9 * i * out_ch * h * w * b
-                timer.launches += kernels_per_call
+                timer.calls.append((conv_kernel_name(out_ch, i, w, upsample), s, e,
+                                    2.0 * 9 * i * out_ch * h * w * b))
                 return y
             return inner
-        hip.conv3x3 = wrap(self._orig[0], 1)
-        hip.conv_transpose3x3s2 = wrap(self._orig[1], 4)
+        hip.conv3x3 = wrap(self._orig[0], False)
+        hip.conv_transpose3x3s2 = wrap(self._orig[1], True)
 
     def remove(self):
         from rewriting_amd import hip
         hip.conv3x3, hip.conv_transpose3x3s2 = self._orig
 
     def result(self):
-        ms = sum(s.elapsed_time(e) for s, e in self.events)
-        achieved = self.flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        return dict(bound='mfma', achieved=round(achieved, 2), peak=FP32_MFMA_PEAK_TFLOPS,
-                    unit='TFLOP/s', frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
-                    kernel='conv_mfma_kernel', launches=self.launches,
-                    avg_launch_us=round(ms * 1e3 / max(self.launches, 1), 2),
-                    flops_per_launch=round(self.flops / max(self.launches, 1)))
+        per = {}
+        for name, s, e, fl in self.calls:
+            d = per.setdefault(name, dict(ms=0.0, flops=0.0, launches=0))
+            d['ms'] += s.elapsed_time(e)
+            d['flops'] += fl
+            d['launches'] += 1
+        if not per:
+            return None
+        dom = max(per, key=lambda n: per[n]['ms'])
+        d = per[dom]
+        achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
+        tot_ms = sum(v['ms'] for v in per.values())
+        tot_fl = sum(v['flops'] for v in per.values())
+        out = dict(bound='mfma', achieved=round(achieved, 2), peak=FP32_MFMA_PEAK_TFLOPS,
+                   unit='TFLOP/s', frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
+                   kernel=dom, launches=d['launches'],
+                   avg_launch_us=round(d['ms'] * 1e3 / d['launches'], 2),
+                   flops_per_launch=round(d['flops'] / d['launches']),
+                   all_conv_kernels=dict(achieved=round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
+                                         frac=round(tot_fl / (tot_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                                         ms_per_step=None))
+        out['_tot_ms'] = tot_ms
+        return out
+
+
+def attach_pmc_traffic(roof, workload, batch):
+    """`traffic` (HBM bytes per launch of the roofline kernel) comes from separate rocprofv3 --pmc
+    passes (FETCH_SIZE, WRITE_SIZE; corrected as MI355X_MICROARCH.md prescribes), whose summary is
+    committed under profiles/.  Filled in only if that summary matches this kernel and workload."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    if not os.path.isfile(path):
+        return
+    with open(path) as f:
+        rec = json.load(f)
+    for r in rec.get('entries', []):
+        if r.get('kernel') == roof['kernel'] and r.get('workload') == workload and r.get('batch') == batch:
+            roof['traffic'] = r['hbm_bytes_per_launch']
+            roof['traffic_source'] = r.get('source')
+            roof['algorithmic_bytes_per_launch'] = r.get('algorithmic_bytes_per_launch')
 
 
 def build_generator(size, device):
@@ -168,9 +213,14 @@ def run_forward(args, rank, world, device, size, batch, name):
                config=dict(workload=name, batch_per_gpu=batch, truncation=0.5, mconv='seq',
                            weights='synthetic seed 0', parallelism='seeds partitioned per rank, no collective',
                            conv_gflop_per_image=round(conv_flops(size) / 1e9, 2)))
-    out['roofline'] = timer.result()
-    out['roofline']['hbm_algorithmic_gbs'] = round(
+    roof = timer.result()
+    tot_ms = roof.pop('_tot_ms')
+    roof['all_conv_kernels']['ms_per_step'] = round(tot_ms / args.steps, 3)
+    # whole-forward algorithmic HBM rate (SURVEY.md 8d bytes/img), for the second roof
+    roof['forward_hbm_algorithmic_gbs'] = round(
         {256: 276.3e6, 1024: 1217.7e6}.get(size, 0) * batch * world * args.steps / dt / 1e9, 1)
+    attach_pmc_traffic(roof, 'ffhq%d' % size, batch)
+    out['roofline'] = roof
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline_forward(size)
     return out
