@@ -529,16 +529,22 @@ __global__ void __launch_bounds__(256, 2) conv_halo_kernel(const HaloProblem p) 
       const bool more = ni0 < p.in_ch;
       const int dy = rw_tap_off(d.dy_bits, t), dx = rw_tap_off(d.dx_bits, t);
       const float* xs = &Xs[buf][frow][wrow0 + dy + 1][fcol + dx + 1];
+      float bf[TN], bnext[TN];
+#pragma unroll
+      for (int b = 0; b < TN; ++b) bf[b] = xs[b * XW];
 #pragma unroll
       for (int kp = 0; kp < KP; ++kp) {
-        float bf[TN];
+        if (kp + 1 < KP) {                      // B fragments one k-pair ahead of the MFMAs that use them
 #pragma unroll
-        for (int b = 0; b < TN; ++b) bf[b] = xs[(2 * kp) * XH * XW + b * XW];
+          for (int b = 0; b < TN; ++b) bnext[b] = xs[(2 * kp + 2) * XH * XW + b * XW];
+        }
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
           for (int b = 0; b < TN; ++b)
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[kp][a], bf[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+        for (int b = 0; b < TN; ++b) bf[b] = bnext[b];
         // this k-pair's weight registers are free again: refill them for the next tap, KP-1 steps
         // (>= 1.5k cycles of MFMA) ahead of their use
         if (more) aload1(kp, nt, ni0);

@@ -428,7 +428,7 @@ extern "C" int rw_pack_conv_weight_f32(const float* w, float* wp, int out_ch, in
 // ---------------------------------------------------------------------------------------
 // Workgroup = 16 x 64 output tile of one (image, channel) plane: the 19 x 67 input patch is
 // staged in LDS with coalesced row loads (the odd row length 2W+1 rules out vector loads), each
-// thread then produces 4 vertically adjacent outputs from 7 x 4 LDS values.
+// thread then produces 4 horizontally adjacent outputs and stores them as one 16-byte vector.
 #define BL_TH 16
 #define BL_TW 64
 __global__ void __launch_bounds__(256) blur_noise_act_kernel(
@@ -436,7 +436,7 @@ __global__ void __launch_bounds__(256) blur_noise_act_kernel(
     const float* __restrict__ nw_ptr, const float* __restrict__ bias, float* __restrict__ y,
     int batch, int channels, int out_h, int out_w, int tiles_x, int tiles_y) {
   __shared__ float kf[16];
-  __shared__ float tile[BL_TH + 3][BL_TW + 4];
+  __shared__ __attribute__((aligned(16))) float tile[BL_TH + 3][BL_TW + 4];
   const int tid = threadIdx.x;
   if (tid < 16) {
     const int a = tid >> 2, c = tid & 3;
@@ -458,36 +458,50 @@ __global__ void __launch_bounds__(256) blur_noise_act_kernel(
     tile[r][cc] = (iy >= 0 && iy < in_h && ix >= 0 && ix < in_w) ? xp[(int64_t)iy * in_w + ix] : 0.f;
   }
   __syncthreads();
-  // thread = one output column x 4 consecutive rows: lanes walk x, so LDS reads are conflict-free
-  // and every global access of the wave is one contiguous 256-byte row piece
-  const int lx = tid & 63, ly = (tid >> 6) * 4;
-  const int ox = ox0 + lx;
-  if (ox >= out_w) return;
+  // thread = 4 consecutive outputs of one row: two 16-byte LDS reads per tap row (8 per thread), one
+  // 16-byte noise load and one 16-byte store -- the store tail is instruction-issue bound, so wide
+  // stores matter more than the (mild, 2-way) LDS bank overlap of this mapping
+  const int lx = (tid & 15) * 4, ly = tid >> 4;
+  const int ox = ox0 + lx, oy = oy0 + ly;
+  if (oy >= out_h || ox >= out_w) return;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int r = 0; r < 7; ++r) {
-    float rowv[4];
+  for (int a = 0; a < 4; ++a) {
+    const float4 lo = *reinterpret_cast<const float4*>(&tile[ly + a][lx]);
+    const float4 hi = *reinterpret_cast<const float4*>(&tile[ly + a][lx + 4]);
+    const float rowv[7] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z};
 #pragma unroll
-    for (int cc = 0; cc < 4; ++cc) rowv[cc] = tile[ly + r][lx + cc];
+    for (int q = 0; q < 4; ++q)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int a = r - q;                    // tap row of output q
-      if (a >= 0 && a < 4) {
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) acc[q] += rowv[cc] * kf[a * 4 + cc];
-      }
-    }
+      for (int cc = 0; cc < 4; ++cc) acc[q] += rowv[q + cc] * kf[a * 4 + cc];
   }
   const float nw = noise ? nw_ptr[0] : 0.f;
   const float bv = bias ? bias[c] : 0.f;
+  const bool full = (out_w % 4 == 0);           // then ox + 3 < out_w and every row start is 16-byte aligned
+  float nzv[4] = {0.f, 0.f, 0.f, 0.f};
+  const int64_t noff = b * (int64_t)out_h * out_w + (int64_t)oy * out_w + ox;
+  if (noise) {
+    if (full) {
+      const float4 nz = *reinterpret_cast<const float4*>(noise + noff);
+      nzv[0] = nz.x; nzv[1] = nz.y; nzv[2] = nz.z; nzv[3] = nz.w;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) if (ox + q < out_w) nzv[q] = noise[noff + q];
+    }
+  }
+  float res[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const int oy = oy0 + ly + q;
-    if (oy >= out_h) break;
-    float v = acc[q];
-    if (noise) v += nw * noise[b * (int64_t)out_h * out_w + (int64_t)oy * out_w + ox];
+    float v = acc[q] + nw * nzv[q];
     if (bias) { v += bv; v = ((v > 0.f) ? v : v * 0.2f) * 1.4142135623730951f; }
-    y[(bc * out_h + oy) * (int64_t)out_w + ox] = v;
+    res[q] = v;
+  }
+  float* yo = y + (bc * out_h + oy) * (int64_t)out_w + ox;
+  if (full) {
+    *reinterpret_cast<float4*>(yo) = make_float4(res[0], res[1], res[2], res[3]);
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) if (ox + q < out_w) yo[q] = res[q];
   }
 }
 

@@ -129,9 +129,24 @@ class ProgressiveGanRewriter(object):
                 if on_gpu:
                     return acts          # NCHW straight into the MFMA kernel
                 return acts.permute(0, 2, 3, 1).reshape(-1, acts.shape[1])
-            r2m = tally.tally_second_moment(key_rows, self.zds, cachefile=self.rf('r2m.npz'),
-                                            shard=parallel.shard(), nchw=on_gpu)
+            if on_gpu and self._noise_periodic():
+                # ten reference batches of 10 per launch; each seed keeps its reference noise row
+                from ..utils.stylegan2.models import noise_batch_period
+                with noise_batch_period(10):
+                    r2m = tally.tally_second_moment(key_rows, self.zds, batch_size=self.sweep_batch,
+                                                    cachefile=self.rf('r2m.npz'),
+                                                    shard=parallel.shard(), nchw=True)
+            else:
+                r2m = tally.tally_second_moment(key_rows, self.zds, cachefile=self.rf('r2m.npz'),
+                                                shard=parallel.shard(), nchw=on_gpu)
             return r2m.moment()
+
+    sweep_batch = 100     # seeds per launch of the statistics sweeps on the GPU (multiple of 10)
+
+    def _noise_periodic(self):
+        """Large sweep launches are only equivalent to the reference's batches of 10 if the dataset
+        length keeps every launch a multiple of 10 (the last reference batch may be ragged)."""
+        return False
 
     def square_scales_for_units(self):
         if self.unit_rs is None:
@@ -143,8 +158,15 @@ class ProgressiveGanRewriter(object):
                     if on_gpu:
                         return acts
                     return acts.permute(0, 2, 3, 1).reshape(-1, acts.shape[1]).pow(2)
-                self.unit_rs = tally.tally_mean(squared_units, self.zds, cachefile=self.rf('unit_rs.npz'),
-                                                nchw=on_gpu, square_input=on_gpu).mean()
+                if on_gpu and self._noise_periodic():
+                    from ..utils.stylegan2.models import noise_batch_period
+                    with noise_batch_period(10):
+                        rv = tally.tally_mean(squared_units, self.zds, batch_size=self.sweep_batch,
+                                              cachefile=self.rf('unit_rs.npz'), nchw=True, square_input=True)
+                else:
+                    rv = tally.tally_mean(squared_units, self.zds, cachefile=self.rf('unit_rs.npz'),
+                                          nchw=on_gpu, square_input=on_gpu)
+                self.unit_rs = rv.mean()
         return self.unit_rs
 
     def covariance_adjusted_query_key(self, k):
@@ -470,6 +492,10 @@ class SeqStyleGanRewriter(ProgressiveGanRewriter):
 
     def target_acts(self, target_out):
         return target_out.fmap
+
+    def _noise_periodic(self):
+        n = len(self.zds)
+        return n % 10 == 0 or n < 10
 
     def merge_target_output(self, target_out, new_acts, crop_bounds):
         merged = type(target_out)({k: d.detach() for k, d in target_out.items()})

@@ -68,7 +68,36 @@ def reference_noise(batch, hw, device):
         host = np.random.RandomState(0).randn(n).astype('float32')
         stream = torch.from_numpy(host).to(device)
         _noise_streams[key] = stream
+    period = _noise_period[0]
+    if period and batch > period:
+        # Several reference-sized batches run as one launch: image j takes the noise row it would have
+        # had in its own batch of `period` (row j mod period), see noise_batch_period().
+        if batch % period:
+            raise ValueError('batch %d is not a multiple of the noise period %d' % (batch, period))
+        rows = reference_noise(period, hw, device)
+        return rows.repeat(batch // period, 1)
     return stream[:need].view(batch, hw)
+
+
+_noise_period = [0]
+
+
+class noise_batch_period:
+    """Context manager.  The reference's noise depends on an image's ROW WITHIN ITS BATCH (quirk Q1),
+    and its statistics sweeps use batches of 10 (utils/tally.py:631-647).  Inside this context a
+    batch of k*period images is treated as k consecutive reference batches, so a sweep can run
+    large launches and still give every seed exactly the noise the reference gives it."""
+
+    def __init__(self, period):
+        self.period = int(period)
+
+    def __enter__(self):
+        self.old = _noise_period[0]
+        _noise_period[0] = self.period
+        return self
+
+    def __exit__(self, *exc):
+        _noise_period[0] = self.old
 
 
 def make_kernel(k):
