@@ -177,8 +177,9 @@ int rw_channel_sums_f32(const float* a, float* sums, int64_t rows, int channels,
 
 /* ---------------------------------------------------------------------------------------
  * The rank-constrained solve -- replaces the body of ProgressiveGanRewriter.insert
- * (rewrite/ganrewrite.py:254-298) for a stride-1 SeqStyleGAN2 layer: forward of
- * target_model, L1 loss, backward to dconv.weight, torch.optim.Adam step, projection.
+ * (rewrite/ganrewrite.py:254-298) and of linear_insert (:201-252) for a SeqStyleGAN2 layer
+ * (stride-1 or upsampling): forward of target_model, L1 loss, backward to dconv.weight,
+ * torch.optim.Adam step, projection.
  * Arithmetic: SURVEY.md section 10.
  * ------------------------------------------------------------------------------------- */
 
@@ -213,6 +214,15 @@ typedef struct rw_solve_problem {
   float beta1, beta2, eps, w_scale;
   int low_rank_gradient;
   float one_minus_beta1, one_minus_beta2;   /* (1 - beta) evaluated in double on the host */
+  /* upsampling (odd) layers: target = conv_transpose2d stride 2 -> blur -> noise -> activate
+   * (utils/stylegan2/models.py:315-316,277-281).  key is (in_ch,h,w); val is (out_ch,2h,2w);
+   * noise is (2h*2w); conv/gd rows are padded counts of the (2h+1)x(2w+1) pre-blur map. */
+  int upsample;
+  const float* blur_k;   /* (4,4) FIR buffer of the layer's BlurF, required iff upsample */
+  /* linear_insert (rewrite/ganrewrite.py:201-252): optimise Lambda (out_ch,rank,3,3) with
+   * weight = ortho(=W0) + Lambda.context; exp_avg / exp_avg_sq then hold Lambda's Adam state. */
+  int linear_insert;
+  float* lambda;
 } rw_solve_problem;
 
 int rw_solve_ksplit(int out_ch, int in_ch, int h, int w);

@@ -229,6 +229,52 @@ def golden_rewriter(ref, name, size, layernum, maskfile, nseeds, mode='edit',
     save(name, **arrays)
 
 
+def golden_rewriter_extras(ref, name, size, layernum, maskfile, nseeds):
+    """Alternate key methods (svd / mean), the UI query key, rank-3 zca context, and linear_insert."""
+    g = build_stylegan(ref, size, 0.5)
+    zds = ref.zdataset.z_dataset_for_model(g, size=nseeds)
+    with open(os.path.join(MASKS, maskfile)) as f:
+        request = remap_request(json.load(f), nseeds)
+
+    def fresh(**kw):
+        return ref.ganrewrite.SeqStyleGanRewriter(g, zds, layernum, cachedir=None, key_method='zca', **kw)
+    gw = fresh()
+    arrays = dict(meta=json.dumps(dict(size=size, layernum=layernum, mask=maskfile, nseeds=nseeds,
+                                       weight_seed=0, truncation=0.5)))
+    keys = request['key']
+    arrays['mkey_svd'] = gw.multi_key_from_selection(keys, rank=2, key_method='svd').numpy()
+    arrays['mkey_mean'] = gw.multi_key_from_selection(keys, rank=1, key_method='mean').numpy()
+    arrays['mkey_zca_r3'] = gw.multi_key_from_selection(keys, rank=3).numpy()
+    arrays['query_key'] = gw.query_key_from_selection(*keys[0]).numpy()
+    o_imgnum, o_mask = request['object']
+    p_imgnum, p_mask = request['paste']
+    obj_acts, _, obj_area, _ = gw.object_from_selection(o_imgnum, o_mask)
+    goal_in, goal_out, _, _ = gw.paste_from_selection(p_imgnum, p_mask, obj_acts, obj_area)
+    mkey = gw.multi_key_from_selection(keys, rank=1)
+    arrays['mkey'] = mkey.numpy()
+    arrays['goal_in_fmap'] = goal_in.fmap.detach().numpy()
+    arrays['goal_in_style'] = goal_in.style.detach().numpy()
+    arrays['goal_out_fmap'] = goal_out.fmap.detach().numpy()
+    W0 = gw.target_weights().detach().clone()
+    for niter in (1, 11):
+        gwl = fresh(use_linear_insert=True)
+        losses = []
+        gwl.insert(goal_in, goal_out, mkey, niter=niter, lr=0.05,
+                   update_callback=lambda it, loss: losses.append(loss.item()))
+        dW = (gwl.target_weights().detach() - W0)[0]
+        arrays['lin_dW_%d_sub' % niter], arrays['lin_dW_%d_norm' % niter] = sub(dW, 8192)
+        arrays['lin_dW_%d_cos' % niter] = torch.einsum('oiyx,di->odyx', dW, mkey).numpy()
+        arrays['lin_losses_%d' % niter] = numpy.array(losses)
+    # rank-3 edit, a few steps
+    mkey3 = torch.from_numpy(arrays['mkey_zca_r3'])
+    gw3 = fresh()
+    gw3.insert(goal_in, goal_out, mkey3, niter=11, piter=10, lr=0.05)
+    dW = (gw3.target_weights().detach() - W0)[0]
+    arrays['r3_dW_11_sub'], arrays['r3_dW_11_norm'] = sub(dW, 8192)
+    arrays['r3_dW_11_cos'] = torch.einsum('oiyx,di->odyx', dW, mkey3).numpy()
+    save(name, **arrays)
+
+
 def golden_proggan(ref, name, resolution, layernum, maskfile, nseeds):
     g = ref.proggan.ProgressiveGenerator(resolution=resolution)
     synthetic.randomize_(g, seed=0, kind='proggan')
@@ -282,6 +328,10 @@ def main():
         'gen_s64_cm1': lambda: golden_generator(ref, 'gen_s64_cm1', 64, 1.0, 1, 2),
         'rw_s64_l8_horsehat': lambda: golden_rewriter(
             ref, 'rw_s64_l8_horsehat', 64, 8, 'recorded_horse_hat.json', 60),
+        'rw_s64_l7_horsehat': lambda: golden_rewriter(
+            ref, 'rw_s64_l7_horsehat', 64, 7, 'recorded_horse_hat.json', 60),
+        'rw_s64_l8_extras': lambda: golden_rewriter_extras(
+            ref, 'rw_s64_l8_extras', 64, 8, 'recorded_horse_hat.json', 60),
         'rw_s64_l6_erase': lambda: golden_rewriter(
             ref, 'rw_s64_l6_erase', 64, 6, 'multikey_markandbottom.json', 20, mode='erase',
             low_rank_gradient=True),

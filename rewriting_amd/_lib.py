@@ -35,6 +35,7 @@ class SolveProblem(Structure):
         ('ksplit', c_int), ('beta1', c_float), ('beta2', c_float), ('eps', c_float),
         ('w_scale', c_float), ('low_rank_gradient', c_int),
         ('one_minus_beta1', c_float), ('one_minus_beta2', c_float),
+        ('upsample', c_int), ('blur_k', c_void_p), ('linear_insert', c_int), ('lambda_', c_void_p),
     ]
 
 

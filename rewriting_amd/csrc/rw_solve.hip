@@ -22,6 +22,30 @@
 
 static inline int sv_pp(int p) { return (int)rw_cdiv(p, 64) * 64; }
 
+// Number of positions of the map the convolution writes: h*w for the stride-1 layer, the
+// (2h+1) x (2w+1) pre-blur map for an upsampling layer (conv_transpose2d stride 2,
+// utils/stylegan2/models.py:315-316).
+__host__ __device__ static inline int sv_conv_w(const rw_solve_problem& p) { return p.upsample ? 2 * p.w + 1 : p.w; }
+__host__ __device__ static inline int sv_conv_h(const rw_solve_problem& p) { return p.upsample ? 2 * p.h + 1 : p.h; }
+
+// xcol[k = (i, tap)][position]: the input sample that weight tap (ky,kx) of channel i multiplies
+// at conv-output position (Y, X); zero outside the crop (quirk Q2) and, for the transposed conv,
+// where the parity of (Y-ky, X-kx) does not land on an input sample.
+__device__ __forceinline__ float sv_gather(const rw_solve_problem& p, const float* key_i, int tap,
+                                           int Y, int X) {
+  const int ky = tap / 3, kx = tap - 3 * ky;
+  int iy, ix;
+  if (p.upsample) {
+    const int ty = Y - ky, tx = X - kx;
+    if ((ty | tx) < 0 || ((ty | tx) & 1)) return 0.f;
+    iy = ty >> 1; ix = tx >> 1;
+  } else {
+    iy = Y + ky - 1; ix = X + kx - 1;
+  }
+  if (iy < 0 || iy >= p.h || ix < 0 || ix >= p.w) return 0.f;
+  return key_i[iy * p.w + ix];
+}
+
 extern "C" int rw_solve_ksplit(int out_ch, int in_ch, int h, int w) {
   const int blocks = (out_ch / SV_BM) * (int)rw_cdiv((int64_t)h * w, SV_BN);
   const int chunks = 9 * in_ch / SV_KC;
@@ -44,7 +68,8 @@ __global__ void __launch_bounds__(256) solve_fwd_kernel(const rw_solve_problem p
   const int o0 = blockIdx.x * SV_BM;
   const int n0 = blockIdx.y * SV_BN;
   const int ks = blockIdx.z;
-  const int P = p.h * p.w;
+  const int CW = sv_conv_w(p);
+  const int P = sv_conv_h(p) * CW;
   const int K = 9 * p.in_ch;
   const int chunks = K / SV_KC;
   const int cbeg = (int)((int64_t)chunks * ks / p.ksplit), cend = (int)((int64_t)chunks * (ks + 1) / p.ksplit);
@@ -56,7 +81,7 @@ __global__ void __launch_bounds__(256) solve_fwd_kernel(const rw_solve_problem p
   const int bn = tid & 63, bk0 = tid >> 6;
   const int pix = n0 + bn;
   const bool pix_ok = pix < P;
-  const int py = pix_ok ? pix / p.w : 0, px = pix_ok ? pix - py * p.w : 0;
+  const int py = pix_ok ? pix / CW : 0, px = pix_ok ? pix - py * CW : 0;
 
   float4 areg;
   float breg[4];
@@ -75,10 +100,7 @@ __global__ void __launch_bounds__(256) solve_fwd_kernel(const rw_solve_problem p
     for (int j = 0; j < 4; ++j) {
       const int k = k0 + bk0 + 4 * j;
       const int i = k / 9, tap = k - 9 * i;
-      const int iy = py + tap / 3 - 1, ix = px + tap % 3 - 1;
-      float v = 0.f;
-      if (pix_ok && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w) v = p.key[((int64_t)i * p.h + iy) * p.w + ix];
-      breg[j] = v;
+      breg[j] = pix_ok ? sv_gather(p, p.key + (int64_t)i * p.h * p.w, tap, py, px) : 0.f;
     }
   };
   auto stash = [&](int buf) {
@@ -159,6 +181,87 @@ __global__ void __launch_bounds__(256) solve_mid_kernel(const rw_solve_problem p
 }
 
 // ---------------------------------------------------------------------------------------
+// K2 for upsampling layers: the whole (2h+1)x(2w+1) pre-blur map of one out channel lives in LDS.
+//   wide = convT*demod -> blur (upfirdn2d 4x4, pad (1,1), flipped taps) -> + noise + bias -> lrelu
+//   loss; g_pre -> blur adjoint (op/upfirdn2d.py:100-115: flipped kernel, pad (2,2)) -> g_wide
+//   gd = g_wide*demod,  c2 from sum g_wide*conv
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) solve_mid_up_kernel(const rw_solve_problem p, int pp, float* lpart) {
+  extern __shared__ float lds[];          // [P] conv (scaled), [Pout] g_pre
+  __shared__ float red[4];
+  __shared__ float kf[16];
+  const int o = blockIdx.x, tid = threadIdx.x;
+  const int CH = 2 * p.h + 1, CW = 2 * p.w + 1, P = CH * CW;
+  const int OH = 2 * p.h, OW = 2 * p.w, PO = OH * OW;
+  float* conv = lds;
+  float* gpre = lds + P;
+  if (tid < 16) kf[tid] = p.blur_k[(3 - (tid >> 2)) * 4 + (3 - (tid & 3))];
+  float wsq = 0.f;
+  for (int s = 0; s < p.ksplit; ++s) wsq += p.wsq[(int64_t)s * p.out_ch + o];
+  const float demod = rsqrtf(wsq + 1e-8f);
+  for (int n = tid; n < P; n += 256) {
+    float c = 0.f;
+    for (int s = 0; s < p.ksplit; ++s) c += p.conv[((int64_t)s * p.out_ch + o) * pp + n];
+    conv[n] = c * p.w_scale;
+  }
+  __syncthreads();
+  const float nw = p.noise_w[0], bv = p.bias[o];
+  const float inv_numel = 1.0f / ((float)p.out_ch * (float)PO);
+  float lsum = 0.f;
+  for (int n = tid; n < PO; n += 256) {
+    const int y = n / OW, x = n - y * OW;
+    float b = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int Y = y + a - 1;
+      if (Y < 0 || Y >= CH) continue;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int X = x + c - 1;
+        if (X < 0 || X >= CW) continue;
+        b += (conv[Y * CW + X] * demod) * kf[a * 4 + c];
+      }
+    }
+    const float pre = b + nw * p.noise[n] + bv;
+    const float out = 1.4142135623730951f * ((pre > 0.f) ? pre : 0.2f * pre);
+    const float diff = out - p.val[(int64_t)o * PO + n];
+    lsum += fabsf(diff);
+    const float sgn = (diff > 0.f) ? 1.f : ((diff < 0.f) ? -1.f : 0.f);
+    const float g_out = sgn * inv_numel;
+    gpre[n] = ((pre > 0.f) ? g_out : g_out * 0.2f) * 1.4142135623730951f;
+  }
+  __syncthreads();
+  float tsum = 0.f;
+  for (int n = tid; n < pp; n += 256) {
+    float gdv = 0.f;
+    if (n < P) {
+      const int Y = n / CW, X = n - Y * CW;
+      float gw = 0.f;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int y = Y - a + 1;
+        if (y < 0 || y >= OH) continue;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int x = X - c + 1;
+          if (x < 0 || x >= OW) continue;
+          gw += gpre[y * OW + x] * kf[a * 4 + c];
+        }
+      }
+      gdv = gw * demod;
+      tsum += gw * conv[n];
+    }
+    p.gd[(int64_t)o * pp + n] = gdv;
+  }
+  lsum = rw_block_sum_256(lsum, red);
+  tsum = rw_block_sum_256(tsum, red);
+  if (tid == 0) {
+    lpart[o] = lsum * inv_numel;
+    p.c2[o] = p.w_scale * p.w_scale * demod * demod * demod * tsum;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // Adam, as torch.optim.Adam's single-tensor path computes it (rewrite/ganrewrite.py:277,287)
 // ---------------------------------------------------------------------------------------
 // omb1 / omb2 are (1 - beta) evaluated in DOUBLE on the host and rounded once, as torch passes them
@@ -183,7 +286,8 @@ __global__ void __launch_bounds__(256) solve_bwd_adam_kernel(const rw_solve_prob
   const int frow = lane >> 5, fcol = lane & 31;
   const int o0 = blockIdx.x * SV_BM;
   const int k0 = blockIdx.y * SV_BNK;
-  const int P = p.h * p.w;
+  const int CW = sv_conv_w(p);
+  const int P = sv_conv_h(p) * CW;
   const int K = 9 * p.in_ch;
   const int it = p.step_counter[0];
 
@@ -199,7 +303,6 @@ __global__ void __launch_bounds__(256) solve_bwd_adam_kernel(const rw_solve_prob
   const int kmine = k0 + bcol;
   const bool col_ok = kmine < K;
   const int ci = col_ok ? kmine / 9 : 0, ctap = col_ok ? kmine - 9 * ci : 0;
-  const int cdy = ctap / 3 - 1, cdx = ctap % 3 - 1;
   const float* kch = p.key + (int64_t)ci * p.h * p.w;
 
   float4 areg;
@@ -212,9 +315,8 @@ __global__ void __launch_bounds__(256) solve_bwd_adam_kernel(const rw_solve_prob
       const int n = p0 + bp0 + 2 * j;
       float v = 0.f;
       if (n < P && col_ok) {
-        const int y = n / p.w, x = n - y * p.w;
-        const int iy = y + cdy, ix = x + cdx;
-        if (iy >= 0 && iy < p.h && ix >= 0 && ix < p.w) v = kch[iy * p.w + ix];
+        const int y = n / CW;
+        v = sv_gather(p, kch, ctap, y, n - y * CW);
       }
       breg[j] = v;
     }
@@ -265,7 +367,7 @@ __global__ void __launch_bounds__(256) solve_bwd_adam_kernel(const rw_solve_prob
       const int64_t idx = (int64_t)o * K + k;
       float wv = p.weight[idx];
       const float g = p.w_scale * acc[b][r] - p.c2[o] * wv * sig2;
-      if (p.low_rank_gradient) {
+      if (p.low_rank_gradient || p.linear_insert) {
         p.grad[idx] = g;
       } else {
         float m = p.exp_avg[idx], v = p.exp_avg_sq[idx];
@@ -282,6 +384,9 @@ __global__ void __launch_bounds__(256) solve_bwd_adam_kernel(const rw_solve_prob
 // in LDS, each rank costs `taps` block reductions.
 //   MODE 0: out = (base ? base : 0) + P(src)                    (projection / ortho / zero())
 //   MODE 1: g = P(grad); Adam(g) on weight                       (low_rank_gradient=True)
+//   MODE 2: linear_insert (rewrite/ganrewrite.py:201-252): dLambda[o][r][t] = sum_i grad[o][i][t] d[r][i];
+//           Adam on Lambda (state in exp_avg / exp_avg_sq, first out_ch*rank*9 floats; Lambda in
+//           p.lambda); weight = base(W0) + sum_r Lambda[o][r][t] d[r][i]
 // ---------------------------------------------------------------------------------------
 #define SV_MAX_TAPS 9
 template <int MODE>
@@ -303,6 +408,7 @@ __global__ void __launch_bounds__(256) project_kernel(const float* __restrict__ 
   for (int r = 0; r < rank; ++r) {
     const float* d = ctx + (int64_t)r * in_ch;
     float part[SV_MAX_TAPS];
+    float lam_new = 0.f;
 #pragma unroll
     for (int t = 0; t < SV_MAX_TAPS; ++t) part[t] = 0.f;
     for (int i = tid; i < in_ch; i += 256) {
@@ -319,13 +425,26 @@ __global__ void __launch_bounds__(256) project_kernel(const float* __restrict__ 
       }
     }
     __syncthreads();
+    if (MODE == 2) {                      // cosv = dLambda[o][r][:]; one thread per tap steps Adam on Lambda
+      if (tid < taps) {
+        const int it = p.step_counter[0];
+        const int64_t li = ((int64_t)o * rank + r) * taps + tid;
+        float lv = p.lambda[li], m = p.exp_avg[li], v = p.exp_avg_sq[li];
+        adam_update(cosv[tid], lv, m, v, p.one_minus_beta1, p.beta2, p.one_minus_beta2, p.eps,
+                    p.step_size[it], p.bc2_sqrt[it]);
+        p.lambda[li] = lv; p.exp_avg[li] = m; p.exp_avg_sq[li] = v;
+        cosv[tid] = lv;
+      }
+      __syncthreads();
+    }
+    (void)lam_new;
     for (int i = tid; i < in_ch; i += 256) {
       const float dv = d[i];
       for (int t = 0; t < taps; ++t) prow[i * taps + t] += cosv[t] * dv;
     }
     __syncthreads();
   }
-  if (MODE == 0) {
+  if (MODE == 0 || MODE == 2) {
     const float* b = base ? base + (int64_t)o * rowlen : nullptr;
     for (int e = tid; e < rowlen; e += 256) out[(int64_t)o * rowlen + e] = (b ? b[e] : 0.f) + prow[e];
   } else {
@@ -360,26 +479,39 @@ extern "C" int rw_solve_step_f32(const rw_solve_problem* pr, int project, rw_str
                p.exp_avg_sq && p.step_size && p.bc2_sqrt && p.step_counter && p.losses && p.conv &&
                p.wsq && p.gd && p.c2);
   RW_CHECK_ARG(p.out_ch > 0 && p.in_ch > 0 && p.h > 0 && p.w > 0 && p.ksplit > 0);
-  RW_CHECK_ARG(!(project || p.low_rank_gradient) || (p.context && p.rank > 0));
-  RW_CHECK_ARG(!project || p.ortho);
-  RW_CHECK_ARG(!p.low_rank_gradient || p.grad);
+  RW_CHECK_ARG(!(project || p.low_rank_gradient || p.linear_insert) || (p.context && p.rank > 0));
+  RW_CHECK_ARG(!(project || p.linear_insert) || p.ortho);
+  RW_CHECK_ARG(!(p.low_rank_gradient || p.linear_insert) || p.grad);
+  RW_CHECK_ARG(!p.linear_insert || (p.lambda && !project && !p.low_rank_gradient));
+  RW_CHECK_ARG(!p.upsample || p.blur_k);
   if (p.out_ch % SV_BM || p.in_ch % SV_KC) return RW_ERR_UNSUPPORTED;
   hipStream_t s = rw_s(stream);
-  const int P = p.h * p.w;
+  const int P = sv_conv_h(p) * sv_conv_w(p);
   const int pp = sv_pp(P);
   float* lpart = p.c2 + p.out_ch;   // c2 is allocated with 2*out_ch floats: [c2 | per-channel loss]
   hipLaunchKernelGGL(solve_fwd_kernel, dim3(p.out_ch / SV_BM, pp / SV_BN, p.ksplit), dim3(256), 0, s, p, pp);
-  hipLaunchKernelGGL(solve_mid_kernel, dim3(p.out_ch), dim3(256), 0, s, p, pp, lpart);
+  if (p.upsample) {
+    const size_t mid_lds = ((size_t)P + (size_t)4 * p.h * p.w) * sizeof(float);
+    if (mid_lds > 64 * 1024) return RW_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(solve_mid_up_kernel, dim3(p.out_ch), dim3(256), mid_lds, s, p, pp, lpart);
+  } else {
+    hipLaunchKernelGGL(solve_mid_kernel, dim3(p.out_ch), dim3(256), 0, s, p, pp, lpart);
+  }
   hipLaunchKernelGGL(solve_bwd_adam_kernel, dim3(p.out_ch / SV_BM, (unsigned)rw_cdiv(9 * p.in_ch, SV_BNK)), dim3(256), 0,
                      s, p, pp, (const float*)lpart);
   const size_t lds = 2 * (size_t)p.in_ch * 9 * sizeof(float);
-  if (p.low_rank_gradient) {
+  if (p.low_rank_gradient || p.linear_insert || project) {
     if (lds > 64 * 1024) return RW_ERR_UNSUPPORTED;
+  }
+  if (p.low_rank_gradient) {
     hipLaunchKernelGGL(project_kernel<1>, dim3(p.out_ch), dim3(256), lds, s, (const float*)p.grad,
                        p.context, (const float*)nullptr, (float*)nullptr, p.in_ch, 9, p.rank, p);
   }
+  if (p.linear_insert) {
+    hipLaunchKernelGGL(project_kernel<2>, dim3(p.out_ch), dim3(256), lds, s, (const float*)p.grad,
+                       p.context, p.ortho, p.weight, p.in_ch, 9, p.rank, p);
+  }
   if (project) {
-    if (lds > 64 * 1024) return RW_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(project_kernel<0>, dim3(p.out_ch), dim3(256), lds, s, (const float*)p.weight,
                        p.context, p.ortho, p.weight, p.in_ch, 9, p.rank, p);
   }

@@ -68,6 +68,34 @@ def allreduce_second_moment(r2mom):
     return r2mom
 
 
+def allreduce_variance(rv):
+    """In place: pooled (count, mean, centred second moment) of a RunningVariance over all ranks
+    (exact pooling: M2 = sum M2_r + sum n_r (mean_r - mean)^2), reduced in float64."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return rv
+    if rv._mean is None:
+        raise RuntimeError('rank %d received no batches' % dist.get_rank())
+    dev = rv._mean.device
+    if dist.get_backend() == 'gloo':
+        dev = torch.device('cpu')
+    elif not rv._mean.is_cuda:
+        dev = torch.device('cuda', torch.cuda.current_device())
+    n = float(rv.count)
+    mean = rv._mean.to(dev, torch.float64)
+    packed = torch.cat([mean * n, rv.v_cmom2.to(dev, torch.float64) + n * mean * mean,
+                        torch.tensor([n, float(rv.batchcount)], dtype=torch.float64, device=dev)])
+    dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+    c = mean.numel()
+    total = packed[-2].item()
+    gmean = packed[:c] / total
+    m2 = packed[c:2 * c] - total * gmean * gmean
+    rv.count = int(round(total))
+    rv.batchcount = int(round(packed[-1].item()))
+    rv._mean = gmean.to(rv._mean.dtype).to(rv._mean.device)
+    rv.v_cmom2 = m2.clamp_(min=0).to(rv.v_cmom2.dtype).to(rv.v_cmom2.device)
+    return rv
+
+
 def gather_images(local_images, seeds_total):
     """all_gather of per-rank image batches produced with seed i -> rank i mod world; returns the
     images in seed order on every rank (optional: ranks normally write their own files)."""

@@ -162,17 +162,20 @@ class ProgressiveGanRewriter(object):
                     from ..utils.stylegan2.models import noise_batch_period
                     with noise_batch_period(10):
                         rv = tally.tally_mean(squared_units, self.zds, batch_size=self.sweep_batch,
-                                              cachefile=self.rf('unit_rs.npz'), nchw=True, square_input=True)
+                                              cachefile=self.rf('unit_rs.npz'), nchw=True, square_input=True,
+                                              shard=parallel.shard())
                 else:
                     rv = tally.tally_mean(squared_units, self.zds, cachefile=self.rf('unit_rs.npz'),
-                                          nchw=on_gpu, square_input=on_gpu)
+                                          nchw=on_gpu, square_input=on_gpu, shard=parallel.shard())
                 self.unit_rs = rv.mean()
         return self.unit_rs
 
     def covariance_adjusted_query_key(self, k):
-        """C^-1 k by least squares (the reference's torch.lstsq, :101-105)."""
-        c = self.c_matrix.double().cpu()
-        rhs = (k[:, None] if k.dim() == 1 else k.permute(1, 0)).double().cpu()
+        """C^-1 k by least squares (the reference's torch.lstsq, :101-105), in float32 LAPACK on the
+        host like the reference's CPU configuration: C is ill-conditioned, so the precision of this
+        solve is part of the result."""
+        c = self.c_matrix.cpu()
+        rhs = (k[:, None] if k.dim() == 1 else k.permute(1, 0)).cpu()
         sol = torch.linalg.lstsq(c, rhs).solution.to(k.dtype).to(k.device)
         return sol[:, 0] if k.dim() == 1 else sol.permute(1, 0)
 
@@ -530,33 +533,53 @@ class SeqStyleGanRewriter(ProgressiveGanRewriter):
         from ..utils.stylegan2 import models as sg
         mods = list(self.target_model.modules())
         leaves = [m for m in mods if len(list(m.children())) == 0]
-        if len(leaves) != 3 or not self._kernels():
+        if len(leaves) not in (3, 4) or not self._kernels():
             return None
-        dconv, noise, act = leaves
+        dconv, noise, act = leaves[0], leaves[-2], leaves[-1]
+        blur = leaves[1] if len(leaves) == 4 else None
         if not (isinstance(dconv, sg.DemodulatedConv2dF) and isinstance(noise, sg.NoiseInjectionF)
                 and isinstance(act, sg.FusedLeakyReLUF)):
             return None
-        if dconv.upsample or not dconv.demodulate or key.fmap.shape[0] != 1:
+        if dconv.upsample != (blur is not None) or (blur is not None and not isinstance(blur, sg.BlurF)):
+            return None
+        if blur is not None and (tuple(blur.kernel.shape) != (4, 4) or tuple(blur.pad) != (1, 1)):
+            return None
+        if not dconv.demodulate or key.fmap.shape[0] != 1:
             return None
         if any('forward' in m.__dict__ for m in mods):
             return None                       # someone hooked the target: keep module semantics
-        return dconv, noise, act
+        return dconv, blur, noise, act
 
-    def _run_insert(self, key, val, context, update_callback, niter, piter, lr):
+    def _run_insert(self, key, val, context, update_callback, niter, piter, lr, linear=False):
         parts = self._hip_solvable(key) if isinstance(key, dict) else None
         if parts is None:
             if self._kernels():
                 raise NotImplementedError(
-                    'the fused HIP solver covers stride-1 SeqStyleGAN2 layers (even layernum, batch-1 '
-                    'goal); the kernels have no autograd path for other targets yet')
+                    'the fused HIP solver covers targets layerN.sconv.mconv.dconv .. layerN.sconv.activate '
+                    'of a SeqStyleGAN2 with a batch-1 goal; the kernels have no autograd path for other '
+                    'targets')
             return super()._run_insert(key, val, context, update_callback, niter, piter, lr)
         from . import hipsolve
-        dconv, noise, act = parts
+        dconv, blur, noise, act = parts
         hipsolve.run(dconv.weight, key.fmap, key.style, val.fmap, act.bias, noise.weight, context,
                      niter=niter, piter=piter, lr=lr,
                      low_rank_insert=self.low_rank_insert, low_rank_gradient=self.low_rank_gradient,
-                     update_callback=update_callback)
+                     update_callback=update_callback,
+                     blur_kernel=None if blur is None else blur.kernel, linear=linear)
         _weights_changed()
+
+    def linear_insert(self, key, val, context=None, update_callback=None, niter=2001, lr=0.05,
+                      return_timing=False):
+        """Optimise Lambda with weight = W0 + Lambda . context (rewrite/ganrewrite.py:201-252): Adam on
+        the (Cout, rank, 3, 3) coefficients only; the weight stays on the rank-r affine subspace."""
+        if return_timing:
+            torch.cuda.synchronize()
+            started = time.time()
+        key, val = self.detach(key), self.detach(val)
+        self._run_insert(key, val, context, update_callback, niter, 10, lr, linear=True)
+        if return_timing:
+            torch.cuda.synchronize()
+            return (time.time() - started) * 1000
 
 
 class SeqTinyStyleGanRewriter(SeqStyleGanRewriter):
@@ -572,8 +595,8 @@ class SeqPreStyleGanRewriter(SeqStyleGanRewriter):
     def covariance_adjusted_key(self, k, kout):
         assert 'adain' in self.firstlayer
         assert kout.style.shape[0] == 1
-        cs = (self.c_matrix * kout.style[0][None, :]).double().cpu()
-        rhs = (k[:, None] if k.dim() == 1 else k.permute(1, 0)).double().cpu()
+        cs = (self.c_matrix * kout.style[0][None, :]).cpu()
+        rhs = (k[:, None] if k.dim() == 1 else k.permute(1, 0)).cpu()
         sol = torch.linalg.lstsq(cs, rhs).solution.to(k.dtype).to(k.device)
         return sol[:, 0] if k.dim() == 1 else sol.permute(1, 0)
 

@@ -24,8 +24,11 @@ def _ptr(t):
 
 class Solver:
     def __init__(self, weight, key, style, val, bias, noise_w, context, niter, piter, lr,
-                 low_rank_insert, low_rank_gradient):
+                 low_rank_insert, low_rank_gradient, blur_kernel=None, linear=False):
         dev = weight.device
+        upsample = blur_kernel is not None
+        if linear:
+            low_rank_insert = low_rank_gradient = False
         self.weight = weight                       # (1,O,I,3,3) parameter, updated in place
         w = weight.detach()
         assert w.is_contiguous() and w.dtype == torch.float32
@@ -37,14 +40,23 @@ class Solver:
         f32 = dict(device=dev, dtype=torch.float32)
         self.key = key.detach().reshape(I, h, wd).contiguous().float()
         self.style = style.detach().reshape(I).contiguous().float()
-        self.val = val.detach().reshape(O, h, wd).contiguous().float()
+        oh, ow = (2 * h, 2 * wd) if upsample else (h, wd)          # value map of the layer
+        ch, cw = (2 * h + 1, 2 * wd + 1) if upsample else (h, wd)  # map the convolution writes
+        assert tuple(val.shape[-2:]) == (oh, ow), (val.shape, (oh, ow))
+        self.val = val.detach().reshape(O, oh, ow).contiguous().float()
         self.bias = bias.detach().contiguous().float()
-        self.noise = reference_noise(1, h * wd, dev).reshape(-1).contiguous()
+        self.noise = reference_noise(1, oh * ow, dev).reshape(-1).contiguous()
+        self.blur_k = blur_kernel.detach().contiguous().float() if upsample else None
+        self.linear = linear
         self.noise_w = noise_w.detach().reshape(1).contiguous().float()
-        constrained = low_rank_insert or low_rank_gradient
+        constrained = low_rank_insert or low_rank_gradient or linear
         self.context = context.detach().contiguous().float().to(dev) if constrained else None
         self.ortho = None
-        if constrained:
+        self.lam = None
+        if linear:
+            self.ortho = w.clone()                              # W0: weight = W0 + Lambda . context
+            self.lam = torch.zeros(O, self.context.shape[0], 9, **f32)
+        elif constrained:
             self.ortho = (w - hip.project_weight(w, self.context).view(w.shape)).contiguous()
         self.exp_avg = torch.zeros_like(w)
         self.exp_avg_sq = torch.zeros_like(w)
@@ -53,13 +65,13 @@ class Solver:
         self.bc2_sqrt = torch.tensor([math.sqrt(1 - 0.999 ** t) for t in steps], **f32)
         self.counter = torch.full((1,), -1, device=dev, dtype=torch.int32)
         self.losses = torch.zeros(niter, **f32)
-        ks = hip.solve_ksplit(O, I, h, wd)
-        pp = -(-(h * wd) // 64) * 64
+        ks = hip.solve_ksplit(O, I, ch, cw)
+        pp = -(-(ch * cw) // 64) * 64
         self.conv = torch.empty(ks, O, pp, **f32)
         self.wsq = torch.empty(ks, O, **f32)
         self.gd = torch.empty(O, pp, **f32)
         self.c2 = torch.empty(2 * O, **f32)
-        self.grad = torch.empty_like(w) if low_rank_gradient else None
+        self.grad = torch.empty_like(w) if (low_rank_gradient or linear) else None
         p = hip.SolveProblem()
         p.out_ch, p.in_ch, p.h, p.w = O, I, h, wd
         p.rank = self.context.shape[0] if constrained else 0
@@ -76,6 +88,10 @@ class Solver:
         p.one_minus_beta1, p.one_minus_beta2 = 1 - 0.9, 1 - 0.999     # python doubles, rounded once
         p.w_scale = 1 / math.sqrt(I * 9)
         p.low_rank_gradient = int(low_rank_gradient)
+        p.upsample = int(upsample)
+        p.blur_k = _ptr(self.blur_k)
+        p.linear_insert = int(linear)
+        p.lambda_ = _ptr(self.lam)
         self.problem = p
         self._w = w
 
@@ -119,8 +135,9 @@ class Solver:
 
 
 def run(weight, key, style, val, bias, noise_w, context, niter=2001, piter=10, lr=0.05,
-        low_rank_insert=True, low_rank_gradient=False, update_callback=None):
+        low_rank_insert=True, low_rank_gradient=False, update_callback=None, blur_kernel=None,
+        linear=False):
     solver = Solver(weight, key, style, val, bias, noise_w, context, niter, piter, lr,
-                    low_rank_insert, low_rank_gradient)
+                    low_rank_insert, low_rank_gradient, blur_kernel=blur_kernel, linear=linear)
     solver.run(update_callback)
     return solver

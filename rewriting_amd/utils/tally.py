@@ -101,15 +101,19 @@ def tally_second_moment(compute, dataset, sample_size=None, batch_size=10, cache
 
 
 def tally_mean(compute, dataset, sample_size=None, batch_size=10, cachefile=None, nchw=False,
-               square_input=False, **kwargs):
+               square_input=False, shard=None, **kwargs):
     args = dict(sample_size=sample_size)
     cached = load_cached_state(cachefile, args)
     if cached is not None:
         return runningstats.RunningVariance(state=cached)
     loader = make_loader(dataset, sample_size, batch_size, **kwargs)
     rv = runningstats.RunningVariance()
-    for batch in pbar(loader):
+    for batch in pbar(_sharded(loader, shard)):
         rv.add(call_compute(compute, batch), nchw=nchw, square_input=square_input)
+    if shard is not None and shard[1] > 1:
+        from .. import parallel
+        parallel.allreduce_variance(rv)
     rv.to_('cpu')
-    save_cached_state(cachefile, rv, args)
+    if shard is None or shard[0] == 0:
+        save_cached_state(cachefile, rv, args)
     return rv

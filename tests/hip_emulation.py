@@ -179,35 +179,41 @@ def register_solver(solver):
 
 
 def solve_step(problem, project):
-    """One iteration of the solve in torch, on the driver's own tensors."""
+    """One iteration of the solve in torch autograd, on the driver's own tensors."""
     import ctypes
     s = _solvers[ctypes.addressof(problem)]
     it = int(s.counter.item()) + 1
     s.counter.fill_(it)
-    W = s._w[0]
-    O, I = W.shape[:2]
-    sc = 1 / math.sqrt(I * 9)
-    h, wd = s.key.shape[1:]
-    xcol = F.unfold(s.key[None], (3, 3), padding=1)[0]
-    conv = (sc * W.reshape(O, -1)) @ xcol
-    sig2 = (s.style ** 2).view(1, I, 1, 1)
-    dm = torch.rsqrt(((sc * W) ** 2 * sig2).sum([1, 2, 3]) + 1e-8)
-    pre = conv * dm[:, None] + s.noise_w * s.noise[None, :] + s.bias[:, None]
-    out = SQRT2 * torch.where(pre > 0, pre, 0.2 * pre)
-    diff = out - s.val.reshape(O, -1)
-    s.losses[it] = diff.abs().mean()
-    g_out = torch.sign(diff) / diff.numel()
-    g_pre = torch.where(pre > 0, g_out, g_out * 0.2) * SQRT2
-    dW = sc * ((g_pre * dm[:, None]) @ xcol.t()).view(O, I, 3, 3)
-    dW = dW - (sc * sc) * W * sig2 * (dm ** 3 * (g_pre * conv).sum(1)).view(O, 1, 1, 1)
+    W = s._w
+    O, I = W.shape[1:3]
+    up = s.blur_k is not None
+    Wg = W.clone().requires_grad_(True)
+    with torch.enable_grad():
+        out = R.demod_conv(s.key[None], s.style[None], Wg, up)
+        if up:
+            out = R.upfirdn2d(out, s.blur_k, pad=(1, 1))
+        out = out + s.noise_w * s.noise.view(1, 1, *out.shape[2:])
+        out = R.fused_leaky_relu(out, s.bias)
+        loss = F.l1_loss(s.val[None], out)
+        loss.backward()
+    s.losses[it] = loss.detach()
+    dW = Wg.grad
+    if s.linear:
+        g = torch.einsum('goiyx,di->godyx', dW, s.context)[0].reshape(O, -1, 9)
+        m, v = s.exp_avg.view(-1)[:g.numel()].view_as(g), s.exp_avg_sq.view(-1)[:g.numel()].view_as(g)
+        m += (g - m) * (1 - 0.9)
+        v.mul_(0.999).add_((1 - 0.999) * g * g)
+        s.lam += (-s.step_size[it] * m) / (v.sqrt() / s.bc2_sqrt[it] + 1e-8)
+        W.copy_(s.ortho + torch.einsum('ody,di->oiy', s.lam, s.context).reshape(W.shape))
+        return
     if s.low_rank_gradient:
         dW = R.projected_conv(dW, s.context)
-    m, v = s.exp_avg[0], s.exp_avg_sq[0]
+    m, v = s.exp_avg, s.exp_avg_sq
     m += (dW - m) * (1 - 0.9)
     v.mul_(0.999).add_((1 - 0.999) * dW * dW)
     W += (-s.step_size[it] * m) / (v.sqrt() / s.bc2_sqrt[it] + 1e-8)
     if project:
-        W.copy_(s.ortho[0] + R.projected_conv(W, s.context))
+        W.copy_(s.ortho + R.projected_conv(W, s.context))
 
 
 def install(monkeypatch):

@@ -36,8 +36,8 @@ def test_every_header_entry_cites_the_reference():
 def test_struct_layouts_match_c():
     # sizes computed by hand from include/rewriting_hip.h (LP64): 5 pointers + int (+pad)
     assert ctypes.sizeof(_lib.ConvEpilogue) == 48
-    # 5 ints (+4 pad) + 20 pointers + int + 4 floats + int + 2 floats = 24 + 160 + 32
-    assert ctypes.sizeof(_lib.SolveProblem) == 216
+    # 5 ints (+4 pad) + 20 pointers + int + 4 floats + int + 2 floats + int(+0 pad) + ptr + int(+4) + ptr
+    assert ctypes.sizeof(_lib.SolveProblem) == 24 + 160 + 32 + 8 + 8 + 8 + 8 - 0
 
 
 def test_missing_gpu_tensor_fails_loudly():

@@ -25,7 +25,9 @@ def _worker(rank, world, port, out):
         seen.append(int(batch.shape[0]))
         return batch * 2.0
     stat = tally.tally_second_moment(compute, data, shard=parallel.shard())
-    torch.save(dict(mom2=stat.mom2, count=stat.count, seen=seen), os.path.join(out, 'r%d.pt' % rank))
+    rv = tally.tally_mean(lambda b: b * 2.0, data, shard=parallel.shard())
+    torch.save(dict(mom2=stat.mom2, count=stat.count, seen=seen, mean=rv.mean(), var=rv.variance(),
+                    n=rv.size()), os.path.join(out, 'r%d.pt' % rank))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -46,6 +48,10 @@ def test_sharded_second_moment_matches_single_process(tmp_path):
         assert g['count'] == 57
         assert torch.allclose(g['mom2'], want, rtol=1e-5, atol=1e-4)
     assert torch.equal(got[0]['mom2'], got[1]['mom2'])
+    for g in got:       # sharded tally_mean: pooled mean / variance on every rank
+        assert g['n'] == 57
+        assert torch.allclose(g['mean'], data.mean(0), atol=1e-5)
+        assert torch.allclose(g['var'], data.var(0), rtol=1e-4, atol=1e-5)
 
 
 def test_batches_for_rank_partition():

@@ -185,3 +185,18 @@ def test_zero_and_projection_helpers(emulated_hip):
     p = ganrewrite.projected_conv(w, d)
     assert (ganrewrite.projected_conv(p, d) - p).abs().max() < 1e-5     # idempotent
     assert (ganrewrite.rank_one_conv(w[0], d[0]) - ganrewrite.projected_conv(w[0], d[:1])).abs().max() < 1e-5
+
+
+def test_odd_layer_edit_matches_golden(emulated_hip):
+    from tests.common_checks import check_odd_layer_edit
+    check_odd_layer_edit('cpu')
+
+
+def test_key_methods_linear_insert_and_rank3(emulated_hip):
+    from tests.common_checks import check_extras
+    check_extras('cpu')
+
+
+def test_fast_mconv_equals_seq(emulated_hip):
+    from tests.common_checks import check_fast_mconv_equals_seq
+    check_fast_mconv_equals_seq('cpu')

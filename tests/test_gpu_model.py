@@ -255,6 +255,53 @@ def test_solver_against_oracle_explicit_arithmetic():
     os.environ.pop('RW_SOLVE_GRAPH', None)
 
 
+def test_odd_layer_edit_matches_reference_golden():
+    from tests.common_checks import check_odd_layer_edit
+    report = check_odd_layer_edit(DEV)
+    os.makedirs('gpurun_out', exist_ok=True)
+    json.dump(report, open('gpurun_out/solve_parity_odd_layer.json', 'w'))
+
+
+def test_key_methods_linear_insert_and_rank3():
+    from tests.common_checks import check_extras
+    report = check_extras(DEV)
+    json.dump(report, open('gpurun_out/solve_parity_extras.json', 'w'))
+
+
+def test_fast_mconv_equals_seq():
+    from tests.common_checks import check_fast_mconv_equals_seq
+    check_fast_mconv_equals_seq(DEV)
+
+
+def test_odd_layer_solver_against_oracle_autograd():
+    """Random upsampling layer: HIP solver vs the oracle's autograd + torch.optim.Adam loop."""
+    from rewriting_amd.rewrite import hipsolve
+    from oracle import restatement as R
+    rs = numpy.random.RandomState(9)
+    O, I, h, w = 64, 128, 5, 7
+    W0 = torch.from_numpy(rs.randn(1, O, I, 3, 3).astype('float32'))
+    key = torch.from_numpy(rs.randn(1, I, h, w).astype('float32'))
+    style = torch.from_numpy((1 + 0.3 * rs.randn(1, I)).astype('float32'))
+    val = torch.from_numpy(rs.randn(1, O, 2 * h, 2 * w).astype('float32'))
+    bias = torch.from_numpy((0.1 * rs.randn(O)).astype('float32'))
+    nw = torch.tensor([0.2])
+    k4 = R.make_kernel([1, 3, 3, 1]) * 4
+    ctx = torch.linalg.qr(torch.from_numpy(rs.randn(I, 2).astype('float32')))[0].t().contiguous()
+
+    def fwd(W):
+        out = R.upfirdn2d(R.demod_conv(key, style, W, True), k4, pad=(1, 1))
+        out = out + nw * R.noise_rows(1, 4 * h * w).view(1, 1, 2 * h, 2 * w)
+        return R.fused_leaky_relu(out, bias)
+    for n in (1, 10, 11, 31):
+        Wref, lref, _ = R.insert_autograd(W0, fwd, val, ctx, niter=n, piter=10)
+        Wd = W0.to(DEV).clone()
+        s = hipsolve.run(Wd, key.to(DEV), style.to(DEV), val.to(DEV), bias.to(DEV), nw.to(DEV), ctx.to(DEV),
+                         niter=n, piter=10, lr=0.05, blur_kernel=k4.to(DEV))
+        r = rel(Wd - W0.to(DEV), Wref - W0)
+        assert r < 1e-4, (n, r)
+        assert numpy.abs(s.losses.cpu().numpy() - numpy.array(lref)).max() < 1e-5
+
+
 # ------------------------------------------------------------------ full-size properties
 @pytest.mark.parametrize('size,batch', [(256, 4), (1024, 2)])
 def test_full_size_generator_properties(monkeypatch, size, batch):
