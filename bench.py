@@ -5,12 +5,12 @@
 Default workload = BASELINE.json's metric: images/sec of the StyleGANv2-1024 sequential
 generator forward (SeqStyleGAN2 size 1024, mconv='seq', truncation 0.5, synthetic seeded
 weights, z = standard_z_sample seed 1), one "step" = one forward pass over a batch of B seeds per
-GPU with inputs resident in HBM.  For N>1 launch with torch.distributed.run (one rank per GPU,
+GPU (default 32) with inputs resident in HBM.  For N>1 launch with torch.distributed.run (one rank per GPU,
 RCCL): seeds are partitioned rank-wise (no data-path collective, weak scaling); the timed region
 is bracketed by barrier + synchronize and the MAX over ranks is reported.
 
-Rank 0 prints ONE JSON line with `roofline` (the conv_mfma_kernel family: algorithmic conv
-FLOPs of its launches / their HIP-event time, against the 157.3 TFLOP/s fp32-MFMA peak) and
+Rank 0 prints ONE JSON line with `roofline` (the dominant conv kernel: algorithmic conv FLOPs of
+its launches / their HIP-event time, against the 157.3 TFLOP/s fp32-MFMA peak) and
 `cpu_baseline` (the oracle restatement timed on the host cores on a bounded sample; N=1 only).
 
 Other workloads (parity-test configurations of BASELINE.json, not the headline line):
@@ -310,7 +310,7 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     if args.workload == 'ffhq1024':
-        out = run_forward(args, rank, world, device, 1024, args.batch or 8,
+        out = run_forward(args, rank, world, device, 1024, args.batch or 32,
                           'stylegan2-1024 generator forward (FFHQ-1024 architecture)')
     elif args.workload == 'ffhq256':
         out = run_forward(args, rank, world, device, 256, args.batch or 64,
