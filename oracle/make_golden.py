@@ -246,6 +246,11 @@ def golden_rewriter_extras(ref, name, size, layernum, maskfile, nseeds):
     arrays['mkey_mean'] = gw.multi_key_from_selection(keys, rank=1, key_method='mean').numpy()
     arrays['mkey_zca_r3'] = gw.multi_key_from_selection(keys, rank=3).numpy()
     arrays['query_key'] = gw.query_key_from_selection(*keys[0]).numpy()
+    torch.manual_seed(0)
+    arrays['gandissect_units'] = gw.multi_key_from_selection(keys, rank=10, key_method='gandissect').argmax(1).numpy()
+    sel, rq = gw.ranking_for_key(torch.from_numpy(arrays['query_key']), k=8)
+    arrays['ranking'] = sel.numpy()
+    arrays['ranking_q'] = rq.quantiles([0.5, 0.99, 0.999])[0].numpy()
     o_imgnum, o_mask = request['object']
     p_imgnum, p_mask = request['paste']
     obj_acts, _, obj_area, _ = gw.object_from_selection(o_imgnum, o_mask)

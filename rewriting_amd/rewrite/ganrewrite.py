@@ -313,8 +313,19 @@ class ProgressiveGanRewriter(object):
                 q = qmat * signs[None, :]
                 return q.t().contiguous().to(self.device)
             if key_method == 'gandissect':
-                raise NotImplementedError(
-                    "key_method='gandissect' needs RunningQuantile (SURVEY.md section 8f.4)")
+                # one-hot rows for the units whose activations under the masks are the most unusual:
+                # mean of -log(1 - quantile rank) (:375-400)
+                observed = self._key_observations(imgnum_mask_pairs)
+                all_obs = torch.cat([obs for obs, _, _ in observed])
+                all_weight = torch.cat([w for _, _, w in observed])
+                rq = self.quantiles_for_units()
+                logscore = -torch.log(1.0 - rq.normalize(all_obs.permute(1, 0))).permute(1, 0)
+                logscore = logscore.to(all_obs.device)
+                mean_logscore = (logscore * all_weight).sum(0) / all_weight.sum()
+                top = mean_logscore.sort(descending=True)[1][:rank]
+                result = torch.zeros(rank, all_obs.shape[1], device=all_obs.device)
+                result[torch.arange(rank), top] = 1.0
+                return result
             assert key_method in ['svd', 'mean']
             gathered = []
             for imgnum, mask in imgnum_mask_pairs:
@@ -419,14 +430,48 @@ class ProgressiveGanRewriter(object):
         return source_z, changed, bounds
 
     # ---- UI conveniences ------------------------------------------------------------------
-    def quantiles_for_units(self):
-        raise NotImplementedError('RunningQuantile is a "next" row (SURVEY.md section 8f.2)')
+    def _flat_units(self, zbatch):
+        acts = self.context_acts(self.context_model(zbatch.to(self.device))).detach()
+        return acts.permute(0, 2, 3, 1).reshape(-1, acts.shape[1])
 
-    quantiles_for_covariance_adjusted_directions = quantiles_for_units
+    def _sweep(self, fn, *args, **kwargs):
+        """Runs a tally over self.zds; on the GPU in launches of sweep_batch seeds with the reference's
+        batch-of-10 noise rows (see collect_2nd_moment)."""
+        with pbar.quiet(), torch.no_grad():
+            if self._kernels() and self._noise_periodic():
+                from ..utils.stylegan2.models import noise_batch_period
+                with noise_batch_period(10):
+                    return fn(*args, batch_size=self.sweep_batch, **kwargs)
+            return fn(*args, **kwargs)
+
+    def quantiles_for_units(self):
+        if self.unit_rq is None:
+            self.unit_rq = self._sweep(tally.tally_quantile, self._flat_units, self.zds,
+                                       cachefile=self.rf('unit_rq.npz'))
+        return self.unit_rq
+
+    def quantiles_for_covariance_adjusted_directions(self):
+        if self.cad_rq is None:
+            def adjusted(zbatch):
+                outs = self.context_model(zbatch.to(self.device))
+                acts = self.context_acts(outs)
+                flat = acts.permute(0, 2, 3, 1).reshape(-1, acts.shape[1])
+                return self.covariance_adjusted_key(flat, outs)
+            self.cad_rq = self._sweep(tally.tally_quantile, adjusted, self.zds,
+                                      cachefile=self.rf('unit_cad.npz'))
+        return self.cad_rq
 
     def ranking_for_key(self, key, k=12):
-        raise NotImplementedError('ranking_for_key needs RunningTopK/RunningQuantile '
-                                  '(SURVEY.md section 8f.2)')
+        """Seeds whose key map responds most to ``key`` + the quantile statistics of the response
+        (the UI's "Search"; rewrite/ganrewrite.py:582-594)."""
+        tensorkey = key.to(self.device)[None, :, None, None]
+
+        def image_max_sel(zbatch):
+            acts = self.context_acts(self.context_model(zbatch.to(self.device)))
+            heatmap = (acts * tensorkey).sum(dim=1)
+            return heatmap.reshape(heatmap.shape[0], -1).max(1)[0], heatmap.reshape(-1)[:, None]
+        topk, rq = self._sweep(tally.tally_topk_and_quantile, image_max_sel, self.zds, k=k)
+        return topk.result()[1], rq
 
     def _overlay(self):
         try:

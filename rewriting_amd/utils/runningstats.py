@@ -168,3 +168,184 @@ class RunningVariance:
         self.batchcount = _item(dic['batchcount'])
         self._mean = torch.from_numpy(numpy.asarray(dic['mean']))
         self.v_cmom2 = torch.from_numpy(numpy.asarray(dic['cmom2']))
+
+
+class RunningTopK:
+    """Running top-k values (and the global sample indexes they came from) for every feature
+    (reference surface: utils/runningstats.py:31-146 -- ``add(data[, index])``, ``result()`` ->
+    (values, indexes) with k last, ``size()``, ``to_``, ``state_dict``).  Candidates are kept in a
+    (features, <= 5k) buffer that is cut back to the best k whenever it fills."""
+
+    def __init__(self, k=100, state=None):
+        if state is not None:
+            self.set_state_dict(resolve_state_dict(state))
+            return
+        self.k = k
+        self.count = 0
+        self.data_shape = None
+        self.top_data = None
+        self.top_index = None
+
+    def add(self, data, index=None):
+        size = data.shape[0]
+        if self.data_shape is None:
+            self.data_shape = tuple(data.shape[1:])
+        flat = data.detach().reshape(size, -1).t()                # (features, size)
+        take = min(size, self.k)
+        vals, idx = flat.topk(take, dim=1, sorted=False)
+        idx = index.to(idx.device)[idx] if index is not None else idx + self.count
+        if self.top_data is None:
+            self.top_data, self.top_index = vals.clone(), idx.clone()
+        else:
+            self.top_data = torch.cat([self.top_data, vals], dim=1)
+            self.top_index = torch.cat([self.top_index, idx], dim=1)
+        if self.top_data.shape[1] > max(10, 5 * self.k):
+            self.top_data, self.top_index = self.result(sorted=False, flat=True)
+        self.count += size
+
+    def size(self):
+        return self.count
+
+    def result(self, sorted=True, flat=False):
+        k = min(self.k, self.top_data.shape[1])
+        vals, pos = self.top_data.topk(k, dim=1, sorted=sorted)
+        idx = self.top_index.gather(1, pos)
+        if flat:
+            return vals, idx
+        shape = tuple(self.data_shape) + (-1,)
+        return vals.reshape(shape), idx.reshape(shape)
+
+    def to_(self, device):
+        self.top_data = self.top_data.to(device)
+        self.top_index = self.top_index.to(device)
+
+    def state_dict(self):
+        vals, idx = self.result(sorted=True, flat=True)
+        return dict(constructor=self.__module__ + '.' + self.__class__.__name__ + '()',
+                    k=self.k, count=self.count, data_shape=tuple(self.data_shape),
+                    top_data=vals.cpu().numpy(), top_index=idx.cpu().numpy())
+
+    def set_state_dict(self, dic):
+        self.k = _item(dic['k'])
+        self.count = _item(dic['count'])
+        self.data_shape = tuple(int(v) for v in dic['data_shape'])
+        self.top_data = torch.from_numpy(numpy.asarray(dic['top_data']))
+        self.top_index = torch.from_numpy(numpy.asarray(dic['top_index']))
+
+
+class RunningQuantile:
+    """Per-unit quantiles of a stream of (samples, units) batches.
+
+    The reference keeps a randomised, resolution-``r`` reservoir sketch (utils/runningstats.py:
+    269-620) because a 2020 GPU could not hold the samples.  With 288 GB of HBM the samples of
+    every sweep on this path fit (1000 seeds x 32x32 x 512 units = 2 GB), so this class keeps them
+    and answers EXACTLY, with the reference's read-out convention (:550-575: midpoint cumulative
+    weights, the extremes pinned at 0 and 1).  ``r`` is accepted for call compatibility.  A
+    ``max_bytes`` guard raises instead of silently approximating."""
+
+    def __init__(self, r=4096, buffersize=None, seed=None, state=None, max_bytes=64 << 30):
+        if state is not None:
+            self.set_state_dict(resolve_state_dict(state))
+            return
+        self.resolution = r
+        self.max_bytes = max_bytes
+        self.count = 0
+        self.batchcount = 0
+        self.depth = None
+        self._chunks = []
+        self._sorted = None
+
+    def add(self, incoming):
+        if incoming.dim() == 1:
+            incoming = incoming[:, None]
+        assert incoming.dim() == 2
+        if self.depth is None:
+            self.depth = incoming.shape[1]
+        assert incoming.shape[1] == self.depth
+        self._chunks.append(incoming.detach().t().contiguous())        # (units, samples)
+        self._sorted = None
+        self.count += incoming.shape[0]
+        self.batchcount += 1
+        if self.count * self.depth * 4 > self.max_bytes:
+            raise MemoryError('RunningQuantile holds %d x %d samples (> max_bytes); pass a smaller '
+                              'sample_size or raise max_bytes' % (self.count, self.depth))
+
+    def size(self):
+        return self.count
+
+    def _data(self):
+        if self._sorted is None:
+            self._sorted = torch.cat(self._chunks, dim=1).sort(dim=1)[0]
+            self._chunks = [self._sorted]
+        return self._sorted
+
+    def _grid(self):
+        n = self.count
+        s = self._data()
+        pos = (torch.arange(n, device=s.device, dtype=torch.float64) + 0.5) / n
+        return s, pos
+
+    def quantiles(self, quantiles, old_style=False):
+        q = torch.as_tensor(quantiles, dtype=torch.float64)
+        qshape = tuple(q.shape)
+        if self.count == 0:
+            return torch.full((self.depth or 0,) + qshape, float('nan'))
+        s, pos = self._grid()
+        qq = q.reshape(-1).to(s.device)
+        if old_style:                       # torch.percentile convention: min at 0, max at 1
+            lo, hi = pos[0], pos[-1]
+            qq = lo + qq * (hi - lo)
+        n = self.count
+        # piecewise linear through (0, min), ((i+.5)/n, s_i), (1, max)
+        t = (qq * n - 0.5).clamp(0, n - 1)
+        i0 = t.floor().long().clamp(0, n - 1)
+        i1 = (i0 + 1).clamp(0, n - 1)
+        frac = (t - i0.double()).to(s.dtype)
+        out = s[:, i0] * (1 - frac) + s[:, i1] * frac
+        return out.reshape((self.depth,) + qshape)
+
+    def minmax(self):
+        s = self._data()
+        return torch.stack([s[:, 0], s[:, -1]], dim=1)
+
+    def median(self):
+        return self.quantiles([0.5])[:, 0]
+
+    def mean(self):
+        return self._data().mean(dim=1)
+
+    def readout(self, count=1001, old_style=True):
+        return self.quantiles(torch.linspace(0.0, 1.0, count), old_style=old_style)
+
+    def normalize(self, data):
+        """data (units, ...) -> its quantile in [0, 1] within each unit's distribution."""
+        assert self.count > 0 and data.shape[0] == self.depth
+        s, _ = self._grid()
+        n = self.count
+        flat = data.detach().reshape(self.depth, -1).to(s.device, s.dtype).contiguous()
+        hi = torch.searchsorted(s, flat, right=False).clamp(1, n - 1)      # s[hi-1] <= x <= s[hi] (interior)
+        lo = hi - 1
+        x0, x1 = s.gather(1, lo), s.gather(1, hi)
+        frac = ((flat - x0) / (x1 - x0).clamp_min(1e-30)).clamp(0, 1)
+        q = ((lo.to(s.dtype) + 0.5) + frac) / n
+        q = torch.where(flat <= s[:, :1], torch.zeros_like(q), q)
+        q = torch.where(flat >= s[:, -1:], torch.ones_like(q), q)
+        return q.clamp_(0, 1).float().reshape(data.shape).to(data.device)
+
+    def to_(self, device):
+        self._chunks = [c.to(device) for c in self._chunks]
+        self._sorted = None if self._sorted is None else self._sorted.to(device)
+
+    def state_dict(self):
+        return dict(constructor=self.__module__ + '.' + self.__class__.__name__ + '()',
+                    resolution=self.resolution, depth=self.depth, size=self.count,
+                    batchcount=self.batchcount, exact_sorted=self._data().cpu().numpy())
+
+    def set_state_dict(self, dic):
+        self.resolution = _item(dic['resolution'])
+        self.depth = _item(dic['depth'])
+        self.count = _item(dic['size'])
+        self.batchcount = _item(dic['batchcount'])
+        self.max_bytes = 64 << 30
+        self._sorted = torch.from_numpy(numpy.asarray(dic['exact_sorted']))
+        self._chunks = [self._sorted]

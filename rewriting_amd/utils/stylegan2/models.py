@@ -69,6 +69,8 @@ def reference_noise(batch, hw, device):
         stream = torch.from_numpy(host).to(device)
         _noise_streams[key] = stream
     period = _noise_period[0]
+    if period == 1 and batch > 1:
+        return reference_noise_row0(hw, device).expand(batch, hw)
     if period and batch > period:
         # Several reference-sized batches run as one launch: image j takes the noise row it would have
         # had in its own batch of `period` (row j mod period), see noise_batch_period().
@@ -77,6 +79,14 @@ def reference_noise(batch, hw, device):
         rows = reference_noise(period, hw, device)
         return rows.repeat(batch // period, 1)
     return stream[:need].view(batch, hw)
+
+
+def reference_noise_row0(hw, device):
+    _noise_period[0], saved = 0, _noise_period[0]
+    try:
+        return reference_noise(1, hw, device)
+    finally:
+        _noise_period[0] = saved
 
 
 _noise_period = [0]

@@ -117,3 +117,46 @@ def tally_mean(compute, dataset, sample_size=None, batch_size=10, cachefile=None
     if shard is None or shard[0] == 0:
         save_cached_state(cachefile, rv, args)
     return rv
+
+
+def tally_quantile(compute, dataset, sample_size=None, batch_size=10, r=4096, cachefile=None, **kwargs):
+    """compute(batch) -> (samples, units); returns RunningQuantile (reference: utils/tally.py:132-154)."""
+    args = dict(sample_size=sample_size, r=r)
+    cached = load_cached_state(cachefile, args)
+    if cached is not None:
+        return runningstats.RunningQuantile(state=cached)
+    loader = make_loader(dataset, sample_size, batch_size, **kwargs)
+    rq = runningstats.RunningQuantile(r=r)
+    for batch in pbar(loader):
+        rq.add(call_compute(compute, batch))
+    rq.to_('cpu')
+    save_cached_state(cachefile, rq, args)
+    return rq
+
+
+def tally_topk_and_quantile(compute, dataset, sample_size=None, batch_size=10, k=100, r=4096,
+                            cachefile=None, **kwargs):
+    """One pass computing both; compute(batch) -> (sample for top-k, sample for quantiles)
+    (reference: utils/tally.py:157-181; its cached branch has two typos, quirk Q11 -- here the
+    cache simply stores both state dicts under the prefixes 'rtk.' and 'rq.')."""
+    args = dict(sample_size=sample_size, k=k, r=r)
+    cached = load_cached_state(cachefile, args)
+    if cached is not None:
+        pick = lambda pre: {key[len(pre):]: cached[key] for key in cached.files if key.startswith(pre)}
+        return (runningstats.RunningTopK(state=pick('rtk.')), runningstats.RunningQuantile(state=pick('rq.')))
+    loader = make_loader(dataset, sample_size, batch_size, **kwargs)
+    rtk, rq = runningstats.RunningTopK(k=k), runningstats.RunningQuantile(r=r)
+    for batch in pbar(loader):
+        sample_tk, sample_q = call_compute(compute, batch)
+        rtk.add(sample_tk)
+        rq.add(sample_q)
+    rtk.to_('cpu')
+    rq.to_('cpu')
+
+    class _Both:
+        def state_dict(self):
+            d = {'rtk.' + a: b for a, b in rtk.state_dict().items()}
+            d.update({'rq.' + a: b for a, b in rq.state_dict().items()})
+            return d
+    save_cached_state(cachefile, _Both(), args)
+    return rtk, rq

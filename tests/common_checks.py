@@ -92,6 +92,17 @@ def check_extras(device):
     q = gw.query_key_from_selection(*keys[0])
     assert principal_cosines(q[None], torch.from_numpy(g['query_key'])[None], C).min() > 0.98
     assert abs(q.norm().item() - 1) < 1e-4
+    # UI search path: ranking of seeds by their response to a key + quantiles of the response.
+    # The key is the golden one (C^-1 is ill-conditioned, see above) so the rankings are comparable.
+    sel, rq = gw.ranking_for_key(torch.from_numpy(g['query_key']), k=8)
+    assert sel.reshape(-1).tolist() == g['ranking'].reshape(-1).tolist()
+    got_q = rq.quantiles([0.5, 0.99, 0.999])[0].cpu().numpy()
+    assert numpy.abs(got_q - g['ranking_q']).max() < 0.05 * numpy.abs(g['ranking_q']).max()   # reference sketch is approximate
+    # gandissect units: exact quantiles here vs the reference's randomised sketch -> same top units mostly
+    units = gw.multi_key_from_selection(keys, rank=10, key_method='gandissect')
+    assert tuple(units.shape) == (10, 512) and units.sum().item() == 10 and (units.sum(0) <= 1).all()
+    assert len(set(units.argmax(1).tolist()) & set(g['gandissect_units'].tolist())) >= 8
+    assert units.argmax(1)[0].item() == int(g['gandissect_units'][0])
     gin = DataBag(fmap=_dev(g['goal_in_fmap'], device), style=_dev(g['goal_in_style'], device))
     gout = DataBag(fmap=_dev(g['goal_out_fmap'], device))
     mkey = _dev(g['mkey'], device)

@@ -212,3 +212,63 @@ def test_proggan_rewriter_config1_on_cpu_matches_golden():
         r = (torch.einsum('oiyx,di->odyx', dW, mkey) - torch.from_numpy(g['dW_%d_cos' % niter])).norm() \
             / float(g['dW_%d_norm' % niter])
         assert r < 1e-4, (niter, r)
+
+
+def test_running_topk_and_exact_quantiles():
+    torch.manual_seed(0)
+    x = torch.randn(3000, 4) * torch.tensor([1., 2., .5, 3.]) + torch.tensor([0., 1., -1., 2.])
+    rq, tk = runningstats.RunningQuantile(), runningstats.RunningTopK(k=5)
+    for i in range(0, 3000, 700):
+        rq.add(x[i:i + 700])
+        tk.add(x[i:i + 700])
+    qs = [0.0, 0.01, 0.5, 0.999, 1.0]
+    got = rq.quantiles(qs).numpy()
+    # the reference's read-out convention (utils/runningstats.py:550-575): sample i sits at (i+.5)/n
+    srt = numpy.sort(x.numpy(), axis=0)
+    grid = (numpy.arange(3000) + 0.5) / 3000
+    want = numpy.stack([numpy.interp(qs, numpy.r_[0, grid, 1], numpy.r_[srt[0, u], srt[:, u], srt[-1, u]])
+                        for u in range(4)])
+    assert numpy.abs(got - want).max() < 1e-5
+    assert numpy.abs(got[:, 2] - numpy.quantile(x.numpy(), 0.5, axis=0)).max() < 5e-3
+    assert numpy.allclose(got[:, 0], x.min(0)[0].numpy()) and numpy.allclose(got[:, -1], x.max(0)[0].numpy())
+    assert tuple(rq.quantiles(0.999).shape) == (4,) and rq.size() == 3000
+    rank = rq.normalize(x[:7].t())
+    emp = (x[None, :, :] < x[:7, None, :]).float().mean(1).t()
+    assert (rank - emp).abs().max() < 1e-3 and rank.min() >= 0 and rank.max() <= 1
+    v, i = tk.result()
+    assert torch.equal(v, x.topk(5, dim=0)[0].t()) and torch.equal(i, x.topk(5, dim=0)[1].t())
+    rq2 = runningstats.RunningQuantile(state=rq.state_dict())
+    assert torch.equal(rq2.quantiles(qs), rq.quantiles(qs))
+
+
+def test_tally_topk_and_quantile_cache(tmp_path):
+    data = torch.arange(40, dtype=torch.float32)[:, None].repeat(1, 2)
+    f = lambda b: (b.sum(1), b[:, :1])
+    cache = str(tmp_path / 'tq.npz')
+    tk, rq = tally.tally_topk_and_quantile(f, data, k=3, cachefile=cache)
+    assert tk.result()[1].tolist() == [39, 38, 37] and abs(rq.median().item() - 19.5) < 0.51
+    tk2, rq2 = tally.tally_topk_and_quantile(lambda b: 1 / 0, data, k=3, cachefile=cache)   # served from cache
+    assert tk2.result()[1].tolist() == [39, 38, 37] and torch.equal(rq2.median(), rq.median())
+
+
+def test_feature_statistics_and_frechet_distance():
+    from rewriting_amd import samples
+    rs = numpy.random.RandomState(0)
+    a = rs.randn(500, 6) @ rs.randn(6, 6)
+    b = rs.randn(400, 6) @ rs.randn(6, 6) + 0.5
+    stats = []
+    for arr in (a, b):
+        st = samples.FeatureStatistics()
+        for i in range(0, len(arr), 64):
+            st.add(torch.from_numpy(arr[i:i + 64]).float())
+        mu, sigma = st.mean_cov()
+        assert numpy.allclose(mu, arr.astype('float32').mean(0), atol=1e-5)
+        assert numpy.allclose(sigma, numpy.cov(arr.astype('float32'), rowvar=False), atol=1e-4)
+        stats.append((mu, sigma))
+    d = samples.frechet_distance(*stats[0], *stats[1])
+    assert d > 0 and abs(samples.frechet_distance(*stats[0], *stats[0])) < 1e-6
+    # 1-d closed form: (m1-m2)^2 + (s1-s2)^2
+    assert abs(samples.frechet_distance([1.0], [[4.0]], [3.0], [[9.0]]) - (4 + 1)) < 1e-9
+    g = proggan.ProgressiveGenerator(resolution=8)
+    z = samples.seed_latents(g, [3, 4])
+    assert torch.equal(z[1:], zdataset.z_sample_for_model(g, size=1, seed=4))
