@@ -100,11 +100,20 @@ int rw_weight_sqsum_f32(const float* w, float* wsq, int out_ch, int in_ch, int t
 int rw_demod_f32(const float* wsq, const float* style, float* demod, int batch, int out_ch,
                  int in_ch, float eps, rw_stream_t stream);
 
-/* Repack a conv weight W[o][i][3][3] for the implicit-GEMM kernels:
+/* Repack a conv weight W[o][i][3][3] for the implicit-GEMM kernels.  wp receives
+ * rw_packed_conv_weight_elems(out_ch, in_ch, mode) floats: first 9*Cin*Cout in slab order
  *   mode 0 (stride-1 conv, models.py:318-319):       wp[tap][i][o] = W[o][i][tap]
  *   mode 1 (stride-2 transposed conv, models.py:315-316), grouped by output parity
  *          phase (py,px): wp = [phase(0,0): 4 taps][phase(0,1): 2][phase(1,0): 2][phase(1,1): 1],
- *          each tap a contiguous [i][o] slab.  The scale 1/sqrt(9*Cin) is NOT folded in. */
+ *          each tap a contiguous [i][o] slab,
+ * then (when Cout % 32 == 0 and Cin % 16 == 0, the shapes the halo-tile kernels take) the same
+ * values in MFMA A-fragment order, so that a wave fetches its operand with 16-byte loads of 1 KiB
+ * of consecutive addresses (IC = 16 input channels per chunk; 8 for mode 0 with Cout % 64 != 0):
+ *   mode 0: wf[tap][i / IC][o / 32][kp / 4][lane][kp % 4],   kp < IC/2
+ *   mode 1: wf[i / 16][o / 32][kp]{[slab / 4][lane][slab % 4] for slab < 8, then [lane] for slab 8}
+ *   with value W[32 (o/32) + (lane & 31)][IC (i/IC) + 2 kp + (lane >> 5)][tap].
+ * The scale 1/sqrt(9*Cin) is NOT folded in. */
+long long rw_packed_conv_weight_elems(int out_ch, int in_ch, int mode);
 int rw_pack_conv_weight_f32(const float* w, float* wp, int out_ch, int in_ch, int mode,
                             rw_stream_t stream);
 

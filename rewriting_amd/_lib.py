@@ -56,6 +56,7 @@ SIGNATURES = {
     'rw_style_mul_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
     'rw_weight_sqsum_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     'rw_demod_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
+    'rw_packed_conv_weight_elems': (ctypes.c_longlong, [c_int, c_int, c_int]),
     'rw_pack_conv_weight_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'rw_conv3x3_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                c_float, POINTER(ConvEpilogue), c_int, c_void_p]),

@@ -421,7 +421,7 @@ struct PhaseDesc {
 };
 
 struct HaloProblem {
-  const float* x; const float* wp; float* y;
+  const float* x; const float* wp; const float* wfrag; float* y;
   const float* style; const float* demod; const float* noise; const float* noise_w; const float* bias;
   int batch, in_ch, out_ch, h, w, oh, ow, sy, sx;
   float w_scale;
@@ -429,7 +429,7 @@ struct HaloProblem {
   PhaseDesc phase[4];
 };
 
-template <int TM, int TN, int WGM, int WGN, int IC>
+template <int TM, int TN, int WGM, int WGN, int IC, bool FRAG>
 __global__ void __launch_bounds__(256, 2) conv_halo_kernel(const HaloProblem p) {
   constexpr int BM = 32 * TM * WGM;
   constexpr int TH = TN * WGN;
@@ -497,11 +497,27 @@ __global__ void __launch_bounds__(256, 2) conv_halo_kernel(const HaloProblem p) 
           dst[ic * XH * XW + xlds[sl]] = xreg[sl][ic] * (xmask[sl] * Ss[i0 + ic]);
       }
   };
-  float areg[KP][TM];
+  // A operand.  FRAG: the weights come in fragment order (rw_pack_conv_weight_f32): one 16-byte load
+  // per lane fetches four k-pairs and a wave's load covers 1 KiB of consecutive addresses, so a tap
+  // costs TM * KP/4 load instructions.  With KP = 8 each half is refilled right after its last use,
+  // four k-pairs (>= 1k cycles of MFMA) ahead of the next tap; with KP = 4 the next tap is
+  // double-buffered.  !FRAG (per-phase transposed conv, impl 4): per-lane dword loads of wp[tap][i][o].
+  constexpr int KH = KP / 4;
+  rw_f32x4 av[KH][TM], an[TM];
+  const int n_chunks = p.in_ch / IC;
+  const int c_stride = (p.out_ch >> 5) * KH * 256;
+  const int64_t t_stride = (int64_t)n_chunks * c_stride;
+  const float* wf = FRAG ? p.wfrag + (int64_t)((o0 + wm0) >> 5) * KH * 256 : nullptr;   // uniform
+  auto fload = [&](rw_f32x4 (&dst)[TM], int h, int t, int c) {
+    const float* base = wf + (int64_t)t * t_stride + (int64_t)c * c_stride;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+      dst[a] = *reinterpret_cast<const rw_f32x4*>(base + (a * KH + h) * 256 + lane * 4);
+  };
   auto aload1 = [&](int kp, int t, int i0) {
     const float* base = wph + ((int64_t)t * p.in_ch + i0) * p.out_ch;   // uniform: SGPR base + 32-bit lane offset
 #pragma unroll
-    for (int a = 0; a < TM; ++a) areg[kp][a] = base[a_lane + (2 * kp) * p.out_ch + 32 * a];
+    for (int a = 0; a < TM; ++a) av[kp >> 2][a][kp & 3] = base[a_lane + (2 * kp) * p.out_ch + 32 * a];
   };
 
   rw_f32x16 acc[TM][TN];
@@ -512,43 +528,60 @@ __global__ void __launch_bounds__(256, 2) conv_halo_kernel(const HaloProblem p) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  const int n_chunks = p.in_ch / IC;
   xfetch(0);
+  if (FRAG) {
 #pragma unroll
-  for (int kp = 0; kp < KP; ++kp) aload1(kp, 0, 0);
+    for (int h = 0; h < KH; ++h) fload(av[h], h, 0, 0);
+  } else {
+#pragma unroll
+    for (int kp = 0; kp < KP; ++kp) aload1(kp, 0, 0);
+  }
   __syncthreads();                            // Ss visible
   xstash(0, 0);
   __syncthreads();
+  // The loop body is straight-line code: prefetches past the end are clamped to valid (unused)
+  // addresses instead of being branched around, and __builtin_amdgcn_sched_barrier pins every
+  // load BEFORE the MFMA group that covers its latency (left alone, the scheduler sinks the loads
+  // next to their first use and each k-pair waits for a full L2 / LDS round trip).
   for (int c = 0; c < n_chunks; ++c) {
     const int buf = c & 1;
     const int i0 = c * IC;
-    if (c + 1 < n_chunks) xfetch(i0 + IC);
-    for (int t = 0; t < d.ntaps; ++t) {
-      int nt = t + 1, ni0 = i0;
-      if (nt == d.ntaps) { nt = 0; ni0 = i0 + IC; }
-      const bool more = ni0 < p.in_ch;
-      const int dy = rw_tap_off(d.dy_bits, t), dx = rw_tap_off(d.dx_bits, t);
-      const float* xs = &Xs[buf][frow][wrow0 + dy + 1][fcol + dx + 1];
-      float bf[TN], bnext[TN];
+    const int cn = c + 1 < n_chunks ? c + 1 : c;
+    xfetch(cn * IC);                       // consumed by xstash at the end of the chunk
+    const float* xs = &Xs[buf][frow][wrow0 + rw_tap_off(d.dy_bits, 0) + 1][fcol + rw_tap_off(d.dx_bits, 0) + 1];
+    float bf[TN], bnext[TN];
 #pragma unroll
-      for (int b = 0; b < TN; ++b) bf[b] = xs[b * XW];
+    for (int b = 0; b < TN; ++b) bf[b] = xs[b * XW];
+    for (int t = 0; t < d.ntaps; ++t) {
+      int nt = t + 1, nc = c;
+      if (nt == d.ntaps) { nt = 0; nc = cn; }
+      // first k-pair of the next tap (for the last tap: re-read after the barrier, this one is unused)
+      const float* xs_next = &Xs[buf][frow][wrow0 + rw_tap_off(d.dy_bits, nt) + 1][fcol + rw_tap_off(d.dx_bits, nt) + 1];
+      if (FRAG && KH == 1) fload(an, 0, nt, nc);
 #pragma unroll
       for (int kp = 0; kp < KP; ++kp) {
-        if (kp + 1 < KP) {                      // B fragments one k-pair ahead of the MFMAs that use them
 #pragma unroll
-          for (int b = 0; b < TN; ++b) bnext[b] = xs[(2 * kp + 2) * XH * XW + b * XW];
-        }
+        for (int b = 0; b < TN; ++b)       // B fragments one k-pair ahead of the MFMAs that use them
+          bnext[b] = kp + 1 < KP ? xs[(2 * kp + 2) * XH * XW + b * XW] : xs_next[b * XW];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
           for (int b = 0; b < TN; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[kp][a], bf[b], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kp >> 2][a][kp & 3], bf[b], acc[a][b], 0, 0, 0);
+        // these weight registers are free again: refill them for the next tap, >= 1k cycles of MFMA
+        // ahead of their use
+        if (!FRAG) aload1(kp, nt, nc * IC);
+        else if (KH > 1 && (kp & 3) == 3) fload(av[kp >> 2], kp >> 2, nt, nc);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int b = 0; b < TN; ++b) bf[b] = bnext[b];
-        // this k-pair's weight registers are free again: refill them for the next tap, KP-1 steps
-        // (>= 1.5k cycles of MFMA) ahead of their use
-        if (more) aload1(kp, nt, ni0);
       }
+      if (FRAG && KH == 1) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a) av[0][a] = an[a];
+      }
+      xs = xs_next;
     }
     if (c + 1 < n_chunks) xstash(buf ^ 1, i0 + IC);
     __syncthreads();
@@ -593,7 +626,7 @@ __global__ void __launch_bounds__(256, 2) conv_halo_kernel(const HaloProblem p) 
 // strip of H+W+1 quads computed by four strip problems of one batched im2col launch.
 // ---------------------------------------------------------------------------------------
 struct UpProblem {
-  const float* x; const float* wp; float* y;
+  const float* x; const float* wfrag; float* y;
   const float* style; const float* demod;
   int batch, in_ch, out_ch, h, w;
   int tiles_x, tiles_y;
@@ -628,9 +661,9 @@ __global__ void __launch_bounds__(256, 2) conv_up_halo_kernel(const UpProblem p)
   const int64_t hw = (int64_t)p.h * p.w;
   const float* xb = p.x + (int64_t)ib * p.in_ch * hw;
   for (int i = tid; i < p.in_ch; i += 256) Ss[i] = p.style ? p.style[(int64_t)ib * p.in_ch + i] : 1.0f;
-  const int64_t slab = (int64_t)p.in_ch * p.out_ch;
-  const float* wph = p.wp + o0;                                  // uniform
-  const int a_lane = frow * p.out_ch + wm0 + fcol;
+  // weights in fragment order (rw_pack_conv_weight_f32 mode 1): [chunk][o / 32][kp][576]
+  const float* wf = p.wfrag + (int64_t)((o0 + wm0) >> 5) * KP * 576;    // uniform
+  const int c_stride = (p.out_ch >> 5) * KP * 576;
 
   int xoff[PSLOT], xlds[PSLOT];
   float xmask[PSLOT];
@@ -662,12 +695,15 @@ __global__ void __launch_bounds__(256, 2) conv_up_halo_kernel(const UpProblem p)
           dst[ic * XH * XW + xlds[sl]] = xreg[sl][ic] * (xmask[sl] * Ss[i0 + ic]);
       }
   };
-  // nine weight slabs (rw_pack_conv_weight_f32 mode 1 order) for one k-pair
-  float acur[9], anxt[9];
-  auto aload = [&](float (&dst)[9], int kp, int i0) {
-    const float* base = wph + (int64_t)(i0 + 2 * kp) * p.out_ch;
-#pragma unroll
-    for (int sb = 0; sb < 9; ++sb) dst[sb] = base[sb * slab + a_lane];
+  // nine weight slabs of one k-pair: two 16-byte loads (slabs 0-3, 4-7; 1 KiB per wave each) and a
+  // dword (slab 8) per lane
+  struct ASlabs { rw_f32x4 v4[2]; float s8; };
+  ASlabs acur, anxt;
+  auto aload = [&](ASlabs& dst, int kp, int c) {
+    const float* base = wf + (int64_t)c * c_stride + kp * 576;
+    dst.v4[0] = *reinterpret_cast<const rw_f32x4*>(base + lane * 4);
+    dst.v4[1] = *reinterpret_cast<const rw_f32x4*>(base + 256 + lane * 4);
+    dst.s8 = base[512 + lane];
   };
 
   rw_f32x16 acc[4][TN];
@@ -684,38 +720,53 @@ __global__ void __launch_bounds__(256, 2) conv_up_halo_kernel(const UpProblem p)
   __syncthreads();
   xstash(0, 0);
   __syncthreads();
+  // Straight-line body, loads pinned ahead of the MFMA group that hides them (see conv_halo_kernel).
   for (int c = 0; c < n_chunks; ++c) {
     const int buf = c & 1;
     const int i0 = c * IC;
-    if (c + 1 < n_chunks) xfetch(i0 + IC);
+    const int cn = c + 1 < n_chunks ? c + 1 : c;
     // LDS row r holds input row y0-1+r, column c holds input column x0-1+c:
     // shift (dy,dx) of quad (row, col) -> Xs[.][row + 1 + dy][col + 1 + dx]
     const float* xs = &Xs[buf][frow][wrow0][fcol];
+    float b00[TN], b0m[TN], bm0[TN], bmm[TN], n00[TN], n0m[TN], nm0[TN], nmm[TN];
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const float* q = xs + b * XW;
+      b00[b] = q[XW + 1]; b0m[b] = q[XW]; bm0[b] = q[1]; bmm[b] = q[0];
+    }
 #pragma unroll
     for (int kp = 0; kp < KP; ++kp) {
-      int nkp = kp + 1, ni0 = i0;
-      if (nkp == KP) { nkp = 0; ni0 = i0 + IC; }
-      if (ni0 < p.in_ch) aload(anxt, nkp, ni0);
-      float b00[TN], b0m[TN], bm0[TN], bmm[TN];
+      int nkp = kp + 1, nc = c;
+      if (nkp == KP) { nkp = 0; nc = cn; }
+      aload(anxt, nkp, nc);
+      if (kp == 0) xfetch(cn * IC);       // after the weight load: its wait must not drain these
+      if (kp + 1 < KP) {
 #pragma unroll
-      for (int b = 0; b < TN; ++b) {
-        const float* q = xs + (2 * kp) * XH * XW + b * XW;
-        b00[b] = q[XW + 1]; b0m[b] = q[XW]; bm0[b] = q[1]; bmm[b] = q[0];
+        for (int b = 0; b < TN; ++b) {
+          const float* q = xs + (2 * kp + 2) * XH * XW + b * XW;
+          n00[b] = q[XW + 1]; n0m[b] = q[XW]; nm0[b] = q[1]; nmm[b] = q[0];
+        }
       }
+      __builtin_amdgcn_sched_barrier(0);
+      // nine slabs x TN rows; consecutive MFMAs never accumulate into the same registers
+#define RW_UP_MFMA(q, sl, bv)                                                                          \
+  _Pragma("unroll") for (int b = 0; b < TN; ++b) acc[q][b] =                                            \
+      __builtin_amdgcn_mfma_f32_32x32x2f32((sl) < 8 ? acur.v4[((sl) >> 2) & 1][(sl) & 3] : acur.s8, bv[b],  \
+                                           acc[q][b], 0, 0, 0)
+      RW_UP_MFMA(0, 0, b00);
+      RW_UP_MFMA(1, 4, b00);
+      RW_UP_MFMA(0, 1, b0m);
+      RW_UP_MFMA(2, 6, b00);
+      RW_UP_MFMA(0, 2, bm0);
+      RW_UP_MFMA(3, 8, b00);
+      RW_UP_MFMA(0, 3, bmm);
+      RW_UP_MFMA(1, 5, bm0);
+      RW_UP_MFMA(2, 7, b0m);
+#undef RW_UP_MFMA
+      __builtin_amdgcn_sched_barrier(0);
+      acur = anxt;
 #pragma unroll
-      for (int b = 0; b < TN; ++b) {
-        acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[0], b00[b], acc[0][b], 0, 0, 0);
-        acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[1], b0m[b], acc[0][b], 0, 0, 0);
-        acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[2], bm0[b], acc[0][b], 0, 0, 0);
-        acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[3], bmm[b], acc[0][b], 0, 0, 0);
-        acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[4], b00[b], acc[1][b], 0, 0, 0);
-        acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[5], bm0[b], acc[1][b], 0, 0, 0);
-        acc[2][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[6], b00[b], acc[2][b], 0, 0, 0);
-        acc[2][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[7], b0m[b], acc[2][b], 0, 0, 0);
-        acc[3][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[8], b00[b], acc[3][b], 0, 0, 0);
-      }
-#pragma unroll
-      for (int sb = 0; sb < 9; ++sb) acur[sb] = anxt[sb];
+      for (int b = 0; b < TN; ++b) { b00[b] = n00[b]; b0m[b] = n0m[b]; bm0[b] = nm0[b]; bmm[b] = nmm[b]; }
     }
     if (c + 1 < n_chunks) xstash(buf ^ 1, i0 + IC);
     __syncthreads();
@@ -755,7 +806,7 @@ static int launch_batch(const ConvProblem* ps, int n, int impl, hipStream_t s);
 static int launch_up_halo(const ConvProblem* ps, const float* wp_all, hipStream_t s) {
   const ConvProblem& c = ps[0];
   UpProblem u;
-  u.x = c.x; u.wp = wp_all; u.y = c.y; u.style = c.style; u.demod = c.demod;
+  u.x = c.x; u.wfrag = wp_all + (int64_t)9 * c.in_ch * c.out_ch; u.y = c.y; u.style = c.style; u.demod = c.demod;
   u.batch = c.batch; u.in_ch = c.in_ch; u.out_ch = c.out_ch; u.h = c.h; u.w = c.w; u.w_scale = c.w_scale;
   u.tiles_x = (int)rw_cdiv(c.w, 32);
   if (c.out_ch % 64 == 0) {
@@ -784,10 +835,10 @@ static bool halo_applicable(const ConvProblem* ps, int n) {
 }
 
 // ps: 1 (stride-1 conv) or 4 (transposed-conv phases) problems sharing x / y / epilogue.
-static int launch_halo(const ConvProblem* ps, int n, hipStream_t s) {
+static int launch_halo(const ConvProblem* ps, int n, const float* wfrag, hipStream_t s) {
   const ConvProblem& c = ps[0];
   HaloProblem h;
-  h.x = c.x; h.wp = ps[0].wp; h.y = c.y; h.style = c.style; h.demod = c.demod; h.noise = c.noise;
+  h.x = c.x; h.wp = ps[0].wp; h.wfrag = wfrag; h.y = c.y; h.style = c.style; h.demod = c.demod; h.noise = c.noise;
   h.noise_w = c.noise_w; h.bias = c.bias; h.batch = c.batch; h.in_ch = c.in_ch; h.out_ch = c.out_ch;
   h.h = c.h; h.w = c.w; h.oh = c.oh; h.ow = c.ow; h.sy = c.sy; h.sx = c.sx; h.w_scale = c.w_scale;
   h.act = c.act; h.nphase = n;
@@ -806,12 +857,21 @@ static int launch_halo(const ConvProblem* ps, int n, hipStream_t s) {
     if (q < n) work += c.batch * d.tiles_x * d.tiles_y * (c.out_ch / bm);
   }
   if (work == 0) return 0;
-  if (bm == 128)
-    hipLaunchKernelGGL((conv_halo_kernel<2, 2, 2, 2, 16>), dim3(work), dim3(256), 0, s, h);
-  else if (bm == 64)
-    hipLaunchKernelGGL((conv_halo_kernel<2, 2, 1, 4, 16>), dim3(work), dim3(256), 0, s, h);
-  else
-    hipLaunchKernelGGL((conv_halo_kernel<1, 4, 1, 4, 8>), dim3(work), dim3(256), 0, s, h);
+  if (wfrag) {        // stride-1 convolution, weights in fragment order
+    if (bm == 128)
+      hipLaunchKernelGGL((conv_halo_kernel<2, 2, 2, 2, 16, true>), dim3(work), dim3(256), 0, s, h);
+    else if (bm == 64)
+      hipLaunchKernelGGL((conv_halo_kernel<2, 2, 1, 4, 16, true>), dim3(work), dim3(256), 0, s, h);
+    else
+      hipLaunchKernelGGL((conv_halo_kernel<1, 4, 1, 4, 8, true>), dim3(work), dim3(256), 0, s, h);
+  } else {
+    if (bm == 128)
+      hipLaunchKernelGGL((conv_halo_kernel<2, 2, 2, 2, 16, false>), dim3(work), dim3(256), 0, s, h);
+    else if (bm == 64)
+      hipLaunchKernelGGL((conv_halo_kernel<2, 2, 1, 4, 16, false>), dim3(work), dim3(256), 0, s, h);
+    else
+      hipLaunchKernelGGL((conv_halo_kernel<1, 4, 1, 4, 8, false>), dim3(work), dim3(256), 0, s, h);
+  }
   return RW_LAUNCH_RESULT();
 }
 
@@ -939,7 +999,8 @@ extern "C" int rw_conv3x3_f32(const float* x, const float* wp, float* y, int bat
   p.ntaps = 9;
   for (int t = 0; t < 9; ++t) set_tap(p, t, t / 3 - 1, t % 3 - 1);
   if (impl == 3 && !halo_applicable(&p, 1)) return RW_ERR_UNSUPPORTED;
-  if (impl == 3 || (impl == 0 && halo_applicable(&p, 1))) return launch_halo(&p, 1, rw_s(stream));
+  if (impl == 3 || (impl == 0 && halo_applicable(&p, 1)))
+    return launch_halo(&p, 1, wp + (int64_t)9 * in_ch * out_ch, rw_s(stream));
   return launch_batch(&p, 1, impl == 2 ? 0 : impl, rw_s(stream));
 }
 
@@ -967,7 +1028,7 @@ extern "C" int rw_conv_transpose3x3s2_f32(const float* x, const float* wp, float
     for (int t = 0; t < p.ntaps; ++t) set_tap(p, t, tdy[phase][t], tdx[phase][t]);
   }
   if ((impl == 3 || impl == 4) && !halo_applicable(ps, 4)) return RW_ERR_UNSUPPORTED;
-  if (impl == 4) return launch_halo(ps, 4, rw_s(stream));         // per-phase halo tiles (kept for A/B)
+  if (impl == 4) return launch_halo(ps, 4, nullptr, rw_s(stream));        // per-phase halo tiles (kept for A/B)
   if (impl == 3 || (impl == 0 && halo_applicable(ps, 4))) return launch_up_halo(ps, wp, rw_s(stream));
   return launch_batch(ps, 4, impl == 2 ? 0 : impl, rw_s(stream));
 }

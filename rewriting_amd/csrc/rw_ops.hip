@@ -396,9 +396,20 @@ extern "C" int rw_demod_f32(const float* wsq, const float* style, float* demod, 
 }
 
 // ---------------------------------------------------------------------------------------
-// Weight repack for the implicit-GEMM convolutions: [o][i][tap] -> [slab][i][o]
+// Weight repack for the implicit-GEMM convolutions: [o][i][tap] -> [slab][i][o], followed by the
+// same weights in MFMA A-fragment order for the halo-tile kernels (see rewriting_hip.h)
 // ---------------------------------------------------------------------------------------
 __constant__ int rw_up_tap_order[9] = {0, 2, 6, 8, 1, 7, 3, 5, 4};
+
+static inline bool rw_frag_ok(int out_ch, int in_ch) { return out_ch % 32 == 0 && in_ch % 16 == 0; }
+static inline int rw_frag_ic(int out_ch, int mode) { return (mode == 1 || out_ch % 64 == 0) ? 16 : 8; }
+
+extern "C" long long rw_packed_conv_weight_elems(int out_ch, int in_ch, int mode) {
+  if (out_ch <= 0 || in_ch <= 0 || (mode != 0 && mode != 1)) return -1;
+  const long long io = (long long)in_ch * out_ch;
+  if (!rw_frag_ok(out_ch, in_ch)) return 9 * io;
+  return 18 * io;
+}
 
 __global__ void __launch_bounds__(256) pack_conv_weight_kernel(const float* __restrict__ w,
                                                                float* __restrict__ wp, int out_ch,
@@ -414,12 +425,55 @@ __global__ void __launch_bounds__(256) pack_conv_weight_kernel(const float* __re
   }
 }
 
+// Fragment order.  A lane of v_mfma_f32_32x32x2_f32 holds A[o = lane & 31][k = lane >> 5]; the
+// kernels walk k-pairs kp of an IC-channel chunk c, so lane l of out-channel block ob needs
+// W[32 ob + (l & 31)][c IC + 2 kp + (l >> 5)][tap].
+//   mode 0: wf[tap][c][ob][kp / 4][lane][kp % 4]       -> one 16-byte load per lane gives 4 k-pairs,
+//   mode 1: wf[c][ob][kp]{[2][lane][4], [lane]}        -> two give slabs 0..7 of one, a dword slab 8,
+// and every 16-byte load instruction of a wave reads 1 KiB of consecutive addresses.
+__global__ void __launch_bounds__(256) pack_conv_frag_kernel(const float* __restrict__ w,
+                                                             float* __restrict__ wf, int out_ch,
+                                                             int in_ch, int mode, int ic) {
+  const int obn = out_ch >> 5, kpn = ic >> 1, chunks = in_ch / ic;
+  const int64_t total = (int64_t)9 * in_ch * out_ch;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = idx;
+    int kp, tap, c, ob, lane;
+    if (mode == 0) {
+      const int e = (int)(r & 3); r >>= 2;
+      lane = (int)(r & 63); r >>= 6;
+      const int h = (int)(r % (kpn >> 2)); r /= (kpn >> 2);
+      ob = (int)(r % obn); r /= obn;
+      c = (int)(r % chunks); r /= chunks;
+      tap = (int)r;
+      kp = 4 * h + e;
+    } else {
+      const int u = (int)(r % 576); r /= 576;
+      kp = (int)(r % kpn); r /= kpn;
+      ob = (int)(r % obn); r /= obn;
+      c = (int)r;
+      int slab;
+      if (u < 512) { slab = 4 * (u >> 8) + (u & 3); lane = (u >> 2) & 63; }
+      else { slab = 8; lane = u - 512; }
+      tap = rw_up_tap_order[slab];
+    }
+    const int o = 32 * ob + (lane & 31);
+    const int i = c * ic + 2 * kp + (lane >> 5);
+    wf[idx] = w[((int64_t)o * in_ch + i) * 9 + tap];
+  }
+}
+
 extern "C" int rw_pack_conv_weight_f32(const float* w, float* wp, int out_ch, int in_ch, int mode,
                                        rw_stream_t stream) {
   RW_CHECK_ARG(w && wp && out_ch > 0 && in_ch > 0 && (mode == 0 || mode == 1));
   const int64_t total = (int64_t)9 * in_ch * out_ch;
   hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(rw_stream_grid(total, 256)), dim3(256), 0,
                      rw_s(stream), w, wp, out_ch, in_ch, mode);
+  if (rw_frag_ok(out_ch, in_ch)) {
+    hipLaunchKernelGGL(pack_conv_frag_kernel, dim3(rw_stream_grid(total, 256)), dim3(256), 0,
+                       rw_s(stream), w, wp + total, out_ch, in_ch, mode, rw_frag_ic(out_ch, mode));
+  }
   return RW_LAUNCH_RESULT();
 }
 

@@ -160,9 +160,18 @@ def demod(wsq, style, eps=1e-8):
 def pack_conv_weight(weight, mode):
     weight = _dev(weight, 'weight')
     o, i = weight.shape[-4], weight.shape[-3]
-    wp = torch.empty(9, i, o, device=weight.device, dtype=weight.dtype)
+    n = lib().rw_packed_conv_weight_elems(o, i, int(mode))
+    if n <= 0:
+        raise ValueError('bad weight shape / mode')
+    wp = torch.empty(n, device=weight.device, dtype=weight.dtype)   # slab order, then fragment order
     check(lib().rw_pack_conv_weight_f32(_p(weight), _p(wp), o, i, int(mode), _stream()))
     return wp
+
+
+def _check_packed(wp, out_ch, in_ch, mode):
+    if wp.numel() != lib().rw_packed_conv_weight_elems(out_ch, in_ch, mode):
+        raise ValueError('packed weight does not come from pack_conv_weight(%d x %d, mode %d)'
+                         % (out_ch, in_ch, mode))
 
 
 def _epilogue(style=None, demod=None, noise=None, noise_w=None, bias=None, act=False):
@@ -180,6 +189,7 @@ def conv3x3(x, wp, out_ch, w_scale, style=None, demod=None, noise=None, noise_w=
     b, i, h, w = x.shape
     y = torch.empty(b, out_ch, h, w, device=x.device, dtype=x.dtype)
     ep, keep = _epilogue(style, demod, noise, noise_w, bias, act)
+    _check_packed(wp, out_ch, i, 0)
     check(lib().rw_conv3x3_f32(_p(x), _p(wp), _p(y), b, i, out_ch, h, w, float(w_scale),
                                ctypes.byref(ep), int(impl), _stream()))
     return y
@@ -191,6 +201,7 @@ def conv_transpose3x3s2(x, wp, out_ch, w_scale, style=None, demod=None, impl=0):
     b, i, h, w = x.shape
     y = torch.empty(b, out_ch, 2 * h + 1, 2 * w + 1, device=x.device, dtype=x.dtype)
     ep, keep = _epilogue(style, demod)
+    _check_packed(wp, out_ch, i, 1)
     check(lib().rw_conv_transpose3x3s2_f32(_p(x), _p(wp), _p(y), b, i, out_ch, h, w, float(w_scale),
                                            ctypes.byref(ep), int(impl), _stream()))
     return y

@@ -23,7 +23,10 @@ LAYERS = [  # (name, cin, cout, input res, upsample)
 def main(batch=int(os.environ.get('RW_BATCH', '8')), iters=5):
     dev = 'cuda'
     rows = []
+    only = os.environ.get('RW_LAYERS')
     for name, cin, cout, res, up in LAYERS:
+        if only and name not in only.split(','):
+            continue
         x = torch.randn(batch, cin, res, res, device=dev)
         w = torch.randn(1, cout, cin, 3, 3, device=dev)
         style = 1 + 0.3 * torch.randn(batch, cin, device=dev)
