@@ -644,7 +644,6 @@ __global__ void __launch_bounds__(256, 2) conv_up_halo_kernel(const UpProblem p)
   constexpr int KP = IC / 2;
   static_assert(WGM * WGN == 4, "4 waves per workgroup");
   __shared__ float Xs[2][IC][XH][XW];
-  __shared__ float Ss[1024];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm0 = (wave / WGN) * 32;
@@ -660,11 +659,14 @@ __global__ void __launch_bounds__(256, 2) conv_up_halo_kernel(const UpProblem p)
   const int y0 = ty * TH, x0 = tx * 32;
   const int64_t hw = (int64_t)p.h * p.w;
   const float* xb = p.x + (int64_t)ib * p.in_ch * hw;
-  for (int i = tid; i < p.in_ch; i += 256) Ss[i] = p.style ? p.style[(int64_t)ib * p.in_ch + i] : 1.0f;
+  const float* st = p.style ? p.style + (int64_t)ib * p.in_ch : nullptr;     // uniform: scalar loads
   // weights in fragment order (rw_pack_conv_weight_f32 mode 1): [chunk][o / 32][kp][576]
   const float* wf = p.wfrag + (int64_t)((o0 + wm0) >> 5) * KP * 576;    // uniform
   const int c_stride = (p.out_ch >> 5) * KP * 576;
 
+  // Halo staging: this thread owns up to PSLOT fixed positions of the (TH+1) x 33 patch; positions
+  // outside the image are loaded from a legal address and multiplied by 0, slots past the patch
+  // are written to a padding column nobody reads, so the staging is branch-free.
   int xoff[PSLOT], xlds[PSLOT];
   float xmask[PSLOT];
 #pragma unroll
@@ -675,25 +677,31 @@ __global__ void __launch_bounds__(256, 2) conv_up_halo_kernel(const UpProblem p)
     const bool ok = pos < NPOS && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
     xoff[sl] = ok ? iy * p.w + ix : 0;
     xmask[sl] = ok ? 1.0f : 0.0f;
-    xlds[sl] = pos < NPOS ? r * XW + c : -1;
+    xlds[sl] = pos < NPOS ? r * XW + c : XW - 1;
   }
   float xreg[PSLOT][IC];
+  float sty[IC];                            // style of the chunk held in xreg (SGPRs)
   auto xfetch = [&](int i0) {
     const float* xc = xb + (int64_t)i0 * hw;
 #pragma unroll
     for (int ic = 0; ic < IC; ++ic)
 #pragma unroll
       for (int sl = 0; sl < PSLOT; ++sl) xreg[sl][ic] = xc[(int64_t)ic * hw + xoff[sl]];
+    if (st) {
+#pragma unroll
+      for (int ic = 0; ic < IC; ++ic) sty[ic] = st[i0 + ic];
+    } else {
+#pragma unroll
+      for (int ic = 0; ic < IC; ++ic) sty[ic] = 1.0f;
+    }
   };
-  auto xstash = [&](int buf, int i0) {
-    float* dst = &Xs[buf][0][0][0];
-#pragma unroll
-    for (int sl = 0; sl < PSLOT; ++sl)
-      if (xlds[sl] >= 0) {
-#pragma unroll
-        for (int ic = 0; ic < IC; ++ic)
-          dst[ic * XH * XW + xlds[sl]] = xreg[sl][ic] * (xmask[sl] * Ss[i0 + ic]);
-      }
+  // one element of the staging (style and the zero padding applied on the way into LDS); the steps
+  // are spread between the MFMAs of the last k-pairs of a chunk instead of forming a VALU/LDS-only
+  // phase in front of the barrier
+  constexpr int NST = PSLOT * IC;
+  auto stash_step = [&](int buf, int j) {
+    const int sl = j / IC, ic = j % IC;
+    (&Xs[buf][0][0][0])[ic * XH * XW + xlds[sl]] = xreg[sl][ic] * (xmask[sl] * sty[ic]);
   };
   // nine weight slabs of one k-pair: two 16-byte loads (slabs 0-3, 4-7; 1 KiB per wave each) and a
   // dword (slab 8) per lane
@@ -717,14 +725,15 @@ __global__ void __launch_bounds__(256, 2) conv_up_halo_kernel(const UpProblem p)
   const int n_chunks = p.in_ch / IC;
   xfetch(0);
   aload(acur, 0, 0);
-  __syncthreads();
-  xstash(0, 0);
+#pragma unroll
+  for (int j = 0; j < NST; ++j) stash_step(0, j);
   __syncthreads();
   // Straight-line body, loads pinned ahead of the MFMA group that hides them (see conv_halo_kernel).
+  constexpr int SLOT0 = 9 * (KP - 4);        // first MFMA statement (of 9 * KP) that carries a staging step
+  static_assert(NST <= 36, "staging steps fit the last four k-pairs");
   for (int c = 0; c < n_chunks; ++c) {
     const int buf = c & 1;
-    const int i0 = c * IC;
-    const int cn = c + 1 < n_chunks ? c + 1 : c;
+    const int cn = c + 1 < n_chunks ? c + 1 : c;     // last chunk: a redundant, unused refill
     // LDS row r holds input row y0-1+r, column c holds input column x0-1+c:
     // shift (dy,dx) of quad (row, col) -> Xs[.][row + 1 + dy][col + 1 + dx]
     const float* xs = &Xs[buf][frow][wrow0][fcol];
@@ -749,53 +758,78 @@ __global__ void __launch_bounds__(256, 2) conv_up_halo_kernel(const UpProblem p)
       }
       __builtin_amdgcn_sched_barrier(0);
       // nine slabs x TN rows; consecutive MFMAs never accumulate into the same registers
-#define RW_UP_MFMA(q, sl, bv)                                                                          \
+#define RW_UP_MFMA(m, q, sl, bv)                                                                        \
   _Pragma("unroll") for (int b = 0; b < TN; ++b) acc[q][b] =                                            \
       __builtin_amdgcn_mfma_f32_32x32x2f32((sl) < 8 ? acur.v4[((sl) >> 2) & 1][(sl) & 3] : acur.s8, bv[b],  \
-                                           acc[q][b], 0, 0, 0)
-      RW_UP_MFMA(0, 0, b00);
-      RW_UP_MFMA(1, 4, b00);
-      RW_UP_MFMA(0, 1, b0m);
-      RW_UP_MFMA(2, 6, b00);
-      RW_UP_MFMA(0, 2, bm0);
-      RW_UP_MFMA(3, 8, b00);
-      RW_UP_MFMA(0, 3, bmm);
-      RW_UP_MFMA(1, 5, bm0);
-      RW_UP_MFMA(2, 7, b0m);
+                                           acc[q][b], 0, 0, 0);                                        \
+  if (9 * kp + (m) >= SLOT0 && 9 * kp + (m) - SLOT0 < NST) {                                            \
+    stash_step(buf ^ 1, 9 * kp + (m) - SLOT0);                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+  }
+      RW_UP_MFMA(0, 0, 0, b00)
+      RW_UP_MFMA(1, 1, 4, b00)
+      RW_UP_MFMA(2, 0, 1, b0m)
+      RW_UP_MFMA(3, 2, 6, b00)
+      RW_UP_MFMA(4, 0, 2, bm0)
+      RW_UP_MFMA(5, 3, 8, b00)
+      RW_UP_MFMA(6, 0, 3, bmm)
+      RW_UP_MFMA(7, 1, 5, bm0)
+      RW_UP_MFMA(8, 2, 7, b0m)
 #undef RW_UP_MFMA
       __builtin_amdgcn_sched_barrier(0);
       acur = anxt;
 #pragma unroll
       for (int b = 0; b < TN; ++b) { b00[b] = n00[b]; b0m[b] = n0m[b]; bm0[b] = nm0[b]; bmm[b] = nmm[b]; }
     }
-    if (c + 1 < n_chunks) xstash(buf ^ 1, i0 + IC);
     __syncthreads();
   }
 
+  // Epilogue.  A lane holds the 2x2 outputs of quad (yy, xx); neighbouring lanes exchange halves
+  // (DPP quad_perm [1,0,3,2]) so that the even lane owns four consecutive floats of output row 2yy
+  // and the odd lane four of row 2yy+1: one 16-byte store per lane instead of an 8-byte and two
+  // strided 4-byte ones (planes have odd size, so the stores are only 4-byte aligned).
+  typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+  typedef float f32x2_u __attribute__((ext_vector_type(2), aligned(4)));
   const int oh = 2 * p.h + 1, ow = 2 * p.w + 1;
   const int64_t ohw = (int64_t)oh * ow;
   const int xx = x0 + fcol;
+  const bool odd_lane = fcol & 1;
+  const bool pair_ok = (xx | 1) < p.w;        // both quads of the lane pair are inside the tiled area
+  float scale[16];                            // w_scale * demod of this lane's 16 out-channels, loaded at once
+  if (p.demod) {
+    const float* dm = p.demod + (int64_t)ib * p.out_ch + o0 + wm0 + 4 * frow;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) scale[r] = dm[(r & 3) + 8 * (r >> 2)];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) scale[r] *= p.w_scale;
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) scale[r] = p.w_scale;
+  }
 #pragma unroll
   for (int b = 0; b < TN; ++b) {
     const int yy = y0 + wrow0 + b;
-    if (yy >= p.h || xx >= p.w) continue;       // the last output row / column come from the strip launch
-    const bool odd_row = true, odd_col = true;
+    if (yy >= p.h) continue;                    // uniform per wave row; row 2H comes from the strip launch
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int o = o0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * frow;
-      float sc = p.w_scale;
-      if (p.demod) sc *= p.demod[(int64_t)ib * p.out_ch + o];
-      float* yo = p.y + ((int64_t)ib * p.out_ch + o) * ohw + (int64_t)(2 * yy) * ow + 2 * xx;
+      const float sc = scale[r];
       const float v00 = acc[0][b][r] * sc, v01 = acc[1][b][r] * sc;
       const float v10 = acc[2][b][r] * sc, v11 = acc[3][b][r] * sc;
-      if (odd_col) {
-        *reinterpret_cast<float2*>(yo) = make_float2(v00, v01);        // (2yy*ow + 2xx) is even: 8-byte aligned
-      } else {
-        yo[0] = v00;
-      }
-      if (odd_row) {
-        yo[ow] = v10;
-        if (odd_col) yo[ow + 1] = v11;
+      const float g0 = __int_as_float(__builtin_amdgcn_update_dpp(
+          0, __float_as_int(odd_lane ? v00 : v10), 0xB1, 0xf, 0xf, true));
+      const float g1 = __int_as_float(__builtin_amdgcn_update_dpp(
+          0, __float_as_int(odd_lane ? v01 : v11), 0xB1, 0xf, 0xf, true));
+      float* yo = p.y + ((int64_t)ib * p.out_ch + o) * ohw + (int64_t)(2 * yy) * ow + 2 * xx;
+      if (pair_ok) {
+        f32x4_u v;
+        if (odd_lane) { v[0] = g0; v[1] = g1; v[2] = v10; v[3] = v11; }
+        else          { v[0] = v00; v[1] = v01; v[2] = g0; v[3] = g1; }
+        *reinterpret_cast<f32x4_u*>(odd_lane ? yo + ow - 2 : yo) = v;
+      } else if (xx < p.w) {                    // odd W: last quad column of the tiled area
+        f32x2_u e = {v00, v01}, d = {v10, v11};
+        *reinterpret_cast<f32x2_u*>(yo) = e;
+        *reinterpret_cast<f32x2_u*>(yo + ow) = d;
       }
     }
   }
