@@ -412,6 +412,8 @@ __global__ void __launch_bounds__(256) conv_mfma_ksplit_kernel(const ConvBatch c
 // The four output-parity phases of the stride-2 transposed convolution are four sub-problems
 // of ONE launch.
 // ---------------------------------------------------------------------------------------
+template <int N> struct rw_int { static constexpr int value = N; };
+
 struct PhaseDesc {
   int ntaps;
   unsigned dy_bits, dx_bits;
@@ -437,7 +439,6 @@ __global__ void __launch_bounds__(256, 2) conv_halo_kernel(const HaloProblem p) 
   constexpr int KP = IC / 2;
   static_assert(WGM * WGN == 4, "4 waves per workgroup");
   __shared__ float Xs[2][IC][XH][XW];
-  __shared__ float Ss[1024];                 // this image's style row (1.0 when style is not fused)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm0 = (wave / WGN) * 32 * TM;
@@ -459,12 +460,14 @@ __global__ void __launch_bounds__(256, 2) conv_halo_kernel(const HaloProblem p) 
   const int y0 = ty * TH, x0 = tx * 32;
   const int64_t hw = (int64_t)p.h * p.w;
   const float* xb = p.x + (int64_t)ib * p.in_ch * hw;
-  for (int i = tid; i < p.in_ch; i += 256) Ss[i] = p.style ? p.style[(int64_t)ib * p.in_ch + i] : 1.0f;
+  const float* st = p.style ? p.style + (int64_t)ib * p.in_ch : nullptr;     // uniform: scalar loads
   const float* wph = p.wp + d.wp_off + o0;            // wave-uniform
   const int a_lane = frow * p.out_ch + wm0 + fcol;    // this lane's offset inside a k-pair of rows
 
   // Halo staging: this thread owns up to PSLOT fixed positions (r, c) of the (TH+2) x 34 patch and
   // walks the IC channels of a chunk for each: one 32-bit offset per slot, channel stride uniform.
+  // Positions outside the image are loaded from a legal address and multiplied by 0, slots past the
+  // patch are written to a padding column nobody reads, so the staging is branch-free.
   constexpr int NPOS = XH * XUSED;
   constexpr int PSLOT = (NPOS + 255) / 256;
   int xoff[PSLOT], xlds[PSLOT];
@@ -477,25 +480,31 @@ __global__ void __launch_bounds__(256, 2) conv_halo_kernel(const HaloProblem p) 
     const bool ok = pos < NPOS && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
     xoff[sl] = ok ? iy * p.w + ix : 0;            // invalid -> any legal address, value masked to 0
     xmask[sl] = ok ? 1.0f : 0.0f;
-    xlds[sl] = pos < NPOS ? r * XW + c : -1;
+    xlds[sl] = pos < NPOS ? r * XW + c : XW - 1;
   }
   float xreg[PSLOT][IC];
+  float sty[IC];                            // style of the chunk held in xreg (SGPRs; 1.0 when not fused)
   auto xfetch = [&](int i0) {
     const float* xc = xb + (int64_t)i0 * hw;               // uniform
 #pragma unroll
     for (int ic = 0; ic < IC; ++ic)
 #pragma unroll
       for (int sl = 0; sl < PSLOT; ++sl) xreg[sl][ic] = xc[(int64_t)ic * hw + xoff[sl]];
+    if (st) {
+#pragma unroll
+      for (int ic = 0; ic < IC; ++ic) sty[ic] = st[i0 + ic];
+    } else {
+#pragma unroll
+      for (int ic = 0; ic < IC; ++ic) sty[ic] = 1.0f;
+    }
   };
-  auto xstash = [&](int buf, int i0) {      // mask + style applied on the way into LDS (Ss: broadcast read)
-    float* dst = &Xs[buf][0][0][0];
-#pragma unroll
-    for (int sl = 0; sl < PSLOT; ++sl)
-      if (xlds[sl] >= 0) {
-#pragma unroll
-        for (int ic = 0; ic < IC; ++ic)
-          dst[ic * XH * XW + xlds[sl]] = xreg[sl][ic] * (xmask[sl] * Ss[i0 + ic]);
-      }
+  // One element of the staging (mask + style applied on the way into LDS).  In the stride-1 kernel
+  // the steps ride between the MFMAs of the last two taps of a chunk, so there is no VALU/LDS-only
+  // phase in front of the barrier.
+  constexpr int NST = PSLOT * IC;
+  auto stash_step = [&](int buf, int j) {
+    const int sl = j / IC, ic = j % IC;
+    (&Xs[buf][0][0][0])[ic * XH * XW + xlds[sl]] = xreg[sl][ic] * (xmask[sl] * sty[ic]);
   };
   // A operand.  FRAG: the weights come in fragment order (rw_pack_conv_weight_f32): one 16-byte load
   // per lane fetches four k-pairs and a wave's load covers 1 KiB of consecutive addresses, so a tap
@@ -536,23 +545,26 @@ __global__ void __launch_bounds__(256, 2) conv_halo_kernel(const HaloProblem p) 
 #pragma unroll
     for (int kp = 0; kp < KP; ++kp) aload1(kp, 0, 0);
   }
-  __syncthreads();                            // Ss visible
-  xstash(0, 0);
+#pragma unroll
+  for (int j = 0; j < NST; ++j) stash_step(0, j);
   __syncthreads();
   // The loop body is straight-line code: prefetches past the end are clamped to valid (unused)
   // addresses instead of being branched around, and __builtin_amdgcn_sched_barrier pins every
   // load BEFORE the MFMA group that covers its latency (left alone, the scheduler sinks the loads
   // next to their first use and each k-pair waits for a full L2 / LDS round trip).
+  constexpr int MPK = TM * TN;               // MFMAs per k-pair
+  static_assert(NST <= 2 * KP * MPK, "staging steps fit the last two taps");
   for (int c = 0; c < n_chunks; ++c) {
     const int buf = c & 1;
-    const int i0 = c * IC;
-    const int cn = c + 1 < n_chunks ? c + 1 : c;
-    xfetch(cn * IC);                       // consumed by xstash at the end of the chunk
+    const int cn = c + 1 < n_chunks ? c + 1 : c;      // last chunk: a redundant, unused refill
+    xfetch(cn * IC);                       // consumed by the staging steps at the end of the chunk
     const float* xs = &Xs[buf][frow][wrow0 + rw_tap_off(d.dy_bits, 0) + 1][fcol + rw_tap_off(d.dx_bits, 0) + 1];
     float bf[TN], bnext[TN];
 #pragma unroll
     for (int b = 0; b < TN; ++b) bf[b] = xs[b * XW];
-    for (int t = 0; t < d.ntaps; ++t) {
+    // one tap; STAGE >= 0 carries staging steps [STAGE * KP * MPK, (STAGE + 1) * KP * MPK)
+    auto tap = [&](int t, auto stage_tag) {
+      constexpr int STAGE = decltype(stage_tag)::value;
       int nt = t + 1, nc = c;
       if (nt == d.ntaps) { nt = 0; nc = cn; }
       // first k-pair of the next tap (for the last tap: re-read after the barrier, this one is unused)
@@ -567,8 +579,13 @@ __global__ void __launch_bounds__(256, 2) conv_halo_kernel(const HaloProblem p) 
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
-          for (int b = 0; b < TN; ++b)
+          for (int b = 0; b < TN; ++b) {
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kp >> 2][a][kp & 3], bf[b], acc[a][b], 0, 0, 0);
+            if (STAGE >= 0 && (STAGE * KP + kp) * MPK + a * TN + b < NST) {
+              stash_step(buf ^ 1, (STAGE * KP + kp) * MPK + a * TN + b);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
         // these weight registers are free again: refill them for the next tap, >= 1k cycles of MFMA
         // ahead of their use
         if (!FRAG) aload1(kp, nt, nc * IC);
@@ -582,8 +599,16 @@ __global__ void __launch_bounds__(256, 2) conv_halo_kernel(const HaloProblem p) 
         for (int a = 0; a < TM; ++a) av[0][a] = an[a];
       }
       xs = xs_next;
+    };
+    if (FRAG) {                            // stride-1 convolution: always nine taps
+      for (int t = 0; t < 7; ++t) tap(t, rw_int<-1>());
+      tap(7, rw_int<0>());
+      tap(8, rw_int<1>());
+    } else {
+      for (int t = 0; t < d.ntaps; ++t) tap(t, rw_int<-1>());
+#pragma unroll
+      for (int j = 0; j < NST; ++j) stash_step(buf ^ 1, j);
     }
-    if (c + 1 < n_chunks) xstash(buf ^ 1, i0 + IC);
     __syncthreads();
   }
 
