@@ -61,8 +61,8 @@ def conv_kernel_name(out_ch, in_ch, width, upsample):
         return 'conv_mfma(+ksplit)_kernel [4 phases]'
     if halo:
         if out_ch % 128 == 0:
-            return 'conv_halo_kernel<2, 2, 2, 2, 16>'
-        return 'conv_halo_kernel<2, 2, 1, 4, 16>' if out_ch % 64 == 0 else 'conv_halo_kernel<1, 4, 1, 4, 8>'
+            return 'conv_halo_kernel<2, 2, 2, 2, 16, true>'
+        return 'conv_halo_kernel<2, 2, 1, 4, 16, true>' if out_ch % 64 == 0 else 'conv_halo_kernel<1, 4, 1, 4, 8, true>'
     return 'conv_mfma(+ksplit)_kernel'
 
 

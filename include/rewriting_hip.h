@@ -137,7 +137,8 @@ typedef struct rw_conv_epilogue {
  * is >= 24 wide, else the im2col kernel, which splits K across the four waves of a workgroup when
  * the launch would otherwise leave most CUs idle), 1 = direct VALU kernel (cross-check), 2 = force
  * the im2col MFMA kernel, 3 = force the halo-tile MFMA kernel (RW_ERR_UNSUPPORTED if not applicable),
- * 4 = (transposed conv only) per-phase halo tiles, 5 = im2col MFMA kernel without split-K. */
+ * 4 = (transposed conv only) per-phase halo tiles, 5 = im2col MFMA kernel without split-K,
+ * 6 = im2col MFMA kernel with split-K forced. */
 int rw_conv3x3_f32(const float* x, const float* wp, float* y, int batch, int in_ch, int out_ch,
                    int h, int w, float w_scale, const rw_conv_epilogue* ep, int impl,
                    rw_stream_t stream);

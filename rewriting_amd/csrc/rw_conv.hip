@@ -1002,7 +1002,7 @@ static int launch_batch(const ConvProblem* ps, int n, int impl, hipStream_t s) {
   ConvBatch cb;
   cb.n = n;
   int ksplit = 0;   // 0 = off, 1 = 32x32 tiles (chunks of 64 k), 2 = 64x64 tiles (chunks of 32 k)
-  if (impl != 5 && blocks < 192) {
+  if (impl == 6 || (impl != 5 && blocks < 192)) {      // 6: force split-K (A/B measurements)
     if (c.out_ch % 64 == 0 && c.in_ch % 32 == 0 && blocks64 >= 128) ksplit = 2;
     else if (c.in_ch % 64 == 0) ksplit = 1;
     else if (c.out_ch % 64 == 0 && c.in_ch % 32 == 0) ksplit = 2;

@@ -154,6 +154,63 @@ __global__ void __launch_bounds__(256) upfirdn2d_kernel(const float* __restrict_
   }
 }
 
+// minor == 1 with up / down factors in {1, 2} (every caller on the generator path): a 256 x 16
+// output tile per workgroup, four consecutive samples per thread (one 16-byte store), 32-bit index
+// arithmetic, compile-time factors and a polyphase tap walk instead of three 64-bit divisions and
+// kh*kw guarded taps per sample.  Same taps in the same order as the kernel above -> bit-identical
+// results.
+#define UF_TW 256
+#define UF_TH 16
+template <int UP, int DOWN>
+__global__ void __launch_bounds__(256) upfirdn2d_plane_kernel(const float* __restrict__ x,
+                                                              const float* __restrict__ k,
+                                                              float* __restrict__ y, UpfirdnParams p,
+                                                              int tiles_x, int tiles_y) {
+  __shared__ float sk[64];
+  for (int t = threadIdx.x; t < p.kh * p.kw; t += 256) {
+    const int ky = t / p.kw, kx = t - ky * p.kw;
+    sk[t] = k[(p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx)];
+  }
+  __syncthreads();
+  int blk = blockIdx.x;
+  const int tx = blk % tiles_x; blk /= tiles_x;
+  const int ty = blk % tiles_y;
+  const int ma = blk / tiles_y;
+  const int ox = tx * UF_TW + (threadIdx.x & 63) * 4;
+  if (ox >= p.out_w) return;
+  const float* xm = x + (int64_t)ma * p.in_h * p.in_w;
+  float* ym = y + (int64_t)ma * p.out_h * p.out_w;
+  const bool vec = (p.out_w % 4 == 0);             // then ox + 3 < out_w and rows start 16-byte aligned
+  for (int oy = ty * UF_TH + (threadIdx.x >> 6); oy < min((ty + 1) * UF_TH, p.out_h); oy += 4) {
+    // polyphase: only taps a = a0, a0 + UP, ... land on real samples (ascending, like the loop above)
+    const int a0 = (((p.py0 - oy * DOWN) % UP) + UP) % UP;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int a = a0; a < p.kh; a += UP) {
+      const int vy = oy * DOWN + a - p.py0;
+      const int iy = vy / UP;
+      if (vy < 0 || iy >= p.in_h) continue;
+      const float* xr = xm + (int64_t)iy * p.in_w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c0 = (((p.px0 - (ox + e) * DOWN) % UP) + UP) % UP;
+        for (int c = c0; c < p.kw; c += UP) {
+          const int vx = (ox + e) * DOWN + c - p.px0;
+          const int ix = vx / UP;
+          if (vx < 0 || ix >= p.in_w) continue;
+          acc[e] += xr[ix] * sk[a * p.kw + c];
+        }
+      }
+    }
+    float* yo = ym + (int64_t)oy * p.out_w + ox;
+    if (vec) {
+      *reinterpret_cast<float4*>(yo) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (ox + e < p.out_w) yo[e] = acc[e];
+    }
+  }
+}
+
 extern "C" int rw_upfirdn2d_f32(const float* x, const float* k, float* y, int major, int in_h,
                                 int in_w, int minor, int kh, int kw, int up_x, int up_y,
                                 int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0,
@@ -167,6 +224,22 @@ extern "C" int rw_upfirdn2d_f32(const float* x, const float* k, float* y, int ma
   p.out_w = (in_w * up_x + pad_x0 + pad_x1 - kw + down_x) / down_x;
   if (p.out_h <= 0 || p.out_w <= 0 || major == 0) return 0;
   const int64_t total = (int64_t)major * p.out_h * p.out_w * minor;
+  const int tiles_x = (int)rw_cdiv(p.out_w, UF_TW), tiles_y = (int)rw_cdiv(p.out_h, UF_TH);
+  const int64_t blocks = (int64_t)major * tiles_x * tiles_y;
+  if (minor == 1 && up_x == up_y && down_x == down_y && up_x <= 2 && down_x <= 2 &&
+      blocks <= 0x7fffffff) {
+    const dim3 grid((unsigned)blocks), block(256);
+    hipStream_t st = rw_s(stream);
+    if (up_x == 1 && down_x == 1)
+      hipLaunchKernelGGL((upfirdn2d_plane_kernel<1, 1>), grid, block, 0, st, x, k, y, p, tiles_x, tiles_y);
+    else if (up_x == 2 && down_x == 1)
+      hipLaunchKernelGGL((upfirdn2d_plane_kernel<2, 1>), grid, block, 0, st, x, k, y, p, tiles_x, tiles_y);
+    else if (up_x == 1 && down_x == 2)
+      hipLaunchKernelGGL((upfirdn2d_plane_kernel<1, 2>), grid, block, 0, st, x, k, y, p, tiles_x, tiles_y);
+    else
+      hipLaunchKernelGGL((upfirdn2d_plane_kernel<2, 2>), grid, block, 0, st, x, k, y, p, tiles_x, tiles_y);
+    return RW_LAUNCH_RESULT();
+  }
   hipLaunchKernelGGL(upfirdn2d_kernel, dim3(rw_stream_grid(total, 256)), dim3(256), 0, rw_s(stream),
                      x, k, y, p);
   return RW_LAUNCH_RESULT();
@@ -480,17 +553,18 @@ extern "C" int rw_pack_conv_weight_f32(const float* w, float* wp, int out_ch, in
 // ---------------------------------------------------------------------------------------
 // Blur(pad 1,1) + noise + bias + leaky-ReLU for upsampling layers: one pass
 // ---------------------------------------------------------------------------------------
-// Workgroup = 16 x 64 output tile of one (image, channel) plane: the 19 x 67 input patch is
+// Workgroup = 32 x 64 output tile of one (image, channel) plane: the 35 x 67 input patch is
 // staged in LDS with coalesced row loads (the odd row length 2W+1 rules out vector loads), each
-// thread then produces 4 horizontally adjacent outputs and stores them as one 16-byte vector.
-#define BL_TH 16
+// thread then produces 4 horizontally adjacent outputs of two rows, one 16-byte store each.
+#define BL_TH 32
 #define BL_TW 64
+#define BL_PITCH (BL_TW + 4)
 __global__ void __launch_bounds__(256) blur_noise_act_kernel(
     const float* __restrict__ x, const float* __restrict__ k4, const float* __restrict__ noise,
     const float* __restrict__ nw_ptr, const float* __restrict__ bias, float* __restrict__ y,
     int batch, int channels, int out_h, int out_w, int tiles_x, int tiles_y) {
   __shared__ float kf[16];
-  __shared__ __attribute__((aligned(16))) float tile[BL_TH + 3][BL_TW + 4];
+  __shared__ __attribute__((aligned(16))) float tile[BL_TH + 3][BL_PITCH];
   const int tid = threadIdx.x;
   if (tid < 16) {
     const int a = tid >> 2, c = tid & 3;
@@ -505,57 +579,85 @@ __global__ void __launch_bounds__(256) blur_noise_act_kernel(
   const int in_h = out_h + 1, in_w = out_w + 1;
   const int oy0 = ty * BL_TH, ox0 = tx * BL_TW;
   const float* xp = x + bc * (int64_t)in_h * in_w;
-  // input patch rows oy0-1 .. oy0+BL_TH+1, cols ox0-1 .. ox0+BL_TW+1
-  for (int e = tid; e < (BL_TH + 3) * (BL_TW + 3); e += 256) {
-    const int r = e / (BL_TW + 3), cc = e - r * (BL_TW + 3);
-    const int iy = oy0 - 1 + r, ix = ox0 - 1 + cc;
-    tile[r][cc] = (iy >= 0 && iy < in_h && ix >= 0 && ix < in_w) ? xp[(int64_t)iy * in_w + ix] : 0.f;
+  // input patch rows oy0-1 .. oy0+BL_TH+1, cols ox0-1 .. ox0+BL_TW+2 (one spare): 17 lanes per row
+  // load four floats each as ONE 16-byte load (rows are 2W+1 floats long, so only 4-byte aligned;
+  // the hardware takes unaligned vector loads), all loads issued before the first LDS write.
+  {
+    typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+    constexpr int LPR = BL_TW / 4 + 1;                  // lanes per patch row
+    constexpr int RPP = 256 / LPR;                      // rows per pass
+    constexpr int NP = (BL_TH + 3 + RPP - 1) / RPP;
+    const int rr = tid / LPR, q4 = (tid - rr * LPR) * 4;
+    rw_f32x4 v[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const int r = rr + RPP * q, iy = oy0 - 1 + r, ix = ox0 - 1 + q4;
+      const bool rok = rr < RPP && r < BL_TH + 3 && iy >= 0 && iy < in_h;
+      const float* src = xp + (int64_t)iy * in_w + ix;
+      if (rok && ix >= 0 && ix + 3 < in_w) {
+        v[q] = *reinterpret_cast<const f32x4_u*>(src);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[q][e] = (rok && ix + e >= 0 && ix + e < in_w) ? src[e] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const int r = rr + RPP * q;
+      if (rr < RPP && r < BL_TH + 3) *reinterpret_cast<rw_f32x4*>(&tile[r][q4]) = v[q];
+    }
   }
   __syncthreads();
-  // thread = 4 consecutive outputs of one row: two 16-byte LDS reads per tap row (8 per thread), one
-  // 16-byte noise load and one 16-byte store -- the store tail is instruction-issue bound, so wide
-  // stores matter more than the (mild, 2-way) LDS bank overlap of this mapping
-  const int lx = (tid & 15) * 4, ly = tid >> 4;
-  const int ox = ox0 + lx, oy = oy0 + ly;
-  if (oy >= out_h || ox >= out_w) return;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    const float4 lo = *reinterpret_cast<const float4*>(&tile[ly + a][lx]);
-    const float4 hi = *reinterpret_cast<const float4*>(&tile[ly + a][lx + 4]);
-    const float rowv[7] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z};
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int cc = 0; cc < 4; ++cc) acc[q] += rowv[q + cc] * kf[a * 4 + cc];
-  }
+  // thread = 4 consecutive outputs of rows ly and ly + 16: two 16-byte LDS reads per tap row, one
+  // 16-byte noise load and one 16-byte store per output row -- the store tail is instruction-issue
+  // bound, so wide stores matter more than the (mild, 2-way) LDS bank overlap of this mapping
+  const int lx = (tid & 15) * 4;
+  const int ox = ox0 + lx;
+  if (ox >= out_w) return;
   const float nw = noise ? nw_ptr[0] : 0.f;
   const float bv = bias ? bias[c] : 0.f;
   const bool full = (out_w % 4 == 0);           // then ox + 3 < out_w and every row start is 16-byte aligned
-  float nzv[4] = {0.f, 0.f, 0.f, 0.f};
-  const int64_t noff = b * (int64_t)out_h * out_w + (int64_t)oy * out_w + ox;
-  if (noise) {
+#pragma unroll
+  for (int half = 0; half < BL_TH / 16; ++half) {
+    const int ly = (tid >> 4) + 16 * half;
+    const int oy = oy0 + ly;
+    if (oy >= out_h) continue;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const float4 lo = *reinterpret_cast<const float4*>(&tile[ly + a][lx]);
+      const float4 hi = *reinterpret_cast<const float4*>(&tile[ly + a][lx + 4]);
+      const float rowv[7] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z};
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) acc[q] += rowv[q + cc] * kf[a * 4 + cc];
+    }
+    float nzv[4] = {0.f, 0.f, 0.f, 0.f};
+    const int64_t noff = b * (int64_t)out_h * out_w + (int64_t)oy * out_w + ox;
+    if (noise) {
+      if (full) {
+        const float4 nz = *reinterpret_cast<const float4*>(noise + noff);
+        nzv[0] = nz.x; nzv[1] = nz.y; nzv[2] = nz.z; nzv[3] = nz.w;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (ox + q < out_w) nzv[q] = noise[noff + q];
+      }
+    }
+    float res[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v = acc[q] + nw * nzv[q];
+      if (bias) { v += bv; v = ((v > 0.f) ? v : v * 0.2f) * 1.4142135623730951f; }
+      res[q] = v;
+    }
+    float* yo = y + (bc * out_h + oy) * (int64_t)out_w + ox;
     if (full) {
-      const float4 nz = *reinterpret_cast<const float4*>(noise + noff);
-      nzv[0] = nz.x; nzv[1] = nz.y; nzv[2] = nz.z; nzv[3] = nz.w;
+      *reinterpret_cast<float4*>(yo) = make_float4(res[0], res[1], res[2], res[3]);
     } else {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) if (ox + q < out_w) nzv[q] = noise[noff + q];
+      for (int q = 0; q < 4; ++q) if (ox + q < out_w) yo[q] = res[q];
     }
-  }
-  float res[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    float v = acc[q] + nw * nzv[q];
-    if (bias) { v += bv; v = ((v > 0.f) ? v : v * 0.2f) * 1.4142135623730951f; }
-    res[q] = v;
-  }
-  float* yo = y + (bc * out_h + oy) * (int64_t)out_w + ox;
-  if (full) {
-    *reinterpret_cast<float4*>(yo) = make_float4(res[0], res[1], res[2], res[3]);
-  } else {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) if (ox + q < out_w) yo[q] = res[q];
   }
 }
 

@@ -12,7 +12,8 @@ sys.path.insert(0, ROOT)
 from rewriting_amd import hip          # noqa: E402
 
 LAYERS = [  # (name, cin, cout, input res, upsample)
-    ('layer4', 512, 512, 8, False), ('layer6', 512, 512, 16, False), ('layer7', 512, 512, 16, True),
+    ('layer2', 512, 512, 4, False), ('layer3', 512, 512, 4, True), ('layer4', 512, 512, 8, False),
+    ('layer5', 512, 512, 8, True), ('layer6', 512, 512, 16, False), ('layer7', 512, 512, 16, True),
     ('layer8', 512, 512, 32, False), ('layer9', 512, 512, 32, True), ('layer10', 512, 512, 64, False),
     ('layer11', 512, 256, 64, True), ('layer12', 256, 256, 128, False), ('layer13', 256, 128, 128, True),
     ('layer14', 128, 128, 256, False), ('layer15', 128, 64, 256, True), ('layer16', 64, 64, 512, False),
@@ -20,7 +21,7 @@ LAYERS = [  # (name, cin, cout, input res, upsample)
 ]
 
 
-def main(batch=int(os.environ.get('RW_BATCH', '8')), iters=5):
+def main(batch=int(os.environ.get('RW_BATCH', '8')), iters=5, impl=int(os.environ.get('RW_IMPL', '0'))):
     dev = 'cuda'
     rows = []
     only = os.environ.get('RW_LAYERS')
@@ -32,8 +33,8 @@ def main(batch=int(os.environ.get('RW_BATCH', '8')), iters=5):
         style = 1 + 0.3 * torch.randn(batch, cin, device=dev)
         wp = hip.pack_conv_weight(w, 1 if up else 0)
         dm = hip.demod(hip.weight_sqsum(w, 1.0), style)
-        fn = (lambda: hip.conv_transpose3x3s2(x, wp, cout, 1.0, style=style, demod=dm)) if up else \
-             (lambda: hip.conv3x3(x, wp, cout, 1.0, style=style, demod=dm))
+        fn = (lambda: hip.conv_transpose3x3s2(x, wp, cout, 1.0, style=style, demod=dm, impl=impl)) if up else \
+             (lambda: hip.conv3x3(x, wp, cout, 1.0, style=style, demod=dm, impl=impl))
         fn()
         torch.cuda.synchronize()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

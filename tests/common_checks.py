@@ -98,10 +98,26 @@ def check_extras(device):
     assert sel.reshape(-1).tolist() == g['ranking'].reshape(-1).tolist()
     got_q = rq.quantiles([0.5, 0.99, 0.999])[0].cpu().numpy()
     assert numpy.abs(got_q - g['ranking_q']).max() < 0.05 * numpy.abs(g['ranking_q']).max()   # reference sketch is approximate
-    # gandissect units: exact quantiles here vs the reference's randomised sketch -> same top units mostly
+    # gandissect units.  With the selected images inside the statistics sample, some activations ARE
+    # the sample maximum: quantile rank 1.0 -> -log(0) = inf, times a zero mask weight = NaN, in the
+    # reference as well (ganrewrite.py:390-393), and torch.sort puts NaN scores first in an
+    # unspecified order among themselves.  So the golden top-10 is one arbitrary draw from the tie
+    # class; what is well defined is the class: every chosen unit must have a score no lower than
+    # the 10th best (NaN counting as highest), recomputed here from the rewriter's own observations.
     units = gw.multi_key_from_selection(keys, rank=10, key_method='gandissect')
     assert tuple(units.shape) == (10, 512) and units.sum().item() == 10 and (units.sum(0) <= 1).all()
-    assert len(set(units.argmax(1).tolist()) & set(g['gandissect_units'].tolist())) >= 6
+    chosen = set(units.argmax(1).tolist())
+    observed = gw._key_observations(keys)
+    all_obs = torch.cat([obs for obs, _, _ in observed])
+    all_weight = torch.cat([w for _, _, w in observed]).to(all_obs.device)
+    rank = gw.quantiles_for_units().normalize(all_obs.permute(1, 0)).permute(1, 0).to(all_obs.device)
+    score = ((-torch.log(1.0 - rank)) * all_weight).sum(0) / all_weight.sum()
+    score = torch.where(torch.isnan(score), torch.full_like(score, float('inf')), score).cpu()
+    tenth = score.sort(descending=True)[0][9]
+    tie_class = set((score >= tenth).nonzero()[:, 0].tolist())
+    assert chosen <= tie_class, (sorted(chosen), sorted(tie_class))
+    if str(device) == 'cpu':      # same arithmetic as the fixture generator: the reference's draw is in the class too
+        assert set(g['gandissect_units'].tolist()) <= tie_class
     gin = DataBag(fmap=_dev(g['goal_in_fmap'], device), style=_dev(g['goal_in_style'], device))
     gout = DataBag(fmap=_dev(g['goal_out_fmap'], device))
     mkey = _dev(g['mkey'], device)
