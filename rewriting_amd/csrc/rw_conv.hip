@@ -17,6 +17,7 @@
 // stride-1 layers -- noise, bias and leaky-ReLU, so a styled-conv block reads its input once
 // and writes its output once.
 #include "rw_common.h"
+#include <stdlib.h>
 
 __host__ __device__ __forceinline__ int rw_tap_off(unsigned bits, int t) {
   return (int)((bits >> (2 * t)) & 3u) - 1;
@@ -414,6 +415,32 @@ __global__ void __launch_bounds__(256) conv_mfma_ksplit_kernel(const ConvBatch c
 // ---------------------------------------------------------------------------------------
 template <int N> struct rw_int { static constexpr int value = N; };
 
+// Phase stagger.  The workgroups of these kernels all do the same amount of work, so the OCC
+// workgroups that share a CU start together, reach their load-only prologue and store-only epilogue
+// together and finish together -- and so do their successors: the matrix pipe idles during every
+// such phase instead of being fed by a neighbour.  Delaying the k-th co-resident workgroup of the
+// FIRST round by k/OCC of a workgroup's duration shifts the phases for the rest of the launch.
+struct Stagger { int first_round, div, mod, sleeps; };
+__device__ __forceinline__ void rw_stagger(const Stagger& g) {
+  const int b = blockIdx.x;
+  if (b < g.first_round) {
+    const int n = ((b / g.div) % g.mod) * g.sleeps;
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);     // 127 * 64 cycles
+  }
+}
+
+// Timing ablations for kernel work (build with -DRW_ABLATION, select with RW_CONV_ABL=<bits>; results
+// are WRONG when a bit is set): 1 = no LDS operand reads in the loop, 2 = no weight refills,
+// 4 = no halo fetch / staging, 8 = no barrier, 16 = no epilogue stores.  Compiled out otherwise.
+#ifdef RW_ABLATION
+#include <stdlib.h>
+#define RW_ABL(p, bit) ((p).abl & (bit))
+static int rw_abl_env() { const char* e = getenv("RW_CONV_ABL"); return e ? atoi(e) : 0; }
+#else
+#define RW_ABL(p, bit) false
+static int rw_abl_env() { return 0; }
+#endif
+
 struct PhaseDesc {
   int ntaps;
   unsigned dy_bits, dx_bits;
@@ -427,7 +454,8 @@ struct HaloProblem {
   const float* style; const float* demod; const float* noise; const float* noise_w; const float* bias;
   int batch, in_ch, out_ch, h, w, oh, ow, sy, sx;
   float w_scale;
-  int act, nphase;
+  int act, nphase, abl;
+  Stagger stag;
   PhaseDesc phase[4];
 };
 
@@ -445,6 +473,7 @@ __global__ void __launch_bounds__(256, 2) conv_halo_kernel(const HaloProblem p) 
   const int wrow0 = (wave % WGN) * TN;
   const int frow = lane >> 5, fcol = lane & 31;
 
+  rw_stagger(p.stag);
   const int work = rw_xcd_remap(blockIdx.x, gridDim.x);
   int phase = 0;
 #pragma unroll
@@ -557,7 +586,7 @@ __global__ void __launch_bounds__(256, 2) conv_halo_kernel(const HaloProblem p) 
   for (int c = 0; c < n_chunks; ++c) {
     const int buf = c & 1;
     const int cn = c + 1 < n_chunks ? c + 1 : c;      // last chunk: a redundant, unused refill
-    xfetch(cn * IC);                       // consumed by the staging steps at the end of the chunk
+    if (!RW_ABL(p, 4)) xfetch(cn * IC);    // consumed by the staging steps at the end of the chunk
     const float* xs = &Xs[buf][frow][wrow0 + rw_tap_off(d.dy_bits, 0) + 1][fcol + rw_tap_off(d.dx_bits, 0) + 1];
     float bf[TN], bnext[TN];
 #pragma unroll
@@ -569,26 +598,27 @@ __global__ void __launch_bounds__(256, 2) conv_halo_kernel(const HaloProblem p) 
       if (nt == d.ntaps) { nt = 0; nc = cn; }
       // first k-pair of the next tap (for the last tap: re-read after the barrier, this one is unused)
       const float* xs_next = &Xs[buf][frow][wrow0 + rw_tap_off(d.dy_bits, nt) + 1][fcol + rw_tap_off(d.dx_bits, nt) + 1];
-      if (FRAG && KH == 1) fload(an, 0, nt, nc);
+      if (FRAG && KH == 1 && !RW_ABL(p, 2)) fload(an, 0, nt, nc);
 #pragma unroll
       for (int kp = 0; kp < KP; ++kp) {
 #pragma unroll
         for (int b = 0; b < TN; ++b)       // B fragments one k-pair ahead of the MFMAs that use them
-          bnext[b] = kp + 1 < KP ? xs[(2 * kp + 2) * XH * XW + b * XW] : xs_next[b * XW];
+          if (!RW_ABL(p, 1)) bnext[b] = kp + 1 < KP ? xs[(2 * kp + 2) * XH * XW + b * XW] : xs_next[b * XW];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
           for (int b = 0; b < TN; ++b) {
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kp >> 2][a][kp & 3], bf[b], acc[a][b], 0, 0, 0);
-            if (STAGE >= 0 && (STAGE * KP + kp) * MPK + a * TN + b < NST) {
+            if (STAGE >= 0 && (STAGE * KP + kp) * MPK + a * TN + b < NST && !RW_ABL(p, 4)) {
               stash_step(buf ^ 1, (STAGE * KP + kp) * MPK + a * TN + b);
               __builtin_amdgcn_sched_barrier(0);
             }
           }
         // these weight registers are free again: refill them for the next tap, >= 1k cycles of MFMA
         // ahead of their use
-        if (!FRAG) aload1(kp, nt, nc * IC);
+        if (RW_ABL(p, 2)) {
+        } else if (!FRAG) aload1(kp, nt, nc * IC);
         else if (KH > 1 && (kp & 3) == 3) fload(av[kp >> 2], kp >> 2, nt, nc);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -609,31 +639,67 @@ __global__ void __launch_bounds__(256, 2) conv_halo_kernel(const HaloProblem p) 
 #pragma unroll
       for (int j = 0; j < NST; ++j) stash_step(buf ^ 1, j);
     }
-    __syncthreads();
+    if (!RW_ABL(p, 8)) __syncthreads();
   }
 
-  const float nw = p.noise ? p.noise_w[0] : 0.f;
+  // Epilogue.  Everything it reads is fetched in batches behind ONE uniform branch each: a load per
+  // store, each behind its own `if`, costs an L2 round trip plus the drain of the previous store
+  // (vmcnt counts both) per element -- as long as the whole K loop on the 32/64-channel layers.
   const int64_t ohw = (int64_t)p.oh * p.ow;
   const int xx = x0 + fcol;
+  int64_t pix[TN];
+  float nz[TN];
+  bool live[TN];
 #pragma unroll
   for (int b = 0; b < TN; ++b) {
     const int yy = y0 + wrow0 + b;
-    if (yy >= d.ph || xx >= d.pw) continue;
-    const int64_t pix = (int64_t)(p.sy * yy + d.oy0) * p.ow + (p.sx * xx + d.ox0);
-    const float nz = p.noise ? nw * p.noise[(int64_t)ib * ohw + pix] : 0.f;
+    live[b] = yy < d.ph && xx < d.pw;
+    pix[b] = live[b] ? (int64_t)(p.sy * yy + d.oy0) * p.ow + (p.sx * xx + d.ox0) : 0;
+    nz[b] = 0.f;
+  }
+  if (p.noise) {
+    const float nw = p.noise_w[0];
+    const float* np = p.noise + (int64_t)ib * ohw;
 #pragma unroll
-    for (int a = 0; a < TM; ++a) {
+    for (int b = 0; b < TN; ++b) nz[b] = np[pix[b]];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int o = o0 + wm0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * frow;
-        float v = acc[a][b][r] * p.w_scale;
-        if (p.demod) v *= p.demod[(int64_t)ib * p.out_ch + o];
-        if (p.noise) v += nz;
-        if (p.act) {
-          v += p.bias[o];
-          v = ((v > 0.f) ? v : v * 0.2f) * 1.4142135623730951f;
+    for (int b = 0; b < TN; ++b) nz[b] *= nw;
+  }
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+    const int ob = o0 + wm0 + 32 * a + 4 * frow;      // row r of the tile is channel ob + (r&3) + 8(r>>2)
+    float scale[16], bias[16];
+    if (p.demod) {
+      const float* dm = p.demod + (int64_t)ib * p.out_ch + ob;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) scale[r] = dm[(r & 3) + 8 * (r >> 2)];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) scale[r] *= p.w_scale;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) scale[r] = p.w_scale;
+    }
+    if (p.act) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bias[r] = p.bias[ob + (r & 3) + 8 * (r >> 2)];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bias[r] = 0.f;
+    }
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      if (!live[b]) continue;
+      if (RW_ABL(p, 16) && acc[0][b][0] != 12345.f) continue;
+      float* yo = p.y + ((int64_t)ib * p.out_ch + ob) * ohw + pix[b];
+      if (p.act) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[a][b][r] * scale[r] + nz[b] + bias[r];
+          yo[((r & 3) + 8 * (r >> 2)) * ohw] = ((v > 0.f) ? v : v * 0.2f) * 1.4142135623730951f;
         }
-        p.y[((int64_t)ib * p.out_ch + o) * ohw + pix] = v;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) yo[((r & 3) + 8 * (r >> 2)) * ohw] = acc[a][b][r] * scale[r] + nz[b];
       }
     }
   }
@@ -656,6 +722,8 @@ struct UpProblem {
   int batch, in_ch, out_ch, h, w;
   int tiles_x, tiles_y;
   float w_scale;
+  int abl;
+  Stagger stag;
 };
 
 template <int WGM, int WGN, int IC>
@@ -675,6 +743,7 @@ __global__ void __launch_bounds__(256, 2) conv_up_halo_kernel(const UpProblem p)
   const int wrow0 = (wave % WGN) * TN;
   const int frow = lane >> 5, fcol = lane & 31;
 
+  rw_stagger(p.stag);
   int local = rw_xcd_remap(blockIdx.x, gridDim.x);
   const int o_tiles = p.out_ch / BM;
   const int o0 = (local % o_tiles) * BM; local /= o_tiles;
@@ -772,9 +841,9 @@ __global__ void __launch_bounds__(256, 2) conv_up_halo_kernel(const UpProblem p)
     for (int kp = 0; kp < KP; ++kp) {
       int nkp = kp + 1, nc = c;
       if (nkp == KP) { nkp = 0; nc = cn; }
-      aload(anxt, nkp, nc);
-      if (kp == 0) xfetch(cn * IC);       // after the weight load: its wait must not drain these
-      if (kp + 1 < KP) {
+      if (!RW_ABL(p, 2)) aload(anxt, nkp, nc);
+      if (kp == 0 && !RW_ABL(p, 4)) xfetch(cn * IC);       // after the weight load: its wait must not drain these
+      if (kp + 1 < KP && !RW_ABL(p, 1)) {
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
           const float* q = xs + (2 * kp + 2) * XH * XW + b * XW;
@@ -787,7 +856,7 @@ __global__ void __launch_bounds__(256, 2) conv_up_halo_kernel(const UpProblem p)
   _Pragma("unroll") for (int b = 0; b < TN; ++b) acc[q][b] =                                            \
       __builtin_amdgcn_mfma_f32_32x32x2f32((sl) < 8 ? acur.v4[((sl) >> 2) & 1][(sl) & 3] : acur.s8, bv[b],  \
                                            acc[q][b], 0, 0, 0);                                        \
-  if (9 * kp + (m) >= SLOT0 && 9 * kp + (m) - SLOT0 < NST) {                                            \
+  if (9 * kp + (m) >= SLOT0 && 9 * kp + (m) - SLOT0 < NST && !RW_ABL(p, 4)) {                                          \
     stash_step(buf ^ 1, 9 * kp + (m) - SLOT0);                                                          \
     __builtin_amdgcn_sched_barrier(0);                                                                  \
   }
@@ -835,6 +904,7 @@ __global__ void __launch_bounds__(256, 2) conv_up_halo_kernel(const UpProblem p)
   for (int b = 0; b < TN; ++b) {
     const int yy = y0 + wrow0 + b;
     if (yy >= p.h) continue;                    // uniform per wave row; row 2H comes from the strip launch
+    if (RW_ABL(p, 16) && acc[0][b][0] != 12345.f) continue;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int o = o0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * frow;
@@ -862,19 +932,35 @@ __global__ void __launch_bounds__(256, 2) conv_up_halo_kernel(const UpProblem p)
 
 static int launch_batch(const ConvProblem* ps, int n, int impl, hipStream_t s);
 
+// mfmas: MFMAs one wave issues per workgroup; occ: workgroups per CU.  RW_CONV_STAGGER (experiments):
+// 0 = off, 1 = classes by (b / 256) % occ, 2 = b % occ, 3 = (b / 8) % occ.
+static Stagger make_stagger(int64_t mfmas, int occ, int64_t blocks) {
+  Stagger g = {0, 1, 1, 0};
+  const char* e = getenv("RW_CONV_STAGGER");
+  const int mode = e ? atoi(e) : 0;
+  if (mode == 0 || blocks < 256 * occ * 2) return g;
+  g.first_round = 256 * occ; g.mod = occ;
+  g.div = mode == 1 ? 256 : (mode == 2 ? 1 : 8);
+  g.sleeps = (int)(mfmas * 64 / 8128);            // one wave's MFMA time = 1/occ of the workgroup's duration
+  return g;
+}
+
 static int launch_up_halo(const ConvProblem* ps, const float* wp_all, hipStream_t s) {
   const ConvProblem& c = ps[0];
   UpProblem u;
   u.x = c.x; u.wfrag = wp_all + (int64_t)9 * c.in_ch * c.out_ch; u.y = c.y; u.style = c.style; u.demod = c.demod;
   u.batch = c.batch; u.in_ch = c.in_ch; u.out_ch = c.out_ch; u.h = c.h; u.w = c.w; u.w_scale = c.w_scale;
-  u.tiles_x = (int)rw_cdiv(c.w, 32);
+  u.tiles_x = (int)rw_cdiv(c.w, 32); u.abl = rw_abl_env();
+  const int64_t up_mfmas = (int64_t)(c.in_ch / 16) * 8 * 18;
   if (c.out_ch % 64 == 0) {
     u.tiles_y = (int)rw_cdiv(c.h, 4);
     const int work = c.batch * u.tiles_x * u.tiles_y * (c.out_ch / 64);
+    u.stag = make_stagger(up_mfmas, 2, work);
     hipLaunchKernelGGL((conv_up_halo_kernel<2, 2, 16>), dim3(work), dim3(256), 0, s, u);
   } else {
     u.tiles_y = (int)rw_cdiv(c.h, 8);
     const int work = c.batch * u.tiles_x * u.tiles_y * (c.out_ch / 32);
+    u.stag = make_stagger(up_mfmas, 2, work);
     hipLaunchKernelGGL((conv_up_halo_kernel<1, 4, 16>), dim3(work), dim3(256), 0, s, u);
   }
   // Output row 2H and column 2W: quads y' = H (phases (0,0),(0,1)) and x' = W, y' < H (phases
@@ -900,7 +986,7 @@ static int launch_halo(const ConvProblem* ps, int n, const float* wfrag, hipStre
   h.x = c.x; h.wp = ps[0].wp; h.wfrag = wfrag; h.y = c.y; h.style = c.style; h.demod = c.demod; h.noise = c.noise;
   h.noise_w = c.noise_w; h.bias = c.bias; h.batch = c.batch; h.in_ch = c.in_ch; h.out_ch = c.out_ch;
   h.h = c.h; h.w = c.w; h.oh = c.oh; h.ow = c.ow; h.sy = c.sy; h.sx = c.sx; h.w_scale = c.w_scale;
-  h.act = c.act; h.nphase = n;
+  h.act = c.act; h.nphase = n; h.abl = rw_abl_env();
   int th, bm;
   if (c.out_ch % 128 == 0) { th = 4; bm = 128; }
   else if (c.out_ch % 64 == 0) { th = 8; bm = 64; }
@@ -916,6 +1002,7 @@ static int launch_halo(const ConvProblem* ps, int n, const float* wfrag, hipStre
     if (q < n) work += c.batch * d.tiles_x * d.tiles_y * (c.out_ch / bm);
   }
   if (work == 0) return 0;
+  h.stag = make_stagger((int64_t)c.in_ch / 2 * 9 * 4, wfrag ? 3 : 2, wfrag ? work : 0);
   if (wfrag) {        // stride-1 convolution, weights in fragment order
     if (bm == 128)
       hipLaunchKernelGGL((conv_halo_kernel<2, 2, 2, 2, 16, true>), dim3(work), dim3(256), 0, s, h);
