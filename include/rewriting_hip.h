@@ -200,7 +200,9 @@ typedef struct rw_solve_problem {
   const float* key;      /* (in_ch, h, w)   goal_in.fmap  = adain output crop            */
   const float* style;    /* (in_ch)         goal_in.style                               */
   const float* val;      /* (out_ch, h, w)  goal_out.fmap                               */
-  const float* bias;     /* (out_ch)        activate.bias                               */
+  const float* bias;     /* (out_ch)        activate.bias; NULL = the target is the demodulated
+                          *                 convolution alone (SeqTinyStyleGanRewriter, ganrewrite.py:731-738):
+                          *                 no blur / noise / bias / activation, val is (out_ch, conv map) */
   const float* noise;    /* (h*w)           RandomState(0).randn(1,h*w)  (quirk Q1)     */
   const float* noise_w;  /* device scalar   noise.weight                                */
   const float* context;  /* (rank, in_ch)   orthonormal rows                            */

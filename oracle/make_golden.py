@@ -280,6 +280,51 @@ def golden_rewriter_extras(ref, name, size, layernum, maskfile, nseeds):
     save(name, **arrays)
 
 
+def golden_rewriter_variants(ref, name, size, layernum, maskfile, nseeds, tags=('tiny', 'pre')):
+    """SeqTinyStyleGanRewriter (target = dconv alone) and SeqPreStyleGanRewriter (target starts at
+    adain: the key is the UN-modulated feature map) on the same edit, a few solver steps each
+    (rewrite/ganrewrite.py:731-760)."""
+    g = build_stylegan(ref, size, 0.5)
+    zds = ref.zdataset.z_dataset_for_model(g, size=nseeds)
+    with open(os.path.join(MASKS, maskfile)) as f:
+        request = remap_request(json.load(f), nseeds)
+    arrays = dict(meta=json.dumps(dict(size=size, layernum=layernum, mask=maskfile, nseeds=nseeds,
+                                       weight_seed=0, truncation=0.5)))
+    for tag, cls in (('tiny', ref.ganrewrite.SeqTinyStyleGanRewriter),
+                     ('pre', ref.ganrewrite.SeqPreStyleGanRewriter)):
+        if tag not in tags:
+            continue
+        def fresh():
+            torch.manual_seed(0)
+            return cls(g, zds, layernum, cachedir=None, low_rank_insert=True, key_method='zca',
+                       tight_paste=True)
+        gw = fresh()
+        arrays[tag + '_c_matrix_norm'] = numpy.float64(gw.c_matrix.double().norm().item())
+        arrays[tag + '_c_matrix_diag'] = gw.c_matrix.diag().numpy()
+        arrays[tag + '_v_shape'] = numpy.array(gw.v_shape)
+        o_imgnum, o_mask = request['object']
+        p_imgnum, p_mask = request['paste']
+        obj_acts, _, obj_area, _ = gw.object_from_selection(o_imgnum, o_mask)
+        goal_in, goal_out, _, pbounds = gw.paste_from_selection(p_imgnum, p_mask, obj_acts, obj_area)
+        mkey = gw.multi_key_from_selection(request['key'], rank=1)
+        arrays[tag + '_mkey'] = mkey.numpy()
+        arrays[tag + '_paste_bounds'] = numpy.array(pbounds)
+        arrays[tag + '_goal_in_fmap'] = goal_in.fmap.detach().numpy()
+        arrays[tag + '_goal_in_style'] = goal_in.style.detach().numpy()
+        arrays[tag + '_goal_out_fmap'] = goal_out.fmap.detach().numpy()
+        W0 = gw.target_weights().detach().clone()
+        for niter in (1, 11):
+            gwn = fresh()
+            losses = []
+            gwn.insert(goal_in, goal_out, mkey, niter=niter, piter=10, lr=0.05,
+                       update_callback=lambda it, loss: losses.append(loss.item()))
+            dW = (gwn.target_weights().detach() - W0)[0]
+            arrays['%s_dW_%d_sub' % (tag, niter)], arrays['%s_dW_%d_norm' % (tag, niter)] = sub(dW, 8192)
+            arrays['%s_dW_%d_cos' % (tag, niter)] = torch.einsum('oiyx,di->odyx', dW, mkey).numpy()
+            arrays['%s_losses_%d' % (tag, niter)] = numpy.array(losses)
+    save(name, **arrays)
+
+
 def golden_proggan(ref, name, resolution, layernum, maskfile, nseeds):
     g = ref.proggan.ProgressiveGenerator(resolution=resolution)
     synthetic.randomize_(g, seed=0, kind='proggan')
@@ -340,6 +385,11 @@ def main():
         'rw_s64_l6_erase': lambda: golden_rewriter(
             ref, 'rw_s64_l6_erase', 64, 6, 'multikey_markandbottom.json', 20, mode='erase',
             low_rank_gradient=True),
+        'rw_s64_l8_variants': lambda: golden_rewriter_variants(
+            ref, 'rw_s64_l8_variants', 64, 8, 'recorded_horse_hat.json', 60),
+        'rw_s64_l7_variants': lambda: golden_rewriter_variants(
+            ref, 'rw_s64_l7_variants', 64, 7, 'recorded_horse_hat.json', 60,
+            tags=('pre',)),     # the reference's own paste logic fails for 'tiny' on an upsampling layer
         'pg64_l6_spire2tree': lambda: golden_proggan(
             ref, 'pg64_l6_spire2tree', 64, 6, 'spire2tree.json', 40),
     }

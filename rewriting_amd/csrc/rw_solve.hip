@@ -147,11 +147,14 @@ __global__ void __launch_bounds__(256) solve_fwd_kernel(const rw_solve_problem p
 __global__ void __launch_bounds__(256) solve_mid_kernel(const rw_solve_problem p, int pp, float* lpart) {
   __shared__ float red[4];
   const int o = blockIdx.x, tid = threadIdx.x;
-  const int P = p.h * p.w;
+  const int P = sv_conv_h(p) * sv_conv_w(p);
   float wsq = 0.f;
   for (int s = 0; s < p.ksplit; ++s) wsq += p.wsq[(int64_t)s * p.out_ch + o];
   const float demod = rsqrtf(wsq + 1e-8f);
-  const float nw = p.noise_w[0], bv = p.bias[o];
+  // bias == NULL: the target is the demodulated convolution alone (SeqTinyStyleGanRewriter,
+  // rewrite/ganrewrite.py:731-738): no noise, no bias, no activation between it and the loss
+  const bool plain = p.bias == nullptr;
+  const float nw = plain ? 0.f : p.noise_w[0], bv = plain ? 0.f : p.bias[o];
   const float inv_numel = 1.0f / ((float)p.out_ch * (float)P);
   float lsum = 0.f, tsum = 0.f;
   for (int n = tid; n < pp; n += 256) {
@@ -160,13 +163,20 @@ __global__ void __launch_bounds__(256) solve_mid_kernel(const rw_solve_problem p
       float conv = 0.f;
       for (int s = 0; s < p.ksplit; ++s) conv += p.conv[((int64_t)s * p.out_ch + o) * pp + n];
       conv *= p.w_scale;
-      const float pre = conv * demod + nw * p.noise[n] + bv;
-      const float out = 1.4142135623730951f * ((pre > 0.f) ? pre : 0.2f * pre);
+      float out, pre;
+      if (plain) {
+        pre = conv * demod;
+        out = pre;
+      } else {
+        pre = conv * demod + nw * p.noise[n] + bv;
+        out = 1.4142135623730951f * ((pre > 0.f) ? pre : 0.2f * pre);
+      }
       const float diff = out - p.val[(int64_t)o * P + n];
       lsum += fabsf(diff);
       const float sgn = (diff > 0.f) ? 1.f : ((diff < 0.f) ? -1.f : 0.f);
       const float g_out = sgn * inv_numel;                      // l1_loss backward, mean reduction
-      const float g_pre = ((pre > 0.f) ? g_out : g_out * 0.2f) * 1.4142135623730951f;  // kernel case 31
+      const float g_pre = plain ? g_out
+                                : ((pre > 0.f) ? g_out : g_out * 0.2f) * 1.4142135623730951f;  // kernel case 31
       gdv = g_pre * demod;
       tsum += g_pre * conv;
     }
@@ -475,22 +485,23 @@ extern "C" int rw_project_weight_f32(const float* w, const float* context, const
 extern "C" int rw_solve_step_f32(const rw_solve_problem* pr, int project, rw_stream_t stream) {
   RW_CHECK_ARG(pr);
   const rw_solve_problem& p = *pr;
-  RW_CHECK_ARG(p.key && p.style && p.val && p.bias && p.noise && p.noise_w && p.weight && p.exp_avg &&
+  RW_CHECK_ARG(p.key && p.style && p.val && p.weight && p.exp_avg &&
                p.exp_avg_sq && p.step_size && p.bc2_sqrt && p.step_counter && p.losses && p.conv &&
                p.wsq && p.gd && p.c2);
+  RW_CHECK_ARG(!p.bias || (p.noise && p.noise_w));          // bias == NULL: plain dconv target
   RW_CHECK_ARG(p.out_ch > 0 && p.in_ch > 0 && p.h > 0 && p.w > 0 && p.ksplit > 0);
   RW_CHECK_ARG(!(project || p.low_rank_gradient || p.linear_insert) || (p.context && p.rank > 0));
   RW_CHECK_ARG(!(project || p.linear_insert) || p.ortho);
   RW_CHECK_ARG(!(p.low_rank_gradient || p.linear_insert) || p.grad);
   RW_CHECK_ARG(!p.linear_insert || (p.lambda && !project && !p.low_rank_gradient));
-  RW_CHECK_ARG(!p.upsample || p.blur_k);
+  RW_CHECK_ARG(!p.upsample || !p.bias || p.blur_k);
   if (p.out_ch % SV_BM || p.in_ch % SV_KC) return RW_ERR_UNSUPPORTED;
   hipStream_t s = rw_s(stream);
   const int P = sv_conv_h(p) * sv_conv_w(p);
   const int pp = sv_pp(P);
   float* lpart = p.c2 + p.out_ch;   // c2 is allocated with 2*out_ch floats: [c2 | per-channel loss]
   hipLaunchKernelGGL(solve_fwd_kernel, dim3(p.out_ch / SV_BM, pp / SV_BN, p.ksplit), dim3(256), 0, s, p, pp);
-  if (p.upsample) {
+  if (p.upsample && p.bias) {
     const size_t mid_lds = ((size_t)P + (size_t)4 * p.h * p.w) * sizeof(float);
     if (mid_lds > 64 * 1024) return RW_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(solve_mid_up_kernel, dim3(p.out_ch), dim3(256), mid_lds, s, p, pp, lpart);

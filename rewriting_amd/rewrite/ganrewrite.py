@@ -322,7 +322,12 @@ class ProgressiveGanRewriter(object):
                 logscore = -torch.log(1.0 - rq.normalize(all_obs.permute(1, 0))).permute(1, 0)
                 logscore = logscore.to(all_obs.device)
                 mean_logscore = (logscore * all_weight).sum(0) / all_weight.sum()
-                top = mean_logscore.sort(descending=True)[1][:rank]
+                # rank 1.0 (an activation that IS the sample maximum) gives inf * 0 = NaN; torch.sort
+                # documents NaN as the greatest value, which a radix sort on the device does not honour
+                # for negative NaNs: make the reference's ordering explicit and the tie order stable
+                mean_logscore = torch.where(torch.isnan(mean_logscore),
+                                            torch.full_like(mean_logscore, float('inf')), mean_logscore)
+                top = mean_logscore.sort(descending=True, stable=True)[1][:rank]
                 result = torch.zeros(rank, all_obs.shape[1], device=all_obs.device)
                 result[torch.arange(rank), top] = 1.0
                 return result
@@ -575,42 +580,58 @@ class SeqStyleGanRewriter(ProgressiveGanRewriter):
 
     # ---- fused HIP solve ------------------------------------------------------------------
     def _hip_solvable(self, key):
+        """The module chains the fused solver restates: [adain] dconv [blur] noise activate
+        (SeqStyleGanRewriter, SeqPreStyleGanRewriter) and dconv alone (SeqTinyStyleGanRewriter).
+        Returns (adain, dconv, blur, noise, act) with None for absent stages, or None."""
         from ..utils.stylegan2 import models as sg
         mods = list(self.target_model.modules())
         leaves = [m for m in mods if len(list(m.children())) == 0]
-        if len(leaves) not in (3, 4) or not self._kernels():
+        if not self._kernels() or not leaves:
             return None
-        dconv, noise, act = leaves[0], leaves[-2], leaves[-1]
-        blur = leaves[1] if len(leaves) == 4 else None
-        if not (isinstance(dconv, sg.DemodulatedConv2dF) and isinstance(noise, sg.NoiseInjectionF)
-                and isinstance(act, sg.FusedLeakyReLUF)):
+        adain = None
+        if isinstance(leaves[0], sg.ApplyStyle):
+            adain, leaves = leaves[0], leaves[1:]
+        if not leaves or not isinstance(leaves[0], sg.DemodulatedConv2dF):
             return None
-        if dconv.upsample != (blur is not None) or (blur is not None and not isinstance(blur, sg.BlurF)):
-            return None
-        if blur is not None and (tuple(blur.kernel.shape) != (4, 4) or tuple(blur.pad) != (1, 1)):
-            return None
+        dconv = leaves[0]
+        blur = noise = act = None
+        if len(leaves) > 1:
+            if len(leaves) not in (3, 4):
+                return None
+            noise, act = leaves[-2], leaves[-1]
+            blur = leaves[1] if len(leaves) == 4 else None
+            if not (isinstance(noise, sg.NoiseInjectionF) and isinstance(act, sg.FusedLeakyReLUF)):
+                return None
+            if dconv.upsample != (blur is not None) or (blur is not None and not isinstance(blur, sg.BlurF)):
+                return None
+            if blur is not None and (tuple(blur.kernel.shape) != (4, 4) or tuple(blur.pad) != (1, 1)):
+                return None
         if not dconv.demodulate or key.fmap.shape[0] != 1:
             return None
         if any('forward' in m.__dict__ for m in mods):
             return None                       # someone hooked the target: keep module semantics
-        return dconv, blur, noise, act
+        return adain, dconv, blur, noise, act
 
     def _run_insert(self, key, val, context, update_callback, niter, piter, lr, linear=False):
         parts = self._hip_solvable(key) if isinstance(key, dict) else None
         if parts is None:
             if self._kernels():
                 raise NotImplementedError(
-                    'the fused HIP solver covers targets layerN.sconv.mconv.dconv .. layerN.sconv.activate '
-                    'of a SeqStyleGAN2 with a batch-1 goal; the kernels have no autograd path for other '
-                    'targets')
+                    'the fused HIP solver covers the targets [adain] dconv [blur] noise activate and dconv '
+                    'alone of a SeqStyleGAN2 layer with a batch-1 goal; the kernels have no autograd path '
+                    'for other targets')
             return super()._run_insert(key, val, context, update_callback, niter, piter, lr)
         from . import hipsolve
-        dconv, blur, noise, act = parts
-        hipsolve.run(dconv.weight, key.fmap, key.style, val.fmap, act.bias, noise.weight, context,
+        adain, dconv, blur, noise, act = parts
+        # a target that starts at adain sees the un-modulated map: ApplyStyle (models.py:616-620) first
+        fmap = key.fmap if adain is None else hip.style_mul(key.fmap.contiguous(), key.style)
+        hipsolve.run(dconv.weight, fmap, key.style, val.fmap,
+                     None if act is None else act.bias, None if noise is None else noise.weight, context,
                      niter=niter, piter=piter, lr=lr,
                      low_rank_insert=self.low_rank_insert, low_rank_gradient=self.low_rank_gradient,
                      update_callback=update_callback,
-                     blur_kernel=None if blur is None else blur.kernel, linear=linear)
+                     blur_kernel=None if blur is None else blur.kernel, upsample=bool(dconv.upsample),
+                     linear=linear)
         _weights_changed()
 
     def linear_insert(self, key, val, context=None, update_callback=None, niter=2001, lr=0.05,

@@ -24,9 +24,14 @@ def _ptr(t):
 
 class Solver:
     def __init__(self, weight, key, style, val, bias, noise_w, context, niter, piter, lr,
-                 low_rank_insert, low_rank_gradient, blur_kernel=None, linear=False):
+                 low_rank_insert, low_rank_gradient, blur_kernel=None, linear=False, upsample=None):
+        """``bias is None``: the target is the demodulated convolution alone (no blur, noise, bias,
+        activation; SeqTinyStyleGanRewriter) and ``upsample`` says whether it is the transposed one."""
         dev = weight.device
-        upsample = blur_kernel is not None
+        plain = bias is None
+        if upsample is None:
+            upsample = blur_kernel is not None
+        assert plain or upsample == (blur_kernel is not None)
         if linear:
             low_rank_insert = low_rank_gradient = False
         self.weight = weight                       # (1,O,I,3,3) parameter, updated in place
@@ -40,15 +45,15 @@ class Solver:
         f32 = dict(device=dev, dtype=torch.float32)
         self.key = key.detach().reshape(I, h, wd).contiguous().float()
         self.style = style.detach().reshape(I).contiguous().float()
-        oh, ow = (2 * h, 2 * wd) if upsample else (h, wd)          # value map of the layer
         ch, cw = (2 * h + 1, 2 * wd + 1) if upsample else (h, wd)  # map the convolution writes
+        oh, ow = (2 * h, 2 * wd) if (upsample and not plain) else (ch, cw)   # value map of the target
         assert tuple(val.shape[-2:]) == (oh, ow), (val.shape, (oh, ow))
         self.val = val.detach().reshape(O, oh, ow).contiguous().float()
-        self.bias = bias.detach().contiguous().float()
-        self.noise = reference_noise(1, oh * ow, dev).reshape(-1).contiguous()
-        self.blur_k = blur_kernel.detach().contiguous().float() if upsample else None
+        self.bias = None if plain else bias.detach().contiguous().float()
+        self.noise = None if plain else reference_noise(1, oh * ow, dev).reshape(-1).contiguous()
+        self.blur_k = blur_kernel.detach().contiguous().float() if (upsample and not plain) else None
         self.linear = linear
-        self.noise_w = noise_w.detach().reshape(1).contiguous().float()
+        self.noise_w = None if plain else noise_w.detach().reshape(1).contiguous().float()
         constrained = low_rank_insert or low_rank_gradient or linear
         self.context = context.detach().contiguous().float().to(dev) if constrained else None
         self.ortho = None
@@ -135,9 +140,10 @@ class Solver:
 
 
 def run(weight, key, style, val, bias, noise_w, context, niter=2001, piter=10, lr=0.05,
-        low_rank_insert=True, low_rank_gradient=False, update_callback=None, blur_kernel=None,
+        low_rank_insert=True, low_rank_gradient=False, update_callback=None, blur_kernel=None, upsample=None,
         linear=False):
     solver = Solver(weight, key, style, val, bias, noise_w, context, niter, piter, lr,
-                    low_rank_insert, low_rank_gradient, blur_kernel=blur_kernel, linear=linear)
+                    low_rank_insert, low_rank_gradient, blur_kernel=blur_kernel, linear=linear,
+                    upsample=upsample)
     solver.run(update_callback)
     return solver

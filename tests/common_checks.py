@@ -10,13 +10,53 @@ def _dev(t, device):
     return torch.from_numpy(t).to(device) if isinstance(t, numpy.ndarray) else t.to(device)
 
 
-def _rewriter(meta, device, **kw):
+def _rewriter(meta, device, cls='SeqStyleGanRewriter', **kw):
     from rewriting_amd.rewrite import ganrewrite
     from rewriting_amd.utils import zdataset
     model = build_stylegan(meta['size'], meta['truncation'], device=device)
     zds = zdataset.z_dataset_for_model(model, size=meta['nseeds'])
-    return ganrewrite.SeqStyleGanRewriter(model, zds, meta['layernum'], cachedir=None, key_method='zca',
-                                          **kw)
+    return getattr(ganrewrite, cls)(model, zds, meta['layernum'], cachedir=None, key_method='zca', **kw)
+
+
+def check_rewriter_variants(device, name='rw_s64_l8_variants'):
+    """SeqTinyStyleGanRewriter (target = dconv alone) and SeqPreStyleGanRewriter (target starts at adain,
+    the key statistics are those of the un-modulated map) against the reference's own classes
+    (rewrite/ganrewrite.py:731-760) on the same edit: statistics, goal tensors, key, 1 and 11 steps."""
+    from rewriting_amd.utils.stylegan2.models import DataBag
+    g = load_golden(name)
+    meta = golden_meta(g)
+    req = load_mask_request(meta['mask'], meta['nseeds'])
+    out = {}
+    for tag, cls in (('tiny', 'SeqTinyStyleGanRewriter'), ('pre', 'SeqPreStyleGanRewriter')):
+        if tag + '_mkey' not in g:
+            continue
+        gw = _rewriter(meta, device, cls=cls)
+        assert abs(gw.c_matrix.double().norm().item() / float(g[tag + '_c_matrix_norm']) - 1) < 1e-5
+        assert (gw.c_matrix.diag().cpu() - torch.from_numpy(g[tag + '_c_matrix_diag'])).abs().max() < 1e-3
+        assert list(gw.v_shape) == list(g[tag + '_v_shape'])
+        obj_acts, _, obj_area, _ = gw.object_from_selection(*req['object'])
+        goal_in, goal_out, _, pb = gw.paste_from_selection(req['paste'][0], req['paste'][1], obj_acts, obj_area)
+        assert list(pb) == list(g[tag + '_paste_bounds'])
+        assert (goal_in.fmap.cpu() - torch.from_numpy(g[tag + '_goal_in_fmap'])).abs().max() < 1e-4
+        assert (goal_out.fmap.cpu() - torch.from_numpy(g[tag + '_goal_out_fmap'])).abs().max() < 1e-4
+        mkey = gw.multi_key_from_selection(req['key'], rank=1)
+        assert (mkey.cpu() - torch.from_numpy(g[tag + '_mkey'])).abs().max() < 2e-3
+        mkey = _dev(g[tag + '_mkey'], device)
+        gin = DataBag(goal_in, fmap=_dev(g[tag + '_goal_in_fmap'], device),
+                      style=_dev(g[tag + '_goal_in_style'], device))
+        gout = DataBag(goal_out, fmap=_dev(g[tag + '_goal_out_fmap'], device))
+        W0 = gw.target_weights().detach().clone()
+        for niter in (1, 11):
+            gwn = _rewriter(meta, device, cls=cls)
+            losses = []
+            gwn.insert(gin, gout, mkey, niter=niter, piter=10, lr=0.05,
+                       update_callback=lambda it, loss: losses.append(float(loss)))
+            dW = (gwn.target_weights().detach() - W0)[0]
+            rel = _cos_rel(dW, mkey, g, '%s_dW_%d' % (tag, niter))
+            out['%s%d' % (tag, niter)] = rel
+            assert rel < 1e-4, (tag, niter, rel)
+            assert numpy.abs(numpy.array(losses) - g['%s_losses_%d' % (tag, niter)]).max() < 2e-5
+    return out
 
 
 def _cos_rel(dW, mkey, g, tag):

@@ -186,14 +186,15 @@ def solve_step(problem, project):
     s.counter.fill_(it)
     W = s._w
     O, I = W.shape[1:3]
-    up = s.blur_k is not None
+    up = bool(problem.upsample)
     Wg = W.clone().requires_grad_(True)
     with torch.enable_grad():
         out = R.demod_conv(s.key[None], s.style[None], Wg, up)
-        if up:
-            out = R.upfirdn2d(out, s.blur_k, pad=(1, 1))
-        out = out + s.noise_w * s.noise.view(1, 1, *out.shape[2:])
-        out = R.fused_leaky_relu(out, s.bias)
+        if s.bias is not None:              # bias None: the target is the demodulated conv alone
+            if up:
+                out = R.upfirdn2d(out, s.blur_k, pad=(1, 1))
+            out = out + s.noise_w * s.noise.view(1, 1, *out.shape[2:])
+            out = R.fused_leaky_relu(out, s.bias)
         loss = F.l1_loss(s.val[None], out)
         loss.backward()
     s.losses[it] = loss.detach()

@@ -192,6 +192,12 @@ def test_odd_layer_edit_matches_golden(emulated_hip):
     check_odd_layer_edit('cpu')
 
 
+@pytest.mark.parametrize('name', ['rw_s64_l8_variants', 'rw_s64_l7_variants'])
+def test_tiny_and_pre_rewriters_match_golden(emulated_hip, name):
+    from tests.common_checks import check_rewriter_variants
+    check_rewriter_variants('cpu', name)
+
+
 def test_key_methods_linear_insert_and_rank3(emulated_hip):
     from tests.common_checks import check_extras
     check_extras('cpu')

@@ -262,6 +262,14 @@ def test_odd_layer_edit_matches_reference_golden():
     json.dump(report, open('gpurun_out/solve_parity_odd_layer.json', 'w'))
 
 
+@pytest.mark.parametrize('name', ['rw_s64_l8_variants', 'rw_s64_l7_variants'])
+def test_tiny_and_pre_rewriters_match_reference_golden(name):
+    from tests.common_checks import check_rewriter_variants
+    report = check_rewriter_variants(DEV, name)
+    os.makedirs('gpurun_out', exist_ok=True)
+    json.dump(report, open('gpurun_out/solve_parity_%s.json' % name, 'w'))
+
+
 def test_key_methods_linear_insert_and_rank3():
     from tests.common_checks import check_extras
     report = check_extras(DEV)
