@@ -56,6 +56,77 @@ __device__ __forceinline__ int rw_xcd_remap(int id, int total) {
   return base + slot;
 }
 
+// Epilogue of the im2col kernels for a wave's TM x TN accumulator tiles (C/D layout: col = lane&31
+// is the position n, row r of a tile is out-channel o_first + 32a + (r&3) + 8(r>>2)).  Every value
+// it reads is fetched in batches behind ONE uniform branch each: a load per store, each behind its
+// own `if`, costs an L2 round trip plus the drain of the previous store (vmcnt counts both).
+template <int TM_, int TN_>
+__device__ __forceinline__ void rw_tile_epilogue(const ConvProblem& p, const rw_f32x16 (&acc)[TM_][TN_],
+                                                 int o_first, int64_t n_first, int ppi, int64_t n_total) {
+  const int64_t ohw = (int64_t)p.oh * p.ow;
+  int ib[TN_];
+  int64_t pix[TN_];
+  bool live[TN_];
+  float nz[TN_];
+#pragma unroll
+  for (int b = 0; b < TN_; ++b) {
+    const int64_t n = n_first + 32 * b;
+    live[b] = n < n_total;
+    const int64_t nn = live[b] ? n : 0;
+    ib[b] = (int)(nn / ppi);
+    const int r0 = (int)(nn - (int64_t)ib[b] * ppi);
+    const int yq = r0 / p.pw;
+    const int yy = yq + p.yoff, xx = r0 - yq * p.pw + p.xoff;
+    pix[b] = (int64_t)(p.sy * yy + p.oy0) * p.ow + (p.sx * xx + p.ox0);
+    nz[b] = 0.f;
+  }
+  if (p.noise) {
+    const float nw = p.noise_w[0];
+#pragma unroll
+    for (int b = 0; b < TN_; ++b) nz[b] = p.noise[(int64_t)ib[b] * ohw + pix[b]];
+#pragma unroll
+    for (int b = 0; b < TN_; ++b) nz[b] *= nw;
+  }
+#pragma unroll
+  for (int a = 0; a < TM_; ++a) {
+    const int ob = o_first + 32 * a;
+    float bias[16];
+    if (p.act) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bias[r] = p.bias[ob + (r & 3) + 8 * (r >> 2)];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bias[r] = 0.f;
+    }
+#pragma unroll
+    for (int b = 0; b < TN_; ++b) {
+      float scale[16];
+      if (p.demod) {
+        const float* dm = p.demod + (int64_t)ib[b] * p.out_ch + ob;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) scale[r] = dm[(r & 3) + 8 * (r >> 2)];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) scale[r] *= p.w_scale;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) scale[r] = p.w_scale;
+      }
+      if (!live[b]) continue;
+      float* yo = p.y + ((int64_t)ib[b] * p.out_ch + ob) * ohw + pix[b];
+      if (p.act) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[a][b][r] * scale[r] + nz[b] + bias[r];
+          yo[((r & 3) + 8 * (r >> 2)) * ohw] = ((v > 0.f) ? v : v * 0.2f) * 1.4142135623730951f;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) yo[((r & 3) + 8 * (r >> 2)) * ohw] = acc[a][b][r] * scale[r] + nz[b];
+      }
+    }
+  }
+}
+
 template <int TM, int TN, int WGM, int WGN>
 __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvBatch cb) {
   constexpr int BM = 32 * TM * WGM;
@@ -166,52 +237,37 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvBatch cb) {
   for (int c = 0; c < n_chunks; ++c) {
     const int buf = c & 1;
     if (c + 1 < n_chunks) gather(c + 1);
+    // fragments one k-pair ahead of the MFMAs that use them, pinned there (see conv_halo_kernel)
+    float af[TM], bf[TN], an[TM], bn[TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) af[a] = As[buf][frow][wm0 + 32 * a + fcol];
+#pragma unroll
+    for (int b = 0; b < TN; ++b) bf[b] = Bs[buf][frow][wn0 + 32 * b + fcol];
 #pragma unroll
     for (int kp = 0; kp < RW_KC / 2; ++kp) {
-      float af[TM], bf[TN];
+      if (kp + 1 < RW_KC / 2) {
 #pragma unroll
-      for (int a = 0; a < TM; ++a) af[a] = As[buf][2 * kp + frow][wm0 + 32 * a + fcol];
+        for (int a = 0; a < TM; ++a) an[a] = As[buf][2 * kp + 2 + frow][wm0 + 32 * a + fcol];
 #pragma unroll
-      for (int b = 0; b < TN; ++b) bf[b] = Bs[buf][2 * kp + frow][wn0 + 32 * b + fcol];
+        for (int b = 0; b < TN; ++b) bn[b] = Bs[buf][2 * kp + 2 + frow][wn0 + 32 * b + fcol];
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int b = 0; b < TN; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int a = 0; a < TM; ++a) af[a] = an[a];
+#pragma unroll
+      for (int b = 0; b < TN; ++b) bf[b] = bn[b];
     }
     if (c + 1 < n_chunks) stash(buf ^ 1);
     __syncthreads();
   }
 
-  // ---- epilogue: C/D layout col = lane&31 (n), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (o)
-  const float nw = p.noise ? p.noise_w[0] : 0.f;
-  const int64_t ohw = (int64_t)p.oh * p.ow;
-#pragma unroll
-  for (int b = 0; b < TN; ++b) {
-    const int64_t n = n0 + wn0 + 32 * b + fcol;
-    if (n >= n_total) continue;
-    const int ib = (int)(n / ppi);
-    const int r0 = (int)(n - (int64_t)ib * ppi);
-    const int yq = r0 / p.pw;
-    const int yy = yq + p.yoff, xx = r0 - yq * p.pw + p.xoff;
-    const int64_t pix = (int64_t)(p.sy * yy + p.oy0) * p.ow + (p.sx * xx + p.ox0);
-    const float nz = p.noise ? nw * p.noise[(int64_t)ib * ohw + pix] : 0.f;
-#pragma unroll
-    for (int a = 0; a < TM; ++a) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int o = o0 + wm0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * frow;
-        float v = acc[a][b][r] * p.w_scale;
-        if (p.demod) v *= p.demod[(int64_t)ib * p.out_ch + o];
-        if (p.noise) v += nz;
-        if (p.act) {
-          v += p.bias[o];
-          v = ((v > 0.f) ? v : v * 0.2f) * 1.4142135623730951f;
-        }
-        p.y[((int64_t)ib * p.out_ch + o) * ohw + pix] = v;
-      }
-    }
-  }
+  rw_tile_epilogue<TM, TN>(p, acc, o0 + wm0 + 4 * frow, n0 + wn0 + fcol, ppi, n_total);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -371,34 +427,7 @@ __global__ void __launch_bounds__(256) conv_mfma_ksplit_kernel(const ConvBatch c
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] += red[slot(a, b, r)];
 
-  const float nw = p.noise ? p.noise_w[0] : 0.f;
-  const int64_t ohw = (int64_t)p.oh * p.ow;
-#pragma unroll
-  for (int b = 0; b < T; ++b) {
-    const int64_t n = n0 + 32 * b + fcol;
-    if (n >= n_total) continue;
-    const int ib = (int)(n / ppi);
-    const int r0 = (int)(n - (int64_t)ib * ppi);
-    const int yq = r0 / p.pw;
-    const int yy = yq + p.yoff, xx = r0 - yq * p.pw + p.xoff;
-    const int64_t pix = (int64_t)(p.sy * yy + p.oy0) * p.ow + (p.sx * xx + p.ox0);
-    const float nz = p.noise ? nw * p.noise[(int64_t)ib * ohw + pix] : 0.f;
-#pragma unroll
-    for (int a = 0; a < T; ++a) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int o = o0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * frow;
-        float v = acc[a][b][r] * p.w_scale;
-        if (p.demod) v *= p.demod[(int64_t)ib * p.out_ch + o];
-        if (p.noise) v += nz;
-        if (p.act) {
-          v += p.bias[o];
-          v = ((v > 0.f) ? v : v * 0.2f) * 1.4142135623730951f;
-        }
-        p.y[((int64_t)ib * p.out_ch + o) * ohw + pix] = v;
-      }
-    }
-  }
+  rw_tile_epilogue<T, T>(p, acc, o0 + 4 * frow, n0 + fcol, ppi, n_total);
 }
 
 // ---------------------------------------------------------------------------------------

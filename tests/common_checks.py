@@ -123,11 +123,23 @@ def check_extras(device):
     # 'svd' / 'mean' / the UI query key apply C^-1 by fp32 least squares with cond(C) ~ 2e5: rounding
     # in C (1e-6) moves the result by O(1) along C's small eigen-directions, in the reference as well.
     # What is well defined is the result seen through C (C.(C^-1 k) = k), so compare there.
+    # Beyond the leading direction even that is noise-limited (the second singular vector of C^-1 k
+    # rows rotates under 1e-7 perturbations of C, here and in the reference under a different BLAS):
+    # the bar for the whole subspace is functional -- seen through C it must capture as much of the
+    # observed key rows (which are well defined) as the reference's subspace does.
+    observed = gw._key_observations(keys)
+    rows = torch.cat([(obs * w)[(w > 0)[:, 0]] for obs, _, w in observed]).double().cpu()
+
+    def captured(sub):
+        q = torch.linalg.qr(C @ sub.double().cpu().t())[0]
+        return ((rows @ q).norm() / rows.norm()).item() ** 2
     for method, rank, name, bar in (('svd', 2, 'mkey_svd', 0.95), ('mean', 1, 'mkey_mean', 0.99)):
         got = gw.multi_key_from_selection(keys, rank=rank, key_method=method)
         want = torch.from_numpy(g[name])
         assert got.shape == want.shape
-        assert principal_cosines(got, want, C).min() > bar, (method, principal_cosines(got, want, C))
+        cosines = principal_cosines(got, want, C)
+        assert cosines.max() > bar, (method, cosines)
+        assert captured(got) > captured(want) - 0.02, (method, captured(got), captured(want), cosines)
         assert abs(got.cpu().norm(dim=1) - 1).max() < 1e-4
     q = gw.query_key_from_selection(*keys[0])
     assert principal_cosines(q[None], torch.from_numpy(g['query_key'])[None], C).min() > 0.98
