@@ -17,7 +17,6 @@
 // stride-1 layers -- noise, bias and leaky-ReLU, so a styled-conv block reads its input once
 // and writes its output once.
 #include "rw_common.h"
-#include <stdlib.h>
 
 __host__ __device__ __forceinline__ int rw_tap_off(unsigned bits, int t) {
   return (int)((bits >> (2 * t)) & 3u) - 1;
@@ -436,27 +435,13 @@ __global__ void __launch_bounds__(256) conv_mfma_ksplit_kernel(const ConvBatch c
 // channels the (TH+2) x 34 input halo is staged in LDS ONCE (coalesced NCHW row pieces, style
 // multiplied on the way in) and all taps read it at shifted addresses, so global gathers drop
 // 9x versus the im2col staging above and there is one barrier per 9*IC/2 MFMA steps instead
-// of per 8.  Weight fragments are not staged at all: every lane loads its A operand
-// wp[tap][i][o] straight from L1/L2 (32 consecutive out-channels per half-wave = one 128-byte
-// line) one tap ahead of its use, which frees the LDS and the VALU for the matrix pipe.
-// The four output-parity phases of the stride-2 transposed convolution are four sub-problems
-// of ONE launch.
+// of per 8.  Weight fragments are not staged at all: the weights are also kept in MFMA fragment
+// order (rw_pack_conv_weight_f32), so every lane fetches its A operand for four k-pairs with ONE
+// 16-byte load (1 KiB of consecutive addresses per wave) straight from L1/L2, half a tap ahead of
+// its use, which frees the LDS and the VALU for the matrix pipe.  (FRAG = false: the per-phase
+// variant of the transposed convolution, impl 4, reads wp[tap][i][o] with dword loads.)
 // ---------------------------------------------------------------------------------------
 template <int N> struct rw_int { static constexpr int value = N; };
-
-// Phase stagger.  The workgroups of these kernels all do the same amount of work, so the OCC
-// workgroups that share a CU start together, reach their load-only prologue and store-only epilogue
-// together and finish together -- and so do their successors: the matrix pipe idles during every
-// such phase instead of being fed by a neighbour.  Delaying the k-th co-resident workgroup of the
-// FIRST round by k/OCC of a workgroup's duration shifts the phases for the rest of the launch.
-struct Stagger { int first_round, div, mod, sleeps; };
-__device__ __forceinline__ void rw_stagger(const Stagger& g) {
-  const int b = blockIdx.x;
-  if (b < g.first_round) {
-    const int n = ((b / g.div) % g.mod) * g.sleeps;
-    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);     // 127 * 64 cycles
-  }
-}
 
 // Timing ablations for kernel work (build with -DRW_ABLATION, select with RW_CONV_ABL=<bits>; results
 // are WRONG when a bit is set): 1 = no LDS operand reads in the loop, 2 = no weight refills,
@@ -484,7 +469,6 @@ struct HaloProblem {
   int batch, in_ch, out_ch, h, w, oh, ow, sy, sx;
   float w_scale;
   int act, nphase, abl;
-  Stagger stag;
   PhaseDesc phase[4];
 };
 
@@ -502,7 +486,6 @@ __global__ void __launch_bounds__(256, 2) conv_halo_kernel(const HaloProblem p) 
   const int wrow0 = (wave % WGN) * TN;
   const int frow = lane >> 5, fcol = lane & 31;
 
-  rw_stagger(p.stag);
   const int work = rw_xcd_remap(blockIdx.x, gridDim.x);
   int phase = 0;
 #pragma unroll
@@ -752,7 +735,6 @@ struct UpProblem {
   int tiles_x, tiles_y;
   float w_scale;
   int abl;
-  Stagger stag;
 };
 
 template <int WGM, int WGN, int IC>
@@ -772,7 +754,6 @@ __global__ void __launch_bounds__(256, 2) conv_up_halo_kernel(const UpProblem p)
   const int wrow0 = (wave % WGN) * TN;
   const int frow = lane >> 5, fcol = lane & 31;
 
-  rw_stagger(p.stag);
   int local = rw_xcd_remap(blockIdx.x, gridDim.x);
   const int o_tiles = p.out_ch / BM;
   const int o0 = (local % o_tiles) * BM; local /= o_tiles;
@@ -961,35 +942,19 @@ __global__ void __launch_bounds__(256, 2) conv_up_halo_kernel(const UpProblem p)
 
 static int launch_batch(const ConvProblem* ps, int n, int impl, hipStream_t s);
 
-// mfmas: MFMAs one wave issues per workgroup; occ: workgroups per CU.  RW_CONV_STAGGER (experiments):
-// 0 = off, 1 = classes by (b / 256) % occ, 2 = b % occ, 3 = (b / 8) % occ.
-static Stagger make_stagger(int64_t mfmas, int occ, int64_t blocks) {
-  Stagger g = {0, 1, 1, 0};
-  const char* e = getenv("RW_CONV_STAGGER");
-  const int mode = e ? atoi(e) : 0;
-  if (mode == 0 || blocks < 256 * occ * 2) return g;
-  g.first_round = 256 * occ; g.mod = occ;
-  g.div = mode == 1 ? 256 : (mode == 2 ? 1 : 8);
-  g.sleeps = (int)(mfmas * 64 / 8128);            // one wave's MFMA time = 1/occ of the workgroup's duration
-  return g;
-}
-
 static int launch_up_halo(const ConvProblem* ps, const float* wp_all, hipStream_t s) {
   const ConvProblem& c = ps[0];
   UpProblem u;
   u.x = c.x; u.wfrag = wp_all + (int64_t)9 * c.in_ch * c.out_ch; u.y = c.y; u.style = c.style; u.demod = c.demod;
   u.batch = c.batch; u.in_ch = c.in_ch; u.out_ch = c.out_ch; u.h = c.h; u.w = c.w; u.w_scale = c.w_scale;
   u.tiles_x = (int)rw_cdiv(c.w, 32); u.abl = rw_abl_env();
-  const int64_t up_mfmas = (int64_t)(c.in_ch / 16) * 8 * 18;
   if (c.out_ch % 64 == 0) {
     u.tiles_y = (int)rw_cdiv(c.h, 4);
     const int work = c.batch * u.tiles_x * u.tiles_y * (c.out_ch / 64);
-    u.stag = make_stagger(up_mfmas, 2, work);
     hipLaunchKernelGGL((conv_up_halo_kernel<2, 2, 16>), dim3(work), dim3(256), 0, s, u);
   } else {
     u.tiles_y = (int)rw_cdiv(c.h, 8);
     const int work = c.batch * u.tiles_x * u.tiles_y * (c.out_ch / 32);
-    u.stag = make_stagger(up_mfmas, 2, work);
     hipLaunchKernelGGL((conv_up_halo_kernel<1, 4, 16>), dim3(work), dim3(256), 0, s, u);
   }
   // Output row 2H and column 2W: quads y' = H (phases (0,0),(0,1)) and x' = W, y' < H (phases
@@ -1031,7 +996,6 @@ static int launch_halo(const ConvProblem* ps, int n, const float* wfrag, hipStre
     if (q < n) work += c.batch * d.tiles_x * d.tiles_y * (c.out_ch / bm);
   }
   if (work == 0) return 0;
-  h.stag = make_stagger((int64_t)c.in_ch / 2 * 9 * 4, wfrag ? 3 : 2, wfrag ? work : 0);
   if (wfrag) {        // stride-1 convolution, weights in fragment order
     if (bm == 128)
       hipLaunchKernelGGL((conv_halo_kernel<2, 2, 2, 2, 16, true>), dim3(work), dim3(256), 0, s, h);
