@@ -198,7 +198,8 @@ def test_fused_epilogues_and_streaming_blocks():
     want = R.fused_leaky_relu(R.upfirdn2d(wide, k4, pad=(1, 1)) + nw * n2.view(b, 1, 2 * h, 2 * w), bias)
     got = hip.blur_noise_act(wide.to(DEV), k4.to(DEV), n2.to(DEV), nw.to(DEV), bias.to(DEV))
     assert rel(got, want) < 1e-6
-    for bb, cc, hh, ww in [(1, 3, 4, 4), (2, 5, 20, 72), (1, 2, 130, 136)]:      # partial tiles, asymmetric taps
+    # partial tiles, asymmetric taps; the last two take the register-window kernel (maps >= 256 rows)
+    for bb, cc, hh, ww in [(1, 3, 4, 4), (2, 5, 20, 72), (1, 2, 130, 136), (1, 2, 256, 128), (2, 1, 300, 70)]:
         kk = k4.clone()
         kk[0, 1] += 0.03
         wd = torch.from_numpy(rs.randn(bb, cc, hh + 1, ww + 1).astype('float32'))
