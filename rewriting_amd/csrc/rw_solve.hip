@@ -363,7 +363,13 @@ __global__ void __launch_bounds__(256) solve_bwd_adam_kernel(const rw_solve_prob
     __syncthreads();
   }
 
+  // Epilogue: gradient, then Adam in place.  W, m, v of the 16 rows a lane owns are fetched in one
+  // batch (48 loads in flight) before anything is stored: weight/exp_avg/exp_avg_sq are read AND
+  // written here, so element-by-element code serialises into 32 dependent L2 round trips per wave.
   const float step_size = p.step_size[it], bc2s = p.bc2_sqrt[it];
+  float c2v[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) c2v[r] = p.c2[o0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * frow];
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
     const int k = k0 + wn0 + 32 * b + fcol;
@@ -371,18 +377,31 @@ __global__ void __launch_bounds__(256) solve_bwd_adam_kernel(const rw_solve_prob
     const int i = k / 9;
     const float sg = p.style[i];
     const float sig2 = sg * sg;
+    const int64_t base = (int64_t)(o0 + wm0 + 4 * frow) * K + k;
+    float wv[16], mv[16], vv[16];
+    const bool adam = !(p.low_rank_gradient || p.linear_insert);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int o = o0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * frow;
-      const int64_t idx = (int64_t)o * K + k;
-      float wv = p.weight[idx];
-      const float g = p.w_scale * acc[b][r] - p.c2[o] * wv * sig2;
-      if (p.low_rank_gradient || p.linear_insert) {
-        p.grad[idx] = g;
-      } else {
-        float m = p.exp_avg[idx], v = p.exp_avg_sq[idx];
-        adam_update(g, wv, m, v, p.one_minus_beta1, p.beta2, p.one_minus_beta2, p.eps, step_size, bc2s);
-        p.weight[idx] = wv; p.exp_avg[idx] = m; p.exp_avg_sq[idx] = v;
+    for (int r = 0; r < 16; ++r) wv[r] = p.weight[base + (int64_t)((r & 3) + 8 * (r >> 2)) * K];
+    if (adam) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mv[r] = p.exp_avg[base + (int64_t)((r & 3) + 8 * (r >> 2)) * K];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) vv[r] = p.exp_avg_sq[base + (int64_t)((r & 3) + 8 * (r >> 2)) * K];
+    }
+    float g[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) g[r] = p.w_scale * acc[b][r] - c2v[r] * wv[r] * sig2;
+    if (!adam) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) p.grad[base + (int64_t)((r & 3) + 8 * (r >> 2)) * K] = g[r];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        adam_update(g[r], wv[r], mv[r], vv[r], p.one_minus_beta1, p.beta2, p.one_minus_beta2, p.eps, step_size, bc2s);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t idx = base + (int64_t)((r & 3) + 8 * (r >> 2)) * K;
+        p.weight[idx] = wv[r]; p.exp_avg[idx] = mv[r]; p.exp_avg_sq[idx] = vv[r];
       }
     }
   }
