@@ -54,15 +54,17 @@ def conv_flops(model_size, channel_multiplier=2):
 def conv_kernel_name(out_ch, in_ch, width, upsample):
     """Which kernel rw_conv3x3_f32 / rw_conv_transpose3x3s2_f32 dispatch to (impl 0), mirroring
     launch_halo / launch_up_halo / launch_batch in rewriting_amd/csrc/rw_conv.hip."""
-    halo = width >= 24 and in_ch % 16 == 0 and in_ch <= 1024 and out_ch % 32 == 0
+    ok = in_ch % 16 == 0 and in_ch <= 1024 and out_ch % 32 == 0
     if upsample:
-        if halo:
+        if ok and width >= 24:
             return 'conv_up_halo_kernel<2, 2, 16>' if out_ch % 64 == 0 else 'conv_up_halo_kernel<1, 4, 16>'
         return 'conv_mfma(+ksplit)_kernel [4 phases]'
-    if halo:
+    if ok and (width >= 24 or 9 <= width <= 16):
+        tw = 32 if width >= 24 else 16
         if out_ch % 128 == 0:
-            return 'conv_halo_kernel<2, 2, 2, 2, 16, true>'
-        return 'conv_halo_kernel<2, 2, 1, 4, 16, true>' if out_ch % 64 == 0 else 'conv_halo_kernel<1, 4, 1, 4, 8, true>'
+            return 'conv_halo_kernel<2, 2, 2, 2, 16, true, %d>' % tw
+        return ('conv_halo_kernel<2, 2, 1, 4, 16, true, %d>' if out_ch % 64 == 0
+                else 'conv_halo_kernel<1, 4, 1, 4, 8, true, %d>') % tw
     return 'conv_mfma(+ksplit)_kernel'
 
 

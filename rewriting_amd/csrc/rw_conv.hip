@@ -472,19 +472,23 @@ struct HaloProblem {
   PhaseDesc phase[4];
 };
 
-template <int TM, int TN, int WGM, int WGN, int IC, bool FRAG>
+// TW = 32: an MFMA column tile is 32 consecutive pixels of one row; TW = 16 (maps 9..16 wide): two
+// rows of 16, so the low-resolution layers keep every lane of the tile busy.
+template <int TM, int TN, int WGM, int WGN, int IC, bool FRAG, int TW>
 __global__ void __launch_bounds__(256, 2) conv_halo_kernel(const HaloProblem p) {
   constexpr int BM = 32 * TM * WGM;
-  constexpr int TH = TN * WGN;
-  constexpr int XH = TH + 2, XW = 36, XUSED = 34;
+  constexpr int RPT = 32 / TW;                // image rows per 32-lane column tile
+  constexpr int TH = TN * WGN * RPT;
+  constexpr int XH = TH + 2, XW = TW == 32 ? 36 : 20, XUSED = TW + 2;
   constexpr int KP = IC / 2;
   static_assert(WGM * WGN == 4, "4 waves per workgroup");
   __shared__ float Xs[2][IC][XH][XW];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm0 = (wave / WGN) * 32 * TM;
-  const int wrow0 = (wave % WGN) * TN;
+  const int wrow0 = (wave % WGN) * TN * RPT;
   const int frow = lane >> 5, fcol = lane & 31;
+  const int lc = fcol & (TW - 1), lr = fcol / TW;     // this lane's column / row inside a column tile
 
   const int work = rw_xcd_remap(blockIdx.x, gridDim.x);
   int phase = 0;
@@ -498,7 +502,7 @@ __global__ void __launch_bounds__(256, 2) conv_halo_kernel(const HaloProblem p) 
   const int tx = local % d.tiles_x; local /= d.tiles_x;
   const int ty = local % d.tiles_y;
   const int ib = local / d.tiles_y;
-  const int y0 = ty * TH, x0 = tx * 32;
+  const int y0 = ty * TH, x0 = tx * TW;
   const int64_t hw = (int64_t)p.h * p.w;
   const float* xb = p.x + (int64_t)ib * p.in_ch * hw;
   const float* st = p.style ? p.style + (int64_t)ib * p.in_ch : nullptr;     // uniform: scalar loads
@@ -599,23 +603,23 @@ __global__ void __launch_bounds__(256, 2) conv_halo_kernel(const HaloProblem p) 
     const int buf = c & 1;
     const int cn = c + 1 < n_chunks ? c + 1 : c;      // last chunk: a redundant, unused refill
     if (!RW_ABL(p, 4)) xfetch(cn * IC);    // consumed by the staging steps at the end of the chunk
-    const float* xs = &Xs[buf][frow][wrow0 + rw_tap_off(d.dy_bits, 0) + 1][fcol + rw_tap_off(d.dx_bits, 0) + 1];
+    const float* xs = &Xs[buf][frow][wrow0 + lr + rw_tap_off(d.dy_bits, 0) + 1][lc + rw_tap_off(d.dx_bits, 0) + 1];
     float bf[TN], bnext[TN];
 #pragma unroll
-    for (int b = 0; b < TN; ++b) bf[b] = xs[b * XW];
+    for (int b = 0; b < TN; ++b) bf[b] = xs[b * RPT * XW];
     // one tap; STAGE >= 0 carries staging steps [STAGE * KP * MPK, (STAGE + 1) * KP * MPK)
     auto tap = [&](int t, auto stage_tag) {
       constexpr int STAGE = decltype(stage_tag)::value;
       int nt = t + 1, nc = c;
       if (nt == d.ntaps) { nt = 0; nc = cn; }
       // first k-pair of the next tap (for the last tap: re-read after the barrier, this one is unused)
-      const float* xs_next = &Xs[buf][frow][wrow0 + rw_tap_off(d.dy_bits, nt) + 1][fcol + rw_tap_off(d.dx_bits, nt) + 1];
+      const float* xs_next = &Xs[buf][frow][wrow0 + lr + rw_tap_off(d.dy_bits, nt) + 1][lc + rw_tap_off(d.dx_bits, nt) + 1];
       if (FRAG && KH == 1 && !RW_ABL(p, 2)) fload(an, 0, nt, nc);
 #pragma unroll
       for (int kp = 0; kp < KP; ++kp) {
 #pragma unroll
         for (int b = 0; b < TN; ++b)       // B fragments one k-pair ahead of the MFMAs that use them
-          if (!RW_ABL(p, 1)) bnext[b] = kp + 1 < KP ? xs[(2 * kp + 2) * XH * XW + b * XW] : xs_next[b * XW];
+          if (!RW_ABL(p, 1)) bnext[b] = kp + 1 < KP ? xs[(2 * kp + 2) * XH * XW + b * RPT * XW] : xs_next[b * RPT * XW];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int a = 0; a < TM; ++a)
@@ -658,13 +662,13 @@ __global__ void __launch_bounds__(256, 2) conv_halo_kernel(const HaloProblem p) 
   // store, each behind its own `if`, costs an L2 round trip plus the drain of the previous store
   // (vmcnt counts both) per element -- as long as the whole K loop on the 32/64-channel layers.
   const int64_t ohw = (int64_t)p.oh * p.ow;
-  const int xx = x0 + fcol;
+  const int xx = x0 + lc;
   int64_t pix[TN];
   float nz[TN];
   bool live[TN];
 #pragma unroll
   for (int b = 0; b < TN; ++b) {
-    const int yy = y0 + wrow0 + b;
+    const int yy = y0 + wrow0 + b * RPT + lr;
     live[b] = yy < d.ph && xx < d.pw;
     pix[b] = live[b] ? (int64_t)(p.sy * yy + d.oy0) * p.ow + (p.sx * xx + d.ox0) : 0;
     nz[b] = 0.f;
@@ -968,9 +972,21 @@ static int launch_up_halo(const ConvProblem* ps, const float* wp_all, hipStream_
 }
 
 static bool halo_applicable(const ConvProblem* ps, int n) {
-  for (int q = 0; q < n; ++q)
-    if (ps[q].pw < 24 || ps[q].in_ch % 16 || ps[q].in_ch > 1024 || ps[q].out_ch % 32) return false;
+  for (int q = 0; q < n; ++q) {
+    const bool wide = ps[q].pw >= 24, narrow = n == 1 && ps[q].pw >= 9 && ps[q].pw <= 16;
+    if (!(wide || narrow) || ps[q].in_ch % 16 || ps[q].in_ch > 1024 || ps[q].out_ch % 32) return false;
+  }
   return true;
+}
+
+template <int TW>
+static void launch_halo_frag(int bm, int work, const HaloProblem& h, hipStream_t s) {
+  if (bm == 128)
+    hipLaunchKernelGGL((conv_halo_kernel<2, 2, 2, 2, 16, true, TW>), dim3(work), dim3(256), 0, s, h);
+  else if (bm == 64)
+    hipLaunchKernelGGL((conv_halo_kernel<2, 2, 1, 4, 16, true, TW>), dim3(work), dim3(256), 0, s, h);
+  else
+    hipLaunchKernelGGL((conv_halo_kernel<1, 4, 1, 4, 8, true, TW>), dim3(work), dim3(256), 0, s, h);
 }
 
 // ps: 1 (stride-1 conv) or 4 (transposed-conv phases) problems sharing x / y / epilogue.
@@ -981,35 +997,33 @@ static int launch_halo(const ConvProblem* ps, int n, const float* wfrag, hipStre
   h.noise_w = c.noise_w; h.bias = c.bias; h.batch = c.batch; h.in_ch = c.in_ch; h.out_ch = c.out_ch;
   h.h = c.h; h.w = c.w; h.oh = c.oh; h.ow = c.ow; h.sy = c.sy; h.sx = c.sx; h.w_scale = c.w_scale;
   h.act = c.act; h.nphase = n; h.abl = rw_abl_env();
+  const int tw = (wfrag && c.pw <= 16) ? 16 : 32;      // two image rows per column tile on narrow maps
   int th, bm;
   if (c.out_ch % 128 == 0) { th = 4; bm = 128; }
   else if (c.out_ch % 64 == 0) { th = 8; bm = 64; }
   else { th = 16; bm = 32; }
+  th *= 32 / tw;
   int work = 0;
   for (int q = 0; q < 4; ++q) {
     PhaseDesc& d = h.phase[q];
     const ConvProblem& pq = ps[q < n ? q : 0];
     d.ntaps = pq.ntaps; d.dy_bits = pq.dy_bits; d.dx_bits = pq.dx_bits; d.ph = pq.ph; d.pw = pq.pw;
     d.oy0 = pq.oy0; d.ox0 = pq.ox0;
-    d.tiles_x = (int)rw_cdiv(pq.pw, 32); d.tiles_y = (int)rw_cdiv(pq.ph, th);
+    d.tiles_x = (int)rw_cdiv(pq.pw, tw); d.tiles_y = (int)rw_cdiv(pq.ph, th);
     d.work0 = work; d.wp_off = (long long)(pq.wp - ps[0].wp);
     if (q < n) work += c.batch * d.tiles_x * d.tiles_y * (c.out_ch / bm);
   }
   if (work == 0) return 0;
   if (wfrag) {        // stride-1 convolution, weights in fragment order
-    if (bm == 128)
-      hipLaunchKernelGGL((conv_halo_kernel<2, 2, 2, 2, 16, true>), dim3(work), dim3(256), 0, s, h);
-    else if (bm == 64)
-      hipLaunchKernelGGL((conv_halo_kernel<2, 2, 1, 4, 16, true>), dim3(work), dim3(256), 0, s, h);
-    else
-      hipLaunchKernelGGL((conv_halo_kernel<1, 4, 1, 4, 8, true>), dim3(work), dim3(256), 0, s, h);
+    if (tw == 16) launch_halo_frag<16>(bm, work, h, s);
+    else launch_halo_frag<32>(bm, work, h, s);
   } else {
     if (bm == 128)
-      hipLaunchKernelGGL((conv_halo_kernel<2, 2, 2, 2, 16, false>), dim3(work), dim3(256), 0, s, h);
+      hipLaunchKernelGGL((conv_halo_kernel<2, 2, 2, 2, 16, false, 32>), dim3(work), dim3(256), 0, s, h);
     else if (bm == 64)
-      hipLaunchKernelGGL((conv_halo_kernel<2, 2, 1, 4, 16, false>), dim3(work), dim3(256), 0, s, h);
+      hipLaunchKernelGGL((conv_halo_kernel<2, 2, 1, 4, 16, false, 32>), dim3(work), dim3(256), 0, s, h);
     else
-      hipLaunchKernelGGL((conv_halo_kernel<1, 4, 1, 4, 8, false>), dim3(work), dim3(256), 0, s, h);
+      hipLaunchKernelGGL((conv_halo_kernel<1, 4, 1, 4, 8, false, 32>), dim3(work), dim3(256), 0, s, h);
   }
   return RW_LAUNCH_RESULT();
 }
