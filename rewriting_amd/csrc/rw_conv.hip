@@ -741,12 +741,13 @@ struct UpProblem {
   int abl;
 };
 
-template <int WGM, int WGN, int IC>
+template <int WGM, int WGN, int IC, int TW>
 __global__ void __launch_bounds__(256, 2) conv_up_halo_kernel(const UpProblem p) {
   constexpr int TN = 2;                       // rows of quads per wave
   constexpr int BM = 32 * WGM;
-  constexpr int TH = TN * WGN;
-  constexpr int XH = TH + 1, XW = 36, XUSED = 33;
+  constexpr int RPT = 32 / TW;                // quad rows per 32-lane column tile (TW = 16: two, narrow maps)
+  constexpr int TH = TN * WGN * RPT;
+  constexpr int XH = TH + 1, XW = TW == 32 ? 36 : 20, XUSED = TW + 1;
   constexpr int NPOS = XH * XUSED;
   constexpr int PSLOT = (NPOS + 255) / 256;
   constexpr int KP = IC / 2;
@@ -755,8 +756,9 @@ __global__ void __launch_bounds__(256, 2) conv_up_halo_kernel(const UpProblem p)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm0 = (wave / WGN) * 32;
-  const int wrow0 = (wave % WGN) * TN;
+  const int wrow0 = (wave % WGN) * TN * RPT;
   const int frow = lane >> 5, fcol = lane & 31;
+  const int lc = fcol & (TW - 1), lr = fcol / TW;
 
   int local = rw_xcd_remap(blockIdx.x, gridDim.x);
   const int o_tiles = p.out_ch / BM;
@@ -764,7 +766,7 @@ __global__ void __launch_bounds__(256, 2) conv_up_halo_kernel(const UpProblem p)
   const int tx = local % p.tiles_x; local /= p.tiles_x;
   const int ty = local % p.tiles_y;
   const int ib = local / p.tiles_y;
-  const int y0 = ty * TH, x0 = tx * 32;
+  const int y0 = ty * TH, x0 = tx * TW;
   const int64_t hw = (int64_t)p.h * p.w;
   const float* xb = p.x + (int64_t)ib * p.in_ch * hw;
   const float* st = p.style ? p.style + (int64_t)ib * p.in_ch : nullptr;     // uniform: scalar loads
@@ -844,11 +846,11 @@ __global__ void __launch_bounds__(256, 2) conv_up_halo_kernel(const UpProblem p)
     const int cn = c + 1 < n_chunks ? c + 1 : c;     // last chunk: a redundant, unused refill
     // LDS row r holds input row y0-1+r, column c holds input column x0-1+c:
     // shift (dy,dx) of quad (row, col) -> Xs[.][row + 1 + dy][col + 1 + dx]
-    const float* xs = &Xs[buf][frow][wrow0][fcol];
+    const float* xs = &Xs[buf][frow][wrow0 + lr][lc];
     float b00[TN], b0m[TN], bm0[TN], bmm[TN], n00[TN], n0m[TN], nm0[TN], nmm[TN];
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
-      const float* q = xs + b * XW;
+      const float* q = xs + b * RPT * XW;
       b00[b] = q[XW + 1]; b0m[b] = q[XW]; bm0[b] = q[1]; bmm[b] = q[0];
     }
 #pragma unroll
@@ -860,7 +862,7 @@ __global__ void __launch_bounds__(256, 2) conv_up_halo_kernel(const UpProblem p)
       if (kp + 1 < KP && !RW_ABL(p, 1)) {
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
-          const float* q = xs + (2 * kp + 2) * XH * XW + b * XW;
+          const float* q = xs + (2 * kp + 2) * XH * XW + b * RPT * XW;
           n00[b] = q[XW + 1]; n0m[b] = q[XW]; nm0[b] = q[1]; nmm[b] = q[0];
         }
       }
@@ -900,7 +902,7 @@ __global__ void __launch_bounds__(256, 2) conv_up_halo_kernel(const UpProblem p)
   typedef float f32x2_u __attribute__((ext_vector_type(2), aligned(4)));
   const int oh = 2 * p.h + 1, ow = 2 * p.w + 1;
   const int64_t ohw = (int64_t)oh * ow;
-  const int xx = x0 + fcol;
+  const int xx = x0 + lc;
   const bool odd_lane = fcol & 1;
   const bool pair_ok = (xx | 1) < p.w;        // both quads of the lane pair are inside the tiled area
   float scale[16];                            // w_scale * demod of this lane's 16 out-channels, loaded at once
@@ -916,8 +918,8 @@ __global__ void __launch_bounds__(256, 2) conv_up_halo_kernel(const UpProblem p)
   }
 #pragma unroll
   for (int b = 0; b < TN; ++b) {
-    const int yy = y0 + wrow0 + b;
-    if (yy >= p.h) continue;                    // uniform per wave row; row 2H comes from the strip launch
+    const int yy = y0 + wrow0 + b * RPT + lr;
+    if (yy >= p.h) continue;                    // row 2H comes from the strip launch
     if (RW_ABL(p, 16) && acc[0][b][0] != 12345.f) continue;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -951,15 +953,19 @@ static int launch_up_halo(const ConvProblem* ps, const float* wp_all, hipStream_
   UpProblem u;
   u.x = c.x; u.wfrag = wp_all + (int64_t)9 * c.in_ch * c.out_ch; u.y = c.y; u.style = c.style; u.demod = c.demod;
   u.batch = c.batch; u.in_ch = c.in_ch; u.out_ch = c.out_ch; u.h = c.h; u.w = c.w; u.w_scale = c.w_scale;
-  u.tiles_x = (int)rw_cdiv(c.w, 32); u.abl = rw_abl_env();
+  u.abl = rw_abl_env();
+  const int tw = c.w <= 16 ? 16 : 32, rpt = 32 / tw;
+  u.tiles_x = (int)rw_cdiv(c.w, tw);
   if (c.out_ch % 64 == 0) {
-    u.tiles_y = (int)rw_cdiv(c.h, 4);
+    u.tiles_y = (int)rw_cdiv(c.h, 4 * rpt);
     const int work = c.batch * u.tiles_x * u.tiles_y * (c.out_ch / 64);
-    hipLaunchKernelGGL((conv_up_halo_kernel<2, 2, 16>), dim3(work), dim3(256), 0, s, u);
+    if (tw == 16) hipLaunchKernelGGL((conv_up_halo_kernel<2, 2, 16, 16>), dim3(work), dim3(256), 0, s, u);
+    else hipLaunchKernelGGL((conv_up_halo_kernel<2, 2, 16, 32>), dim3(work), dim3(256), 0, s, u);
   } else {
-    u.tiles_y = (int)rw_cdiv(c.h, 8);
+    u.tiles_y = (int)rw_cdiv(c.h, 8 * rpt);
     const int work = c.batch * u.tiles_x * u.tiles_y * (c.out_ch / 32);
-    hipLaunchKernelGGL((conv_up_halo_kernel<1, 4, 16>), dim3(work), dim3(256), 0, s, u);
+    if (tw == 16) hipLaunchKernelGGL((conv_up_halo_kernel<1, 4, 16, 16>), dim3(work), dim3(256), 0, s, u);
+    else hipLaunchKernelGGL((conv_up_halo_kernel<1, 4, 16, 32>), dim3(work), dim3(256), 0, s, u);
   }
   // Output row 2H and column 2W: quads y' = H (phases (0,0),(0,1)) and x' = W, y' < H (phases
   // (0,0),(1,0)) as four strip problems of ONE batched im2col launch.
@@ -972,8 +978,11 @@ static int launch_up_halo(const ConvProblem* ps, const float* wp_all, hipStream_
 }
 
 static bool halo_applicable(const ConvProblem* ps, int n) {
+  // column tiles of 32 pixels for maps at least 24 wide, of 2 x 16 for maps 9..16 wide
+  // (for the four phases of a transposed convolution: by the input width, pw = W or W + 1)
   for (int q = 0; q < n; ++q) {
-    const bool wide = ps[q].pw >= 24, narrow = n == 1 && ps[q].pw >= 9 && ps[q].pw <= 16;
+    const int wref = n == 1 ? ps[q].pw : ps[q].w;
+    const bool wide = ps[q].pw >= 24, narrow = wref >= 9 && wref <= 16;
     if (!(wide || narrow) || ps[q].in_ch % 16 || ps[q].in_ch > 1024 || ps[q].out_ch % 32) return false;
   }
   return true;
