@@ -56,10 +56,14 @@ def conv_kernel_name(out_ch, in_ch, width, upsample):
     launch_halo / launch_up_halo / launch_batch in rewriting_amd/csrc/rw_conv.hip."""
     ok = in_ch % 16 == 0 and in_ch <= 1024 and out_ch % 32 == 0
     if upsample:
+        if ok and 5 <= width <= 8 and out_ch % 128 == 0:
+            return 'conv_up_halo_kernel<4, 1, 16, 8>'
         if ok and (width >= 24 or 9 <= width <= 16):
             tw = 32 if width >= 24 else 16
             return ('conv_up_halo_kernel<2, 2, 16, %d>' if out_ch % 64 == 0 else 'conv_up_halo_kernel<1, 4, 16, %d>') % tw
         return 'conv_mfma(+ksplit)_kernel [4 phases]'
+    if ok and 5 <= width <= 8 and out_ch % 128 == 0:
+        return 'conv_halo_kernel<2, 1, 2, 2, 16, true, 8>'
     if ok and (width >= 24 or 9 <= width <= 16):
         tw = 32 if width >= 24 else 16
         if out_ch % 128 == 0:

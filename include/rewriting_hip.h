@@ -134,7 +134,7 @@ typedef struct rw_conv_epilogue {
 /* F.conv2d(x, scale*W, padding=1) [* demod]           (DemodulatedConv2dF, models.py:318-329)
  * x (B,Cin,H,W) -> y (B,Cout,H,W), wp from rw_pack_conv_weight_f32 mode 0.
  * impl: 0 = auto (fp32 MFMA implicit GEMM, v_mfma_f32_32x32x2_f32: halo-tile kernel when the map
- * is >= 24 wide, else the im2col kernel, which splits K across the four waves of a workgroup when
+ * is >= 24 wide (or 5..16 wide: column tiles of 2 x 16 / 4 x 8 pixels), else the im2col kernel, which splits K across the four waves of a workgroup when
  * the launch would otherwise leave most CUs idle), 1 = direct VALU kernel (cross-check), 2 = force
  * the im2col MFMA kernel, 3 = force the halo-tile MFMA kernel (RW_ERR_UNSUPPORTED if not applicable),
  * 4 = (transposed conv only) per-phase halo tiles, 5 = im2col MFMA kernel without split-K,

@@ -473,13 +473,14 @@ struct HaloProblem {
 };
 
 // TW = 32: an MFMA column tile is 32 consecutive pixels of one row; TW = 16 (maps 9..16 wide): two
-// rows of 16, so the low-resolution layers keep every lane of the tile busy.
+// rows of 16; TW = 8 (maps 5..8 wide): four rows of 8 -- the low-resolution layers keep every lane of
+// the tile busy.
 template <int TM, int TN, int WGM, int WGN, int IC, bool FRAG, int TW>
 __global__ void __launch_bounds__(256, 2) conv_halo_kernel(const HaloProblem p) {
   constexpr int BM = 32 * TM * WGM;
   constexpr int RPT = 32 / TW;                // image rows per 32-lane column tile
   constexpr int TH = TN * WGN * RPT;
-  constexpr int XH = TH + 2, XW = TW == 32 ? 36 : 20, XUSED = TW + 2;
+  constexpr int XH = TH + 2, XW = TW == 32 ? 36 : (TW == 16 ? 20 : 12), XUSED = TW + 2;
   constexpr int KP = IC / 2;
   static_assert(WGM * WGN == 4, "4 waves per workgroup");
   __shared__ float Xs[2][IC][XH][XW];
@@ -747,7 +748,7 @@ __global__ void __launch_bounds__(256, 2) conv_up_halo_kernel(const UpProblem p)
   constexpr int BM = 32 * WGM;
   constexpr int RPT = 32 / TW;                // quad rows per 32-lane column tile (TW = 16: two, narrow maps)
   constexpr int TH = TN * WGN * RPT;
-  constexpr int XH = TH + 1, XW = TW == 32 ? 36 : 20, XUSED = TW + 1;
+  constexpr int XH = TH + 1, XW = TW == 32 ? 36 : (TW == 16 ? 20 : 12), XUSED = TW + 1;
   constexpr int NPOS = XH * XUSED;
   constexpr int PSLOT = (NPOS + 255) / 256;
   constexpr int KP = IC / 2;
@@ -954,9 +955,13 @@ static int launch_up_halo(const ConvProblem* ps, const float* wp_all, hipStream_
   u.x = c.x; u.wfrag = wp_all + (int64_t)9 * c.in_ch * c.out_ch; u.y = c.y; u.style = c.style; u.demod = c.demod;
   u.batch = c.batch; u.in_ch = c.in_ch; u.out_ch = c.out_ch; u.h = c.h; u.w = c.w; u.w_scale = c.w_scale;
   u.abl = rw_abl_env();
-  const int tw = c.w <= 16 ? 16 : 32, rpt = 32 / tw;
+  const int tw = c.w > 16 ? 32 : (c.w > 8 ? 16 : 8), rpt = 32 / tw;
   u.tiles_x = (int)rw_cdiv(c.w, tw);
-  if (c.out_ch % 64 == 0) {
+  if (tw == 8) {                                   // 128 out-channels x (8 x 8 quads)
+    u.tiles_y = (int)rw_cdiv(c.h, 8);
+    const int work = c.batch * u.tiles_x * u.tiles_y * (c.out_ch / 128);
+    hipLaunchKernelGGL((conv_up_halo_kernel<4, 1, 16, 8>), dim3(work), dim3(256), 0, s, u);
+  } else if (c.out_ch % 64 == 0) {
     u.tiles_y = (int)rw_cdiv(c.h, 4 * rpt);
     const int work = c.batch * u.tiles_x * u.tiles_y * (c.out_ch / 64);
     if (tw == 16) hipLaunchKernelGGL((conv_up_halo_kernel<2, 2, 16, 16>), dim3(work), dim3(256), 0, s, u);
@@ -978,12 +983,14 @@ static int launch_up_halo(const ConvProblem* ps, const float* wp_all, hipStream_
 }
 
 static bool halo_applicable(const ConvProblem* ps, int n) {
-  // column tiles of 32 pixels for maps at least 24 wide, of 2 x 16 for maps 9..16 wide
+  // column tiles of 32 pixels for maps at least 24 wide, of 2 x 16 for maps 9..16 wide, of 4 x 8 for
+  // maps 5..8 wide (128 out-channel tiles only)
   // (for the four phases of a transposed convolution: by the input width, pw = W or W + 1)
   for (int q = 0; q < n; ++q) {
     const int wref = n == 1 ? ps[q].pw : ps[q].w;
     const bool wide = ps[q].pw >= 24, narrow = wref >= 9 && wref <= 16;
-    if (!(wide || narrow) || ps[q].in_ch % 16 || ps[q].in_ch > 1024 || ps[q].out_ch % 32) return false;
+    const bool tiny = wref >= 5 && wref <= 8 && ps[q].out_ch % 128 == 0;
+    if (!(wide || narrow || tiny) || ps[q].in_ch % 16 || ps[q].in_ch > 1024 || ps[q].out_ch % 32) return false;
   }
   return true;
 }
@@ -1006,12 +1013,14 @@ static int launch_halo(const ConvProblem* ps, int n, const float* wfrag, hipStre
   h.noise_w = c.noise_w; h.bias = c.bias; h.batch = c.batch; h.in_ch = c.in_ch; h.out_ch = c.out_ch;
   h.h = c.h; h.w = c.w; h.oh = c.oh; h.ow = c.ow; h.sy = c.sy; h.sx = c.sx; h.w_scale = c.w_scale;
   h.act = c.act; h.nphase = n; h.abl = rw_abl_env();
-  const int tw = (wfrag && c.pw <= 16) ? 16 : 32;      // two image rows per column tile on narrow maps
+  // 2 (4) image rows per column tile on maps 9..16 (5..8) wide
+  const int tw = !wfrag || c.pw > 16 ? 32 : (c.pw > 8 ? 16 : 8);
   int th, bm;
   if (c.out_ch % 128 == 0) { th = 4; bm = 128; }
   else if (c.out_ch % 64 == 0) { th = 8; bm = 64; }
   else { th = 16; bm = 32; }
   th *= 32 / tw;
+  if (tw == 8) { th = 8; bm = 128; }                   // one variant: 128 out-channels x (8 rows x 8 columns)
   int work = 0;
   for (int q = 0; q < 4; ++q) {
     PhaseDesc& d = h.phase[q];
@@ -1024,7 +1033,9 @@ static int launch_halo(const ConvProblem* ps, int n, const float* wfrag, hipStre
   }
   if (work == 0) return 0;
   if (wfrag) {        // stride-1 convolution, weights in fragment order
-    if (tw == 16) launch_halo_frag<16>(bm, work, h, s);
+    if (tw == 8)
+      hipLaunchKernelGGL((conv_halo_kernel<2, 1, 2, 2, 16, true, 8>), dim3(work), dim3(256), 0, s, h);
+    else if (tw == 16) launch_halo_frag<16>(bm, work, h, s);
     else launch_halo_frag<32>(bm, work, h, s);
   } else {
     if (bm == 128)
