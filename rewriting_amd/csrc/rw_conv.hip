@@ -922,24 +922,31 @@ __global__ void __launch_bounds__(256, 2) conv_up_halo_kernel(const UpProblem p)
     const int yy = y0 + wrow0 + b * RPT + lr;
     if (yy >= p.h) continue;                    // row 2H comes from the strip launch
     if (RW_ABL(p, 16) && acc[0][b][0] != 12345.f) continue;
+    // row r of the tile is channel o0 + wm0 + 4 frow + (r&3) + 8(r>>2): one 64-bit address per b, the
+    // per-row plane offsets are scalar
+    float* yb = p.y + ((int64_t)ib * p.out_ch + o0 + wm0 + 4 * frow) * ohw + (int64_t)(2 * yy) * ow + 2 * xx;
+    if (pair_ok) {
+      float* yv = odd_lane ? yb + ow - 2 : yb;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int o = o0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * frow;
-      const float sc = scale[r];
-      const float v00 = acc[0][b][r] * sc, v01 = acc[1][b][r] * sc;
-      const float v10 = acc[2][b][r] * sc, v11 = acc[3][b][r] * sc;
-      const float g0 = __int_as_float(__builtin_amdgcn_update_dpp(
-          0, __float_as_int(odd_lane ? v00 : v10), 0xB1, 0xf, 0xf, true));
-      const float g1 = __int_as_float(__builtin_amdgcn_update_dpp(
-          0, __float_as_int(odd_lane ? v01 : v11), 0xB1, 0xf, 0xf, true));
-      float* yo = p.y + ((int64_t)ib * p.out_ch + o) * ohw + (int64_t)(2 * yy) * ow + 2 * xx;
-      if (pair_ok) {
+      for (int r = 0; r < 16; ++r) {
+        const float sc = scale[r];
+        const float v00 = acc[0][b][r] * sc, v01 = acc[1][b][r] * sc;
+        const float v10 = acc[2][b][r] * sc, v11 = acc[3][b][r] * sc;
+        const float g0 = __int_as_float(__builtin_amdgcn_update_dpp(
+            0, __float_as_int(odd_lane ? v00 : v10), 0xB1, 0xf, 0xf, true));
+        const float g1 = __int_as_float(__builtin_amdgcn_update_dpp(
+            0, __float_as_int(odd_lane ? v01 : v11), 0xB1, 0xf, 0xf, true));
         f32x4_u v;
-        if (odd_lane) { v[0] = g0; v[1] = g1; v[2] = v10; v[3] = v11; }
-        else          { v[0] = v00; v[1] = v01; v[2] = g0; v[3] = g1; }
-        *reinterpret_cast<f32x4_u*>(odd_lane ? yo + ow - 2 : yo) = v;
-      } else if (xx < p.w) {                    // odd W: last quad column of the tiled area
-        f32x2_u e = {v00, v01}, d = {v10, v11};
+        v[0] = odd_lane ? g0 : v00; v[1] = odd_lane ? g1 : v01;
+        v[2] = odd_lane ? v10 : g0; v[3] = odd_lane ? v11 : g1;
+        *reinterpret_cast<f32x4_u*>(yv + (int64_t)((r & 3) + 8 * (r >> 2)) * ohw) = v;
+      }
+    } else if (xx < p.w) {                      // odd W: last quad column of the tiled area
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float sc = scale[r];
+        float* yo = yb + (int64_t)((r & 3) + 8 * (r >> 2)) * ohw;
+        f32x2_u e = {acc[0][b][r] * sc, acc[1][b][r] * sc}, d = {acc[2][b][r] * sc, acc[3][b][r] * sc};
         *reinterpret_cast<f32x2_u*>(yo) = e;
         *reinterpret_cast<f32x2_u*>(yo + ow) = d;
       }
