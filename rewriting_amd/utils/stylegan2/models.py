@@ -127,6 +127,19 @@ def fusion_enabled():
     return os.environ.get('RW_FUSE', '1') != '0'
 
 
+# The RGB branch (up_rgbK, to_rgbK) is HBM-bound and hangs off the feature-map trunk, whose convolutions
+# are MFMA-bound: when the WHOLE generator runs un-hooked (SeqStyleGAN2.forward below) the branch is
+# issued on a second HIP stream so that it overlaps the next styled convolutions, and is joined
+# before the image is returned.  Hooked / sliced models (nethook) never see this: the mode is on only
+# inside that forward.
+_rgb_branch = {'stream': None}
+_rgb_side_streams = {}          # one per device, module-level: models are deep-copied by the rewriters
+
+
+def _rgb_stream():
+    return _rgb_branch['stream']
+
+
 _CONV_IMPLS = {'auto': 0, 'mfma': 0, 'direct': 1, 'generic': 2, 'halo': 3, 'nosplitk': 5}
 
 
@@ -381,7 +394,11 @@ class UpsampleO(Upsample):
         super().__init__(kernel, factor)
 
     def forward(self, d):
-        return DataBag(d, output=super().forward(d.output))
+        side = _rgb_stream()
+        if side is None:
+            return DataBag(d, output=super().forward(d.output))
+        with torch.cuda.stream(side):              # the previous RGB image was produced on this stream
+            return DataBag(d, output=super().forward(d.output))
 
 
 class NoiseInjectionF(nn.Module):
@@ -483,11 +500,25 @@ class ToRGBF(nn.Module):
         skip = d.output if self.skip else None
         if skip is not None and tuple(skip.shape[2:]) != tuple(d.fmap.shape[2:]):
             up = self.upsample if hasattr(self, 'upsample') else Upsample([1, 3, 3, 1]).to(skip.device)
-            skip = up(skip)
+            if _rgb_stream() is None:
+                skip = up(skip)
+            else:
+                with torch.cuda.stream(_rgb_stream()):
+                    skip = up(skip)
         conv = self.conv
-        style = conv.modulation(d.style)
-        out = hip.to_rgb(d.fmap, conv.weight.view(3, conv.in_channel), style, self.bias.view(3), skip,
-                         conv.scale)
+        side = _rgb_stream()
+        if side is None:
+            style = conv.modulation(d.style)
+            out = hip.to_rgb(d.fmap, conv.weight.view(3, conv.in_channel), style, self.bias.view(3), skip,
+                             conv.scale)
+            return DataBag(d, output=out)
+        side.wait_stream(torch.cuda.current_stream())      # the feature map and the latent come from the trunk
+        with torch.cuda.stream(side):
+            style = conv.modulation(d.style)
+            out = hip.to_rgb(d.fmap, conv.weight.view(3, conv.in_channel), style, self.bias.view(3), skip,
+                             conv.scale)
+        d.fmap.record_stream(side)                         # keep the allocator from recycling them under it
+        d.style.record_stream(side)
         return DataBag(d, output=out)
 
 
@@ -622,6 +653,27 @@ class SeqStyleGAN2(nn.Sequential):
         if not bag_output:
             steps.append(('output', ReturnOutput()))
         super().__init__(OrderedDict(steps))
+
+    def forward(self, input):
+        side_ok = (fusion_enabled() and os.environ.get('RW_RGB_STREAM', '1') != '0' and torch.is_tensor(input)
+                   and input.is_cuda and not self.bag_output and _rgb_branch['stream'] is None
+                   and not torch.cuda.is_current_stream_capturing()
+                   and _unhooked(*self.modules()))
+        if not side_ok:
+            return super().forward(input)
+        main = torch.cuda.current_stream()
+        side = _rgb_side_streams.get(input.device)
+        if side is None:
+            side = _rgb_side_streams[input.device] = torch.cuda.Stream(device=input.device)
+        _rgb_branch['stream'] = side
+        try:
+            out = super().forward(input)
+        finally:
+            _rgb_branch['stream'] = None
+            main.wait_stream(side)                          # join: the image is complete on the caller's stream
+        if torch.is_tensor(out):
+            out.record_stream(main)
+        return out
 
     def bag_from_z(self, z):
         return InputLatent()(z)
