@@ -317,7 +317,7 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     if args.workload == 'ffhq1024':
-        out = run_forward(args, rank, world, device, 1024, args.batch or 32,
+        out = run_forward(args, rank, world, device, 1024, args.batch or 64,
                           'stylegan2-1024 generator forward (FFHQ-1024 architecture)')
     elif args.workload == 'ffhq256':
         out = run_forward(args, rank, world, device, 256, args.batch or 64,

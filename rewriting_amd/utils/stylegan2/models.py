@@ -132,7 +132,7 @@ def fusion_enabled():
 # issued on a second HIP stream so that it overlaps the next styled convolutions, and is joined
 # before the image is returned.  Hooked / sliced models (nethook) never see this: the mode is on only
 # inside that forward.
-_rgb_branch = {'stream': None}
+_rgb_branch = {'stream': None, 'keep': []}
 _rgb_side_streams = {}          # one per device, module-level: models are deep-copied by the rewriters
 
 
@@ -517,8 +517,10 @@ class ToRGBF(nn.Module):
             style = conv.modulation(d.style)
             out = hip.to_rgb(d.fmap, conv.weight.view(3, conv.in_channel), style, self.bias.view(3), skip,
                              conv.scale)
-        d.fmap.record_stream(side)                         # keep the allocator from recycling them under it
-        d.style.record_stream(side)
+        # The branch reads trunk tensors from another stream: they stay referenced until the join
+        # (Tensor.record_stream would do, but it defers the allocator's reuse of multi-GB blocks
+        # unpredictably and shows up as intermittent hipMalloc stalls at large batch).
+        _rgb_branch['keep'].append((d.fmap, d.style))
         return DataBag(d, output=out)
 
 
@@ -671,6 +673,7 @@ class SeqStyleGAN2(nn.Sequential):
         finally:
             _rgb_branch['stream'] = None
             main.wait_stream(side)                          # join: the image is complete on the caller's stream
+            del _rgb_branch['keep'][:]                      # freed to the trunk's pool AFTER the join is queued
         if torch.is_tensor(out):
             out.record_stream(main)
         return out
