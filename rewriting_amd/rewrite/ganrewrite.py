@@ -176,7 +176,9 @@ class ProgressiveGanRewriter(object):
         solve is part of the result."""
         c = self.c_matrix.cpu()
         rhs = (k[:, None] if k.dim() == 1 else k.permute(1, 0)).cpu()
-        sol = torch.linalg.lstsq(c, rhs).solution.to(k.dtype).to(k.device)
+        with host_linalg_threads():
+            sol = torch.linalg.lstsq(c, rhs).solution
+        sol = sol.to(k.dtype).to(k.device)
         return sol[:, 0] if k.dim() == 1 else sol.permute(1, 0)
 
     def covariance_adjusted_key(self, k, kout):
@@ -305,10 +307,11 @@ class ProgressiveGanRewriter(object):
                                        for (obs, _, w), s in zip(observed, sel)])
                 zk = all_zca_k.cpu()
                 zca = self.zca_matrix.cpu()
-                _, _, vh = torch.linalg.svd(zk, full_matrices=False)
-                top = vh.t()[:, :rank]
-                row_dirs = torch.mm(zca, top).t()
-                qmat, _ = torch.linalg.qr(row_dirs.t())
+                with host_linalg_threads():
+                    _, _, vh = torch.linalg.svd(zk, full_matrices=False)
+                    top = vh.t()[:, :rank]
+                    row_dirs = torch.mm(zca, top).t()
+                    qmat, _ = torch.linalg.qr(row_dirs.t())
                 signs = (qmat * zk.sum(0)[:, None]).sum(0).sign()
                 q = qmat * signs[None, :]
                 return q.t().contiguous().to(self.device)
@@ -345,7 +348,8 @@ class ProgressiveGanRewriter(object):
             if key_method == 'mean':
                 assert rank == 1
                 return just_avg[None, :] / just_avg.norm()
-            u, _, _ = torch.linalg.svd(all_k.permute(1, 0).cpu(), full_matrices=True)
+            with host_linalg_threads():
+                u, _, _ = torch.linalg.svd(all_k.permute(1, 0).cpu(), full_matrices=True)
             u = u.to(self.device)
             if (just_avg * u[:, 0]).sum() < 0:
                 u[:, 0] = -u[:, 0]
@@ -663,7 +667,9 @@ class SeqPreStyleGanRewriter(SeqStyleGanRewriter):
         assert kout.style.shape[0] == 1
         cs = (self.c_matrix * kout.style[0][None, :]).cpu()
         rhs = (k[:, None] if k.dim() == 1 else k.permute(1, 0)).cpu()
-        sol = torch.linalg.lstsq(cs, rhs).solution.to(k.dtype).to(k.device)
+        with host_linalg_threads():
+            sol = torch.linalg.lstsq(cs, rhs).solution
+        sol = sol.to(k.dtype).to(k.device)
         return sol[:, 0] if k.dim() == 1 else sol.permute(1, 0)
 
 
@@ -734,9 +740,30 @@ def rank_one_conv(weight, direction):
     return cos * direction[None, :, None, None]
 
 
+class host_linalg_threads:
+    """The host LAPACK calls on this path are small (a 512 x 512 eigh, a ~100 x 512 svd, a lstsq): on a
+    128-thread box the default OpenMP team makes them slower and leaves spinning workers that starve
+    the single-threaded PIL mask rasterisation that follows (measured: 16 ms instead of 0.2 ms per
+    mask).  Inside this context torch's intra-op parallelism is capped; restored on exit."""
+
+    def __init__(self, n=8):
+        self.n = n
+
+    def __enter__(self):
+        self.old = torch.get_num_threads()
+        if self.old > self.n:
+            torch.set_num_threads(self.n)
+        return self
+
+    def __exit__(self, *exc):
+        if torch.get_num_threads() != self.old:
+            torch.set_num_threads(self.old)
+
+
 def zca_from_cov(cov):
     """Z = V diag(1/sqrt(lambda)) V^T in float64 -> cov.dtype (:821-826).  LAPACK on the host;
     the reference's symeig read the upper triangle."""
-    evals, evecs = torch.linalg.eigh(cov.double().cpu(), UPLO='U')
-    zca = evecs @ torch.diag(evals.sqrt().clamp(1e-20).reciprocal()) @ evecs.t()
+    with host_linalg_threads():
+        evals, evecs = torch.linalg.eigh(cov.double().cpu(), UPLO='U')
+        zca = evecs @ torch.diag(evals.sqrt().clamp(1e-20).reciprocal()) @ evecs.t()
     return zca.to(cov.dtype).to(cov.device)
