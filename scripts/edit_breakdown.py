@@ -37,6 +37,8 @@ def main():
         t.append(tick())
         names = ['rewriter init (sweep + zca)', 'object_from_selection', 'paste_from_selection',
                  'multi_key_from_selection', 'insert (2001 steps)']
+        t0 = tick(); ganrewrite.zca_from_cov(gw.c_matrix); t1 = tick()
+        print('  of which zca_from_cov %.1f ms' % ((t1 - t0) * 1e3))
         print(' | '.join('%s %.1f ms' % (n, (b - a) * 1e3) for n, a, b in zip(names, t, t[1:])))
 
 

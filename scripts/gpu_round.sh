@@ -23,6 +23,8 @@ echo "== rocprofv3 kernel-trace stats" | tee -a "$OUT/summary.txt"
 find "$OUT/prof" -name "*.csv" | head -8 | tee -a "$OUT/summary.txt"
 F=$(find "$OUT/prof" -name "*kernel_stats*.csv" | head -1)
 [ -n "$F" ] && head -25 "$F" | tee -a "$OUT/summary.txt"
+T=$(find "$OUT/prof" -name "*kernel_trace.csv" | head -1)
+[ -n "$T" ] && python scripts/trace_stats.py "$T" 0.3 > "$OUT/kernel_stats_steady.csv"   # warm-up launches left out
 # keep only the small summaries (traces can be large)
 find "$OUT/prof" -name "*kernel_trace*" -size +20M -delete 2>/dev/null
 echo done
