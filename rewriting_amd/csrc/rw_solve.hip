@@ -145,8 +145,11 @@ __global__ void __launch_bounds__(256) solve_fwd_kernel(const rw_solve_problem p
 // K2: one workgroup per out channel
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) solve_mid_kernel(const rw_solve_problem p, int pp, float* lpart) {
-  __shared__ float red[4];
-  const int o = blockIdx.x, tid = threadIdx.x;
+  // one WAVE per out channel (4 per workgroup): the crop has a few dozen pixels, so a lane owns one or two
+  // of them and the two per-channel sums are wave butterflies -- no LDS, no barrier
+  const int lane = threadIdx.x & 63;
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (o >= p.out_ch) return;
   const int P = sv_conv_h(p) * sv_conv_w(p);
   float wsq = 0.f;
   for (int s = 0; s < p.ksplit; ++s) wsq += p.wsq[(int64_t)s * p.out_ch + o];
@@ -157,7 +160,7 @@ __global__ void __launch_bounds__(256) solve_mid_kernel(const rw_solve_problem p
   const float nw = plain ? 0.f : p.noise_w[0], bv = plain ? 0.f : p.bias[o];
   const float inv_numel = 1.0f / ((float)p.out_ch * (float)P);
   float lsum = 0.f, tsum = 0.f;
-  for (int n = tid; n < pp; n += 256) {
+  for (int n = lane; n < pp; n += 64) {
     float gdv = 0.f;
     if (n < P) {
       float conv = 0.f;
@@ -182,9 +185,9 @@ __global__ void __launch_bounds__(256) solve_mid_kernel(const rw_solve_problem p
     }
     p.gd[(int64_t)o * pp + n] = gdv;
   }
-  lsum = rw_block_sum_256(lsum, red);
-  tsum = rw_block_sum_256(tsum, red);
-  if (tid == 0) {
+  lsum = rw_wave_sum(lsum);
+  tsum = rw_wave_sum(tsum);
+  if (lane == 0) {
     lpart[o] = lsum * inv_numel;
     p.c2[o] = p.w_scale * p.w_scale * demod * demod * demod * tsum;
   }
@@ -525,7 +528,7 @@ extern "C" int rw_solve_step_f32(const rw_solve_problem* pr, int project, rw_str
     if (mid_lds > 64 * 1024) return RW_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(solve_mid_up_kernel, dim3(p.out_ch), dim3(256), mid_lds, s, p, pp, lpart);
   } else {
-    hipLaunchKernelGGL(solve_mid_kernel, dim3(p.out_ch), dim3(256), 0, s, p, pp, lpart);
+    hipLaunchKernelGGL(solve_mid_kernel, dim3((unsigned)rw_cdiv(p.out_ch, 4)), dim3(256), 0, s, p, pp, lpart);
   }
   hipLaunchKernelGGL(solve_bwd_adam_kernel, dim3(p.out_ch / SV_BM, (unsigned)rw_cdiv(9 * p.in_ch, SV_BNK)), dim3(256), 0,
                      s, p, pp, (const float*)lpart);

@@ -133,7 +133,7 @@ class ProgressiveGanRewriter(object):
                 # ten reference batches of 10 per launch; each seed keeps its reference noise row
                 from ..utils.stylegan2.models import noise_batch_period
                 with noise_batch_period(10):
-                    r2m = tally.tally_second_moment(key_rows, self.zds, batch_size=self.sweep_batch,
+                    r2m = tally.tally_second_moment(key_rows, self.zds, batch_size=self._sweep_batch(),
                                                     cachefile=self.rf('r2m.npz'),
                                                     shard=parallel.shard(), nchw=True)
             else:
@@ -141,7 +141,15 @@ class ProgressiveGanRewriter(object):
                                                 shard=parallel.shard(), nchw=on_gpu)
             return r2m.moment()
 
-    sweep_batch = 100     # seeds per launch of the statistics sweeps on the GPU (multiple of 10)
+    sweep_batch = 250     # seeds per launch of the statistics sweeps on the GPU (multiple of 10), at most
+
+    def _sweep_batch(self):
+        """Seeds per launch: large launches amortise the host side of ~100 kernel launches per batch, but
+        every rank of a sharded sweep must still receive at least one batch (batches are dealt round-robin)."""
+        sh = parallel.shard()
+        world = sh[1] if sh else 1
+        per_rank = max(1, len(self.zds) // world)
+        return max(10, min(self.sweep_batch, per_rank // 10 * 10))
 
     def _noise_periodic(self):
         """Large sweep launches are only equivalent to the reference's batches of 10 if the dataset
@@ -161,7 +169,7 @@ class ProgressiveGanRewriter(object):
                 if on_gpu and self._noise_periodic():
                     from ..utils.stylegan2.models import noise_batch_period
                     with noise_batch_period(10):
-                        rv = tally.tally_mean(squared_units, self.zds, batch_size=self.sweep_batch,
+                        rv = tally.tally_mean(squared_units, self.zds, batch_size=self._sweep_batch(),
                                               cachefile=self.rf('unit_rs.npz'), nchw=True, square_input=True,
                                               shard=parallel.shard())
                 else:
@@ -450,7 +458,7 @@ class ProgressiveGanRewriter(object):
             if self._kernels() and self._noise_periodic():
                 from ..utils.stylegan2.models import noise_batch_period
                 with noise_batch_period(10):
-                    return fn(*args, batch_size=self.sweep_batch, **kwargs)
+                    return fn(*args, batch_size=self._sweep_batch(), **kwargs)
             return fn(*args, **kwargs)
 
     def quantiles_for_units(self):
