@@ -83,26 +83,28 @@ class ConvTimer:
 
     def install(self):
         from rewriting_amd import hip
-        self._orig = (hip.conv3x3, hip.conv_transpose3x3s2)
+        self._orig = (hip.conv3x3, hip.conv_transpose3x3s2, hip.conv3x3_bf16x6)
         timer = self
 
-        def wrap(fn, upsample):
+        def wrap(fn, upsample, split=False):
             def inner(x, wp, out_ch, w_scale, *a, **k):
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record()
                 y = fn(x, wp, out_ch, w_scale, *a, **k)
                 e.record()
                 b, i, h, w = x.shape
-                timer.calls.append((conv_kernel_name(out_ch, i, w, upsample), s, e,
-                                    2.0 * 9 * i * out_ch * h * w * b))
+                name = ('conv_halo_bf16x6_kernel<2, 2, %s>' % ('2, 2' if out_ch % 128 == 0 else '1, 4') if split
+                        else conv_kernel_name(out_ch, i, w, upsample))
+                timer.calls.append((name, s, e, 2.0 * 9 * i * out_ch * h * w * b))
                 return y
             return inner
         hip.conv3x3 = wrap(self._orig[0], False)
         hip.conv_transpose3x3s2 = wrap(self._orig[1], True)
+        hip.conv3x3_bf16x6 = wrap(self._orig[2], False, split=True)
 
     def remove(self):
         from rewriting_amd import hip
-        hip.conv3x3, hip.conv_transpose3x3s2 = self._orig
+        hip.conv3x3, hip.conv_transpose3x3s2, hip.conv3x3_bf16x6 = self._orig
 
     def result(self):
         per = {}
@@ -216,7 +218,9 @@ def run_forward(args, rank, world, device, size, batch, name):
     images = batch * world * args.steps
     out = dict(metric='images/sec StyleGANv2-%d fwd' % size, value=round(images / dt, 2), unit='images/sec',
                n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3),
-               higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+               higher_is_better=True, scaling='weak', vs_baseline=None,
+               dtype='f32' if args.precision == 'f32' else 'f32 via bf16x6 split (stride-1 convs), f32 elsewhere',
+               data='synthetic',
                config=dict(workload=name, batch_per_gpu=batch, truncation=0.5, mconv='seq',
                            weights='synthetic seed 0', parallelism='seeds partitioned per rank, no collective',
                            conv_gflop_per_image=round(conv_flops(size) / 1e9, 2)))
@@ -305,8 +309,13 @@ def main():
     ap.add_argument('--layer', type=int, default=8)
     ap.add_argument('--seeds', type=int, default=1000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--precision', default='f32', choices=['f32', 'bf16x6'],
+                    help='bf16x6: opt-in split-precision stride-1 convolutions (fp32-product accuracy); '
+                         'the default and the headline number are exact fp32 MFMA')
     args = ap.parse_args()
 
+    if args.precision != 'f32':
+        os.environ['RW_CONV_PRECISION'] = args.precision
     from rewriting_amd import parallel
     rank, world, local = parallel.init_from_env()
     if args.gpus != world and world == 1 and args.gpus > 1:

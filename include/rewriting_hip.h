@@ -143,6 +143,17 @@ int rw_conv3x3_f32(const float* x, const float* wp, float* y, int batch, int in_
                    int h, int w, float w_scale, const rw_conv_epilogue* ep, int impl,
                    rw_stream_t stream);
 
+/* OPT-IN split-precision stride-1 convolution ("bf16x6"): same operation and epilogue as rw_conv3x3_f32,
+ * computed on the bf16 matrix pipe with every fp32 operand split exactly into three bf16 pieces and the
+ * six leading piece products accumulated in fp32 (relative error of a product < 2^-22; no range loss).
+ * wb from rw_pack_conv_weight_bf16x3 (rw_packed_conv_weight_bf16x3_bytes bytes).  RW_ERR_UNSUPPORTED
+ * unless w >= 24, in_ch % 16 == 0 and out_ch % 64 == 0 -- callers then use rw_conv3x3_f32, which is
+ * also the default everywhere: nothing selects this path implicitly. */
+long long rw_packed_conv_weight_bf16x3_bytes(int out_ch, int in_ch);
+int rw_pack_conv_weight_bf16x3(const float* w, void* wb, int out_ch, int in_ch, rw_stream_t stream);
+int rw_conv3x3_bf16x6_f32(const float* x, const void* wb, float* y, int batch, int in_ch, int out_ch,
+                          int h, int w, float w_scale, const rw_conv_epilogue* ep, rw_stream_t stream);
+
 /* F.conv_transpose2d(x, scale*W^T, stride=2, padding=0) [* demod]     (models.py:315-316,328)
  * x (B,Cin,H,W) -> y (B,Cout,2H+1,2W+1), wp from rw_pack_conv_weight_f32 mode 1. */
 int rw_conv_transpose3x3s2_f32(const float* x, const float* wp, float* y, int batch, int in_ch,

@@ -60,6 +60,10 @@ SIGNATURES = {
     'rw_pack_conv_weight_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'rw_conv3x3_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                c_float, POINTER(ConvEpilogue), c_int, c_void_p]),
+    'rw_packed_conv_weight_bf16x3_bytes': (ctypes.c_longlong, [c_int, c_int]),
+    'rw_pack_conv_weight_bf16x3': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    'rw_conv3x3_bf16x6_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                      c_float, POINTER(ConvEpilogue), c_void_p]),
     'rw_conv_transpose3x3s2_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                            c_int, c_float, POINTER(ConvEpilogue), c_int, c_void_p]),
     'rw_noise_add_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64,

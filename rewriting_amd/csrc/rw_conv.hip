@@ -472,6 +472,74 @@ struct HaloProblem {
   PhaseDesc phase[4];
 };
 
+// Epilogue of the stride-1 halo kernels for a wave's TM x TN accumulator tiles: row r of tile a is
+// out-channel o_first + 32a + (r&3) + 8(r>>2), tile b is image row y_first + b * RPT, the lane's
+// column is xx.  Everything it reads is fetched in batches behind ONE uniform branch each: a load per
+// store, each behind its own `if`, costs an L2 round trip plus the drain of the previous store
+// (vmcnt counts both) per element -- as long as the whole K loop on the 32/64-channel layers.
+template <int TM, int TN, int RPT>
+__device__ __forceinline__ void rw_halo_epilogue(const HaloProblem& p, const PhaseDesc& d,
+                                                 const rw_f32x16 (&acc)[TM][TN], int ib, int o_first,
+                                                 int y_first, int xx) {
+  const int64_t ohw = (int64_t)p.oh * p.ow;
+  int64_t pix[TN];
+  float nz[TN];
+  bool live[TN];
+#pragma unroll
+  for (int b = 0; b < TN; ++b) {
+    const int yy = y_first + b * RPT;
+    live[b] = yy < d.ph && xx < d.pw;
+    pix[b] = live[b] ? (int64_t)(p.sy * yy + d.oy0) * p.ow + (p.sx * xx + d.ox0) : 0;
+    nz[b] = 0.f;
+  }
+  if (p.noise) {
+    const float nw = p.noise_w[0];
+    const float* np = p.noise + (int64_t)ib * ohw;
+#pragma unroll
+    for (int b = 0; b < TN; ++b) nz[b] = np[pix[b]];
+#pragma unroll
+    for (int b = 0; b < TN; ++b) nz[b] *= nw;
+  }
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+    const int ob = o_first + 32 * a;
+    float scale[16], bias[16];
+    if (p.demod) {
+      const float* dm = p.demod + (int64_t)ib * p.out_ch + ob;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) scale[r] = dm[(r & 3) + 8 * (r >> 2)];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) scale[r] *= p.w_scale;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) scale[r] = p.w_scale;
+    }
+    if (p.act) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bias[r] = p.bias[ob + (r & 3) + 8 * (r >> 2)];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bias[r] = 0.f;
+    }
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      if (!live[b]) continue;
+      if (RW_ABL(p, 16) && acc[0][b][0] != 12345.f) continue;
+      float* yo = p.y + ((int64_t)ib * p.out_ch + ob) * ohw + pix[b];
+      if (p.act) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[a][b][r] * scale[r] + nz[b] + bias[r];
+          yo[((r & 3) + 8 * (r >> 2)) * ohw] = ((v > 0.f) ? v : v * 0.2f) * 1.4142135623730951f;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) yo[((r & 3) + 8 * (r >> 2)) * ohw] = acc[a][b][r] * scale[r] + nz[b];
+      }
+    }
+  }
+}
+
 // TW = 32: an MFMA column tile is 32 consecutive pixels of one row; TW = 16 (maps 9..16 wide): two
 // rows of 16; TW = 8 (maps 5..8 wide): four rows of 8 -- the low-resolution layers keep every lane of
 // the tile busy.
@@ -659,67 +727,7 @@ __global__ void __launch_bounds__(256, 2) conv_halo_kernel(const HaloProblem p) 
     if (!RW_ABL(p, 8)) __syncthreads();
   }
 
-  // Epilogue.  Everything it reads is fetched in batches behind ONE uniform branch each: a load per
-  // store, each behind its own `if`, costs an L2 round trip plus the drain of the previous store
-  // (vmcnt counts both) per element -- as long as the whole K loop on the 32/64-channel layers.
-  const int64_t ohw = (int64_t)p.oh * p.ow;
-  const int xx = x0 + lc;
-  int64_t pix[TN];
-  float nz[TN];
-  bool live[TN];
-#pragma unroll
-  for (int b = 0; b < TN; ++b) {
-    const int yy = y0 + wrow0 + b * RPT + lr;
-    live[b] = yy < d.ph && xx < d.pw;
-    pix[b] = live[b] ? (int64_t)(p.sy * yy + d.oy0) * p.ow + (p.sx * xx + d.ox0) : 0;
-    nz[b] = 0.f;
-  }
-  if (p.noise) {
-    const float nw = p.noise_w[0];
-    const float* np = p.noise + (int64_t)ib * ohw;
-#pragma unroll
-    for (int b = 0; b < TN; ++b) nz[b] = np[pix[b]];
-#pragma unroll
-    for (int b = 0; b < TN; ++b) nz[b] *= nw;
-  }
-#pragma unroll
-  for (int a = 0; a < TM; ++a) {
-    const int ob = o0 + wm0 + 32 * a + 4 * frow;      // row r of the tile is channel ob + (r&3) + 8(r>>2)
-    float scale[16], bias[16];
-    if (p.demod) {
-      const float* dm = p.demod + (int64_t)ib * p.out_ch + ob;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) scale[r] = dm[(r & 3) + 8 * (r >> 2)];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) scale[r] *= p.w_scale;
-    } else {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) scale[r] = p.w_scale;
-    }
-    if (p.act) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) bias[r] = p.bias[ob + (r & 3) + 8 * (r >> 2)];
-    } else {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) bias[r] = 0.f;
-    }
-#pragma unroll
-    for (int b = 0; b < TN; ++b) {
-      if (!live[b]) continue;
-      if (RW_ABL(p, 16) && acc[0][b][0] != 12345.f) continue;
-      float* yo = p.y + ((int64_t)ib * p.out_ch + ob) * ohw + pix[b];
-      if (p.act) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float v = acc[a][b][r] * scale[r] + nz[b] + bias[r];
-          yo[((r & 3) + 8 * (r >> 2)) * ohw] = ((v > 0.f) ? v : v * 0.2f) * 1.4142135623730951f;
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) yo[((r & 3) + 8 * (r >> 2)) * ohw] = acc[a][b][r] * scale[r] + nz[b];
-      }
-    }
-  }
+  rw_halo_epilogue<TM, TN, RPT>(p, d, acc, ib, o0 + wm0 + 4 * frow, y0 + wrow0 + lr, x0 + lc);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1211,4 +1219,244 @@ extern "C" int rw_conv_transpose3x3s2_f32(const float* x, const float* wp, float
   if (impl == 4) return launch_halo(ps, 4, nullptr, rw_s(stream));        // per-phase halo tiles (kept for A/B)
   if (impl == 3 || (impl == 0 && halo_applicable(ps, 4))) return launch_up_halo(ps, wp, rw_s(stream));
   return launch_batch(ps, 4, impl == 2 ? 0 : impl, rw_s(stream));
+}
+
+// ---------------------------------------------------------------------------------------
+// OPT-IN split-precision variant of the stride-1 halo kernel ("bf16x6").  fp32 MFMA runs at the fp32
+// vector rate (157 TFLOP/s); the bf16 matrix rate is 16x that.  Every fp32 operand is split EXACTLY into
+// three bf16 pieces (8 + 8 + 8 mantissa bits, by truncation: x = x1 + x2 + x3), and a product keeps the six
+// piece products down to 2^-16 relative (x1y1, x1y2, x2y1, x2y2, x1y3, x3y1), dropping terms below
+// 2^-23 -- fp32-product accuracy, fp32 accumulation in the MFMA, no range loss (bf16 has fp32's exponent).
+// Six v_mfma_f32_32x32x16_bf16 (32 cycles each, K = 16 = one whole channel chunk) replace eight
+// v_mfma_f32_32x32x2_f32 (64 cycles each): 192 instead of 512 matrix-pipe cycles per tile and tap.
+// Operand layout (probed on the device, scripts/probe/mfma_bf16_layout.hip): lane l holds
+// A[row l&31][k = 8 (l>>5) + j], B[k = 8 (l>>5) + j][col l&31], j = 0..7.
+//   weights: wb[tap][chunk][o/32][piece][lane] 16-byte cells (rw_pack_conv_weight_bf16x3)
+//   input:   Xb[buf][piece][k-group][row][col] 16-byte cells in LDS, split while staging
+// The default path stays exact fp32 MFMA; this one is selected explicitly (rw_conv3x3_bf16x6_f32).
+// ---------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 rw_bf16x8;
+
+__device__ __forceinline__ void rw_split3(float x, unsigned& p1, unsigned& p2, unsigned& p3) {
+  const unsigned u = __float_as_uint(x) & 0xffff0000u;
+  const float r = x - __uint_as_float(u);                    // exact
+  const unsigned v = __float_as_uint(r) & 0xffff0000u;
+  const float r2 = r - __uint_as_float(v);                   // exact, <= 8 significant bits left
+  p1 = u >> 16; p2 = v >> 16; p3 = __float_as_uint(r2) >> 16;
+}
+
+__global__ void __launch_bounds__(256) pack_conv_bf16x3_kernel(const float* __restrict__ w, uint4* __restrict__ wb,
+                                                               int out_ch, int in_ch) {
+  const int obn = out_ch >> 5, chunks = in_ch >> 4;
+  const int64_t total = (int64_t)9 * chunks * obn * 64;       // one thread: the three pieces of one lane cell
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = idx;
+    const int lane = (int)(r & 63); r >>= 6;
+    const int ob = (int)(r % obn); r /= obn;
+    const int c = (int)(r % chunks); r /= chunks;
+    const int tap = (int)r;
+    const int o = 32 * ob + (lane & 31), i0 = 16 * c + 8 * (lane >> 5);
+    unsigned pc[3][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) rw_split3(w[((int64_t)o * in_ch + i0 + j) * 9 + tap], pc[0][j], pc[1][j], pc[2][j]);
+    uint4* dst = wb + (((int64_t)tap * chunks + c) * obn + ob) * 192 + lane;
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3)
+      dst[s3 * 64] = make_uint4(pc[s3][0] | (pc[s3][1] << 16), pc[s3][2] | (pc[s3][3] << 16),
+                                pc[s3][4] | (pc[s3][5] << 16), pc[s3][6] | (pc[s3][7] << 16));
+  }
+}
+
+template <int TM, int TN, int WGM, int WGN>
+__global__ void __launch_bounds__(256, 2) conv_halo_bf16x6_kernel(const HaloProblem p) {
+  constexpr int IC = 16;
+  constexpr int BM = 32 * TM * WGM;
+  constexpr int TH = TN * WGN;
+  constexpr int XH = TH + 2, XW = 36, XUSED = 34;
+  static_assert(WGM * WGN == 4, "4 waves per workgroup");
+  __shared__ uint4 Xb[2][3][2][XH][XW];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave / WGN) * 32 * TM;
+  const int wrow0 = (wave % WGN) * TN;
+  const int frow = lane >> 5, fcol = lane & 31;
+
+  const PhaseDesc d = p.phase[0];
+  int local = rw_xcd_remap(blockIdx.x, gridDim.x);
+  const int o_tiles = p.out_ch / BM;
+  const int o0 = (local % o_tiles) * BM; local /= o_tiles;
+  const int tx = local % d.tiles_x; local /= d.tiles_x;
+  const int ty = local % d.tiles_y;
+  const int ib = local / d.tiles_y;
+  const int y0 = ty * TH, x0 = tx * 32;
+  const int64_t hw = (int64_t)p.h * p.w;
+  const float* xb = p.x + (int64_t)ib * p.in_ch * hw;
+  const float* st = p.style ? p.style + (int64_t)ib * p.in_ch : nullptr;
+
+  constexpr int NPOS = XH * XUSED;
+  constexpr int PSLOT = (NPOS + 255) / 256;
+  int xoff[PSLOT], xlds[PSLOT];
+  float xmask[PSLOT];
+#pragma unroll
+  for (int sl = 0; sl < PSLOT; ++sl) {
+    const int pos = tid + 256 * sl;
+    const int r = pos / XUSED, c = pos - r * XUSED;
+    const int iy = y0 - 1 + r, ix = x0 - 1 + c;
+    const bool ok = pos < NPOS && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
+    xoff[sl] = ok ? iy * p.w + ix : 0;
+    xmask[sl] = ok ? 1.0f : 0.0f;
+    xlds[sl] = pos < NPOS ? r * XW + c : XW - 1;
+  }
+  float xreg[PSLOT][IC];
+  float sty[IC];
+  auto xfetch = [&](int i0) {
+    const float* xc = xb + (int64_t)i0 * hw;
+#pragma unroll
+    for (int ic = 0; ic < IC; ++ic)
+#pragma unroll
+      for (int sl = 0; sl < PSLOT; ++sl) xreg[sl][ic] = xc[(int64_t)ic * hw + xoff[sl]];
+    if (st) {
+#pragma unroll
+      for (int ic = 0; ic < IC; ++ic) sty[ic] = st[i0 + ic];
+    } else {
+#pragma unroll
+      for (int ic = 0; ic < IC; ++ic) sty[ic] = 1.0f;
+    }
+  };
+  // style and zero padding in fp32, then the exact three-way split, 8 channels per 16-byte LDS cell;
+  // one unit = the 8 channels (sl, g) of one staged position
+  constexpr int NU = 2 * PSLOT;
+  static_assert(NU <= 8, "staging units fit the taps of a chunk");
+  auto stash_unit = [&](int buf, int u) {
+    const int sl = u >> 1, g = u & 1;
+    unsigned pc[3][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      rw_split3(xreg[sl][8 * g + j] * (xmask[sl] * sty[8 * g + j]), pc[0][j], pc[1][j], pc[2][j]);
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3)
+      (&Xb[buf][s3][g][0][0])[xlds[sl]] =
+          make_uint4(pc[s3][0] | (pc[s3][1] << 16), pc[s3][2] | (pc[s3][3] << 16),
+                     pc[s3][4] | (pc[s3][5] << 16), pc[s3][6] | (pc[s3][7] << 16));
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < NU; ++u) stash_unit(buf, u);
+  };
+
+  const int n_chunks = p.in_ch / IC;
+  const int obn = p.out_ch >> 5;
+  const uint4* wb = reinterpret_cast<const uint4*>(p.wfrag) + (int64_t)((o0 + wm0) >> 5) * 192 + lane;
+  const int c_stride = obn * 192;
+  const int64_t t_stride = (int64_t)n_chunks * c_stride;
+  uint4 acur[TM][3], anxt[TM][3];
+  auto aload = [&](uint4 (&dst)[TM][3], int t, int c) {
+    const uint4* base = wb + (int64_t)t * t_stride + (int64_t)c * c_stride;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int s3 = 0; s3 < 3; ++s3) dst[a][s3] = base[a * 192 + s3 * 64];
+  };
+
+  rw_f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  xfetch(0);
+  aload(acur, 0, 0);
+  stash(0);
+  __syncthreads();
+  for (int c = 0; c < n_chunks; ++c) {
+    const int buf = c & 1;
+    const int cn = c + 1 < n_chunks ? c + 1 : c;
+    xfetch(cn * IC);
+    // one tap; UNIT >= 0 also converts and stages unit UNIT of the next chunk between the MFMAs
+    auto tap = [&](int t, auto unit_tag) {
+      constexpr int UNIT = decltype(unit_tag)::value;
+      int nt = t + 1, nc = c;
+      if (nt == 9) { nt = 0; nc = cn; }
+      aload(anxt, nt, nc);
+      const int dy = rw_tap_off(d.dy_bits, t), dx = rw_tap_off(d.dx_bits, t);
+      uint4 bq[TN][3];
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) bq[b][s3] = Xb[buf][s3][frow][wrow0 + b + dy + 1][fcol + dx + 1];
+      __builtin_amdgcn_sched_barrier(0);
+#define RW_BF(v) __builtin_bit_cast(rw_bf16x8, v)
+      // six piece products (small terms first); consecutive MFMAs go to different accumulators
+      constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(RW_BF(acur[a][PA[q]]), RW_BF(bq[b][PB[q]]),
+                                                                acc[a][b], 0, 0, 0);
+#undef RW_BF
+      if (UNIT >= 0) stash_unit(buf ^ 1, UNIT);      // VALU + LDS writes in the shadow of the MFMAs above
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) acur[a][s3] = anxt[a][s3];
+    };
+#pragma unroll 1
+    for (int t = 0; t < 9 - NU; ++t) tap(t, rw_int<-1>());
+    if (NU >= 4) { tap(9 - NU, rw_int<(NU >= 4 ? 0 : -1)>()); tap(10 - NU, rw_int<(NU >= 4 ? 1 : -1)>()); }
+    tap(7, rw_int<NU - 2>());
+    tap(8, rw_int<NU - 1>());
+    __syncthreads();
+  }
+  rw_halo_epilogue<TM, TN, 1>(p, d, acc, ib, o0 + wm0 + 4 * frow, y0 + wrow0, x0 + fcol);
+}
+
+extern "C" long long rw_packed_conv_weight_bf16x3_bytes(int out_ch, int in_ch) {
+  if (out_ch <= 0 || in_ch <= 0 || out_ch % 32 || in_ch % 16) return -1;
+  return (long long)9 * in_ch * out_ch * 6;
+}
+
+extern "C" int rw_pack_conv_weight_bf16x3(const float* w, void* wb, int out_ch, int in_ch, rw_stream_t stream) {
+  RW_CHECK_ARG(w && wb && out_ch > 0 && in_ch > 0);
+  if (out_ch % 32 || in_ch % 16) return RW_ERR_UNSUPPORTED;
+  const int64_t total = (int64_t)9 * (in_ch >> 4) * (out_ch >> 5) * 64;
+  hipLaunchKernelGGL(pack_conv_bf16x3_kernel, dim3(rw_stream_grid(total, 256)), dim3(256), 0, rw_s(stream), w,
+                     reinterpret_cast<uint4*>(wb), out_ch, in_ch);
+  return RW_LAUNCH_RESULT();
+}
+
+extern "C" int rw_conv3x3_bf16x6_f32(const float* x, const void* wb, float* y, int batch, int in_ch, int out_ch,
+                                     int h, int w, float w_scale, const rw_conv_epilogue* ep, rw_stream_t stream) {
+  RW_CHECK_ARG(x && wb && y && batch > 0 && in_ch > 0 && out_ch > 0 && h > 0 && w > 0);
+  RW_CHECK_ARG(!ep || ((!ep->noise || ep->noise_w) && (!ep->act || ep->bias)));
+  if (w < 24 || in_ch % 16 || in_ch > 1024 || out_ch % 64) return RW_ERR_UNSUPPORTED;
+  HaloProblem hp;
+  hp.x = x; hp.wp = nullptr; hp.wfrag = reinterpret_cast<const float*>(wb); hp.y = y;
+  hp.style = ep ? ep->style : nullptr; hp.demod = ep ? ep->demod : nullptr; hp.noise = ep ? ep->noise : nullptr;
+  hp.noise_w = ep ? ep->noise_w : nullptr; hp.bias = ep ? ep->bias : nullptr; hp.act = ep ? ep->act : 0;
+  hp.batch = batch; hp.in_ch = in_ch; hp.out_ch = out_ch; hp.h = h; hp.w = w; hp.oh = h; hp.ow = w;
+  hp.sy = 1; hp.sx = 1; hp.w_scale = w_scale; hp.nphase = 1; hp.abl = 0;
+  const int bm = out_ch % 128 == 0 ? 128 : 64, th = bm == 128 ? 4 : 8;
+  PhaseDesc& d = hp.phase[0];
+  d.ntaps = 9; d.dy_bits = 0; d.dx_bits = 0;
+  for (int t = 0; t < 9; ++t) {
+    d.dy_bits |= (unsigned)(t / 3) << (2 * t);          // (dy + 1), (dx + 1)
+    d.dx_bits |= (unsigned)(t % 3) << (2 * t);
+  }
+  d.ph = h; d.pw = w; d.oy0 = 0; d.ox0 = 0;
+  d.tiles_x = (int)rw_cdiv(w, 32); d.tiles_y = (int)rw_cdiv(h, th); d.work0 = 0; d.wp_off = 0;
+  for (int q = 1; q < 4; ++q) hp.phase[q] = d;
+  const int64_t work = (int64_t)batch * d.tiles_x * d.tiles_y * (out_ch / bm);
+  if (work > 0x7fffffff) return RW_ERR_UNSUPPORTED;
+  if (bm == 128)
+    hipLaunchKernelGGL((conv_halo_bf16x6_kernel<2, 2, 2, 2>), dim3((unsigned)work), dim3(256), 0, rw_s(stream), hp);
+  else
+    hipLaunchKernelGGL((conv_halo_bf16x6_kernel<2, 2, 1, 4>), dim3((unsigned)work), dim3(256), 0, rw_s(stream), hp);
+  return RW_LAUNCH_RESULT();
 }

@@ -195,6 +195,38 @@ def conv3x3(x, wp, out_ch, w_scale, style=None, demod=None, noise=None, noise_w=
     return y
 
 
+def bf16x6_supported(out_ch, in_ch, width):
+    """Shapes the opt-in split-precision convolution takes (rw_conv3x3_bf16x6_f32)."""
+    return width >= 24 and in_ch % 16 == 0 and in_ch <= 1024 and out_ch % 64 == 0
+
+
+def pack_conv_weight_bf16x3(weight):
+    weight = _dev(weight, 'weight')
+    o, i = weight.shape[-4], weight.shape[-3]
+    n = lib().rw_packed_conv_weight_bf16x3_bytes(o, i)
+    if n <= 0:
+        raise ValueError('no bf16x3 packing for a %d x %d weight' % (o, i))
+    wb = torch.empty(n // 4, device=weight.device, dtype=torch.float32)     # opaque: bf16 fragments
+    check(lib().rw_pack_conv_weight_bf16x3(_p(weight), _p(wb), o, i, _stream()))
+    return wb
+
+
+def conv3x3_bf16x6(x, wb, out_ch, w_scale, style=None, demod=None, noise=None, noise_w=None, bias=None,
+                   act=False):
+    """Opt-in: the stride-1 convolution on the bf16 matrix pipe with exact three-way operand splits
+    (six piece products, fp32 accumulation); same arguments and epilogue as conv3x3."""
+    x = _dev(x, 'fmap')
+    wb = _dev(wb, 'packed weight')
+    b, i, h, w = x.shape
+    if wb.numel() * 4 != lib().rw_packed_conv_weight_bf16x3_bytes(out_ch, i):
+        raise ValueError('packed weight does not come from pack_conv_weight_bf16x3(%d x %d)' % (out_ch, i))
+    y = torch.empty(b, out_ch, h, w, device=x.device, dtype=x.dtype)
+    ep, keep = _epilogue(style, demod, noise, noise_w, bias, act)
+    check(lib().rw_conv3x3_bf16x6_f32(_p(x), _p(wb), _p(y), b, i, out_ch, h, w, float(w_scale),
+                                      ctypes.byref(ep), _stream()))
+    return y
+
+
 def conv_transpose3x3s2(x, wp, out_ch, w_scale, style=None, demod=None, impl=0):
     x = _dev(x, 'fmap')
     wp = _dev(wp, 'packed weight')

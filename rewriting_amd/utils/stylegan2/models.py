@@ -150,6 +150,13 @@ def conv_impl():
     return _CONV_IMPLS[os.environ.get('RW_CONV_IMPL', 'auto')]
 
 
+def conv_precision():
+    """'f32' (default: exact fp32 MFMA) or 'bf16x6' (RW_CONV_PRECISION=bf16x6, opt-in): the stride-1 3x3
+    convolutions of eligible shapes run on the bf16 matrix pipe with exact three-way operand splits
+    (hip.conv3x3_bf16x6, fp32-product accuracy); every other kernel is unchanged."""
+    return os.environ.get('RW_CONV_PRECISION', 'f32')
+
+
 class DataBag(dict):
     """dict with attribute access, carrying latent / style / fmap / output / noise through the
     sequential generator (reference: utils/stylegan2/models.py:204-230)."""
@@ -347,6 +354,11 @@ class DemodulatedConv2dF(nn.Module):
         if self.upsample:
             return hip.conv_transpose3x3s2(fmap, self.packed_weight(), self.out_channel, self.scale,
                                            style=load_style, demod=demod, impl=conv_impl())
+        if (conv_precision() == 'bf16x6' and conv_impl() == 0
+                and hip.bf16x6_supported(self.out_channel, self.in_channel, fmap.shape[-1])):
+            wb = self._derived.get('packed_bf16x3', self.weight, lambda: hip.pack_conv_weight_bf16x3(self.weight))
+            return hip.conv3x3_bf16x6(fmap, wb, self.out_channel, self.scale, style=load_style, demod=demod,
+                                      **epilogue)
         return hip.conv3x3(fmap, self.packed_weight(), self.out_channel, self.scale,
                            style=load_style, demod=demod, impl=conv_impl(), **epilogue)
 

@@ -33,7 +33,10 @@ def main(batch=int(os.environ.get('RW_BATCH', '8')), iters=5, impl=int(os.enviro
         style = 1 + 0.3 * torch.randn(batch, cin, device=dev)
         wp = hip.pack_conv_weight(w, 1 if up else 0)
         dm = hip.demod(hip.weight_sqsum(w, 1.0), style)
-        fn = (lambda: hip.conv_transpose3x3s2(x, wp, cout, 1.0, style=style, demod=dm, impl=impl)) if up else \
+        split = os.environ.get('RW_PRECISION') == 'bf16x6' and not up and hip.bf16x6_supported(cout, cin, res)
+        if split:
+            wb = hip.pack_conv_weight_bf16x3(w)
+        fn = (lambda: hip.conv3x3_bf16x6(x, wb, cout, 1.0, style=style, demod=dm)) if split else (lambda: hip.conv_transpose3x3s2(x, wp, cout, 1.0, style=style, demod=dm, impl=impl)) if up else \
              (lambda: hip.conv3x3(x, wp, cout, 1.0, style=style, demod=dm, impl=impl))
         fn()
         torch.cuda.synchronize()

@@ -158,6 +158,36 @@ def test_demodulated_conv_matches_oracle(case, impl):
     assert rel(fused, want) < 1e-5
 
 
+@pytest.mark.parametrize('case', [(1, 512, 512, 32, 32), (2, 128, 64, 40, 64), (1, 64, 128, 29, 70),
+                                  (2, 32, 64, 24, 33)])
+def test_split_bf16x6_conv_matches_fp32(case):
+    """The opt-in bf16x6 path against the float64 convolution and against the exact-fp32 MFMA kernel:
+    it must be as close to the exact result as the fp32 kernel is (operands split exactly, six piece
+    products, fp32 accumulation), with the same fused epilogue."""
+    from rewriting_amd import hip
+    b, i, o, h, w = case
+    x, wt, style = _conv_inputs(*case, seed=3)
+    rs = numpy.random.RandomState(5)
+    x = x * torch.from_numpy(numpy.exp(3 * rs.randn(1, i, 1, 1)).astype('float32'))     # channels over 4 decades
+    noise = torch.from_numpy(rs.randn(b, h * w).astype('float32'))
+    nw = torch.tensor([0.3])
+    bias = torch.from_numpy(rs.randn(o).astype('float32'))
+    s = 1 / math.sqrt(i * 9)
+    dm = hip.demod(hip.weight_sqsum(wt.to(DEV), s), style.to(DEV))
+    key = (style[:, :, None, None] * x).double()
+    ref = torch.nn.functional.conv2d(key, wt[0].double(), padding=1) * s * dm.cpu().double()[:, :, None, None]
+    ref = ref + 0.3 * noise.view(b, 1, h, w).double() + bias.double().view(1, o, 1, 1)
+    ref = torch.where(ref > 0, ref, 0.2 * ref) * math.sqrt(2)
+    args = dict(style=style.to(DEV), demod=dm, noise=noise.to(DEV), noise_w=nw.to(DEV), bias=bias.to(DEV), act=True)
+    f32 = hip.conv3x3(x.to(DEV), hip.pack_conv_weight(wt.to(DEV), 0), o, s, **args)
+    got = hip.conv3x3_bf16x6(x.to(DEV), hip.pack_conv_weight_bf16x3(wt.to(DEV)), o, s, **args)
+    e32 = (f32.cpu().double() - ref).norm() / ref.norm()
+    e16 = (got.cpu().double() - ref).norm() / ref.norm()
+    assert e16 < 2e-6, (e16.item(), e32.item())
+    assert e16 < 4 * e32 + 2e-7, (e16.item(), e32.item())
+    assert (got - f32).abs().max().item() < 2e-5 * ref.abs().max().item()
+
+
 @pytest.mark.parametrize('impl', [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize('case', CONV_CASES[:9] + CONV_CASES[11:])
 def test_transposed_conv_matches_oracle(case, impl):
