@@ -66,6 +66,27 @@ def test_generator_matches_reference_golden(monkeypatch, name, impl, fuse):
     assert fuse == '1' or checked >= 40
 
 
+def test_generator_with_split_bf16x6_convs_matches_reference_golden(monkeypatch):
+    """The opt-in bf16x6 convolutions (32^2 and 64^2 layers of this generator) hold the same image bar."""
+    g = load_golden('gen_s64_cm1')
+    meta = golden_meta(g)
+    z = torch.from_numpy(g['z']).to(DEV)
+    model = build_stylegan(meta['size'], meta['truncation'], meta['channel_multiplier'], device=DEV)
+    with torch.no_grad():
+        exact = model(z)
+    monkeypatch.setenv('RW_CONV_PRECISION', 'bf16x6')
+    from rewriting_amd import hip
+    calls = []
+    orig = hip.conv3x3_bf16x6
+    monkeypatch.setattr(hip, 'conv3x3_bf16x6', lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    with torch.no_grad():
+        img = model(z)
+    assert len(calls) >= 2                                        # the path was actually taken
+    want = torch.from_numpy(g['image'])
+    assert (img.cpu() - want).abs().max().item() < 1e-4
+    assert (img - exact).abs().max().item() < 2e-5
+
+
 def test_hook_surface_on_gpu():
     from rewriting_amd.utils import nethook
     g = load_golden('gen_s32_t05')
