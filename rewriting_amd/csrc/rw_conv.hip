@@ -1374,19 +1374,20 @@ __global__ void __launch_bounds__(256, 2) conv_halo_bf16x6_kernel(const HaloProb
   for (int c = 0; c < n_chunks; ++c) {
     const int buf = c & 1;
     const int cn = c + 1 < n_chunks ? c + 1 : c;
-    xfetch(cn * IC);
+    if (!RW_ABL(p, 4)) xfetch(cn * IC);
     // one tap; UNIT >= 0 also converts and stages unit UNIT of the next chunk between the MFMAs
     auto tap = [&](int t, auto unit_tag) {
       constexpr int UNIT = decltype(unit_tag)::value;
       int nt = t + 1, nc = c;
       if (nt == 9) { nt = 0; nc = cn; }
-      aload(anxt, nt, nc);
+      if (!RW_ABL(p, 2)) aload(anxt, nt, nc);
       const int dy = rw_tap_off(d.dy_bits, t), dx = rw_tap_off(d.dx_bits, t);
       uint4 bq[TN][3];
 #pragma unroll
       for (int b = 0; b < TN; ++b)
 #pragma unroll
-        for (int s3 = 0; s3 < 3; ++s3) bq[b][s3] = Xb[buf][s3][frow][wrow0 + b + dy + 1][fcol + dx + 1];
+        for (int s3 = 0; s3 < 3; ++s3)
+          bq[b][s3] = RW_ABL(p, 1) ? acur[0][s3] : Xb[buf][s3][frow][wrow0 + b + dy + 1][fcol + dx + 1];
       __builtin_amdgcn_sched_barrier(0);
 #define RW_BF(v) __builtin_bit_cast(rw_bf16x8, v)
       // six piece products (small terms first); consecutive MFMAs go to different accumulators
@@ -1400,7 +1401,7 @@ __global__ void __launch_bounds__(256, 2) conv_halo_bf16x6_kernel(const HaloProb
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(RW_BF(acur[a][PA[q]]), RW_BF(bq[b][PB[q]]),
                                                                 acc[a][b], 0, 0, 0);
 #undef RW_BF
-      if (UNIT >= 0) stash_unit(buf ^ 1, UNIT);      // VALU + LDS writes in the shadow of the MFMAs above
+      if (UNIT >= 0 && !RW_ABL(p, 4)) stash_unit(buf ^ 1, UNIT);      // VALU + LDS writes in the shadow of the MFMAs above
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int a = 0; a < TM; ++a)
@@ -1441,7 +1442,7 @@ extern "C" int rw_conv3x3_bf16x6_f32(const float* x, const void* wb, float* y, i
   hp.style = ep ? ep->style : nullptr; hp.demod = ep ? ep->demod : nullptr; hp.noise = ep ? ep->noise : nullptr;
   hp.noise_w = ep ? ep->noise_w : nullptr; hp.bias = ep ? ep->bias : nullptr; hp.act = ep ? ep->act : 0;
   hp.batch = batch; hp.in_ch = in_ch; hp.out_ch = out_ch; hp.h = h; hp.w = w; hp.oh = h; hp.ow = w;
-  hp.sy = 1; hp.sx = 1; hp.w_scale = w_scale; hp.nphase = 1; hp.abl = 0;
+  hp.sy = 1; hp.sx = 1; hp.w_scale = w_scale; hp.nphase = 1; hp.abl = rw_abl_env();
   const int bm = out_ch % 128 == 0 ? 128 : 64, th = bm == 128 ? 4 : 8;
   PhaseDesc& d = hp.phase[0];
   d.ntaps = 9; d.dy_bits = 0; d.dx_bits = 0;
