@@ -14,6 +14,7 @@ rewriter observes, because any hook or split turns the fusion off for that block
 import math
 import os
 import re
+import threading
 import warnings
 from collections import OrderedDict
 
@@ -132,12 +133,18 @@ def fusion_enabled():
 # issued on a second HIP stream so that it overlaps the next styled convolutions, and is joined
 # before the image is returned.  Hooked / sliced models (nethook) never see this: the mode is on only
 # inside that forward.
-_rgb_branch = {'stream': None, 'keep': []}
+class _RgbBranch(threading.local):      # per thread: two threads may run generators concurrently
+    def __init__(self):
+        self.stream = None
+        self.keep = []
+
+
+_rgb_branch = _RgbBranch()
 _rgb_side_streams = {}          # one per device, module-level: models are deep-copied by the rewriters
 
 
 def _rgb_stream():
-    return _rgb_branch['stream']
+    return _rgb_branch.stream
 
 
 _CONV_IMPLS = {'auto': 0, 'mfma': 0, 'direct': 1, 'generic': 2, 'halo': 3, 'nosplitk': 5}
@@ -532,7 +539,7 @@ class ToRGBF(nn.Module):
         # The branch reads trunk tensors from another stream: they stay referenced until the join
         # (Tensor.record_stream would do, but it defers the allocator's reuse of multi-GB blocks
         # unpredictably and shows up as intermittent hipMalloc stalls at large batch).
-        _rgb_branch['keep'].append((d.fmap, d.style))
+        _rgb_branch.keep.append((d.fmap, d.style))
         return DataBag(d, output=out)
 
 
@@ -670,7 +677,7 @@ class SeqStyleGAN2(nn.Sequential):
 
     def forward(self, input):
         side_ok = (fusion_enabled() and os.environ.get('RW_RGB_STREAM', '1') != '0' and torch.is_tensor(input)
-                   and input.is_cuda and not self.bag_output and _rgb_branch['stream'] is None
+                   and input.is_cuda and not self.bag_output and _rgb_branch.stream is None
                    and not torch.cuda.is_current_stream_capturing()
                    and _unhooked(*self.modules()))
         if not side_ok:
@@ -679,13 +686,13 @@ class SeqStyleGAN2(nn.Sequential):
         side = _rgb_side_streams.get(input.device)
         if side is None:
             side = _rgb_side_streams[input.device] = torch.cuda.Stream(device=input.device)
-        _rgb_branch['stream'] = side
+        _rgb_branch.stream = side
         try:
             out = super().forward(input)
         finally:
-            _rgb_branch['stream'] = None
+            _rgb_branch.stream = None
             main.wait_stream(side)                          # join: the image is complete on the caller's stream
-            del _rgb_branch['keep'][:]                      # freed to the trunk's pool AFTER the join is queued
+            del _rgb_branch.keep[:]                      # freed to the trunk's pool AFTER the join is queued
         if torch.is_tensor(out):
             out.record_stream(main)
         return out
