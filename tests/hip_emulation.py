@@ -217,6 +217,16 @@ def solve_step(problem, project):
         W.copy_(s.ortho + R.projected_conv(W, s.context))
 
 
+def pack_conv_weight_bf16x3(weight):
+    return pack_conv_weight(weight, 0)          # opaque handle; the emulated product is exact
+
+
+def conv3x3_bf16x6(x, wb, out_ch, w_scale, style=None, demod=None, noise=None, noise_w=None, bias=None,
+                   act=False):
+    return conv3x3(x, wb, out_ch, w_scale, style=style, demod=demod, noise=noise, noise_w=noise_w, bias=bias,
+                   act=act)
+
+
 def install(monkeypatch):
     """Replaces the kernel wrappers of rewriting_amd.hip and makes host code take the
     'tensors live on the device' branches."""
@@ -224,7 +234,8 @@ def install(monkeypatch):
     from rewriting_amd.rewrite import hipsolve
     names = ['fused_bias_act', 'bias_grad', 'upfirdn2d_major', 'pixel_norm', 'equal_linear',
              'adjust_latent', 'style_mul', 'weight_sqsum', 'demod', 'pack_conv_weight', 'conv3x3',
-             'conv_transpose3x3s2', 'noise_add', 'blur_noise_act', 'to_rgb',
+             'conv_transpose3x3s2', 'noise_add', 'blur_noise_act', 'to_rgb', 'pack_conv_weight_bf16x3',
+             'conv3x3_bf16x6',
              'second_moment_accumulate', 'channel_sums', 'project_weight', 'solve_ksplit',
              'solve_step']
     for n in names:

@@ -272,3 +272,43 @@ def test_feature_statistics_and_frechet_distance():
     g = proggan.ProgressiveGenerator(resolution=8)
     z = samples.seed_latents(g, [3, 4])
     assert torch.equal(z[1:], zdataset.z_sample_for_model(g, size=1, seed=4))
+
+
+def test_split_precision_switch_only_takes_eligible_stride1_layers(emulated_hip, monkeypatch):
+    """RW_CONV_PRECISION=bf16x6 routes exactly the eligible stride-1 convolutions (map >= 24 wide,
+    Cin % 16 == 0, Cout % 64 == 0) to conv3x3_bf16x6 and changes nothing else; off by default."""
+    import torch
+    from rewriting_amd import hip
+    from tests.conftest import build_stylegan
+    model = build_stylegan(64, 0.5, device='cpu')
+    z = torch.randn(2, 512)
+    seen = []
+    orig = hip.conv3x3_bf16x6
+
+    def spy(x, wb, out_ch, *a, **k):
+        seen.append((x.shape[1], out_ch, x.shape[-1]))
+        return orig(x, wb, out_ch, *a, **k)
+    monkeypatch.setattr(hip, 'conv3x3_bf16x6', spy)
+    with torch.no_grad():
+        base = model(z)
+    assert seen == []                                              # default: exact fp32 kernels only
+    monkeypatch.setenv('RW_CONV_PRECISION', 'bf16x6')
+    with torch.no_grad():
+        img = model(z)
+    assert seen and all(w >= 24 and i % 16 == 0 and o % 64 == 0 for i, o, w in seen), seen
+    assert sorted(w for _, _, w in seen) == [32, 64]               # layers 8 and 10 of the 64^2 generator
+    assert torch.equal(img, base)                                  # emulated product is exact
+
+
+def test_sweep_batch_never_starves_a_rank(monkeypatch):
+    from rewriting_amd import parallel
+    from rewriting_amd.rewrite import ganrewrite
+
+    class Fake(ganrewrite.ProgressiveGanRewriter):
+        def __init__(self, n):
+            self.zds = list(range(n))
+    for world, n, want in ((1, 1000, 250), (8, 1000, 120), (4, 10000, 250), (8, 100, 10), (2, 35, 10)):
+        monkeypatch.setattr(parallel, 'shard', lambda world=world: (0, world) if world > 1 else None)
+        b = Fake(n)._sweep_batch()
+        assert b == want and b % 10 == 0
+        assert (n + b - 1) // b >= min(world, n // 10)             # at least one batch per rank
