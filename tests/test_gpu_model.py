@@ -346,9 +346,13 @@ def test_full_size_generator_properties(monkeypatch, size, batch):
         plain = model(z)
         monkeypatch.setenv('RW_FUSE', '1')
         first = model(z[:1])
+        monkeypatch.setenv('RW_CONV_PRECISION', 'bf16x6')          # opt-in split-precision stride-1 convolutions
+        split = model(z)
+        monkeypatch.delenv('RW_CONV_PRECISION')
     assert fused.shape == (batch, 3, size, size) and torch.isfinite(fused).all()
     assert (fused - plain).abs().max().item() < 1e-4 * max(1.0, plain.abs().max().item())
     assert (first - fused[:1]).abs().max().item() < 1e-4 * max(1.0, plain.abs().max().item())   # row 0 noise
+    assert (split - fused).abs().max().item() < 1e-4 * max(1.0, plain.abs().max().item())
 
 
 def test_full_size_statistics_and_solve_properties():
