@@ -130,7 +130,7 @@ class ProgressiveGanRewriter(object):
                     return acts          # NCHW straight into the MFMA kernel
                 return acts.permute(0, 2, 3, 1).reshape(-1, acts.shape[1])
             if on_gpu and self._noise_periodic():
-                # ten reference batches of 10 per launch; each seed keeps its reference noise row
+                # many reference batches of 10 per launch; each seed keeps its reference noise row
                 from ..utils.stylegan2.models import noise_batch_period
                 with noise_batch_period(10):
                     r2m = tally.tally_second_moment(key_rows, self.zds, batch_size=self._sweep_batch(),
