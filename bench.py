@@ -284,18 +284,23 @@ def run_sweep(args, rank, world, device):
     nseeds = args.seeds
     zds = zdataset.z_dataset_for_model(g, size=nseeds)
 
+    # as the rewriters run it: launches of k x 10 seeds, every seed with the noise row of its reference
+    # batch of 10 (noise_batch_period), launches dealt round-robin to the ranks, one all-reduce
+    from rewriting_amd.utils.stylegan2.models import noise_batch_period
+    launch = max(10, min(250, (nseeds // world) // 10 * 10))
+
     def step():
-        with torch.no_grad():
+        with torch.no_grad(), noise_batch_period(10):
             r = tally.tally_second_moment(lambda zb: ctx(zb.to(device)).fmap, zds, shard=parallel.shard(),
-                                          nchw=True)
+                                          nchw=True, batch_size=launch)
         return r
     dt = timed(step, args.steps, args.warmup, world)
     return dict(metric='key-statistics sweep seeds/sec (layer %d of stylegan2-%d)' % (layer, args.size),
                 value=round(nseeds * args.steps / dt, 1), unit='seeds/sec', n_gpus=world, steps=args.steps,
                 warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 2), higher_is_better=True,
                 scaling='strong', vs_baseline=None, dtype='f32', data='synthetic',
-                config=dict(workload='%d-seed second-moment sweep, batches of 10 dealt round-robin, '
-                                     'one all-reduce' % nseeds))
+                config=dict(workload='%d-seed second-moment sweep, launches of %d seeds (reference batches of 10 '
+                                     'inside) dealt round-robin, one all-reduce' % (nseeds, launch)))
 
 
 def main():
