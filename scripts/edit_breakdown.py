@@ -23,7 +23,7 @@ def main():
     def tick():
         torch.cuda.synchronize()
         return time.perf_counter()
-    for rep in range(3):
+    for rep in range(5):
         t = [tick()]
         gw = ganrewrite.SeqStyleGanRewriter(g, zds, 8)
         t.append(tick())
