@@ -138,7 +138,9 @@ typedef struct rw_conv_epilogue {
  * the launch would otherwise leave most CUs idle), 1 = direct VALU kernel (cross-check), 2 = force
  * the im2col MFMA kernel, 3 = force the halo-tile MFMA kernel (RW_ERR_UNSUPPORTED if not applicable),
  * 4 = (transposed conv only) per-phase halo tiles, 5 = im2col MFMA kernel without split-K,
- * 6 = im2col MFMA kernel with split-K forced. */
+ * 6 = im2col MFMA kernel with split-K forced; transposed conv only: 7 = the quad tiles of the halo
+ * kernel without output row 2H / column 2W, 8 = that row and column only (disjoint writes: the two may be
+ * issued on different streams; RW_ERR_UNSUPPORTED where the halo kernel does not apply). */
 int rw_conv3x3_f32(const float* x, const float* wp, float* y, int batch, int in_ch, int out_ch,
                    int h, int w, float w_scale, const rw_conv_epilogue* ep, int impl,
                    rw_stream_t stream);

@@ -964,7 +964,9 @@ __global__ void __launch_bounds__(256, 2) conv_up_halo_kernel(const UpProblem p)
 
 static int launch_batch(const ConvProblem* ps, int n, int impl, hipStream_t s);
 
-static int launch_up_halo(const ConvProblem* ps, const float* wp_all, hipStream_t s) {
+// part: 0 = everything, 1 = the quad tiles only, 2 = output row 2H / column 2W only (the two parts write
+// disjoint elements, so a caller may issue them on two streams)
+static int launch_up_halo(const ConvProblem* ps, const float* wp_all, int part, hipStream_t s) {
   const ConvProblem& c = ps[0];
   UpProblem u;
   u.x = c.x; u.wfrag = wp_all + (int64_t)9 * c.in_ch * c.out_ch; u.y = c.y; u.style = c.style; u.demod = c.demod;
@@ -972,7 +974,8 @@ static int launch_up_halo(const ConvProblem* ps, const float* wp_all, hipStream_
   u.abl = rw_abl_env();
   const int tw = c.w > 16 ? 32 : (c.w > 8 ? 16 : 8), rpt = 32 / tw;
   u.tiles_x = (int)rw_cdiv(c.w, tw);
-  if (tw == 8) {                                   // 128 out-channels x (8 x 8 quads)
+  if (part == 2) {
+  } else if (tw == 8) {                            // 128 out-channels x (8 x 8 quads)
     u.tiles_y = (int)rw_cdiv(c.h, 8);
     const int work = c.batch * u.tiles_x * u.tiles_y * (c.out_ch / 128);
     hipLaunchKernelGGL((conv_up_halo_kernel<4, 1, 16, 8>), dim3(work), dim3(256), 0, s, u);
@@ -987,6 +990,7 @@ static int launch_up_halo(const ConvProblem* ps, const float* wp_all, hipStream_
     if (tw == 16) hipLaunchKernelGGL((conv_up_halo_kernel<1, 4, 16, 16>), dim3(work), dim3(256), 0, s, u);
     else hipLaunchKernelGGL((conv_up_halo_kernel<1, 4, 16, 32>), dim3(work), dim3(256), 0, s, u);
   }
+  if (part == 1) return RW_LAUNCH_RESULT();
   // Output row 2H and column 2W: quads y' = H (phases (0,0),(0,1)) and x' = W, y' < H (phases
   // (0,0),(1,0)) as four strip problems of ONE batched im2col launch.
   ConvProblem e[4] = {ps[0], ps[1], ps[0], ps[2]};
@@ -1215,9 +1219,10 @@ extern "C" int rw_conv_transpose3x3s2_f32(const float* x, const float* wp, float
     p.ntaps = ntaps[phase];
     for (int t = 0; t < p.ntaps; ++t) set_tap(p, t, tdy[phase][t], tdx[phase][t]);
   }
-  if ((impl == 3 || impl == 4) && !halo_applicable(ps, 4)) return RW_ERR_UNSUPPORTED;
+  if ((impl == 3 || impl == 4 || impl == 7 || impl == 8) && !halo_applicable(ps, 4)) return RW_ERR_UNSUPPORTED;
+  if (impl == 7 || impl == 8) return launch_up_halo(ps, wp, impl - 6, rw_s(stream));
   if (impl == 4) return launch_halo(ps, 4, nullptr, rw_s(stream));        // per-phase halo tiles (kept for A/B)
-  if (impl == 3 || (impl == 0 && halo_applicable(ps, 4))) return launch_up_halo(ps, wp, rw_s(stream));
+  if (impl == 3 || (impl == 0 && halo_applicable(ps, 4))) return launch_up_halo(ps, wp, 0, rw_s(stream));
   return launch_batch(ps, 4, impl == 2 ? 0 : impl, rw_s(stream));
 }
 

@@ -227,11 +227,19 @@ def conv3x3_bf16x6(x, wb, out_ch, w_scale, style=None, demod=None, noise=None, n
     return y
 
 
-def conv_transpose3x3s2(x, wp, out_ch, w_scale, style=None, demod=None, impl=0):
+def up_halo_applicable(out_ch, in_ch, width):
+    """Shapes conv_transpose3x3s2 runs on the halo-tile kernel (halo_applicable() in rw_conv.hip)."""
+    return (in_ch % 16 == 0 and in_ch <= 1024 and out_ch % 32 == 0
+            and (width >= 24 or 9 <= width <= 16 or (5 <= width <= 8 and out_ch % 128 == 0)))
+
+
+def conv_transpose3x3s2(x, wp, out_ch, w_scale, style=None, demod=None, impl=0, out=None):
     x = _dev(x, 'fmap')
     wp = _dev(wp, 'packed weight')
     b, i, h, w = x.shape
-    y = torch.empty(b, out_ch, 2 * h + 1, 2 * w + 1, device=x.device, dtype=x.dtype)
+    y = out if out is not None else torch.empty(b, out_ch, 2 * h + 1, 2 * w + 1, device=x.device, dtype=x.dtype)
+    if tuple(y.shape) != (b, out_ch, 2 * h + 1, 2 * w + 1) or not y.is_contiguous():
+        raise ValueError('out has the wrong shape')
     ep, keep = _epilogue(style, demod)
     _check_packed(wp, out_ch, i, 1)
     check(lib().rw_conv_transpose3x3s2_f32(_p(x), _p(wp), _p(y), b, i, out_ch, h, w, float(w_scale),

@@ -136,6 +136,7 @@ def fusion_enabled():
 class _RgbBranch(threading.local):      # per thread: two threads may run generators concurrently
     def __init__(self):
         self.stream = None
+        self.aux = None
         self.keep = []
 
 
@@ -359,6 +360,23 @@ class DemodulatedConv2dF(nn.Module):
         demod = self.demod_factors(style)
         load_style = style if style_on_load else None
         if self.upsample:
+            aux = _rgb_branch.aux
+            if (aux is not None and conv_impl() == 0
+                    and hip.up_halo_applicable(self.out_channel, self.in_channel, fmap.shape[-1])):
+                # un-hooked full forward: the border row/column strips (latency-bound, 2 % of the step) go to
+                # a third stream beside the quad tiles; they write disjoint elements of the same map
+                b, _, h, w = fmap.shape
+                out = torch.empty(b, self.out_channel, 2 * h + 1, 2 * w + 1, device=fmap.device, dtype=fmap.dtype)
+                wp = self.packed_weight()      # (re)packed on the trunk's stream BEFORE the fork
+                main = torch.cuda.current_stream()
+                aux.wait_stream(main)
+                with torch.cuda.stream(aux):
+                    hip.conv_transpose3x3s2(fmap, wp, self.out_channel, self.scale,
+                                            style=load_style, demod=demod, impl=8, out=out)
+                hip.conv_transpose3x3s2(fmap, wp, self.out_channel, self.scale,
+                                        style=load_style, demod=demod, impl=7, out=out)
+                main.wait_stream(aux)          # queued while fmap / style / demod / out are still referenced
+                return out
             return hip.conv_transpose3x3s2(fmap, self.packed_weight(), self.out_channel, self.scale,
                                            style=load_style, demod=demod, impl=conv_impl())
         if (conv_precision() == 'bf16x6' and conv_impl() == 0
@@ -686,11 +704,16 @@ class SeqStyleGAN2(nn.Sequential):
         side = _rgb_side_streams.get(input.device)
         if side is None:
             side = _rgb_side_streams[input.device] = torch.cuda.Stream(device=input.device)
+        aux = _rgb_side_streams.get((input.device, 'aux'))
+        if aux is None:
+            aux = _rgb_side_streams[(input.device, 'aux')] = torch.cuda.Stream(device=input.device)
         _rgb_branch.stream = side
+        _rgb_branch.aux = aux
         try:
             out = super().forward(input)
         finally:
             _rgb_branch.stream = None
+            _rgb_branch.aux = None
             main.wait_stream(side)                          # join: the image is complete on the caller's stream
             del _rgb_branch.keep[:]                      # freed to the trunk's pool AFTER the join is queued
         if torch.is_tensor(out):

@@ -158,6 +158,25 @@ def test_demodulated_conv_matches_oracle(case, impl):
     assert rel(fused, want) < 1e-5
 
 
+@pytest.mark.parametrize('case', [(2, 128, 64, 40, 64), (1, 64, 32, 32, 32), (2, 512, 256, 16, 16), (3, 512, 512, 8, 8)])
+def test_transposed_conv_tiles_and_border_parts_compose(case):
+    """impl 7 (quad tiles) and impl 8 (output row 2H / column 2W) write disjoint elements and together
+    give exactly what one call gives (they are issued on two streams in the un-hooked forward)."""
+    from rewriting_amd import hip
+    b, i, o, h, w = case
+    x, wt, style = _conv_inputs(*case, seed=2)
+    s = 1 / math.sqrt(i * 9)
+    dm = hip.demod(hip.weight_sqsum(wt.to(DEV), s), style.to(DEV))
+    wp = hip.pack_conv_weight(wt.to(DEV), 1)
+    whole = hip.conv_transpose3x3s2(x.to(DEV), wp, o, s, style=style.to(DEV), demod=dm)
+    out = torch.full_like(whole, float('nan'))
+    hip.conv_transpose3x3s2(x.to(DEV), wp, o, s, style=style.to(DEV), demod=dm, impl=7, out=out)
+    assert torch.isnan(out[:, :, -1, :]).all() and torch.isnan(out[:, :, :, -1]).all()      # untouched border
+    assert torch.equal(out[:, :, :-1, :-1], whole[:, :, :-1, :-1])
+    hip.conv_transpose3x3s2(x.to(DEV), wp, o, s, style=style.to(DEV), demod=dm, impl=8, out=out)
+    assert torch.equal(out, whole)
+
+
 @pytest.mark.parametrize('case', [(1, 512, 512, 32, 32), (2, 128, 64, 40, 64), (1, 64, 128, 29, 70),
                                   (2, 32, 64, 24, 33)])
 def test_split_bf16x6_conv_matches_fp32(case):
