@@ -145,6 +145,24 @@ int rw_conv3x3_f32(const float* x, const float* wp, float* y, int batch, int in_
                    int h, int w, float w_scale, const rw_conv_epilogue* ep, int impl,
                    rw_stream_t stream);
 
+/* ToRGB (ToRGBF.forward, models.py:639-655) fused into the epilogue of the styled convolution that feeds it:
+ *   rgb[b][c] = sum_o (scale * weight[c][o] * style[b][o]) * out[b][o] + bias[c] + skip[b][c]
+ * computed from the activated outputs while they are still in registers.  y may be NULL: the feature map is
+ * then not stored at all (the last layer of the generator, which only ToRGB consumes).
+ * RW_ERR_UNSUPPORTED unless out_ch is 32 or 64 (the tile shapes in which one wave holds all out-channels of
+ * its pixels), w >= 24 and in_ch % 16 == 0; callers then run rw_conv3x3_f32 and rw_to_rgb_f32. */
+typedef struct rw_rgb_epilogue {
+  const float* weight;   /* (3, out_ch) ToRGB conv weight */
+  const float* style;    /* (batch, out_ch) ToRGB modulation */
+  const float* bias;     /* (3) nullable */
+  const float* skip;     /* (batch, 3, h, w) nullable: the upsampled running image */
+  float* out;            /* (batch, 3, h, w) */
+  float scale;           /* 1/sqrt(out_ch) */
+} rw_rgb_epilogue;
+int rw_conv3x3_to_rgb_f32(const float* x, const float* wp, float* y, int batch, int in_ch, int out_ch,
+                          int h, int w, float w_scale, const rw_conv_epilogue* ep,
+                          const rw_rgb_epilogue* rgb, rw_stream_t stream);
+
 /* OPT-IN split-precision stride-1 convolution ("bf16x6"): same operation and epilogue as rw_conv3x3_f32,
  * computed on the bf16 matrix pipe with every fp32 operand split exactly into three bf16 pieces and the
  * six leading piece products accumulated in fp32 (relative error of a product < 2^-22; no range loss).

@@ -22,6 +22,11 @@ class ConvEpilogue(Structure):
                 ('noise_w', c_void_p), ('bias', c_void_p), ('act', c_int)]
 
 
+class RgbEpilogue(Structure):
+    _fields_ = [('weight', c_void_p), ('style', c_void_p), ('bias', c_void_p), ('skip', c_void_p),
+                ('out', c_void_p), ('scale', c_float)]
+
+
 class SolveProblem(Structure):
     _fields_ = [
         ('out_ch', c_int), ('in_ch', c_int), ('h', c_int), ('w', c_int), ('rank', c_int),
@@ -64,6 +69,8 @@ SIGNATURES = {
     'rw_pack_conv_weight_bf16x3': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     'rw_conv3x3_bf16x6_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                       c_float, POINTER(ConvEpilogue), c_void_p]),
+    'rw_conv3x3_to_rgb_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                      c_float, POINTER(ConvEpilogue), POINTER(RgbEpilogue), c_void_p]),
     'rw_conv_transpose3x3s2_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                            c_int, c_float, POINTER(ConvEpilogue), c_int, c_void_p]),
     'rw_noise_add_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64,

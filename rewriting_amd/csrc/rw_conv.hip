@@ -469,6 +469,9 @@ struct HaloProblem {
   int batch, in_ch, out_ch, h, w, oh, ow, sy, sx;
   float w_scale;
   int act, nphase, abl;
+  // ToRGB fused into the epilogue (rw_conv3x3_to_rgb_f32; the workgroup holds ALL out-channels): nullable
+  const float* rgb_weight; const float* rgb_style; const float* rgb_bias; const float* rgb_skip; float* rgb_out;
+  float rgb_scale;
   PhaseDesc phase[4];
 };
 
@@ -500,6 +503,13 @@ __device__ __forceinline__ void rw_halo_epilogue(const HaloProblem& p, const Pha
 #pragma unroll
     for (int b = 0; b < TN; ++b) nz[b] *= nw;
   }
+  // Fused ToRGB (models.py:639-655): rgb[c] = sum_o (s W[c][o] style[b][o]) * out[o] + bias[c] + skip.  The
+  // workgroup holds every out-channel of its pixels: a lane sums its 16 * TM channels, the partner lane
+  // (other half of the wave, same pixel) the rest.
+  const bool rgb = p.rgb_weight != nullptr;
+  float part[TN][3];
+#pragma unroll
+  for (int b = 0; b < TN; ++b) part[b][0] = part[b][1] = part[b][2] = 0.f;
 #pragma unroll
   for (int a = 0; a < TM; ++a) {
     const int ob = o_first + 32 * a;
@@ -521,20 +531,56 @@ __device__ __forceinline__ void rw_halo_epilogue(const HaloProblem& p, const Pha
 #pragma unroll
       for (int r = 0; r < 16; ++r) bias[r] = 0.f;
     }
+    float wr[3][16];
+    if (rgb) {
+      float sr[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sr[r] = p.rgb_style[(int64_t)ib * p.out_ch + ob + (r & 3) + 8 * (r >> 2)];
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wr[c][r] = p.rgb_weight[c * p.out_ch + ob + (r & 3) + 8 * (r >> 2)];
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wr[c][r] = p.rgb_scale * wr[c][r] * sr[r];
+    }
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
       if (!live[b]) continue;
       if (RW_ABL(p, 16) && acc[0][b][0] != 12345.f) continue;
-      float* yo = p.y + ((int64_t)ib * p.out_ch + ob) * ohw + pix[b];
-      if (p.act) {
+      float* yo = p.y ? p.y + ((int64_t)ib * p.out_ch + ob) * ohw + pix[b] : nullptr;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float v = acc[a][b][r] * scale[r] + nz[b] + bias[r];
-          yo[((r & 3) + 8 * (r >> 2)) * ohw] = ((v > 0.f) ? v : v * 0.2f) * 1.4142135623730951f;
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[a][b][r] * scale[r] + nz[b];
+        if (p.act) {
+          v += bias[r];
+          v = ((v > 0.f) ? v : v * 0.2f) * 1.4142135623730951f;
         }
-      } else {
+        if (yo) yo[((r & 3) + 8 * (r >> 2)) * ohw] = v;
+        if (rgb) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) yo[((r & 3) + 8 * (r >> 2)) * ohw] = acc[a][b][r] * scale[r] + nz[b];
+          for (int c = 0; c < 3; ++c) part[b][c] += v * wr[c][r];
+        }
+      }
+    }
+  }
+  if (rgb) {
+    const bool low_half = (threadIdx.x & 32) == 0;
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) part[b][c] += __shfl_xor(part[b][c], 32, 64);
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      if (!live[b] || !low_half) continue;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int64_t idx = ((int64_t)ib * 3 + c) * ohw + pix[b];
+        float o = part[b][c];
+        if (p.rgb_bias) o += p.rgb_bias[c];
+        if (p.rgb_skip) o += p.rgb_skip[idx];
+        p.rgb_out[idx] = o;
       }
     }
   }
@@ -1025,9 +1071,14 @@ static void launch_halo_frag(int bm, int work, const HaloProblem& h, hipStream_t
 }
 
 // ps: 1 (stride-1 conv) or 4 (transposed-conv phases) problems sharing x / y / epilogue.
-static int launch_halo(const ConvProblem* ps, int n, const float* wfrag, hipStream_t s) {
+struct RgbFusion { const float* weight; const float* style; const float* bias; const float* skip; float* out; float scale; };
+
+static int launch_halo(const ConvProblem* ps, int n, const float* wfrag, hipStream_t s, const RgbFusion* rgb = nullptr) {
   const ConvProblem& c = ps[0];
   HaloProblem h;
+  h.rgb_weight = rgb ? rgb->weight : nullptr; h.rgb_style = rgb ? rgb->style : nullptr;
+  h.rgb_bias = rgb ? rgb->bias : nullptr; h.rgb_skip = rgb ? rgb->skip : nullptr; h.rgb_out = rgb ? rgb->out : nullptr;
+  h.rgb_scale = rgb ? rgb->scale : 0.f;
   h.x = c.x; h.wp = ps[0].wp; h.wfrag = wfrag; h.y = c.y; h.style = c.style; h.demod = c.demod; h.noise = c.noise;
   h.noise_w = c.noise_w; h.bias = c.bias; h.batch = c.batch; h.in_ch = c.in_ch; h.out_ch = c.out_ch;
   h.h = c.h; h.w = c.w; h.oh = c.oh; h.ow = c.ow; h.sy = c.sy; h.sx = c.sx; h.w_scale = c.w_scale;
@@ -1194,6 +1245,23 @@ extern "C" int rw_conv3x3_f32(const float* x, const float* wp, float* y, int bat
   if (impl == 3 || (impl == 0 && halo_applicable(&p, 1)))
     return launch_halo(&p, 1, wp + (int64_t)9 * in_ch * out_ch, rw_s(stream));
   return launch_batch(&p, 1, impl == 2 ? 0 : impl, rw_s(stream));
+}
+
+extern "C" int rw_conv3x3_to_rgb_f32(const float* x, const float* wp, float* y, int batch, int in_ch, int out_ch,
+                                    int h, int w, float w_scale, const rw_conv_epilogue* ep,
+                                    const rw_rgb_epilogue* rgb, rw_stream_t stream) {
+  RW_CHECK_ARG(x && wp && rgb && rgb->weight && rgb->style && rgb->out && batch > 0 && in_ch > 0 && out_ch > 0);
+  RW_CHECK_ARG(h > 0 && w > 0 && (!ep || ((!ep->noise || ep->noise_w) && (!ep->act || ep->bias))));
+  // ONE WAVE must hold every out-channel of its pixels (the 32- and 64-channel tile shapes), 32-pixel column tiles
+  if (!(out_ch == 32 || out_ch == 64) || w < 24 || in_ch % 16 || in_ch > 1024)
+    return RW_ERR_UNSUPPORTED;
+  ConvProblem p;
+  fill_common(p, x, wp, y, batch, in_ch, out_ch, h, w, w_scale, ep);
+  p.ph = h; p.pw = w; p.oh = h; p.ow = w; p.sy = 1; p.sx = 1; p.oy0 = 0; p.ox0 = 0;
+  p.ntaps = 9;
+  for (int t = 0; t < 9; ++t) set_tap(p, t, t / 3 - 1, t % 3 - 1);
+  const RgbFusion f = {rgb->weight, rgb->style, rgb->bias, rgb->skip, rgb->out, rgb->scale};
+  return launch_halo(&p, 1, wp + (int64_t)9 * in_ch * out_ch, rw_s(stream), &f);
 }
 
 extern "C" int rw_conv_transpose3x3s2_f32(const float* x, const float* wp, float* y, int batch,
@@ -1448,6 +1516,8 @@ extern "C" int rw_conv3x3_bf16x6_f32(const float* x, const void* wb, float* y, i
   hp.noise_w = ep ? ep->noise_w : nullptr; hp.bias = ep ? ep->bias : nullptr; hp.act = ep ? ep->act : 0;
   hp.batch = batch; hp.in_ch = in_ch; hp.out_ch = out_ch; hp.h = h; hp.w = w; hp.oh = h; hp.ow = w;
   hp.sy = 1; hp.sx = 1; hp.w_scale = w_scale; hp.nphase = 1; hp.abl = rw_abl_env();
+  hp.rgb_weight = nullptr; hp.rgb_style = nullptr; hp.rgb_bias = nullptr; hp.rgb_skip = nullptr; hp.rgb_out = nullptr;
+  hp.rgb_scale = 0.f;
   const int bm = out_ch % 128 == 0 ? 128 : 64, th = bm == 128 ? 4 : 8;
   PhaseDesc& d = hp.phase[0];
   d.ntaps = 9; d.dy_bits = 0; d.dx_bits = 0;

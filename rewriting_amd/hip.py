@@ -195,6 +195,37 @@ def conv3x3(x, wp, out_ch, w_scale, style=None, demod=None, noise=None, noise_w=
     return y
 
 
+def to_rgb_fusable(out_ch, in_ch, width):
+    """Shapes rw_conv3x3_to_rgb_f32 takes: one wave holds every out-channel of its pixels."""
+    return out_ch in (32, 64) and width >= 24 and in_ch % 16 == 0 and in_ch <= 1024
+
+
+def conv3x3_to_rgb(x, wp, out_ch, w_scale, rgb_weight, rgb_style, rgb_bias, rgb_skip, rgb_scale, style=None,
+                   demod=None, noise=None, noise_w=None, bias=None, act=False, store_fmap=False):
+    """The styled convolution with ToRGB fused into its epilogue: returns (fmap or None, rgb image)."""
+    x = _dev(x, 'fmap')
+    wp = _dev(wp, 'packed weight')
+    rgb_weight = _dev(rgb_weight, 'rgb weight').contiguous()
+    rgb_style = _dev(rgb_style, 'rgb style').contiguous()
+    rgb_bias = _opt(rgb_bias, 'rgb bias')
+    rgb_skip = _opt(rgb_skip, 'rgb skip')
+    b, i, h, w = x.shape
+    if tuple(rgb_weight.shape) != (3, out_ch) or tuple(rgb_style.shape) != (b, out_ch):
+        raise ValueError('rgb weight / style shapes')
+    if rgb_skip is not None and tuple(rgb_skip.shape) != (b, 3, h, w):
+        raise ValueError('rgb skip shape')
+    _check_packed(wp, out_ch, i, 0)
+    y = torch.empty(b, out_ch, h, w, device=x.device, dtype=x.dtype) if store_fmap else None
+    rgb = torch.empty(b, 3, h, w, device=x.device, dtype=x.dtype)
+    ep, keep = _epilogue(style, demod, noise, noise_w, bias, act)
+    from ._lib import RgbEpilogue
+    re = RgbEpilogue(_p(rgb_weight).value, _p(rgb_style).value, _p(rgb_bias).value, _p(rgb_skip).value,
+                     _p(rgb).value, float(rgb_scale))
+    check(lib().rw_conv3x3_to_rgb_f32(_p(x), _p(wp), _p(y), b, i, out_ch, h, w, float(w_scale),
+                                      ctypes.byref(ep), ctypes.byref(re), _stream()))
+    return y, rgb
+
+
 def bf16x6_supported(out_ch, in_ch, width):
     """Shapes the opt-in split-precision convolution takes (rw_conv3x3_bf16x6_f32)."""
     return width >= 24 and in_ch % 16 == 0 and in_ch <= 1024 and out_ch % 64 == 0

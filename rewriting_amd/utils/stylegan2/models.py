@@ -138,6 +138,7 @@ class _RgbBranch(threading.local):      # per thread: two threads may run genera
         self.stream = None
         self.aux = None
         self.keep = []
+        self.final = None        # (last StyledConvSeq, its ToRGBF, latent index of the ToRGB) of the running forward
 
 
 _rgb_branch = _RgbBranch()
@@ -534,6 +535,8 @@ class ToRGBF(nn.Module):
         self.skip = skip
 
     def forward(self, d):
+        if d.get('fused_rgb') is not None:          # already computed in the epilogue of the last styled conv
+            return DataBag(d, output=d.fused_rgb, fused_rgb=None)
         skip = d.output if self.skip else None
         if skip is not None and tuple(skip.shape[2:]) != tuple(d.fmap.shape[2:]):
             up = self.upsample if hasattr(self, 'upsample') else Upsample([1, 3, 3, 1]).to(skip.device)
@@ -634,9 +637,35 @@ class StyledConvSeq(nn.Sequential):
         else:
             h, w = fmap.shape[2:]
             noise = self.noise.noise_for(d, b, h, w, fmap.device)
+            fin = _rgb_branch.final
+            if (fin is not None and fin[0] is self and conv_impl() == 0 and conv_precision() == 'f32'
+                    and hip.to_rgb_fusable(dconv.out_channel, dconv.in_channel, w)):
+                # last styled conv of the un-hooked generator: ToRGB runs in its epilogue and the feature
+                # map, which nothing else reads, is never written (models.py:639-655 fused)
+                torgb, idx = fin[1], fin[2]
+                skip = d.output if torgb.skip else None
+                if skip is not None and tuple(skip.shape[2:]) != (h, w):
+                    return self._unfused_final(d)
+                main = torch.cuda.current_stream()
+                if _rgb_branch.stream is not None:
+                    main.wait_stream(_rgb_branch.stream)           # the running image comes from the RGB stream
+                rgb_style = torgb.conv.modulation(d.latent[:, idx])
+                _, rgb = hip.conv3x3_to_rgb(
+                    fmap, dconv.packed_weight(), dconv.out_channel, dconv.scale,
+                    torgb.conv.weight.view(3, torgb.conv.in_channel), rgb_style, torgb.bias.view(3), skip,
+                    torgb.conv.scale, style=style, demod=dconv.demod_factors(style), noise=noise,
+                    noise_w=self.noise.weight, bias=act.bias, act=True)
+                return DataBag(d, style=style, fmap=None, fused_rgb=rgb)
             out = dconv.run(fmap, style, style_on_load=True, noise=noise,
                             noise_w=self.noise.weight, bias=act.bias, act=True)
         return DataBag(d, style=style, fmap=out)
+
+    def _unfused_final(self, d):
+        saved, _rgb_branch.final = _rgb_branch.final, None
+        try:
+            return self.forward(d)
+        finally:
+            _rgb_branch.final = saved
 
 
 class SeqStyleGAN2(nn.Sequential):
@@ -709,16 +738,35 @@ class SeqStyleGAN2(nn.Sequential):
             aux = _rgb_side_streams[(input.device, 'aux')] = torch.cuda.Stream(device=input.device)
         _rgb_branch.stream = side
         _rgb_branch.aux = aux
+        _rgb_branch.final = self._final_pair()
         try:
             out = super().forward(input)
         finally:
             _rgb_branch.stream = None
             _rgb_branch.aux = None
+            _rgb_branch.final = None
             main.wait_stream(side)                          # join: the image is complete on the caller's stream
             del _rgb_branch.keep[:]                      # freed to the trunk's pool AFTER the join is queued
         if torch.is_tensor(out):
             out.record_stream(main)
         return out
+
+    def _final_pair(self):
+        """(last StyledConvSeq, the ToRGBF that consumes it, latent index of that ToRGB) or None."""
+        if os.environ.get('RW_FUSE_FINAL_RGB', '1') == '0':
+            return None
+        names = list(self._modules)
+        last_rgb = 'to_rgb%d' % (self.log_size - 1)
+        last_layer = 'layer%d' % (self.num_layers + 1)
+        if last_rgb not in names or last_layer not in names or names.index(last_rgb) != names.index(last_layer) + 1:
+            return None
+        layer, rgbseq = self._modules[last_layer], self._modules[last_rgb]
+        sconv = getattr(layer, 'sconv', None)
+        torgb = getattr(rgbseq, 'rgb', None)
+        picks = [m for m in rgbseq.children() if isinstance(m, PickLatent)]
+        if not isinstance(sconv, StyledConvSeq) or not isinstance(torgb, ToRGBF) or len(picks) != 1:
+            return None
+        return sconv, torgb, picks[0].index
 
     def bag_from_z(self, z):
         return InputLatent()(z)

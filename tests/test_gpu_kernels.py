@@ -158,6 +158,37 @@ def test_demodulated_conv_matches_oracle(case, impl):
     assert rel(fused, want) < 1e-5
 
 
+@pytest.mark.parametrize('case', [(2, 32, 32, 40, 64), (1, 64, 64, 32, 32), (2, 16, 32, 24, 70), (1, 128, 64, 24, 33)])
+@pytest.mark.parametrize('store', [False, True])
+def test_conv_with_fused_to_rgb_matches_separate_kernels(case, store):
+    """rw_conv3x3_to_rgb_f32 (ToRGB in the epilogue of the styled conv, feature map optionally not stored)
+    against rw_conv3x3_f32 followed by rw_to_rgb_f32."""
+    from rewriting_amd import hip
+    b, i, o, h, w = case
+    x, wt, style = _conv_inputs(*case, seed=7)
+    rs = numpy.random.RandomState(11)
+    noise = torch.from_numpy(rs.randn(b, h * w).astype('float32')).to(DEV)
+    nw = torch.tensor([0.2]).to(DEV)
+    bias = torch.from_numpy(rs.randn(o).astype('float32')).to(DEV)
+    wrgb = torch.from_numpy(rs.randn(3, o).astype('float32')).to(DEV)
+    srgb = torch.from_numpy((1 + 0.3 * rs.randn(b, o)).astype('float32')).to(DEV)
+    brgb = torch.from_numpy(rs.randn(3).astype('float32')).to(DEV)
+    skip = torch.from_numpy(rs.randn(b, 3, h, w).astype('float32')).to(DEV)
+    s = 1 / math.sqrt(i * 9)
+    dm = hip.demod(hip.weight_sqsum(wt.to(DEV), s), style.to(DEV))
+    wp = hip.pack_conv_weight(wt.to(DEV), 0)
+    args = dict(style=style.to(DEV), demod=dm, noise=noise, noise_w=nw, bias=bias, act=True)
+    fmap = hip.conv3x3(x.to(DEV), wp, o, s, **args)
+    want = hip.to_rgb(fmap, wrgb, srgb, brgb, skip, 1 / math.sqrt(o))
+    y, rgb = hip.conv3x3_to_rgb(x.to(DEV), wp, o, s, wrgb, srgb, brgb, skip, 1 / math.sqrt(o), store_fmap=store, **args)
+    assert (y is None) == (not store)
+    if store:
+        assert torch.equal(y, fmap)
+    assert rel(rgb, want) < 2e-6
+    _, rgb2 = hip.conv3x3_to_rgb(x.to(DEV), wp, o, s, wrgb, srgb, None, None, 1 / math.sqrt(o), **args)
+    assert rel(rgb2, want - skip - brgb.view(1, 3, 1, 1)) < 1e-5
+
+
 @pytest.mark.parametrize('case', [(2, 128, 64, 40, 64), (1, 64, 32, 32, 32), (2, 512, 256, 16, 16), (3, 512, 512, 8, 8)])
 def test_transposed_conv_tiles_and_border_parts_compose(case):
     """impl 7 (quad tiles) and impl 8 (output row 2H / column 2W) write disjoint elements and together
