@@ -83,7 +83,7 @@ class ConvTimer:
 
     def install(self):
         from rewriting_amd import hip
-        self._orig = (hip.conv3x3, hip.conv_transpose3x3s2, hip.conv3x3_bf16x6)
+        self._orig = (hip.conv3x3, hip.conv_transpose3x3s2, hip.conv3x3_bf16x6, hip.conv3x3_to_rgb)
         timer = self
 
         def wrap(fn, upsample, split=False):
@@ -103,10 +103,11 @@ class ConvTimer:
         hip.conv3x3 = wrap(self._orig[0], False)
         hip.conv_transpose3x3s2 = wrap(self._orig[1], True)
         hip.conv3x3_bf16x6 = wrap(self._orig[2], False, split=True)
+        hip.conv3x3_to_rgb = wrap(self._orig[3], False)         # same kernel, ToRGB in the epilogue
 
     def remove(self):
         from rewriting_amd import hip
-        hip.conv3x3, hip.conv_transpose3x3s2, hip.conv3x3_bf16x6 = self._orig
+        hip.conv3x3, hip.conv_transpose3x3s2, hip.conv3x3_bf16x6, hip.conv3x3_to_rgb = self._orig
 
     def result(self):
         per = {}

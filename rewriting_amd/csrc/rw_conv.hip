@@ -571,17 +571,27 @@ __device__ __forceinline__ void rw_halo_epilogue(const HaloProblem& p, const Pha
     for (int b = 0; b < TN; ++b)
 #pragma unroll
       for (int c = 0; c < 3; ++c) part[b][c] += __shfl_xor(part[b][c], 32, 64);
+    // bias and the running image are fetched in one batch each (not one dependent load per store)
+    float rb[3] = {0.f, 0.f, 0.f}, sk[TN][3];
+    if (p.rgb_bias) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) rb[c] = p.rgb_bias[c];
+    }
+    if (p.rgb_skip) {
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) sk[b][c] = p.rgb_skip[((int64_t)ib * 3 + c) * ohw + pix[b]];
+    } else {
+#pragma unroll
+      for (int b = 0; b < TN; ++b) sk[b][0] = sk[b][1] = sk[b][2] = 0.f;
+    }
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
       if (!live[b] || !low_half) continue;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const int64_t idx = ((int64_t)ib * 3 + c) * ohw + pix[b];
-        float o = part[b][c];
-        if (p.rgb_bias) o += p.rgb_bias[c];
-        if (p.rgb_skip) o += p.rgb_skip[idx];
-        p.rgb_out[idx] = o;
-      }
+      for (int c = 0; c < 3; ++c)
+        p.rgb_out[((int64_t)ib * 3 + c) * ohw + pix[b]] = part[b][c] + rb[c] + sk[b][c];
     }
   }
 }
