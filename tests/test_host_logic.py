@@ -312,3 +312,16 @@ def test_sweep_batch_never_starves_a_rank(monkeypatch):
         b = Fake(n)._sweep_batch()
         assert b == want and b % 10 == 0
         assert (n + b - 1) // b >= min(world, n // 10)             # at least one batch per rank
+
+
+def test_final_pair_identifies_last_styled_conv_and_its_to_rgb():
+    """SeqStyleGAN2._final_pair: the layer whose ToRGB is fused into its epilogue in the un-hooked forward."""
+    from rewriting_amd.utils.stylegan2 import models as sg
+    g = sg.SeqStyleGAN2(64, 512, 2, mconv='seq')
+    sconv, torgb, idx = g._final_pair()
+    assert sconv is g.layer10.sconv and torgb is g.to_rgb5.rgb
+    assert idx == g.n_latent - 1 == 9                      # ToRGB of the last resolution takes the last latent
+    assert torgb.skip and torgb.conv.in_channel == sconv.mconv.dconv.out_channel
+    from rewriting_amd import hip
+    assert hip.to_rgb_fusable(32, 32, 1024) and hip.to_rgb_fusable(64, 64, 512)
+    assert not hip.to_rgb_fusable(128, 128, 256) and not hip.to_rgb_fusable(32, 32, 16)
