@@ -5,19 +5,26 @@
 Default workload = BASELINE.json's metric: images/sec of the StyleGANv2-1024 sequential
 generator forward (SeqStyleGAN2 size 1024, mconv='seq', truncation 0.5, synthetic seeded
 weights, z = standard_z_sample seed 1), one "step" = one forward pass over a batch of B seeds per
-GPU (default 32) with inputs resident in HBM.  For N>1 launch with torch.distributed.run (one rank per GPU,
-RCCL): seeds are partitioned rank-wise (no data-path collective, weak scaling); the timed region
-is bracketed by barrier + synchronize and the MAX over ranks is reported.
+GPU (default 64) with inputs resident in HBM.  For N>1 either launch it under torch.distributed.run (one rank
+per GPU, RCCL) or just run `python bench.py --gpus N`: without RANK/WORLD_SIZE in the environment it re-executes
+itself under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`.  Seeds are
+partitioned rank-wise (no data-path collective, weak scaling); the timed region is bracketed by barrier +
+synchronize and the MAX over ranks is reported.
 
 Rank 0 prints ONE JSON line with `roofline` (the dominant conv kernel: algorithmic conv FLOPs of
 its launches / their HIP-event time, against the 157.3 TFLOP/s fp32-MFMA peak) and
-`cpu_baseline` (the oracle restatement timed on the host cores on a bounded sample; N=1 only).
+`cpu_baseline` (the reference's own files when /root/reference is present, else the oracle restatement, timed
+on the host cores on a bounded sample at the best of several thread counts; N=1 only) and `extra`: the other
+half of BASELINE.json's metric (seconds per rank-1 edit = 1000-seed key statistics + 2001-step solve), the
+256^2 forward (configs[1]) and the key-statistics sweep (configs[3]), each timed in this process.
 
 Other workloads (parity-test configurations of BASELINE.json, not the headline line):
   ffhq256   StyleGANv2-256 forward, batch 64         (configs[1])
   edit      horse->hat rank-1 edit at layer 8 of the 256 model: 1000-seed key statistics +
             2001-step solve, seconds per edit       (configs[2])
-  sweep     key-statistics sweep only (seeds/s), sharded over ranks with one all-reduce (configs[3])
+  sweep     key-statistics sweep only (seeds/s), sharded over ranks with one all-reduce (configs[3]);
+            --layer 8|10|14 --seeds 10000
+  watermark the five watermark.sh variants (erase edits, configs[4]) as replicas, one per rank, + sample sets
 """
 import argparse
 import json
@@ -159,27 +166,61 @@ def build_generator(size, device):
     return g.eval().to(device)
 
 
-def cpu_baseline_forward(size, seconds=12.0, max_images=16):
-    """The oracle (a port: oracle/restatement.py on torch-CPU kernels) on the host cores."""
+def _cpu_forward_fn(size):
+    """(callable(z) -> images, kind): the reference's own SeqStyleGAN2 through oracle/reference_shim.py when
+    /root/reference exists (build container), else the oracle restatement (a port; the GPU box)."""
     from rewriting_amd import synthetic
-    from rewriting_amd.utils import zdataset
+    from oracle import reference_shim
+    if reference_shim.available():
+        ref = reference_shim.load()
+        g = ref.models.SeqStyleGAN2(size, 512, 8, truncation=0.5, mconv='seq')
+        synthetic.randomize_(g, seed=0)
+        g.eval()
+        return (lambda z: g(z)), 'reference'
     from rewriting_amd.utils.stylegan2 import models
     from oracle import restatement as R
     g = models.SeqStyleGAN2(size, 512, 8, truncation=0.5, mconv='seq')
     synthetic.randomize_(g, seed=0)
     sd = {k: v.detach() for k, v in g.state_dict().items()}
-    z = zdataset.standard_z_sample(max_images, 512, seed=1)
-    with torch.no_grad():
-        R.generator_forward(sd, z[:1], size, truncation=0.5)        # warm-up
-        t0 = time.perf_counter()
-        n = 0
-        while n < max_images and time.perf_counter() - t0 < seconds:
-            R.generator_forward(sd, z[n:n + 1], size, truncation=0.5)
-            n += 1
-        dt = time.perf_counter() - t0
-    return dict(value=round(n / dt, 4), unit='images/sec', cores=torch.get_num_threads(), kind='port',
-                sample='%d images of the stylegan2-%d forward at batch 1 through oracle/restatement.py '
-                       '(torch CPU kernels), %.1f s' % (n, size, dt))
+    return (lambda z: R.generator_forward(sd, z, size, truncation=0.5)), 'port'
+
+
+def cpu_baseline_forward(size, batch=4, images=12):
+    """The same forward on the host cores: one batch of `batch` at each thread count of a sweep (torch's CPU
+    kernels stop scaling well before 128 threads and lose to oversubscription beyond), then `images` images at
+    the best count.  ~25 s of CPU work."""
+    from rewriting_amd.utils import zdataset
+    fwd, kind = _cpu_forward_fn(size)
+    z = zdataset.standard_z_sample(max(images, batch), 512, seed=1)
+    ncpu = os.cpu_count() or 1
+    counts = sorted({min(c, ncpu) for c in (8, 16, 32, 64, 128)})
+    saved = torch.get_num_threads()
+    probe = {}
+    try:
+        with torch.no_grad():
+            torch.set_num_threads(counts[0])
+            fwd(z[:1])                                          # warm-up (allocator, thread pool)
+            for c in counts:
+                torch.set_num_threads(c)
+                t0 = time.perf_counter()
+                fwd(z[:batch])
+                probe[c] = batch / (time.perf_counter() - t0)
+            best = max(probe, key=probe.get)
+            torch.set_num_threads(best)
+            t0 = time.perf_counter()
+            n = 0
+            while n < images:
+                fwd(z[n:n + batch])
+                n += batch
+            dt = time.perf_counter() - t0
+    finally:
+        torch.set_num_threads(saved)
+    return dict(value=round(n / dt, 4), unit='images/sec', cores=best, kind=kind,
+                sample='%d images of the stylegan2-%d forward in batches of %d through %s (torch %s CPU kernels), '
+                       '%.1f s at %d threads; one-batch probe img/s by thread count: %s; host has %d logical cpus'
+                       % (n, size, batch, "the reference's own utils/stylegan2/models.py (oracle/reference_shim.py)"
+                          if kind == 'reference' else 'oracle/restatement.py', torch.__version__.split('+')[0], dt,
+                          best, json.dumps({str(k): round(v, 3) for k, v in probe.items()}), ncpu))
 
 
 def timed(fn, steps, warmup, world):
@@ -203,7 +244,7 @@ def timed(fn, steps, warmup, world):
     return dt
 
 
-def run_forward(args, rank, world, device, size, batch, name):
+def run_forward(args, rank, world, device, size, batch, name, cpu=True):
     from rewriting_amd.utils import zdataset
     g = build_generator(size, device)
     # seed i -> rank i mod world; every rank holds its own `batch` seeds, resident in HBM
@@ -235,75 +276,165 @@ def run_forward(args, rank, world, device, size, batch, name):
         {256: 276.3e6, 1024: 1217.7e6}.get(size, 0) * batch * world * args.steps / dt / 1e9, 1)
     attach_pmc_traffic(roof, 'ffhq%d' % size, batch)
     out['roofline'] = roof
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    del g, z
+    if cpu and rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline_forward(size)
     return out
 
 
-def run_edit(args, rank, world, device):
+def context_flops(model_size, layer, channel_multiplier=2):
+    """Conv FLOPs per seed of the context model of `layer` (styled convs of layers 2..layer-1)
+    and (key channels, key height) of that layer."""
+    ch = {4: 512, 8: 512, 16: 512, 32: 512, 64: 256 * channel_multiplier, 128: 128 * channel_multiplier,
+          256: 64 * channel_multiplier, 512: 32 * channel_multiplier, 1024: 16 * channel_multiplier}
+    total, cin, res, idx = 0, 512, 4, 2
+    layers = [(2, 512, 512, 4, False)]
+    while res < model_size:
+        cout = ch[res * 2]
+        layers.append((idx + 1, cin, cout, res, True))
+        res *= 2
+        layers.append((idx + 2, cout, cout, res, False))
+        cin, idx = cout, idx + 2
+    key = None
+    for n, ci, co, r, up in layers:
+        if n == layer:
+            key = (ci, r)
+            break
+        total += 2 * 9 * ci * co * r * r
+    return total, key
+
+
+def measure_edit(device, reps, warmup):
+    """configs[2]: horse->hat rank-1 edit at layer 8 of the 256 model.  Every repetition builds a fresh
+    rewriter (1000-seed key statistics in batches of 10 + ZCA) and runs apply_edit (goal, context direction,
+    2001-step solve)."""
     from rewriting_amd.rewrite import ganrewrite
     from rewriting_amd.utils import zdataset
     g = build_generator(256, device)
     zds = zdataset.z_dataset_for_model(g, size=1000)
     with open(os.path.join(ROOT, 'tests', 'golden', 'masks', 'recorded_horse_hat.json')) as f:
         req = json.load(f)
-    times = dict(stats=[], solve=[], total=[])
-
-    def step():
+    times = dict(stats=[], edit=[], solve=[], total=[])
+    for i in range(warmup + reps):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         gw = ganrewrite.SeqStyleGanRewriter(g, zds, 8)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        gw.apply_edit(req, rank=1, niter=2001, piter=10, lr=0.05)
+        solve_ms = gw.apply_edit(req, rank=1, niter=2001, piter=10, lr=0.05, return_timing=True)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        times['stats'].append(t1 - t0)
-        times['solve'].append(t2 - t1)
-        times['total'].append(t2 - t0)
-    dt = timed(step, args.steps, args.warmup, world)
-    n = args.steps
-    med = lambda v: sorted(v[-n:])[n // 2]
+        if i >= warmup:
+            times['stats'].append(t1 - t0)
+            times['edit'].append(t2 - t1)
+            times['solve'].append((solve_ms or 0.0) / 1e3)
+            times['total'].append(t2 - t0)
+    med = lambda v: sorted(v)[len(v) // 2]
     solve_bytes = 7 * 512 * 512 * 9 * 4 * 2001
+    solve_s = med(times['solve']) or med(times['edit'])
+    return dict(seconds_per_edit=round(med(times['total']), 4), key_collect_s=round(med(times['stats']), 4),
+                apply_edit_s=round(med(times['edit']), 4), solve_s=round(solve_s, 4), reps=reps,
+                workload='stylegan2-256 layer 8, recorded_horse_hat.json: 1000-seed key statistics + ZCA, goal, '
+                         'context direction, 2001-step rank-1 solve',
+                solve_roofline=dict(bound='hbm', achieved=round(solve_bytes / solve_s / 1e9, 1), peak=HBM_PEAK_GBS,
+                                    unit='GB/s', frac=round(solve_bytes / solve_s / 1e9 / HBM_PEAK_GBS, 4),
+                                    note='7 x |W| x 4 B per step algorithmic (SURVEY.md 8d); latency-bound'))
+
+
+def run_edit(args, rank, world, device):
+    e = measure_edit(device, args.steps, args.warmup)
     return dict(metric='wall-clock per rank-1 edit (1000-seed key collect + 2001-step solve)',
-                value=round(dt / n, 4), unit='s', n_gpus=world, steps=n, warmup=args.warmup,
-                ms_per_step=round(dt / n * 1e3, 2), higher_is_better=False, scaling='weak',
+                value=e['seconds_per_edit'], unit='s', n_gpus=world, steps=args.steps, warmup=args.warmup,
+                ms_per_step=round(e['seconds_per_edit'] * 1e3, 2), higher_is_better=False, scaling='weak',
                 vs_baseline=None, dtype='f32', data='synthetic',
-                config=dict(workload='stylegan2-256 layer 8 horse->hat edit (recorded_horse_hat.json)',
-                            key_collect_s=round(med(times['stats']), 4), edit_s=round(med(times['solve']), 4),
-                            replicas=world),
-                roofline=dict(bound='hbm', achieved=round(solve_bytes / med(times['solve']) / 1e9, 1),
-                              peak=HBM_PEAK_GBS, unit='GB/s',
-                              frac=round(solve_bytes / med(times['solve']) / 1e9 / HBM_PEAK_GBS, 4), traffic=None,
-                              note='solve: 7 x |W| x 4 B per step algorithmic (SURVEY.md 8d); latency-bound'))
+                config=dict(workload=e['workload'], key_collect_s=e['key_collect_s'], edit_s=e['apply_edit_s'],
+                            solve_s=e['solve_s'], replicas=world),
+                roofline=dict(e['solve_roofline'], traffic=None))
 
 
-def run_sweep(args, rank, world, device):
+def measure_sweep(device, size, layer, nseeds, steps, warmup, world):
+    """configs[3]: the key second-moment sweep as the rewriters run it -- launches of k x 10 seeds, every seed
+    with the noise row of its reference batch of 10 (noise_batch_period), launches dealt round-robin to the
+    ranks, ONE all-reduce of (mom2, count)."""
     from rewriting_amd import parallel
     from rewriting_amd.utils import tally, zdataset, nethook
-    g = build_generator(args.size, device)
-    layer = args.layer
-    ctx = nethook.subsequence(g, upto_layer='layer%d.sconv.mconv.dconv' % layer, share_weights=True)
-    nseeds = args.seeds
-    zds = zdataset.z_dataset_for_model(g, size=nseeds)
-
-    # as the rewriters run it: launches of k x 10 seeds, every seed with the noise row of its reference
-    # batch of 10 (noise_batch_period), launches dealt round-robin to the ranks, one all-reduce
     from rewriting_amd.utils.stylegan2.models import noise_batch_period
-    launch = max(10, min(250, (nseeds // world) // 10 * 10))
+    g = build_generator(size, device)
+    ctx = nethook.subsequence(g, upto_layer='layer%d.sconv.mconv.dconv' % layer, share_weights=True)
+    zds = zdataset.z_dataset_for_model(g, size=nseeds)
+    flops_ctx, (cin, res) = context_flops(size, layer)
+    # launch size: as many reference batches as fit in ~2 GB of key map, at most 250 seeds, >= one launch per rank
+    per_seed_bytes = cin * res * res * 4
+    launch = max(10, min(250, (2 << 30) // per_seed_bytes // 10 * 10, (nseeds // world) // 10 * 10))
 
     def step():
         with torch.no_grad(), noise_batch_period(10):
-            r = tally.tally_second_moment(lambda zb: ctx(zb.to(device)).fmap, zds, shard=parallel.shard(),
-                                          nchw=True, batch_size=launch)
-        return r
-    dt = timed(step, args.steps, args.warmup, world)
-    return dict(metric='key-statistics sweep seeds/sec (layer %d of stylegan2-%d)' % (layer, args.size),
-                value=round(nseeds * args.steps / dt, 1), unit='seeds/sec', n_gpus=world, steps=args.steps,
-                warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 2), higher_is_better=True,
+            return tally.tally_second_moment(lambda zb: ctx(zb.to(device)).fmap, zds, shard=parallel.shard(),
+                                             nchw=True, batch_size=launch)
+    dt = timed(step, steps, warmup, world)
+    flops = (flops_ctx + 2.0 * res * res * cin * cin) * nseeds * steps
+    achieved = flops / dt / 1e12 / world
+    return dict(seeds_per_s=round(nseeds * steps / dt, 1), ms_per_sweep=round(dt / steps * 1e3, 2), size=size,
+                layer=layer, seeds=nseeds, launch=launch, key_map='%d x %d x %d' % (cin, res, res),
+                gflop_per_seed=round((flops_ctx + 2.0 * res * res * cin * cin) / 1e9, 3),
+                roofline=dict(bound='mfma', achieved=round(achieved, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
+                              frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
+                              note='per GPU: context-forward conv FLOPs of layers 2..%d + 2 H W C^2 of a^T a per seed '
+                                   '(SURVEY.md 8d) / wall time; the key map itself (%.1f MB per seed) is read once'
+                                   % (layer - 1, per_seed_bytes / 1e6)))
+
+
+def run_sweep(args, rank, world, device):
+    m = measure_sweep(device, args.size, args.layer, args.seeds, args.steps, args.warmup, world)
+    return dict(metric='key-statistics sweep seeds/sec (layer %d of stylegan2-%d)' % (args.layer, args.size),
+                value=m['seeds_per_s'], unit='seeds/sec', n_gpus=world, steps=args.steps,
+                warmup=args.warmup, ms_per_step=m['ms_per_sweep'], higher_is_better=True,
                 scaling='strong', vs_baseline=None, dtype='f32', data='synthetic',
                 config=dict(workload='%d-seed second-moment sweep, launches of %d seeds (reference batches of 10 '
-                                     'inside) dealt round-robin, one all-reduce' % (nseeds, launch)))
+                                     'inside) dealt round-robin, one all-reduce' % (args.seeds, m['launch']),
+                            key_map=m['key_map'], gflop_per_seed=m['gflop_per_seed']),
+                roofline=m['roofline'])
+
+
+def run_watermark(args, rank, world, device):
+    from rewriting_amd import workloads
+    return workloads.watermark_bench(args, rank, world, device, timed)
+
+
+def extras(args, rank, world, device):
+    """The rest of BASELINE.json's metric, timed in this process after the headline workload (whose buffers
+    are released first).  Sweep: every rank takes part (it contains the path's one collective); the edit and
+    the 256^2 forward are per-GPU quantities and are measured on one GPU runs only."""
+    out = {}
+    torch.cuda.empty_cache()
+    sw = measure_sweep(device, 1024, 8, 10000 if world > 1 else 2000, 2, 1, world)
+    out['sweep_ffhq1024_layer8'] = sw
+    if world == 1:
+        torch.cuda.empty_cache()
+        out['edit_horse256_layer8'] = measure_edit(device, 3, 1)
+        torch.cuda.empty_cache()
+        saved = (args.steps, args.warmup)
+        args.steps, args.warmup = 5, 2
+        f = run_forward(args, rank, world, device, 256, 64, 'stylegan2-256 generator forward, 64-seed batch', cpu=False)
+        args.steps, args.warmup = saved
+        out['forward_ffhq256_b64'] = dict(images_per_s=f['value'], ms_per_step=f['ms_per_step'],
+                                          all_conv_kernels=f['roofline']['all_conv_kernels'],
+                                          forward_hbm_algorithmic_gbs=f['roofline']['forward_hbm_algorithmic_gbs'])
+    return out
+
+
+def self_launch(argv, gpus):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU
+    (backend nccl = RCCL), rendezvous on 127.0.0.1; rank 0's JSON line is this process's output."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -311,24 +442,32 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--workload', default='ffhq1024', choices=['ffhq1024', 'ffhq256', 'edit', 'sweep'])
+    ap.add_argument('--workload', default='ffhq1024', choices=['ffhq1024', 'ffhq256', 'edit', 'sweep', 'watermark'])
     ap.add_argument('--batch', type=int, default=None)
     ap.add_argument('--size', type=int, default=1024)
     ap.add_argument('--layer', type=int, default=8)
     ap.add_argument('--seeds', type=int, default=1000)
+    ap.add_argument('--samples', type=int, default=1000, help='watermark: images per variant sample set')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extra', action='store_true', help='headline workload only')
     ap.add_argument('--precision', default='f32', choices=['f32', 'bf16x6'],
                     help='bf16x6: opt-in split-precision stride-1 convolutions (fp32-product accuracy); '
                          'the default and the headline number are exact fp32 MFMA')
+    ap.add_argument('--conv-algo', default=None, choices=['direct', 'winograd'],
+                    help='stride-1 3x3 convolutions: winograd F(2x2,3x3) in fp32 (default where it applies) or '
+                         'direct implicit GEMM')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'RANK' not in os.environ and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(self_launch(sys.argv[1:], args.gpus))
     if args.precision != 'f32':
         os.environ['RW_CONV_PRECISION'] = args.precision
+    if args.conv_algo:
+        os.environ['RW_CONV_ALGO'] = args.conv_algo
     from rewriting_amd import parallel
     rank, world, local = parallel.init_from_env()
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d '
-                         '--master-addr 127.0.0.1 bench.py --gpus %d ...' % (args.gpus, args.gpus))
+    if args.gpus != world:
+        raise SystemExit('bench.py: --gpus %d but the launcher started %d ranks' % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (the HIP kernels have no CPU path)')
     torch.cuda.set_device(local)
@@ -336,17 +475,25 @@ def main():
     if args.workload == 'ffhq1024':
         out = run_forward(args, rank, world, device, 1024, args.batch or 64,
                           'stylegan2-1024 generator forward (FFHQ-1024 architecture)')
+        if not args.no_extra:
+            out['extra'] = extras(args, rank, world, device)
     elif args.workload == 'ffhq256':
         out = run_forward(args, rank, world, device, 256, args.batch or 64,
                           'stylegan2-256 generator forward, 64-seed batch (FFHQ-256 architecture)')
     elif args.workload == 'edit':
         out = run_edit(args, rank, world, device)
-    else:
+    elif args.workload == 'sweep':
         out = run_sweep(args, rank, world, device)
-    if rank == 0:
-        print(json.dumps(out))
+    else:
+        out = run_watermark(args, rank, world, device)
     if world > 1:
         import torch.distributed as dist
+        out['rccl'] = dict(backend=dist.get_backend(), world_size=dist.get_world_size())
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
         dist.destroy_process_group()
 
 

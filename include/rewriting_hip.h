@@ -245,13 +245,15 @@ typedef struct rw_solve_problem {
   /* per-step tables (device, length niter), computed on the host in double like torch.optim.Adam */
   const float* step_size;   /* lr / (1 - beta1^t)      */
   const float* bc2_sqrt;    /* sqrt(1 - beta2^t)       */
-  int32_t* step_counter;    /* device int: index of the NEXT step; incremented by the library */
+  int32_t* step_counter;    /* device int: index of the LAST step taken; the library pre-increments it, so it
+                             * starts at -1 and step t reads step_size[t], bc2_sqrt[t], writes losses[t] */
   float* losses;            /* (niter) l1 loss of every step, written by the library        */
-  /* scratch (device) */
-  float* conv;           /* (ksplit, out_ch, P16)  partial conv sums                      */
+  /* scratch (device); element counts from rw_solve_scratch_elems().  P64 = ceil64(positions of the map the
+   * convolution writes): h*w, or (2h+1)*(2w+1) for an upsampling target */
+  float* conv;           /* (ksplit, out_ch, P64)  partial conv sums                      */
   float* wsq;            /* (ksplit, out_ch)                                              */
-  float* gd;             /* (out_ch, P16)  g_pre*demod, zero padded to P16 = ceil16(h*w)  */
-  float* c2;             /* (out_ch)       s^2 * demod^3 * sum_p g_pre*conv                */
+  float* gd;             /* (out_ch, P64)  g_pre*demod, zero padded                       */
+  float* c2;             /* (2*out_ch)     s^2 * demod^3 * sum_p g_pre*conv | per-channel loss */
   float* grad;           /* (out_ch,in_ch,9) only for low_rank_gradient, else nullable     */
   int ksplit;
   float beta1, beta2, eps, w_scale;
@@ -268,7 +270,14 @@ typedef struct rw_solve_problem {
   float* lambda;
 } rw_solve_problem;
 
+/* split-K factor for a convolution-output map of h x w positions ((2h+1) x (2w+1) of the key for upsampling) */
 int rw_solve_ksplit(int out_ch, int in_ch, int h, int w);
+/* 0 when rw_solve_step_f32 takes this shape (h, w of the key crop), RW_ERR_UNSUPPORTED otherwise: out_ch % 64,
+ * in_ch % 16, <= 64 KB of LDS for the blur staging of an upsampling target (plain == 0) and for the rank-r
+ * projection (constrained != 0).  rw_solve_step_f32 runs the same check before its first launch. */
+int rw_solve_supported(int out_ch, int in_ch, int h, int w, int upsample, int plain, int constrained);
+/* sizes[0..4] = element counts of conv, wsq, gd, c2, grad for this shape */
+int rw_solve_scratch_elems(int out_ch, int in_ch, int h, int w, int upsample, long long* sizes);
 /* one iteration `it` (loss, gradient, Adam); project != 0 also applies W <- ortho + P(W) */
 int rw_solve_step_f32(const rw_solve_problem* p, int project, rw_stream_t stream);
 /* W <- W - P(W) + amount*P(1)  (zero(), ganrewrite.py:190-195) and ortho = W - P(W) helpers */

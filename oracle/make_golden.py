@@ -89,6 +89,192 @@ def golden_generator(ref, name, size, truncation, cm, batch):
     save(name, **arrays)
 
 
+def image_digest(img, stride, crop=64):
+    """Small fixture that still covers EVERY pixel of a large image batch: a strided sub-sample, four
+    full-resolution crops, float64 row / column sums per channel (linear in every pixel) and the norm."""
+    b, c, h, w = img.shape
+    d = img.double()
+    corners = [(0, 0), (h // 2 - crop // 2, w // 2 - crop // 2), (h - crop, w // 3), (h // 5, w - crop)]
+    return dict(strided=img[:, :, ::stride, ::stride].numpy().copy(),
+                crops=numpy.stack([img[:, :, y:y + crop, x:x + crop].numpy() for y, x in corners]),
+                crop_origin=numpy.array(corners), stride=numpy.array(stride),
+                rowsum=d.sum(3).numpy(), colsum=d.sum(2).numpy(),
+                norm=numpy.float64(d.norm().item()), shape=numpy.array(img.shape))
+
+
+def golden_generator_full(ref, name, size, batch, stride):
+    """BASELINE.json's own generator sizes (utils/stylegan2/models.py:41-141): image digest + strided
+    sub-samples of every leaf module's output."""
+    g = build_stylegan(ref, size, 0.5)
+    z = ref.zdataset.standard_z_sample(batch, 512, seed=1)
+    store, handles = capture_stages(g)
+    with torch.no_grad():
+        img = g(z)
+    for h in handles:
+        h.remove()
+    arrays = dict(z=z.numpy(), meta=json.dumps(dict(size=size, truncation=0.5, channel_multiplier=2,
+                                                    batch=batch, weight_seed=0)))
+    for k, v in image_digest(img, stride).items():
+        arrays['image/' + k] = v
+    for lname, out in store.items():
+        if isinstance(out, dict):
+            field = 'output' if (lname.startswith('to_rgb') and lname.endswith('.rgb')) or \
+                lname.startswith('up_rgb') else 'fmap'
+            if lname.endswith('modulation'):
+                field = 'style'
+            if lname.startswith('style.') or lname in ('latents',):
+                field = 'latent'
+            if field not in out:
+                continue
+            t = out[field]
+        else:
+            t = out
+        s, nrm = sub(t, 2048)
+        arrays['stage/%s/sub' % lname] = s
+        arrays['stage/%s/norm' % lname] = nrm
+        arrays['stage/%s/shape' % lname] = numpy.array(t.shape)
+    save(name, **arrays)
+
+
+def golden_edit_full(ref, name):
+    """BASELINE.json configs[2] at its own size: StyleGAN2-256, layer 8, 1000 seeds in batches of 10
+    (rewrite/ganrewrite.py:83-96), the recorded horse->hat request with its real seed indices
+    (:148-169), weights after 1/10/11/100/101 steps (:254-298) and the 2001-step result at 8 threads and
+    at 1 thread -- the reference's own scatter is the bar for that horizon."""
+    g = build_stylegan(ref, 256, 0.5)
+    zds = ref.zdataset.z_dataset_for_model(g, size=1000)
+    with open(os.path.join(MASKS, 'recorded_horse_hat.json')) as f:
+        request = json.load(f)
+
+    import tempfile
+    cachedir = tempfile.mkdtemp()        # the reference's own r2m.npz cache makes the later rewriters cheap
+
+    def rewriter():
+        return ref.ganrewrite.SeqStyleGanRewriter(g, zds, 8, cachedir=cachedir, low_rank_insert=True,
+                                                  key_method='zca', tight_paste=True)
+    gw = rewriter()
+    arrays = dict(meta=json.dumps(dict(size=256, layernum=8, mask='recorded_horse_hat.json', nseeds=1000,
+                                       weight_seed=0, truncation=0.5, rank=1)))
+    C = gw.c_matrix
+    arrays['c_matrix'] = C.numpy()[::4, ::4].copy()
+    arrays['c_matrix_norm'] = numpy.float64(C.double().norm().item())
+    arrays['c_matrix_diag'] = C.diag().numpy()
+    arrays['c_matrix_rows'] = C.numpy()[[0, 17, 255, 511]].copy()
+    arrays['zca'] = gw.zca_matrix.numpy()[::4, ::4].copy()
+    arrays['zca_rows'] = gw.zca_matrix.numpy()[[0, 17, 255, 511]].copy()
+    arrays['zca_norm'] = numpy.float64(gw.zca_matrix.double().norm().item())
+    ev = torch.linalg.eigvalsh(C.double())
+    arrays['c_eig_minmax'] = numpy.array([ev.min().item(), ev.max().item()])
+    cached = numpy.load(os.path.join(cachedir, 'r2m.npz'), allow_pickle=True)
+    arrays['count'] = numpy.array(int(cached['count']))
+    # The reference accumulates 1 024 000 outer products per entry in float32 (utils/runningstats.py:1086-1097,
+    # addbmm_ into an fp32 mom2): its C carries ~1e-4 of accumulation error.  The same key maps -- the
+    # reference's own context_model, batches of 10 -- accumulated in float64 give the statistic both sides
+    # approximate; how far the reference's C is from it is the bar for anybody else's.
+    exact = torch.zeros(C.shape[0], C.shape[0], dtype=torch.float64)
+    with torch.no_grad():
+        for b0 in range(0, 1000, 10):
+            zb = torch.stack([zds[i][0] for i in range(b0, b0 + 10)])
+            a = gw.context_model(zb).fmap.permute(0, 2, 3, 1).reshape(-1, C.shape[0]).double()
+            exact += a.t() @ a
+    exact /= float(arrays['count'])
+    arrays['c_exact'] = exact.numpy()[::4, ::4].copy()
+    arrays['c_exact_rows'] = exact.numpy()[[0, 17, 255, 511]].copy()
+    arrays['c_exact_diag'] = exact.diag().numpy()
+    arrays['c_exact_norm'] = numpy.float64(exact.norm().item())
+    arrays['c_ref_vs_exact'] = numpy.float64(((C.double() - exact).norm() / exact.norm()).item())
+    arrays['c_ref_vs_exact_max'] = numpy.float64((C.double() - exact).abs().max().item())
+    print('reference C vs float64 accumulation of its own key maps: rel %.3e, max abs %.3e (max |C| %.3f)' % (
+        arrays['c_ref_vs_exact'], arrays['c_ref_vs_exact_max'], C.abs().max().item()))
+    vals, vecs = torch.linalg.eigh(exact)
+    zca_exact = (vecs * (1.0 / vals.sqrt().clamp(1e-20))[None, :]) @ vecs.t()
+    arrays['zca_exact'] = zca_exact.float().numpy()[::4, ::4].copy()
+    arrays['zca_ref_vs_exact_max'] = numpy.float64((gw.zca_matrix.double() - zca_exact).abs().max().item())
+    print('reference ZCA vs exact: max abs %.3e (max |Z| %.3f)' % (
+        arrays['zca_ref_vs_exact_max'], gw.zca_matrix.abs().max().item()))
+    arrays['k_shape'] = numpy.array(gw.k_shape)
+    arrays['v_shape'] = numpy.array(gw.v_shape)
+    o_imgnum, o_mask = request['object']
+    p_imgnum, p_mask = request['paste']
+    obj_acts, _, obj_area, bounds = gw.object_from_selection(o_imgnum, o_mask)
+    goal_in, goal_out, _, pbounds = gw.paste_from_selection(p_imgnum, p_mask, obj_acts, obj_area)
+    arrays['obj_bounds'] = numpy.array(bounds)
+    arrays['paste_bounds'] = numpy.array(pbounds)
+    arrays['obj_area'] = obj_area.detach().numpy()
+    mkey = gw.multi_key_from_selection(request['key'], rank=1)
+    arrays['mkey'] = mkey.numpy()
+    arrays['n_sel'] = numpy.array(ref.ganrewrite.all_obs.shape[0])
+    arrays['all_obs_norm'] = numpy.float64(ref.ganrewrite.all_obs.double().norm().item())
+    for nm, bag in (('goal_in', goal_in), ('goal_out', goal_out)):
+        arrays[nm + '_fmap'] = bag.fmap.detach().numpy()
+        arrays[nm + '_style'] = bag.style.detach().numpy()
+    W0 = gw.target_weights().detach().clone()
+    arrays['W0_sub'], arrays['W0_norm'] = sub(W0, 16384)
+
+    def record(tag, W):
+        dW = (W - W0)[0]
+        arrays['dW_%s_sub' % tag], arrays['dW_%s_norm' % tag] = sub(dW, 8192)
+        arrays['dW_%s_cos' % tag] = torch.einsum('oiyx,di->odyx', dW, mkey).numpy()
+        return dW
+
+    for niter in (1, 11, 101):
+        gwn = rewriter()
+        pre, losses = {}, []
+
+        def cb(it, loss, pre=pre, gwn=gwn, losses=losses):
+            losses.append(loss.item())
+            if it in (9, 99):
+                pre[it] = gwn.target_weights().detach().clone()
+        gwn.insert(goal_in, goal_out, mkey, niter=niter, piter=10, lr=0.05, update_callback=cb)
+        record('%d' % niter, gwn.target_weights().detach())
+        for it, W in pre.items():
+            record('%d' % (it + 1), W)
+        if niter == 101:
+            arrays['losses'] = numpy.array(losses)
+            with torch.no_grad():
+                zs = torch.cat([gwn.get_z(i) for i in (p_imgnum, 0)])
+                for k, v in image_digest(gwn.sample_image_from_latent(zs), 4).items():
+                    arrays['edited_image/' + k] = v
+    full = {}
+    for nthreads in (8, 1):
+        with reference_shim.threads(nthreads):
+            gwn = rewriter()
+            losses = []
+            gwn.insert(goal_in, goal_out, mkey, niter=2001, piter=10, lr=0.05,
+                       update_callback=lambda it, loss: losses.append(loss.item()))
+            full[nthreads] = record('2001_t%d' % nthreads, gwn.target_weights().detach())
+            arrays['losses_2001_t%d' % nthreads] = numpy.array(losses)[::50]
+    arrays['self_scatter_2001'] = numpy.float64(((full[8] - full[1]).norm() / full[1].norm()).item())
+    print('reference self-scatter of dW after 2001 steps, 8 threads vs 1:', arrays['self_scatter_2001'])
+    save(name, **arrays)
+
+
+def golden_sweep_1024(ref, name):
+    """BASELINE.json configs[3] (rewrite/ganrewrite.py:83-96 on the 1024 generator): for the sweep layers
+    {8, 10, 14} the second moment of the first two reference batches of 10 seeds, and the key maps
+    (adain outputs) of rows 0, 3 and 9 of the first batch -- each seed with the noise row of its batch."""
+    g = build_stylegan(ref, 1024, 0.5)
+    zds = ref.zdataset.z_dataset_for_model(g, size=20)
+    arrays = dict(meta=json.dumps(dict(size=1024, truncation=0.5, nseeds=20, weight_seed=0,
+                                       layers=[8, 10, 14])))
+    for layer in (8, 10, 14):
+        gw = ref.ganrewrite.SeqStyleGanRewriter(g, zds, layer, cachedir=None)
+        C = gw.c_matrix
+        arrays['l%d/c_matrix' % layer] = C.numpy()[::4, ::4].copy() if C.shape[0] > 128 else C.numpy().copy()
+        arrays['l%d/c_matrix_norm' % layer] = numpy.float64(C.double().norm().item())
+        arrays['l%d/c_matrix_diag' % layer] = C.diag().numpy()
+        arrays['l%d/k_shape' % layer] = numpy.array(gw.k_shape)
+        with torch.no_grad():
+            zb = torch.stack([zds[i][0] for i in range(10)])
+            kmap = gw.context_model(zb).fmap
+        for row in (0, 3, 9):
+            arrays['l%d/key_row%d_sub' % (layer, row)], arrays['l%d/key_row%d_norm' % (layer, row)] = \
+                sub(kmap[row], 4096)
+        print('layer', layer, 'done', tuple(kmap.shape))
+    save(name, **arrays)
+
+
+
 def golden_ops(ref):
     """op-level: the reference's own upfirdn2d_native spec + kernel formula."""
     rs = numpy.random.RandomState(7)
@@ -392,6 +578,11 @@ def main():
             tags=('pre',)),     # the reference's own paste logic fails for 'tiny' on an upsampling layer
         'pg64_l6_spire2tree': lambda: golden_proggan(
             ref, 'pg64_l6_spire2tree', 64, 6, 'spire2tree.json', 40),
+        # BASELINE.json's own sizes (minutes of CPU each)
+        'gen_s256_full': lambda: golden_generator_full(ref, 'gen_s256_full', 256, 4, 4),
+        'gen_s1024_full': lambda: golden_generator_full(ref, 'gen_s1024_full', 1024, 2, 8),
+        'rw_s256_l8_horsehat_1000': lambda: golden_edit_full(ref, 'rw_s256_l8_horsehat_1000'),
+        'sweep_s1024': lambda: golden_sweep_1024(ref, 'sweep_s1024'),
     }
     for nm, fn in jobs.items():
         if args.only in (None, nm):

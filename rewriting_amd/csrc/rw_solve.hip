@@ -504,6 +504,37 @@ extern "C" int rw_project_weight_f32(const float* w, const float* context, const
   return RW_LAUNCH_RESULT();
 }
 
+// Shape limits of the solver kernels, in one place (rw_solve_step_f32 calls it before its first launch and
+// the host mirrors it in _hip_solvable): 64 out-channels per workgroup in both GEMMs, 16-channel K chunks,
+// the blur / blur-backward staging of an upsampling target in <= 64 KB of LDS, and the two weight rows of the
+// rank-r projection in <= 64 KB.
+extern "C" int rw_solve_supported(int out_ch, int in_ch, int h, int w, int upsample, int plain, int constrained) {
+  if (out_ch <= 0 || in_ch <= 0 || h <= 0 || w <= 0) return RW_ERR_BAD_ARGUMENT;
+  if (out_ch % SV_BM || in_ch % SV_KC) return RW_ERR_UNSUPPORTED;
+  if (upsample && !plain) {
+    const size_t P = (size_t)(2 * h + 1) * (2 * w + 1);
+    if ((P + (size_t)4 * h * w) * sizeof(float) > 64 * 1024) return RW_ERR_UNSUPPORTED;
+  }
+  if (constrained && 2 * (size_t)in_ch * 9 * sizeof(float) > 64 * 1024) return RW_ERR_UNSUPPORTED;
+  return 0;
+}
+
+// Element counts of the scratch buffers of rw_solve_problem for this shape: sizes[0..4] =
+// {conv, wsq, gd, c2, grad} (floats).  Rows of conv / gd are padded to ceil64 of the positions of the map the
+// convolution writes (h*w, or (2h+1)(2w+1) for an upsampling target); c2 carries the per-channel loss behind it.
+extern "C" int rw_solve_scratch_elems(int out_ch, int in_ch, int h, int w, int upsample, long long* sizes) {
+  if (!sizes || out_ch <= 0 || in_ch <= 0 || h <= 0 || w <= 0) return RW_ERR_BAD_ARGUMENT;
+  const int ch = upsample ? 2 * h + 1 : h, cw = upsample ? 2 * w + 1 : w;
+  const long long pp = sv_pp(ch * cw);
+  const long long ks = rw_solve_ksplit(out_ch, in_ch, ch, cw);
+  sizes[0] = ks * out_ch * pp;
+  sizes[1] = ks * out_ch;
+  sizes[2] = (long long)out_ch * pp;
+  sizes[3] = 2LL * out_ch;
+  sizes[4] = (long long)out_ch * in_ch * 9;
+  return 0;
+}
+
 extern "C" int rw_solve_step_f32(const rw_solve_problem* pr, int project, rw_stream_t stream) {
   RW_CHECK_ARG(pr);
   const rw_solve_problem& p = *pr;
@@ -517,7 +548,12 @@ extern "C" int rw_solve_step_f32(const rw_solve_problem* pr, int project, rw_str
   RW_CHECK_ARG(!(p.low_rank_gradient || p.linear_insert) || p.grad);
   RW_CHECK_ARG(!p.linear_insert || (p.lambda && !project && !p.low_rank_gradient));
   RW_CHECK_ARG(!p.upsample || !p.bias || p.blur_k);
-  if (p.out_ch % SV_BM || p.in_ch % SV_KC) return RW_ERR_UNSUPPORTED;
+  // every shape / LDS limit is checked BEFORE the first launch: a step either runs completely or not at all
+  {
+    const int rc = rw_solve_supported(p.out_ch, p.in_ch, p.h, p.w, p.upsample, p.bias ? 0 : 1,
+                                      (project || p.low_rank_gradient || p.linear_insert) ? 1 : 0);
+    if (rc) return rc;
+  }
   hipStream_t s = rw_s(stream);
   const int P = sv_conv_h(p) * sv_conv_w(p);
   const int pp = sv_pp(P);
@@ -525,7 +561,6 @@ extern "C" int rw_solve_step_f32(const rw_solve_problem* pr, int project, rw_str
   hipLaunchKernelGGL(solve_fwd_kernel, dim3(p.out_ch / SV_BM, pp / SV_BN, p.ksplit), dim3(256), 0, s, p, pp);
   if (p.upsample && p.bias) {
     const size_t mid_lds = ((size_t)P + (size_t)4 * p.h * p.w) * sizeof(float);
-    if (mid_lds > 64 * 1024) return RW_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(solve_mid_up_kernel, dim3(p.out_ch), dim3(256), mid_lds, s, p, pp, lpart);
   } else {
     hipLaunchKernelGGL(solve_mid_kernel, dim3((unsigned)rw_cdiv(p.out_ch, 4)), dim3(256), 0, s, p, pp, lpart);
@@ -533,9 +568,6 @@ extern "C" int rw_solve_step_f32(const rw_solve_problem* pr, int project, rw_str
   hipLaunchKernelGGL(solve_bwd_adam_kernel, dim3(p.out_ch / SV_BM, (unsigned)rw_cdiv(9 * p.in_ch, SV_BNK)), dim3(256), 0,
                      s, p, pp, (const float*)lpart);
   const size_t lds = 2 * (size_t)p.in_ch * 9 * sizeof(float);
-  if (p.low_rank_gradient || p.linear_insert || project) {
-    if (lds > 64 * 1024) return RW_ERR_UNSUPPORTED;
-  }
   if (p.low_rank_gradient) {
     hipLaunchKernelGGL(project_kernel<1>, dim3(p.out_ch), dim3(256), lds, s, (const float*)p.grad,
                        p.context, (const float*)nullptr, (float*)nullptr, p.in_ch, 9, p.rank, p);

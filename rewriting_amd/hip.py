@@ -380,6 +380,18 @@ def solve_ksplit(out_ch, in_ch, h, w):
     return lib().rw_solve_ksplit(out_ch, in_ch, h, w)
 
 
+def solve_supported(out_ch, in_ch, h, w, upsample, plain, constrained):
+    """True when rw_solve_step_f32 takes this target (h, w: the key crop); never raises."""
+    return lib().rw_solve_supported(out_ch, in_ch, h, w, int(bool(upsample)), int(bool(plain)),
+                                    int(bool(constrained))) == 0
+
+
+def solve_scratch_elems(out_ch, in_ch, h, w, upsample):
+    sizes = (ctypes.c_longlong * 5)()
+    check(lib().rw_solve_scratch_elems(out_ch, in_ch, h, w, int(bool(upsample)), sizes))
+    return dict(zip(('conv', 'wsq', 'gd', 'c2', 'grad'), (int(v) for v in sizes)))
+
+
 def solve_step(problem, project):
     check(lib().rw_solve_step_f32(ctypes.byref(problem), int(bool(project)), _stream()))
 

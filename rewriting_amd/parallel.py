@@ -37,11 +37,50 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+_independent = [0]
+
+
+class replicas:
+    """Context manager: inside it the ranks run INDEPENDENT jobs (different edits / watermark variants on
+    different GPUs -- the part of the path that does not shard), so ``shard()`` is None and every
+    sweep a rewriter runs is local to its rank: no collective is entered."""
+
+    def __enter__(self):
+        _independent[0] += 1
+        return self
+
+    def __exit__(self, *exc):
+        _independent[0] -= 1
+
+
 def shard():
-    """(rank, world) for ``tally.tally_second_moment(shard=...)``; None when single-process."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    """(rank, world) for ``tally.tally_second_moment(shard=...)``; None when single-process or inside
+    ``replicas()``."""
+    if _independent[0] == 0 and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         return dist.get_rank(), dist.get_world_size()
     return None
+
+
+def _coll_device():
+    if dist.get_backend() == 'nccl':
+        return torch.device('cuda', torch.cuda.current_device())
+    return torch.device('cpu')
+
+
+def all_agree(flag):
+    """True only if `flag` is true on EVERY rank (one tiny MIN all-reduce); the local value when single-process.
+    Used for decisions that must be collective -- e.g. "everybody found the statistics cache" -- so that no rank
+    enters a sweep's all-reduce while another returns early."""
+    if shard() is None:
+        return bool(flag)
+    t = torch.tensor([1.0 if flag else 0.0], device=_coll_device())
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item() > 0.5)
+
+
+def barrier():
+    if shard() is not None:
+        dist.barrier()
 
 
 def batches_for_rank(n_batches, rank, world):
@@ -49,50 +88,61 @@ def batches_for_rank(n_batches, rank, world):
 
 
 def allreduce_second_moment(r2mom):
-    """In place: every rank ends with the global (mom2, count)."""
+    """In place: every rank ends with the global (mom2, count).  A rank whose shard was empty (fewer batches
+    than ranks) contributes zeros: the channel count is agreed first, so nobody blocks while another raises."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return r2mom
-    backend = dist.get_backend()
-    if r2mom.mom2 is None:
-        raise RuntimeError('rank %d received no batches; use at least world_size batches' % dist.get_rank())
-    dev = r2mom.mom2.device
-    if backend == 'nccl' and not r2mom.mom2.is_cuda:
-        dev = torch.device('cuda', torch.cuda.current_device())
-    if backend == 'gloo':
-        dev = torch.device('cpu')
-    packed = torch.cat([r2mom.mom2.to(dev, torch.float64).reshape(-1),
-                        torch.tensor([float(r2mom.count)], dtype=torch.float64, device=dev)])
+    dev = _coll_device()
+    have = r2mom.mom2 is not None
+    shape = torch.tensor([float(r2mom.mom2.shape[0]) if have else 0.0], device=dev)
+    dist.all_reduce(shape, op=dist.ReduceOp.MAX)
+    c = int(shape.item())
+    if c == 0:
+        raise RuntimeError('second-moment sweep: no rank received a batch')
+    if have:
+        home_dev, home_dtype = r2mom.mom2.device, r2mom.mom2.dtype
+        local = r2mom.mom2.to(dev, torch.float64).reshape(-1)
+    else:
+        home_dev, home_dtype = dev, torch.float32
+        local = torch.zeros(c * c, dtype=torch.float64, device=dev)
+    packed = torch.cat([local, torch.tensor([float(r2mom.count)], dtype=torch.float64, device=dev)])
     dist.all_reduce(packed, op=dist.ReduceOp.SUM)
-    r2mom.mom2 = packed[:-1].reshape(r2mom.mom2.shape).to(r2mom.mom2.dtype).to(r2mom.mom2.device)
+    r2mom.mom2 = packed[:-1].reshape(c, c).to(home_dtype).to(home_dev)
     r2mom.count = int(round(packed[-1].item()))
     return r2mom
 
 
 def allreduce_variance(rv):
     """In place: pooled (count, mean, centred second moment) of a RunningVariance over all ranks
-    (exact pooling: M2 = sum M2_r + sum n_r (mean_r - mean)^2), reduced in float64."""
+    (exact pooling: M2 = sum M2_r + sum n_r (mean_r - mean)^2), reduced in float64.  Empty shards contribute
+    zeros (see allreduce_second_moment)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return rv
-    if rv._mean is None:
-        raise RuntimeError('rank %d received no batches' % dist.get_rank())
-    dev = rv._mean.device
-    if dist.get_backend() == 'gloo':
-        dev = torch.device('cpu')
-    elif not rv._mean.is_cuda:
-        dev = torch.device('cuda', torch.cuda.current_device())
-    n = float(rv.count)
-    mean = rv._mean.to(dev, torch.float64)
-    packed = torch.cat([mean * n, rv.v_cmom2.to(dev, torch.float64) + n * mean * mean,
-                        torch.tensor([n, float(rv.batchcount)], dtype=torch.float64, device=dev)])
-    dist.all_reduce(packed, op=dist.ReduceOp.SUM)
-    c = mean.numel()
+    dev = _coll_device()
+    have = rv._mean is not None
+    shape = torch.tensor([float(rv._mean.numel()) if have else 0.0], device=dev)
+    dist.all_reduce(shape, op=dist.ReduceOp.MAX)
+    c = int(shape.item())
+    if c == 0:
+        raise RuntimeError('mean/variance sweep: no rank received a batch')
+    if have:
+        home_dev, home_dtype = rv._mean.device, rv._mean.dtype
+        n = float(rv.count)
+        mean = rv._mean.to(dev, torch.float64)
+        local = torch.cat([mean * n, rv.v_cmom2.to(dev, torch.float64) + n * mean * mean,
+                           torch.tensor([n, float(rv.batchcount)], dtype=torch.float64, device=dev)])
+    else:
+        home_dev, home_dtype = dev, torch.float32
+        local = torch.zeros(2 * c + 2, dtype=torch.float64, device=dev)
+    dist.all_reduce(local, op=dist.ReduceOp.SUM)
+    packed = local
     total = packed[-2].item()
     gmean = packed[:c] / total
     m2 = packed[c:2 * c] - total * gmean * gmean
     rv.count = int(round(total))
     rv.batchcount = int(round(packed[-1].item()))
-    rv._mean = gmean.to(rv._mean.dtype).to(rv._mean.device)
-    rv.v_cmom2 = m2.clamp_(min=0).to(rv.v_cmom2.dtype).to(rv.v_cmom2.device)
+    rv._mean = gmean.to(home_dtype).to(home_dev)
+    rv.v_cmom2 = m2.clamp_(min=0).to(home_dtype).to(home_dev)
     return rv
 
 

@@ -15,7 +15,7 @@ import os
 import torch
 
 from .. import hip
-from ..utils.stylegan2.models import reference_noise
+from ..utils.stylegan2.models import bump_weight_epoch, reference_noise
 
 
 def _ptr(t):
@@ -70,13 +70,18 @@ class Solver:
         self.bc2_sqrt = torch.tensor([math.sqrt(1 - 0.999 ** t) for t in steps], **f32)
         self.counter = torch.full((1,), -1, device=dev, dtype=torch.int32)
         self.losses = torch.zeros(niter, **f32)
+        if not hip.solve_supported(O, I, h, wd, upsample, plain, constrained):
+            raise NotImplementedError(
+                'the fused HIP solver takes out_ch %% 64 == 0, in_ch %% 16 == 0, in_ch <= 910 with a context '
+                'direction, and for an upsampling target a key crop with (2h+1)(2w+1) + 4hw <= 16384 '
+                '(got %d -> %d channels, key crop %d x %d, upsample=%s)' % (I, O, h, wd, bool(upsample)))
         ks = hip.solve_ksplit(O, I, ch, cw)
-        pp = -(-(ch * cw) // 64) * 64
-        self.conv = torch.empty(ks, O, pp, **f32)
-        self.wsq = torch.empty(ks, O, **f32)
-        self.gd = torch.empty(O, pp, **f32)
-        self.c2 = torch.empty(2 * O, **f32)
-        self.grad = torch.empty_like(w) if (low_rank_gradient or linear) else None
+        n = hip.solve_scratch_elems(O, I, h, wd, upsample)      # sizes as the library states them
+        self.conv = torch.empty(n['conv'], **f32)
+        self.wsq = torch.empty(n['wsq'], **f32)
+        self.gd = torch.empty(n['gd'], **f32)
+        self.c2 = torch.empty(n['c2'], **f32)
+        self.grad = torch.empty(n['grad'], **f32) if (low_rank_gradient or linear) else None
         p = hip.SolveProblem()
         p.out_ch, p.in_ch, p.h, p.w = O, I, h, wd
         p.rank = self.context.shape[0] if constrained else 0
@@ -110,11 +115,23 @@ class Solver:
         hip.project_weight(self._w, self.context, base=self.ortho, out=self._w)
 
     def run(self, update_callback=None):
+        """The kernels write the parameter through its raw pointer, which torch's version counter cannot
+        see: every cache of tensors derived from it (packed weights, squared sums) is invalidated before each
+        callback -- a callback that renders through the model sees the stepped weight, as the reference's
+        does (rewrite/ganrewrite.py:288-289) -- and, whatever happens (an exception in the callback,
+        KeyboardInterrupt in the middle of 2001 steps), once more on the way out."""
+        try:
+            self._run(update_callback)
+        finally:
+            bump_weight_epoch()
+
+    def _run(self, update_callback):
         niter, piter = self.niter, self.piter
         if update_callback is not None:
             # reference order: step, callback (sees the stepped, not yet projected weight), projection
             for it in range(niter):
                 self.step(it, project=False)
+                bump_weight_epoch()
                 update_callback(it, self.losses[it])
                 if self.projects(it):
                     self.project_now()

@@ -38,31 +38,51 @@ def make_loader(dataset, sample_size=None, batch_size=10, sampler=None, **kwargs
     return torch.utils.data.DataLoader(dataset, sampler=sampler, batch_size=batch_size, **kwargs)
 
 
-def load_cached_state(cachefile, args):
-    if cachefile is None:
+def load_cached_state(cachefile, args, construct=None, shard=None):
+    """The cached statistic, or None.  A cache counts only if its stored arguments match (utils/tally.py:703-718),
+    if `construct(state)` can rebuild the statistic from it -- a file of another schema (e.g. a unit_rq.npz
+    written by the reference's randomised RunningQuantile) is a miss, not an error -- and, in a sharded sweep,
+    if EVERY rank found it: the decision is collective, so no rank returns early while the others enter the
+    sweep's all-reduce."""
+    from .. import parallel
+    result = None
+    if cachefile is not None:
+        try:
+            dat = numpy.load(cachefile, allow_pickle=True)
+            ok = True
+            for a, v in args.items():
+                if a not in dat or dat[a] != v:
+                    pbar.print('%s %s changed from %s to %s' % (cachefile, a, dat[a] if a in dat else None, v))
+                    ok = False
+                    break
+            if ok:
+                result = construct(dat) if construct is not None else dat
+        except Exception:
+            result = None
+    if shard is not None and shard[1] > 1 and not parallel.all_agree(result is not None):
         return None
-    try:
-        dat = numpy.load(cachefile, allow_pickle=True)
+    if result is not None:
+        pbar.print('Loading cached %s' % cachefile)
+    return result
+
+
+def save_cached_state(cachefile, obj, args, shard=None):
+    """numpy.savez of the state dict plus the call arguments (utils/tally.py:721-730).  Written by rank 0 only,
+    to a temporary file that is renamed into place (readers never see a partial file), and followed by a
+    barrier in a sharded sweep: when any rank goes on, the cache exists."""
+    from .. import parallel
+    if cachefile is not None and (shard is None or shard[0] == 0):
+        os.makedirs(os.path.dirname(cachefile) or '.', exist_ok=True)
+        dat = obj.state_dict()
         for a, v in args.items():
-            if a not in dat or dat[a] != v:
-                pbar.print('%s %s changed from %s to %s' % (cachefile, a, dat[a], v))
-                return None
-    except Exception:
-        return None
-    pbar.print('Loading cached %s' % cachefile)
-    return dat
-
-
-def save_cached_state(cachefile, obj, args):
-    if cachefile is None:
-        return
-    os.makedirs(os.path.dirname(cachefile) or '.', exist_ok=True)
-    dat = obj.state_dict()
-    for a, v in args.items():
-        if a in dat:
-            assert dat[a] == v
-        dat[a] = v
-    numpy.savez(cachefile, **dat)
+            if a in dat:
+                assert dat[a] == v
+            dat[a] = v
+        tmp = '%s.tmp.%d.npz' % (cachefile, os.getpid())
+        numpy.savez(tmp, **dat)
+        os.replace(tmp, cachefile)
+    if shard is not None and shard[1] > 1:
+        parallel.barrier()
 
 
 def _sharded(loader, shard):
@@ -80,9 +100,9 @@ def tally_second_moment(compute, dataset, sample_size=None, batch_size=10, cache
     """compute(batch) -> (rows, C) samples [or (B, C, H, W) when nchw]; returns RunningSecondMoment
     (on the CPU, like the reference)."""
     args = dict(sample_size=sample_size)
-    cached = load_cached_state(cachefile, args)
+    cached = load_cached_state(cachefile, args, lambda st: runningstats.RunningSecondMoment(state=st), shard)
     if cached is not None:
-        return runningstats.RunningSecondMoment(state=cached)
+        return cached
     loader = make_loader(dataset, sample_size, batch_size, **kwargs)
     r2mom = runningstats.RunningSecondMoment()
     for batch in pbar(_sharded(loader, shard)):
@@ -95,17 +115,16 @@ def tally_second_moment(compute, dataset, sample_size=None, batch_size=10, cache
         from .. import parallel
         parallel.allreduce_second_moment(r2mom)
     r2mom.to_('cpu')
-    if shard is None or shard[0] == 0:
-        save_cached_state(cachefile, r2mom, args)
+    save_cached_state(cachefile, r2mom, args, shard)
     return r2mom
 
 
 def tally_mean(compute, dataset, sample_size=None, batch_size=10, cachefile=None, nchw=False,
                square_input=False, shard=None, **kwargs):
     args = dict(sample_size=sample_size)
-    cached = load_cached_state(cachefile, args)
+    cached = load_cached_state(cachefile, args, lambda st: runningstats.RunningVariance(state=st), shard)
     if cached is not None:
-        return runningstats.RunningVariance(state=cached)
+        return cached
     loader = make_loader(dataset, sample_size, batch_size, **kwargs)
     rv = runningstats.RunningVariance()
     for batch in pbar(_sharded(loader, shard)):
@@ -114,23 +133,29 @@ def tally_mean(compute, dataset, sample_size=None, batch_size=10, cachefile=None
         from .. import parallel
         parallel.allreduce_variance(rv)
     rv.to_('cpu')
-    if shard is None or shard[0] == 0:
-        save_cached_state(cachefile, rv, args)
+    save_cached_state(cachefile, rv, args, shard)
     return rv
+
+
+def _replicated():
+    """tally_quantile / tally_topk_and_quantile are not sharded: under torch.distributed every rank that calls
+    them computes the whole statistic for itself, takes its own cache decision and may write the (identical)
+    cache -- through its own temporary file and an atomic rename, so concurrent writers cannot tear it."""
+    return None
 
 
 def tally_quantile(compute, dataset, sample_size=None, batch_size=10, r=4096, cachefile=None, **kwargs):
     """compute(batch) -> (samples, units); returns RunningQuantile (reference: utils/tally.py:132-154)."""
     args = dict(sample_size=sample_size, r=r)
-    cached = load_cached_state(cachefile, args)
+    cached = load_cached_state(cachefile, args, lambda st: runningstats.RunningQuantile(state=st), _replicated())
     if cached is not None:
-        return runningstats.RunningQuantile(state=cached)
+        return cached
     loader = make_loader(dataset, sample_size, batch_size, **kwargs)
     rq = runningstats.RunningQuantile(r=r)
     for batch in pbar(loader):
         rq.add(call_compute(compute, batch))
     rq.to_('cpu')
-    save_cached_state(cachefile, rq, args)
+    save_cached_state(cachefile, rq, args, _replicated())
     return rq
 
 
@@ -140,10 +165,13 @@ def tally_topk_and_quantile(compute, dataset, sample_size=None, batch_size=10, k
     (reference: utils/tally.py:157-181; its cached branch has two typos, quirk Q11 -- here the
     cache simply stores both state dicts under the prefixes 'rtk.' and 'rq.')."""
     args = dict(sample_size=sample_size, k=k, r=r)
-    cached = load_cached_state(cachefile, args)
-    if cached is not None:
-        pick = lambda pre: {key[len(pre):]: cached[key] for key in cached.files if key.startswith(pre)}
+
+    def both(st):
+        pick = lambda pre: {key[len(pre):]: st[key] for key in st.files if key.startswith(pre)}
         return (runningstats.RunningTopK(state=pick('rtk.')), runningstats.RunningQuantile(state=pick('rq.')))
+    cached = load_cached_state(cachefile, args, both, _replicated())
+    if cached is not None:
+        return cached
     loader = make_loader(dataset, sample_size, batch_size, **kwargs)
     rtk, rq = runningstats.RunningTopK(k=k), runningstats.RunningQuantile(r=r)
     for batch in pbar(loader):
@@ -158,5 +186,5 @@ def tally_topk_and_quantile(compute, dataset, sample_size=None, batch_size=10, k
             d = {'rtk.' + a: b for a, b in rtk.state_dict().items()}
             d.update({'rq.' + a: b for a, b in rq.state_dict().items()})
             return d
-    save_cached_state(cachefile, _Both(), args)
+    save_cached_state(cachefile, _Both(), args, _replicated())
     return rtk, rq

@@ -158,6 +158,73 @@ def test_demodulated_conv_matches_oracle(case, impl):
     assert rel(fused, want) < 1e-5
 
 
+# The shapes the benchmark actually runs (BASELINE.json configs[1] and the headline 1024^2 forward; the
+# kernels that carry the bench line: conv_halo_kernel<1,4,1,4,8> 32->32 @1024^2, <2,2,1,4,16> 64->64 @512^2,
+# <2,2,2,2,16> 128->128 @256^2 and conv_up_halo_kernel<1,4,16,32> 64->32 @512->1024, <2,2,16,32> 128->64 @256->512),
+# batch 1, against the oracle's conv on the host (utils/stylegan2/models.py:313-329).
+BENCH_CONV_CASES = [(1, 32, 32, 1024, 1024), (1, 64, 64, 512, 512), (1, 128, 128, 256, 256), (1, 256, 256, 128, 128)]
+BENCH_UP_CASES = [(1, 64, 32, 512, 512), (1, 128, 64, 256, 256), (1, 256, 128, 128, 128)]
+
+
+@pytest.mark.parametrize('case', BENCH_CONV_CASES)
+def test_bench_shape_convs_match_oracle(case):
+    from rewriting_amd import hip
+    from oracle import restatement as R
+    b, i, o, h, w = case
+    x, wt, style = _conv_inputs(*case, seed=21)
+    rs = numpy.random.RandomState(22)
+    bias = torch.from_numpy(rs.randn(o).astype('float32'))
+    nw = torch.tensor([0.1])
+    noise = R.noise_rows(b, h * w)
+    s = 1 / math.sqrt(i * 9)
+    conv = R.demod_conv(style[:, :, None, None] * x, style, wt, upsample=False)
+    want = R.fused_leaky_relu(conv + nw * noise.view(b, 1, h, w), bias)
+    wp = hip.pack_conv_weight(wt.to(DEV), 0)
+    dm = hip.demod(hip.weight_sqsum(wt.to(DEV), s), style.to(DEV))
+    plain = hip.conv3x3(x.to(DEV), wp, o, s, style=style.to(DEV), demod=dm)
+    assert rel(plain, conv) < 1e-5
+    assert (plain.cpu() - conv).abs().max().item() < 1e-4 * max(1.0, conv.abs().max().item())
+    got = hip.conv3x3(x.to(DEV), wp, o, s, style=style.to(DEV), demod=dm, noise=noise.to(DEV),
+                      noise_w=nw.to(DEV), bias=bias.to(DEV), act=True)
+    assert rel(got, want) < 1e-5
+    assert (got.cpu() - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())
+    if hip.to_rgb_fusable(o, i, w):             # the last layer's call in the bench: ToRGB in the epilogue
+        wrgb = torch.from_numpy(rs.randn(3, o).astype('float32'))
+        srgb = torch.from_numpy((1 + 0.3 * rs.randn(b, o)).astype('float32'))
+        brgb = torch.from_numpy(rs.randn(3).astype('float32'))
+        skip = torch.from_numpy(rs.randn(b, 3, h, w).astype('float32'))
+        wm = (1 / math.sqrt(o)) * wrgb[None] * srgb[:, None, :]
+        want_rgb = torch.einsum('bco,bohw->bchw', wm, want) + brgb.view(1, 3, 1, 1) + skip
+        _, rgb = hip.conv3x3_to_rgb(x.to(DEV), wp, o, s, wrgb.to(DEV), srgb.to(DEV), brgb.to(DEV), skip.to(DEV),
+                                    1 / math.sqrt(o), style=style.to(DEV), demod=dm, noise=noise.to(DEV),
+                                    noise_w=nw.to(DEV), bias=bias.to(DEV), act=True)
+        assert rel(rgb, want_rgb) < 1e-5
+
+
+@pytest.mark.parametrize('case', BENCH_UP_CASES)
+def test_bench_shape_transposed_convs_and_blur_match_oracle(case):
+    from rewriting_amd import hip
+    from oracle import restatement as R
+    b, i, o, h, w = case
+    x, wt, style = _conv_inputs(*case, seed=23)
+    rs = numpy.random.RandomState(24)
+    bias = torch.from_numpy(rs.randn(o).astype('float32'))
+    nw = torch.tensor([0.1])
+    noise = R.noise_rows(b, 4 * h * w)
+    s = 1 / math.sqrt(i * 9)
+    wide = R.demod_conv(style[:, :, None, None] * x, style, wt, upsample=True)
+    k4 = R.make_kernel([1, 3, 3, 1]) * 4
+    want = R.fused_leaky_relu(R.upfirdn2d(wide, k4, pad=(1, 1)) + nw * noise.view(b, 1, 2 * h, 2 * w), bias)
+    wp = hip.pack_conv_weight(wt.to(DEV), 1)
+    dm = hip.demod(hip.weight_sqsum(wt.to(DEV), s), style.to(DEV))
+    got_wide = hip.conv_transpose3x3s2(x.to(DEV), wp, o, s, style=style.to(DEV), demod=dm)
+    assert rel(got_wide, wide) < 1e-5
+    assert (got_wide.cpu() - wide).abs().max().item() < 1e-4 * max(1.0, wide.abs().max().item())
+    got = hip.blur_noise_act(got_wide, k4.to(DEV), noise.to(DEV), nw.to(DEV), bias.to(DEV))
+    assert rel(got, want) < 1e-5
+    assert (got.cpu() - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())
+
+
 @pytest.mark.parametrize('case', [(2, 32, 32, 40, 64), (1, 64, 64, 32, 32), (2, 16, 32, 24, 70), (1, 128, 64, 24, 33)])
 @pytest.mark.parametrize('store', [False, True])
 def test_conv_with_fused_to_rgb_matches_separate_kernels(case, store):
