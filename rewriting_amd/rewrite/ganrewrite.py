@@ -491,12 +491,17 @@ class ProgressiveGanRewriter(object):
         return topk.result()[1], rq
 
     def _overlay(self):
-        try:
-            from ..utils import imgviz      # optional: visualisation is outside the hot path
-            return imgviz
-        except ImportError:
-            raise NotImplementedError('heat-map / mask overlays need utils.imgviz (visualisation is '
-                                      'outside the hot path); plain rendering works')
+        """utils.imgviz (heat-map / mask overlays, outside the hot path): this package's own if it has one,
+        else the reference's through install_reference_aliases(reference_root=...)."""
+        import importlib
+        for name in ('rewriting_amd.utils.imgviz', 'utils.imgviz'):
+            try:
+                return importlib.import_module(name)
+            except ImportError:
+                continue
+        raise NotImplementedError('heat-map / mask overlays need utils.imgviz (visualisation is outside the hot '
+                                  'path; install_reference_aliases(reference_root=...) provides the '
+                                  "reference's); plain rendering works")
 
     def render_object(self, target_output, obj_area=None, box=None):
         with torch.no_grad():

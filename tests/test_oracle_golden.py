@@ -2,6 +2,7 @@
 produced by the reference's own files (oracle/make_golden.py), and -- when /root/reference is
 present -- against the reference executed live."""
 import json
+import os
 import math
 
 import numpy
@@ -181,3 +182,53 @@ def test_restatement_against_live_reference():
     sd = {k: v.detach().clone() for k, v in g.state_dict().items()}
     got = R.generator_forward(sd, z, 16, truncation=0.7)
     assert (got - want).abs().max() < 1e-5
+
+
+@pytest.mark.skipif(not reference_shim.available(), reason='the cache file lives in /root/reference')
+def test_statistics_cache_interoperates_with_the_reference(tmp_path):
+    """the reference's own notebooks/masks/reflections/progan-kitchen/r2m.npz loads into this
+    package's RunningSecondMoment and through tally.load_cached_state (utils/tally.py:703-718,
+    utils/runningstats.py:1111-1120); a cache written here loads into the REFERENCE's RunningSecondMoment and
+    through the reference's own tally.tally_second_moment cache branch; byte-level schema equal."""
+    import numpy
+    from rewriting_amd.utils import runningstats, tally
+    ref = reference_shim.load()
+    path = os.path.join(reference_shim.REFERENCE_ROOT, 'notebooks/masks/reflections/progan-kitchen/r2m.npz')
+    theirs = numpy.load(path, allow_pickle=True)
+    r = runningstats.RunningSecondMoment(state=theirs)
+    assert r.count == int(theirs['count']) == 256000 and tuple(r.mom2.shape) == (512, 512)
+    assert torch.equal(r.mom2, torch.from_numpy(theirs['mom2']))
+    want = ref.runningstats.RunningSecondMoment(state=theirs).moment()
+    assert torch.equal(r.moment(), want)
+    via_tally = tally.tally_second_moment(lambda z: None, torch.zeros(1, 1), sample_size=None, cachefile=path)
+    assert torch.equal(via_tally.moment(), want)                   # found, matched on sample_size, never swept
+    # round trip: what this package writes has the reference's keys and dtypes ...
+    mine = str(tmp_path / 'r2m.npz')
+    tally.save_cached_state(mine, r, dict(sample_size=None))
+    back = numpy.load(mine, allow_pickle=True)
+    assert sorted(back.files) == sorted(theirs.files) == ['constructor', 'count', 'mom2', 'sample_size']
+    for k in ('count', 'mom2'):
+        assert back[k].dtype == theirs[k].dtype and back[k].shape == theirs[k].shape, k
+    assert numpy.array_equal(back['mom2'], theirs['mom2']) and back['sample_size'].dtype == object
+    # ... and the reference reads it: directly, and through its tally cache branch (which returns before sweeping)
+    assert torch.equal(ref.runningstats.RunningSecondMoment(state=back).moment(), want)
+    got = ref.tally.tally_second_moment(lambda z: None, torch.zeros(1, 1), sample_size=None, cachefile=mine)
+    assert torch.equal(got.moment(), want)
+    # a statistic accumulated here (CPU reference path of the class) and cached is read back identically by both
+    fresh = runningstats.RunningSecondMoment()
+    rows = torch.randn(300, 16, generator=torch.Generator().manual_seed(0))
+    fresh.mom2, fresh.count = rows.t() @ rows, 300
+    tally.save_cached_state(str(tmp_path / 'b.npz'), fresh, dict(sample_size=7))
+    assert ref.tally.load_cached_state(str(tmp_path / 'b.npz'), dict(sample_size=7)) is not None
+    assert ref.tally.load_cached_state(str(tmp_path / 'b.npz'), dict(sample_size=8)) is None     # args mismatch
+    theirs2 = ref.runningstats.RunningSecondMoment(state=numpy.load(str(tmp_path / 'b.npz'), allow_pickle=True))
+    assert torch.equal(theirs2.moment(), fresh.moment())
+    # RunningVariance (unit_rs.npz, used by the erase goal): both directions
+    rv = ref.runningstats.RunningVariance()
+    rv.add(rows)
+    numpy.savez(str(tmp_path / 'rs.npz'), **rv.state_dict())
+    ours = runningstats.RunningVariance(state=numpy.load(str(tmp_path / 'rs.npz'), allow_pickle=True))
+    assert torch.allclose(ours.mean(), rv.mean()) and torch.allclose(ours.variance(), rv.variance())
+    numpy.savez(str(tmp_path / 'rs2.npz'), **ours.state_dict())
+    back2 = ref.runningstats.RunningVariance(state=numpy.load(str(tmp_path / 'rs2.npz'), allow_pickle=True))
+    assert torch.allclose(back2.mean(), rv.mean()) and torch.allclose(back2.variance(), rv.variance())
