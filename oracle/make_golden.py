@@ -264,9 +264,21 @@ def golden_sweep_1024(ref, name):
         arrays['l%d/c_matrix_norm' % layer] = numpy.float64(C.double().norm().item())
         arrays['l%d/c_matrix_diag' % layer] = C.diag().numpy()
         arrays['l%d/k_shape' % layer] = numpy.array(gw.k_shape)
-        with torch.no_grad():
-            zb = torch.stack([zds[i][0] for i in range(10)])
-            kmap = gw.context_model(zb).fmap
+        exact = torch.zeros(C.shape[0], C.shape[0], dtype=torch.float64)     # see golden_edit_full: the reference
+        with torch.no_grad():                                                  # accumulates in float32
+            for b0 in (10, 0):
+                zb = torch.stack([zds[i][0] for i in range(b0, b0 + 10)])
+                kmap = gw.context_model(zb).fmap
+                a = kmap.permute(0, 2, 3, 1).reshape(-1, C.shape[0]).double()
+                exact += a.t() @ a
+        exact /= 20.0 * kmap.shape[2] * kmap.shape[3]
+        arrays['l%d/c_exact' % layer] = exact.numpy()[::4, ::4].copy() if C.shape[0] > 128 else exact.numpy().copy()
+        arrays['l%d/c_exact_diag' % layer] = exact.diag().numpy()
+        arrays['l%d/c_exact_norm' % layer] = numpy.float64(exact.norm().item())
+        arrays['l%d/c_ref_vs_exact_max' % layer] = numpy.float64((C.double() - exact).abs().max().item())
+        arrays['l%d/c_ref_vs_exact' % layer] = numpy.float64(((C.double() - exact).norm() / exact.norm()).item())
+        print('layer', layer, 'reference C vs exact: max abs %.3e of %.3f' % (
+            arrays['l%d/c_ref_vs_exact_max' % layer], C.abs().max().item()))
         for row in (0, 3, 9):
             arrays['l%d/key_row%d_sub' % (layer, row)], arrays['l%d/key_row%d_norm' % (layer, row)] = \
                 sub(kmap[row], 4096)
