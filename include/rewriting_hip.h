@@ -174,6 +174,25 @@ int rw_pack_conv_weight_bf16x3(const float* w, void* wb, int out_ch, int in_ch, 
 int rw_conv3x3_bf16x6_f32(const float* x, const void* wb, float* y, int batch, int in_ch, int out_ch,
                           int h, int w, float w_scale, const rw_conv_epilogue* ep, rw_stream_t stream);
 
+/* The same stride-1 convolution (and the same fused epilogues) by the Winograd minimal-filtering algorithm
+ * F(2x2, 3x3) in fp32: 16 instead of 36 multiplications per 2x2 output tile and channel pair, i.e. 2.25x fewer
+ * matrix FLOPs for a result that is identical in exact arithmetic and of the direct kernel's error class in
+ * fp32 (transform coefficients 0, +-1, +-1/2; fp32 MFMA accumulation).  rw_conv3x3_wino_supported() says which
+ * shapes it takes (out_ch % 32 == 0, in_ch % 8 == 0, w % 32 == 0, h % 8 == 0); elsewhere, and whenever the
+ * caller prefers the direct sum, rw_conv3x3_f32 is the kernel.
+ *   uf: rw_packed_conv_weight_wino_elems(out_ch, in_ch) = 16*out_ch*in_ch floats from rw_pack_conv_weight_wino_f32:
+ *       U = G g G^T of every (o, i) filter in MFMA A-fragment order
+ *       uf[o / 32][i / 2][xi / 8][(xi % 8) / 4][lane][xi % 4],  o = 32 (o/32) + (lane & 31), i = 2 (i/2) + (lane >> 5).
+ * rw_conv3x3_wino_to_rgb_f32: ToRGB in the epilogue as rw_conv3x3_to_rgb_f32 (out_ch == 32 only). */
+int rw_conv3x3_wino_supported(int out_ch, int in_ch, int h, int w);
+long long rw_packed_conv_weight_wino_elems(int out_ch, int in_ch);
+int rw_pack_conv_weight_wino_f32(const float* w, float* uf, int out_ch, int in_ch, rw_stream_t stream);
+int rw_conv3x3_wino_f32(const float* x, const float* uf, float* y, int batch, int in_ch, int out_ch, int h,
+                        int w, float w_scale, const rw_conv_epilogue* ep, rw_stream_t stream);
+int rw_conv3x3_wino_to_rgb_f32(const float* x, const float* uf, float* y, int batch, int in_ch, int out_ch,
+                               int h, int w, float w_scale, const rw_conv_epilogue* ep,
+                               const rw_rgb_epilogue* rgb, rw_stream_t stream);
+
 /* F.conv_transpose2d(x, scale*W^T, stride=2, padding=0) [* demod]     (models.py:315-316,328)
  * x (B,Cin,H,W) -> y (B,Cout,2H+1,2W+1), wp from rw_pack_conv_weight_f32 mode 1. */
 int rw_conv_transpose3x3s2_f32(const float* x, const float* wp, float* y, int batch, int in_ch,

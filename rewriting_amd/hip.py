@@ -226,6 +226,63 @@ def conv3x3_to_rgb(x, wp, out_ch, w_scale, rgb_weight, rgb_style, rgb_bias, rgb_
     return y, rgb
 
 
+def wino_supported(out_ch, in_ch, height, width):
+    """Shapes the Winograd F(2x2,3x3) stride-1 convolution takes (rw_conv3x3_wino_supported)."""
+    return bool(lib().rw_conv3x3_wino_supported(int(out_ch), int(in_ch), int(height), int(width)))
+
+
+def pack_conv_weight_wino(weight):
+    weight = _dev(weight, 'weight')
+    o, i = weight.shape[-4], weight.shape[-3]
+    n = lib().rw_packed_conv_weight_wino_elems(o, i)
+    if n <= 0:
+        raise ValueError('no Winograd packing for a %d x %d weight' % (o, i))
+    uf = torch.empty(n, device=weight.device, dtype=torch.float32)
+    check(lib().rw_pack_conv_weight_wino_f32(_p(weight), _p(uf), o, i, _stream()))
+    return uf
+
+
+def conv3x3_wino(x, uf, out_ch, w_scale, style=None, demod=None, noise=None, noise_w=None, bias=None, act=False):
+    """Stride-1 3x3 convolution by Winograd F(2x2,3x3) in fp32; same arguments and epilogue as conv3x3."""
+    x = _dev(x, 'fmap')
+    uf = _dev(uf, 'packed weight')
+    b, i, h, w = x.shape
+    if uf.numel() != lib().rw_packed_conv_weight_wino_elems(out_ch, i):
+        raise ValueError('packed weight does not come from pack_conv_weight_wino(%d x %d)' % (out_ch, i))
+    y = torch.empty(b, out_ch, h, w, device=x.device, dtype=x.dtype)
+    ep, keep = _epilogue(style, demod, noise, noise_w, bias, act)
+    check(lib().rw_conv3x3_wino_f32(_p(x), _p(uf), _p(y), b, i, out_ch, h, w, float(w_scale), ctypes.byref(ep),
+                                    _stream()))
+    return y
+
+
+def conv3x3_wino_to_rgb(x, uf, out_ch, w_scale, rgb_weight, rgb_style, rgb_bias, rgb_skip, rgb_scale, style=None,
+                        demod=None, noise=None, noise_w=None, bias=None, act=False, store_fmap=False):
+    """conv3x3_wino with ToRGB in the epilogue (out_ch == 32): returns (fmap or None, rgb image)."""
+    x = _dev(x, 'fmap')
+    uf = _dev(uf, 'packed weight')
+    rgb_weight = _dev(rgb_weight, 'rgb weight').contiguous()
+    rgb_style = _dev(rgb_style, 'rgb style').contiguous()
+    rgb_bias = _opt(rgb_bias, 'rgb bias')
+    rgb_skip = _opt(rgb_skip, 'rgb skip')
+    b, i, h, w = x.shape
+    if tuple(rgb_weight.shape) != (3, out_ch) or tuple(rgb_style.shape) != (b, out_ch):
+        raise ValueError('rgb weight / style shapes')
+    if rgb_skip is not None and tuple(rgb_skip.shape) != (b, 3, h, w):
+        raise ValueError('rgb skip shape')
+    if uf.numel() != lib().rw_packed_conv_weight_wino_elems(out_ch, i):
+        raise ValueError('packed weight does not come from pack_conv_weight_wino(%d x %d)' % (out_ch, i))
+    y = torch.empty(b, out_ch, h, w, device=x.device, dtype=x.dtype) if store_fmap else None
+    rgb = torch.empty(b, 3, h, w, device=x.device, dtype=x.dtype)
+    ep, keep = _epilogue(style, demod, noise, noise_w, bias, act)
+    from ._lib import RgbEpilogue
+    re = RgbEpilogue(_p(rgb_weight).value, _p(rgb_style).value, _p(rgb_bias).value, _p(rgb_skip).value,
+                     _p(rgb).value, float(rgb_scale))
+    check(lib().rw_conv3x3_wino_to_rgb_f32(_p(x), _p(uf), _p(y), b, i, out_ch, h, w, float(w_scale),
+                                           ctypes.byref(ep), ctypes.byref(re), _stream()))
+    return y, rgb
+
+
 def bf16x6_supported(out_ch, in_ch, width):
     """Shapes the opt-in split-precision convolution takes (rw_conv3x3_bf16x6_f32)."""
     return width >= 24 and in_ch % 16 == 0 and in_ch <= 1024 and out_ch % 64 == 0

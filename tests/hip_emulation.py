@@ -227,6 +227,38 @@ def conv3x3_bf16x6(x, wb, out_ch, w_scale, style=None, demod=None, noise=None, n
                    act=act)
 
 
+def pack_conv_weight_wino(weight):
+    return pack_conv_weight(weight, 0)          # opaque handle
+
+
+_WG = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]])
+_WBT = torch.tensor([[1., 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]])
+_WAT = torch.tensor([[1., 1, 1, 0], [0, 1, -1, -1]])
+
+
+def conv3x3_wino(x, uf, out_ch, w_scale, style=None, demod=None, noise=None, noise_w=None, bias=None, act=False):
+    """The arithmetic of rw_wino.hip in torch fp32: U = G g G^T, V = B^T d B on 4x4 tiles of stride 2,
+    M = sum_i U.V per transform point, Y = A^T M A; then the shared epilogue."""
+    x = x.detach()
+    if style is not None:
+        x = x * style.detach()[:, :, None, None]
+    wt = _unpack(uf, 0)
+    b, i, h, w = x.shape
+    U = torch.einsum('ab,oibc,dc->oiad', _WG, wt, _WG)
+    d = F.pad(x, (1, 1, 1, 1)).unfold(2, 4, 2).unfold(3, 4, 2)
+    V = torch.einsum('ab,nithbc,dc->nithad', _WBT, d, _WBT)
+    M = torch.einsum('oiad,nithad->nothad', U, V)
+    Y = torch.einsum('ab,nothbc,dc->nothad', _WAT, M, _WAT)
+    y = Y.permute(0, 1, 2, 4, 3, 5).reshape(b, out_ch, h, w) * w_scale
+    if demod is not None:
+        y = y * demod[:, :, None, None]
+    if noise is not None:
+        y = y + noise_w.detach().reshape(1) * noise.reshape(b, 1, h, w)
+    if act:
+        y = F.leaky_relu(y + bias.detach().view(1, -1, 1, 1), 0.2) * SQRT2
+    return y
+
+
 def install(monkeypatch):
     """Replaces the kernel wrappers of rewriting_amd.hip and makes host code take the
     'tensors live on the device' branches."""
@@ -235,7 +267,7 @@ def install(monkeypatch):
     names = ['fused_bias_act', 'bias_grad', 'upfirdn2d_major', 'pixel_norm', 'equal_linear',
              'adjust_latent', 'style_mul', 'weight_sqsum', 'demod', 'pack_conv_weight', 'conv3x3',
              'conv_transpose3x3s2', 'noise_add', 'blur_noise_act', 'to_rgb', 'pack_conv_weight_bf16x3',
-             'conv3x3_bf16x6',
+             'conv3x3_bf16x6', 'pack_conv_weight_wino', 'conv3x3_wino',
              'second_moment_accumulate', 'channel_sums', 'project_weight', 'solve_ksplit',
              'solve_step']
     for n in names:

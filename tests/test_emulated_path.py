@@ -206,3 +206,28 @@ def test_key_methods_linear_insert_and_rank3(emulated_hip):
 def test_fast_mconv_equals_seq(emulated_hip):
     from tests.common_checks import check_fast_mconv_equals_seq
     check_fast_mconv_equals_seq('cpu')
+
+
+def test_generator_with_winograd_convolutions_holds_the_golden_bars(emulated_hip, monkeypatch):
+    """RW_CONV_ALGO=winograd routes the eligible stride-1 convolutions (32^2 and 64^2 maps of this generator)
+    through hip.conv3x3_wino -- here the same F(2x2,3x3) arithmetic in torch fp32 -- and the reference golden
+    still holds at the bars of the direct path (images 1e-4, stages 5e-5 relative)."""
+    from rewriting_amd import hip
+    g = load_golden('gen_s64_cm1')
+    meta = golden_meta(g)
+    model = build_stylegan(meta['size'], meta['truncation'], meta['channel_multiplier'])
+    z = torch.from_numpy(g['z'])
+    calls = []
+    orig = hip.conv3x3_wino
+    monkeypatch.setattr(hip, 'conv3x3_wino', lambda *a, **k: (calls.append(a[0].shape), orig(*a, **k))[1])
+    monkeypatch.setenv('RW_CONV_ALGO', 'winograd')
+    with torch.no_grad():
+        fused = model(z)
+    assert len(calls) == 2 and sorted(s[-1] for s in calls) == [32, 64]        # layers 8 and 10 (maps >= 32 wide)
+    assert (fused - torch.from_numpy(g['image'])).abs().max() < 1e-4
+    monkeypatch.setenv('RW_FUSE', '0')
+    img, store = _stage_outputs(model, z)
+    assert (img - torch.from_numpy(g['image'])).abs().max() < 1e-4
+    for lname in ('layer8.sconv.mconv.dconv', 'layer10.sconv.mconv.dconv'):
+        w = torch.from_numpy(g['stage/%s/sub' % lname])
+        assert (subsample(store[lname].fmap) - w).abs().max() < 5e-5 * max(1.0, w.abs().max().item()), lname

@@ -225,6 +225,76 @@ def test_bench_shape_transposed_convs_and_blur_match_oracle(case):
     assert (got.cpu() - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())
 
 
+# ---- Winograd F(2x2,3x3) stride-1 convolution (rw_wino.hip)
+WINO_CASES = [(1, 16, 32, 8, 32), (2, 64, 64, 16, 32), (1, 128, 128, 32, 64), (2, 32, 32, 16, 64), (1, 512, 512, 32, 32),
+              (1, 8, 64, 8, 32), (3, 24, 96, 24, 96), (2, 40, 160, 8, 64), (1, 32, 32, 1024, 1024), (1, 64, 64, 512, 512),
+              (1, 128, 128, 256, 256), (1, 256, 256, 128, 128), (1, 512, 512, 64, 64)]
+
+
+@pytest.mark.parametrize('case', WINO_CASES)
+def test_winograd_conv_matches_oracle_and_direct_kernel(case):
+    """hip.conv3x3_wino against the oracle's convolution (DemodulatedConv2dF, models.py:313-329) with the full
+    epilogue, at the direct kernel's bars, and against the direct MFMA kernel itself; asymmetric random weights
+    and inputs (a transposed transform or swapped tile rows / columns cannot pass), input channels spread over
+    two decades so that cancellation in B^T d B is exercised."""
+    from rewriting_amd import hip
+    from oracle import restatement as R
+    b, i, o, h, w = case
+    assert hip.wino_supported(o, i, h, w)
+    x, wt, style = _conv_inputs(*case, seed=31)
+    rs = numpy.random.RandomState(32)
+    x = x * torch.from_numpy(numpy.exp(1.5 * rs.randn(1, i, 1, 1)).astype('float32'))
+    bias = torch.from_numpy(rs.randn(o).astype('float32'))
+    nw = torch.tensor([0.2])
+    noise = torch.from_numpy(rs.randn(b, h * w).astype('float32'))
+    s = 1 / math.sqrt(i * 9)
+    dm = hip.demod(hip.weight_sqsum(wt.to(DEV), s), style.to(DEV))
+    uf = hip.pack_conv_weight_wino(wt.to(DEV))
+    wp = hip.pack_conv_weight(wt.to(DEV), 0)
+    plain = hip.conv3x3_wino(x.to(DEV), uf, o, s, style=style.to(DEV), demod=dm)
+    direct = hip.conv3x3(x.to(DEV), wp, o, s, style=style.to(DEV), demod=dm)
+    scale = direct.abs().max().item()
+    assert (plain - direct).abs().max().item() < 2e-5 * scale, (plain - direct).abs().max().item() / scale
+    assert rel(plain, direct) < 3e-6
+    args = dict(style=style.to(DEV), demod=dm, noise=noise.to(DEV), noise_w=nw.to(DEV), bias=bias.to(DEV), act=True)
+    got = hip.conv3x3_wino(x.to(DEV), uf, o, s, **args)
+    if b * i * o * h * w <= 2 ** 32:                       # the oracle on the host cores
+        key = style[:, :, None, None] * x
+        conv = R.demod_conv(key, style, wt, upsample=False)
+        want = R.fused_leaky_relu(conv + nw * noise.view(b, 1, h, w), bias)
+        assert rel(plain, conv) < 1e-5
+        assert (plain.cpu() - conv).abs().max().item() < 1e-4 * max(1.0, conv.abs().max().item())
+        assert rel(got, want) < 1e-5
+        # against float64: the Winograd kernel is in the direct kernel's error class
+        ref = torch.nn.functional.conv2d(key.double(), wt[0].double(), padding=1) * s * dm.cpu().double()[:, :, None, None]
+        e_w = ((plain.cpu().double() - ref).norm() / ref.norm()).item()
+        e_d = ((direct.cpu().double() - ref).norm() / ref.norm()).item()
+        assert e_w < 4 * e_d + 2e-7 and e_w < 3e-6, (e_w, e_d)
+    same = hip.conv3x3(x.to(DEV), wp, o, s, **args)
+    assert (got - same).abs().max().item() < 2e-5 * max(1.0, same.abs().max().item())
+    if o == 32:                                             # ToRGB in the epilogue, feature map stored or not
+        wrgb = torch.from_numpy(rs.randn(3, o).astype('float32')).to(DEV)
+        srgb = torch.from_numpy((1 + 0.3 * rs.randn(b, o)).astype('float32')).to(DEV)
+        brgb = torch.from_numpy(rs.randn(3).astype('float32')).to(DEV)
+        skip = torch.from_numpy(rs.randn(b, 3, h, w).astype('float32')).to(DEV)
+        want_rgb = hip.to_rgb(got, wrgb, srgb, brgb, skip, 1 / math.sqrt(o))
+        y, rgb = hip.conv3x3_wino_to_rgb(x.to(DEV), uf, o, s, wrgb, srgb, brgb, skip, 1 / math.sqrt(o),
+                                         store_fmap=True, **args)
+        assert torch.equal(y, got)
+        assert rel(rgb, want_rgb) < 2e-6
+        y2, rgb2 = hip.conv3x3_wino_to_rgb(x.to(DEV), uf, o, s, wrgb, srgb, None, None, 1 / math.sqrt(o), **args)
+        assert y2 is None and rel(rgb2, want_rgb - skip - brgb.view(1, 3, 1, 1)) < 1e-5
+
+
+def test_winograd_rejects_shapes_it_does_not_take():
+    from rewriting_amd import hip
+    assert not hip.wino_supported(32, 32, 16, 16) and not hip.wino_supported(48, 32, 32, 32)
+    assert not hip.wino_supported(32, 12, 32, 32) and not hip.wino_supported(32, 32, 36, 32)
+    x, wt, _ = _conv_inputs(1, 32, 32, 16, 16)
+    with pytest.raises(RuntimeError):
+        hip.conv3x3_wino(x.to(DEV), hip.pack_conv_weight_wino(wt.to(DEV)), 32, 0.1)
+
+
 @pytest.mark.parametrize('case', [(2, 32, 32, 40, 64), (1, 64, 64, 32, 32), (2, 16, 32, 24, 70), (1, 128, 64, 24, 33)])
 @pytest.mark.parametrize('store', [False, True])
 def test_conv_with_fused_to_rgb_matches_separate_kernels(case, store):
