@@ -145,6 +145,12 @@ class ConvTimer:
                    all_conv_kernels=dict(achieved=round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
                                          frac=round(tot_fl / (tot_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
                                          ms_per_step=None))
+        if dom.startswith('conv_wino'):
+            # Winograd F(2x2,3x3): the matrix pipe issues 16/36 of the algorithmic (direct-sum) multiply-adds
+            out['algorithm'] = 'winograd F(2x2,3x3), fp32: `achieved` counts the direct sum\'s FLOPs (SURVEY 8d); the matrix ' \
+                               'pipe issues 1/2.25 of them'
+            out['mfma_issued_tflops'] = round(achieved / 2.25, 2)
+            out['mfma_issued_frac'] = round(achieved / 2.25 / FP32_MFMA_PEAK_TFLOPS, 4)
         out['per_kernel'] = {n: dict(tflops=round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 1), ms=round(v['ms'], 2),
                                      launches=v['launches']) for n, v in sorted(per.items(), key=lambda kv: -kv[1]['ms'])}
         out['_tot_ms'] = tot_ms
@@ -194,13 +200,14 @@ def _cpu_forward_fn(size):
     return (lambda z: R.generator_forward(sd, z, size, truncation=0.5)), 'port'
 
 
-def cpu_baseline_forward(size, batch=4, images=12):
-    """The same forward on the host cores: one batch of `batch` at each thread count of a sweep (torch's CPU
-    kernels stop scaling well before 128 threads and lose to oversubscription beyond), then `images` images at
-    the best count.  ~25 s of CPU work."""
+def cpu_baseline_forward(size, images=8):
+    """The same forward on the host cores, at the best of a small sweep: one image at each thread count (torch's
+    CPU kernels stop scaling well before 128 threads and lose to oversubscription beyond), then batch 4 at the
+    best count (larger batches are SLOWER per image on the CPU: the working set leaves the caches), then
+    `images` images in the winning configuration.  ~25 s of CPU work."""
     from rewriting_amd.utils import zdataset
     fwd, kind = _cpu_forward_fn(size)
-    z = zdataset.standard_z_sample(max(images, batch), 512, seed=1)
+    z = zdataset.standard_z_sample(max(images, 4), 512, seed=1)
     ncpu = os.cpu_count() or 1
     counts = sorted({min(c, ncpu) for c in (8, 16, 32, 64, 128)})
     saved = torch.get_num_threads()
@@ -212,10 +219,14 @@ def cpu_baseline_forward(size, batch=4, images=12):
             for c in counts:
                 torch.set_num_threads(c)
                 t0 = time.perf_counter()
-                fwd(z[:batch])
-                probe[c] = batch / (time.perf_counter() - t0)
-            best = max(probe, key=probe.get)
+                fwd(z[:1])
+                probe['%dt_b1' % c] = 1 / (time.perf_counter() - t0)
+            best = max(counts, key=lambda c: probe['%dt_b1' % c])
             torch.set_num_threads(best)
+            t0 = time.perf_counter()
+            fwd(z[:4])
+            probe['%dt_b4' % best] = 4 / (time.perf_counter() - t0)
+            batch = 4 if probe['%dt_b4' % best] > probe['%dt_b1' % best] else 1
             t0 = time.perf_counter()
             n = 0
             while n < images:
@@ -226,10 +237,10 @@ def cpu_baseline_forward(size, batch=4, images=12):
         torch.set_num_threads(saved)
     return dict(value=round(n / dt, 4), unit='images/sec', cores=best, kind=kind,
                 sample='%d images of the stylegan2-%d forward in batches of %d through %s (torch %s CPU kernels), '
-                       '%.1f s at %d threads; one-batch probe img/s by thread count: %s; host has %d logical cpus'
+                       '%.1f s at %d threads; probe img/s by (threads, batch): %s; host has %d logical cpus'
                        % (n, size, batch, "the reference's own utils/stylegan2/models.py (oracle/reference_shim.py)"
                           if kind == 'reference' else 'oracle/restatement.py', torch.__version__.split('+')[0], dt,
-                          best, json.dumps({str(k): round(v, 3) for k, v in probe.items()}), ncpu))
+                          best, json.dumps({k: round(v, 3) for k, v in probe.items()}), ncpu))
 
 
 def timed(fn, steps, warmup, world):

@@ -181,8 +181,9 @@ int rw_conv3x3_bf16x6_f32(const float* x, const void* wb, float* y, int batch, i
  * shapes it takes (out_ch % 32 == 0, in_ch % 8 == 0, w % 32 == 0, h % 8 == 0); elsewhere, and whenever the
  * caller prefers the direct sum, rw_conv3x3_f32 is the kernel.
  *   uf: rw_packed_conv_weight_wino_elems(out_ch, in_ch) = 16*out_ch*in_ch floats from rw_pack_conv_weight_wino_f32:
- *       U = G g G^T of every (o, i) filter in MFMA A-fragment order
- *       uf[o / 32][i / 2][xi / 8][(xi % 8) / 4][lane][xi % 4],  o = 32 (o/32) + (lane & 31), i = 2 (i/2) + (lane >> 5).
+ *       U = G g G^T of every (o, i) filter in the A-fragment order of v_mfma_f32_16x16x4_f32
+ *       uf[o / 32][i / 4][xi / 4][(o % 32) / 16][lane][xi % 4],  o = 32 (o/32) + 16 ((o%32)/16) + (lane & 15),
+ *       i = 4 (i/4) + (lane >> 4), xi = 4 a + b the transform point (row a, column b of G g G^T).
  * rw_conv3x3_wino_to_rgb_f32: ToRGB in the epilogue as rw_conv3x3_to_rgb_f32 (out_ch == 32 only). */
 int rw_conv3x3_wino_supported(int out_ch, int in_ch, int h, int w);
 long long rw_packed_conv_weight_wino_elems(int out_ch, int in_ch);

@@ -75,12 +75,14 @@ def upfirdn2d_major(x, k, up_x, up_y, down_x, down_y, px0, px1, py0, py1):
     kh, kw = k.shape
     out_h = (in_h * up_y + py0 + py1 - kh + down_y) // down_y
     out_w = (in_w * up_x + px0 + px1 - kw + down_x) // down_x
-    xd = x.double()
-    kd = k.double()
-    up = torch.zeros(major, in_h * up_y, in_w * up_x, minor, dtype=torch.float64)
+    # in the tensor's own precision, as the kernel (scalar_t accumulators, upfirdn2d_kernel.cu:108-133) and the
+    # reference's torch spec (op/upfirdn2d.py:152-186) compute it
+    xd = x
+    kd = k.to(x.dtype)
+    up = torch.zeros(major, in_h * up_y, in_w * up_x, minor, dtype=x.dtype)
     up[:, ::up_y, ::up_x, :] = xd
     ph, pw = in_h * up_y + py0 + py1, in_w * up_x + px0 + px1
-    pad = torch.zeros(major, max(ph, 0), max(pw, 0), minor, dtype=torch.float64)
+    pad = torch.zeros(major, max(ph, 0), max(pw, 0), minor, dtype=x.dtype)
     # copy the overlap of the upsampled image into the padded/cropped canvas
     sy0, sx0 = max(-py0, 0), max(-px0, 0)
     dy0, dx0 = max(py0, 0), max(px0, 0)

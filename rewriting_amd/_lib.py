@@ -12,7 +12,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int
                     c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'librewriting_hip.so')
+LIB_PATH = os.environ.get('RW_HIP_LIB') or os.path.join(_HERE, 'librewriting_hip.so')    # RW_HIP_LIB: tuning builds
 
 ABI_VERSION = 1
 

@@ -3,8 +3,8 @@
 # to its own object (in parallel, only when it is newer than its object) and the objects are linked.
 set -e
 HERE="$(cd "$(dirname "$0")" && pwd)"
-OUT="$HERE/../librewriting_hip.so"
-OBJ="$HERE/build"
+OUT="${RW_LIB_OUT:-$HERE/../librewriting_hip.so}"
+OBJ="${RW_OBJ_DIR:-$HERE/build}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result $RW_EXTRA_FLAGS"
 mkdir -p "$OBJ"

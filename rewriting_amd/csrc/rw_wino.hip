@@ -10,25 +10,19 @@
 //
 //   U[xi][o][i] = (G g G^T)[xi]      weights, once per weight version       (rw_pack_conv_weight_wino_f32)
 //   V[xi][i][t] = (B^T d B)[xi]      input tiles d (4x4, stride 2), per workgroup, in LDS
-//   M[xi][o][t] = sum_i U[xi][o][i] V[xi][i][t]          16 independent GEMMs -> v_mfma_f32_32x32x2_f32
+//   M[xi][o][t] = sum_i U[xi][o][i] V[xi][i][t]          16 independent GEMMs -> v_mfma_f32_16x16x4_f32
 //   Y[o][t]     = A^T M A            2x2 outputs, then the fused epilogue (demod, noise, bias, leaky-ReLU, ToRGB)
 //
-// Geometry.  An MFMA column tile is 32 Winograd tiles = 2 tile rows x 16 tile columns = 4 x 32 output pixels
-// ("tile group").  A wave owns 32 out-channels x one tile group x EIGHT of the sixteen xi (128 accumulator
-// registers: two waves per SIMD, two workgroups per CU, so one workgroup's prologue / transform / epilogue
-// overlaps the other's MFMAs); its partner wave owns the other eight xi of the same outputs and hands its partial
-// 2x2 outputs over through LDS at the end.  A workgroup is 4 waves: 2 xi-halves x (WGM out-channel blocks x
-// WGN tile groups), WGM * WGN = 2.
-//
-// Per chunk of IC = 8 input channels the (4 WGN + 2) x 34 input patch is fetched once (coalesced NCHW row
-// pieces, zero padding and the style multiply applied on the way into LDS), transformed cooperatively into
-// V[2][16][IC][32 WGN] (double buffered) and consumed by 4 k-pairs x 8 MFMAs per wave.  Weight fragments come
-// straight from L2 in MFMA A-fragment order (two 16-byte loads per lane and k-pair).  Fetch, staging and
-// transform of chunk c+1 / c+2 ride between the MFMAs of chunk c.
+// Kernel design: see conv_wino16_kernel below.
 #include "rw_common.h"
 
-#define WN_IC 8                 // input channels per chunk
-#define WN_KP (WN_IC / 2)       // k-pairs per chunk
+// Timing ablations for kernel work (build a second library with -DWN_ABL=<bits>; results are WRONG when a bit is
+// set): 1 = no staging writes / transform, 2 = no barriers in the loop, 4 = no patch fetch, 8 = no B operand reads in
+// the loop, 16 = no weight loads in the loop.  0 in the product build.
+#ifndef WN_ABL
+#define WN_ABL 0
+#endif
+
 #define WN_RS 48                // LDS row pitch of the raw patch (floats): 2 rows = 96 dwords = 32 mod 64 banks
 #define WN_PC 34                // patch columns
 
@@ -37,6 +31,7 @@ struct WinoProblem {
   const float* style; const float* demod; const float* noise; const float* noise_w; const float* bias;
   int batch, in_ch, out_ch, h, w;
   int groups_x, groups_y;
+  int gpw;                      // tile groups along x per workgroup (divides groups_x)
   float w_scale;
   int act;
   const float* rgb_weight; const float* rgb_style; const float* rgb_bias; const float* rgb_skip; float* rgb_out;
@@ -52,57 +47,100 @@ __device__ __forceinline__ int wn_xcd_remap(int id, int total) {
 
 template <int N> struct wn_int { static constexpr int value = N; };
 
-template <int WGM, int WGN, bool RGB>
-__global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoProblem p) {
-  static_assert(WGM * WGN == 2, "two (out-channel block, tile group) pairs per workgroup");
-  constexpr int IC = WN_IC, KP = WN_KP;
-  constexpr int NT = 32 * WGN;                     // tiles per workgroup
-  constexpr int PR = 4 * WGN + 2;                  // patch rows
+// ---------------------------------------------------------------------------------------
+// The GEMMs run on v_mfma_f32_16x16x4_f32 (32 cycles per instruction, 64 FLOP/clk/SIMD: the rate of 32x32x2).  A
+// 16 x 16 accumulator tile is 4 registers, so ONE wave holds all sixteen transform points of 32 out-channels x 16
+// tiles (one tile row of 16 tile columns = 2 x 32 output pixels) in 128 registers: two waves per SIMD / two
+// workgroups per CU, and the output transform A^T M A is lane-local.  (A first version on 32x32x2 needed 256
+// accumulator registers per wave or a partner wave and an exchange through LDS; it measured the same.)
+//
+// A workgroup (4 waves = WGM out-channel blocks x WGN tile rows) walks a RUN of `gpw` tile groups along x as ONE
+// flattened pipeline of "virtual chunks" v = group * n_chunks + chunk:
+//   * the raw patch is double buffered (Rs[2]) and a chunk needs ONE barrier: during the MFMAs of chunk v the
+//     workgroup transforms chunk v+1 (Rs[(v+1)&1] -> V[(v+1)&1]), stores the fetched chunk v+2 (registers ->
+//     Rs[v&1]) and fetches chunk v+3 -- across group boundaries, so only the first group of a run pays a prologue
+//     (the 32- and 64-channel layers have only 4 - 16 chunks per group);
+//   * the barrier sits right behind the last staging step, a few MFMAs before the end of the chunk, and the B
+//     operands of the next chunk are read in the shadow of those MFMAs;
+//   * operands are single buffered and streamed: the registers of a weight / V fragment are refilled for the next
+//     k-quad right after the MFMAs that consumed them (28 MFMAs ~ 900 cycles ahead of their next use); the weight
+//     stream wraps around at the end of a group (same out-channel tile for the whole run).
+// LDS: V rows are padded by 16 floats (the 16x16x4 B operand reads 16 tiles of 4 consecutive channels: without
+// the pad channels k and k+1 share banks).  IC = 8 input channels per chunk (4 for the 32-out-channel shape).
+//   weights: uf[o/32][i/4][xi/4][(o%32)/16][lane][xi%4], o = 32 (o/32) + 16 ((o%32)/16) + (lane & 15),
+//            i = 4 (i/4) + (lane >> 4)                                     (rw_pack_conv_weight_wino_f32)
+// ---------------------------------------------------------------------------------------
+typedef float wn_f32x4 __attribute__((ext_vector_type(4)));
+
+template <int WGM, int WGN, int IC, bool RGB>
+__global__ void __launch_bounds__(256, 2) conv_wino16_kernel(const WinoProblem p) {
+  static_assert(WGM * WGN == 4, "4 waves per workgroup");
+  constexpr int KQ = IC / 4;                       // k-quads per chunk
+  constexpr int NT = 16 * WGN;                     // tiles per workgroup: WGN tile rows x 16 tile columns
+  constexpr int VP = NT + 16;                      // padded channel-row pitch of V
+  constexpr int PR = 2 * WGN + 2;                  // patch rows
   constexpr int NPOS = PR * WN_PC;
   constexpr int PSLOT = (NPOS + 255) / 256;
-  constexpr int NRAW = PSLOT * IC;                 // raw elements per thread and chunk
-  constexpr int NIT = NT * IC / 256;               // transform items (tile, channel) per thread and chunk
+  constexpr int NRAW = PSLOT * IC;
+  constexpr int NIT = NT * IC / 256;
   static_assert(NIT >= 1 && NT * IC % 256 == 0, "transform items");
-  constexpr int CH_STEP = 256 / NT;                // channel stride between a thread's items
-  __shared__ __attribute__((aligned(16))) float Rs[IC][PR][WN_RS];
-  __shared__ __attribute__((aligned(16))) float Vs[2][16][IC][NT];
+  constexpr int CH_STEP = 256 / NT;
+  constexpr int SLOTS = 32 * KQ;                   // MFMA slots per chunk and wave
+  constexpr int NXS = 1 + 4 * NIT;                 // transform slots: the reads, then two compute steps per slot
+  constexpr int STRIDE = (SLOTS - 6) / (NXS + NRAW);           // staging step every STRIDE slots
+  static_assert(STRIDE >= 1, "staging fits the slots of a chunk");
+  constexpr int FETCH_SLOT = STRIDE * (NXS + NRAW);             // first slot after the last staging step
+  constexpr int BAR_SLOT = FETCH_SLOT;                          // barrier right there; >= 5 MFMAs follow it
+  static_assert(BAR_SLOT + 5 <= SLOTS, "room for the B prefetch behind the barrier");
+  __shared__ __attribute__((aligned(16))) float Rs[2][IC][PR][WN_RS];
+  __shared__ __attribute__((aligned(16))) float Vs[2][16][IC][VP];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int xh = wave & 1;                         // which eight xi: rows a in {2 xh, 2 xh + 1} of the 4x4 transform
-  const int pw = wave >> 1;                        // (out-channel block, tile group) pair
-  const int wm = pw / WGN, wn = pw % WGN;
-  const int frow = lane >> 5, fcol = lane & 31;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int lk = lane >> 4, lt = lane & 15;        // k within the quad / tile column (A: out-channel row)
 
-  int local = wn_xcd_remap(blockIdx.x, gridDim.x);
+  const int local = wn_xcd_remap(blockIdx.x, gridDim.x);
   const int o_tiles = p.out_ch / (32 * WGM);
-  const int o0 = (local % o_tiles) * 32 * WGM; local /= o_tiles;
-  const int gx = local % p.groups_x; local /= p.groups_x;
-  const int gy = local % p.groups_y;
-  const int ib = local / p.groups_y;
-  const int y0 = gy * 4 * WGN, x0 = gx * 32;
+  const int runs_x = p.groups_x / p.gpw;
+  const int ot = local % o_tiles;
+  int pg = local / o_tiles;
+  const int run = pg % runs_x; pg /= runs_x;
+  const int gy = pg % p.groups_y;
+  const int ib = pg / p.groups_y;
+  const int o0 = ot * 32 * WGM;
+  const int y0 = gy * 2 * WGN, gx0 = run * p.gpw;
   const int64_t hw = (int64_t)p.h * p.w;
   const float* xb = p.x + (int64_t)ib * p.in_ch * hw;
-  const float* st = p.style ? p.style + (int64_t)ib * p.in_ch : nullptr;      // uniform: scalar loads
-  const int n_chunks = p.in_ch / IC;
+  const float* st = p.style ? p.style + (int64_t)ib * p.in_ch : nullptr;
+  const int NC = p.in_ch / IC;
+  const int VT = p.gpw * NC;
 
-  // ---- raw patch: this thread owns up to PSLOT fixed positions (r, c) and walks the IC channels of a chunk.
-  // Outside the image: a legal address, value multiplied by 0.  Slots past the patch: a padding column.
+  // ---- raw patch slots: position (r, c) = (pos / 34, pos % 34) of the patch; the global offset and the
+  // zero-padding mask are recomputed when the fetch cursor enters a new group of the run
   int xoff[PSLOT], xlds[PSLOT];
   float xmask[PSLOT];
 #pragma unroll
   for (int sl = 0; sl < PSLOT; ++sl) {
     const int pos = tid + 256 * sl;
     const int r = pos / WN_PC, c = pos - r * WN_PC;
-    const int iy = y0 - 1 + r, ix = x0 - 1 + c;
-    const bool ok = pos < NPOS && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
-    xoff[sl] = ok ? iy * p.w + ix : 0;
-    xmask[sl] = ok ? 1.0f : 0.0f;
     xlds[sl] = pos < NPOS ? r * WN_RS + c : WN_RS - 1;
   }
+  auto set_group = [&](int g) __attribute__((always_inline)) {
+    const int x0 = (gx0 + g) * 32;
+#pragma unroll
+    for (int sl = 0; sl < PSLOT; ++sl) {
+      const int pos = tid + 256 * sl;
+      const int r = pos / WN_PC, c = pos - r * WN_PC;
+      const int iy = y0 - 1 + r, ix = x0 - 1 + c;
+      const bool ok = pos < NPOS && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
+      xoff[sl] = ok ? iy * p.w + ix : 0;
+      xmask[sl] = ok ? 1.0f : 0.0f;
+    }
+  };
   float xreg[PSLOT][IC];
   float sty[IC];
-  auto xfetch = [&](int i0) {
+  auto xfetch = [&](int i0) __attribute__((always_inline)) {
     const float* xc = xb + (int64_t)i0 * hw;
 #pragma unroll
     for (int ic = 0; ic < IC; ++ic)
@@ -116,24 +154,26 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoProblem p) 
       for (int ic = 0; ic < IC; ++ic) sty[ic] = 1.0f;
     }
   };
-  auto raw_step = [&](int j) {                     // j < NRAW
+  auto raw_step = [&](int rbuf, int j) __attribute__((always_inline)) {
     const int sl = j / IC, ic = j % IC;
-    (&Rs[0][0][0])[ic * PR * WN_RS + xlds[sl]] = xreg[sl][ic] * (xmask[sl] * sty[ic]);
+    (&Rs[0][0][0][0])[rbuf * IC * PR * WN_RS + ic * PR * WN_RS + xlds[sl]] = xreg[sl][ic] * (xmask[sl] * sty[ic]);
+  };
+  // fetch of virtual chunk vf (uniform arguments, computed by the caller): chunk fc of group fg
+  auto fetch_chunk = [&](int fg, int fc) __attribute__((always_inline)) {
+    if (fc == 0) set_group(fg);
+    xfetch(fc * IC);
   };
 
-  // ---- transform items: tile tl of the workgroup, channel tch + CH_STEP * item
+  // ---- transform items: tile tl of the workgroup (tile row tl >> 4, column tl & 15), channel tch + CH_STEP * item
   const int tl = tid % NT, tch = tid / NT;
-  const int tg = tl >> 5, ttr = (tl >> 4) & 1, ttc = tl & 15;
-  const float* rsrc = &Rs[tch][4 * tg + 2 * ttr][2 * ttc];
+  const float* rsrc = &Rs[0][tch][2 * (tl >> 4)][2 * (tl & 15)];
   float* vdst = &Vs[0][0][tch][tl];
-  float2 drow[NIT][4][2];                          // the 4x4 input tiles of this thread's items
+  float2 drow[NIT][4][2];
   float e[4][4];
-  // micro-steps of a chunk's transform: NIT reads (one per item), then per item four column transforms (row a)
-  // and four row transforms + stores (column b)
   constexpr int NXF = 9 * NIT;
-  auto xform_step = [&](int buf, int s) {
+  auto xform_step = [&](int buf, int s) __attribute__((always_inline)) {          // Rs[buf] -> Vs[buf]
     if (s < NIT) {
-      const float* src = rsrc + s * CH_STEP * PR * WN_RS;
+      const float* src = rsrc + buf * IC * PR * WN_RS + s * CH_STEP * PR * WN_RS;
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
         drow[s][a][0] = *reinterpret_cast<const float2*>(src + a * WN_RS);
@@ -148,15 +188,14 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoProblem p) 
       e[a][0] = d0 - d2; e[a][1] = d1 + d2; e[a][2] = d2 - d1; e[a][3] = d1 - d3;
     } else {
       const int b = ms - 4;
-      float* dst = vdst + buf * 16 * IC * NT + item * CH_STEP * NT;
-      dst[(0 * 4 + b) * IC * NT] = e[0][b] - e[2][b];
-      dst[(1 * 4 + b) * IC * NT] = e[1][b] + e[2][b];
-      dst[(2 * 4 + b) * IC * NT] = e[2][b] - e[1][b];
-      dst[(3 * 4 + b) * IC * NT] = e[1][b] - e[3][b];
+      float* dst = vdst + buf * 16 * IC * VP + item * CH_STEP * VP;
+      dst[(0 * 4 + b) * IC * VP] = e[0][b] - e[2][b];
+      dst[(1 * 4 + b) * IC * VP] = e[1][b] + e[2][b];
+      dst[(2 * 4 + b) * IC * VP] = e[2][b] - e[1][b];
+      dst[(3 * 4 + b) * IC * VP] = e[1][b] - e[3][b];
     }
   };
-  // slot s2 of the second half of a chunk carries: s2 == 0 the reads, s2 >= 1 compute steps 2 (s2-1), 2 (s2-1) + 1
-  auto xform_slot = [&](int buf, int s2) {
+  auto xform_slot = [&](int buf, int s2) __attribute__((always_inline)) {
     if (s2 == 0) {
 #pragma unroll
       for (int i = 0; i < NIT; ++i) xform_step(buf, i);
@@ -167,237 +206,229 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoProblem p) 
     }
   };
 
-  // ---- operands.  A: U in fragment order uf[o/32][k-pair][xi half][2][lane][4]; B: V[buf][xi][2 kp + frow][tile]
-  const int kpg_total = p.in_ch >> 1;
-  const float* ufw = p.uf + (((int64_t)((o0 >> 5) + wm) * kpg_total) * 2 + xh) * 512 + lane * 4;    // + kpg * 1024
-  rw_f32x4 areg[2][2];
-  float breg[2][8];
-  auto aload = [&](int slot, int kpg) {
-    const float* base = ufw + (int64_t)kpg * 1024;
-    areg[slot][0] = *reinterpret_cast<const rw_f32x4*>(base);
-    areg[slot][1] = *reinterpret_cast<const rw_f32x4*>(base + 256);
+  // ---- operands.  A: uniform base + 32-bit lane offset; one 16-byte load = four transform points of one
+  // 16-channel half.  B: V[buf][xi][4 kq + lk][16 wn + lt].
+  const int kq_total = p.in_ch >> 2;
+  const float* ufs = p.uf + ((int64_t)((o0 >> 5) + wm) * kq_total) * 2048;     // uniform; + kq * 2048
+  const int a_lane = lane * 4;
+  wn_f32x4 areg[4][2];                              // [xi / 4][16-channel half] over xi % 4
+  float breg[16];
+  auto aload = [&](int xq, int kq) __attribute__((always_inline)) {
+    const float* base = ufs + (int64_t)kq * 2048 + xq * 512;
+    areg[xq][0] = *reinterpret_cast<const wn_f32x4*>(base + a_lane);
+    areg[xq][1] = *reinterpret_cast<const wn_f32x4*>(base + 256 + a_lane);
   };
-  const float* vsrc = &Vs[0][8 * xh][frow][wn * 32 + fcol];
-  auto bload1 = [&](int slot, int buf, int kp, int q) {
-    breg[slot][q] = vsrc[buf * 16 * IC * NT + q * IC * NT + 2 * kp * NT];
+  const float* vsrc = &Vs[0][0][lk][wn * 16 + lt];
+  auto bload = [&](int buf, int kq, int xi) __attribute__((always_inline)) {
+    breg[xi] = vsrc[buf * 16 * IC * VP + xi * IC * VP + 4 * kq * VP];
   };
 
-  rw_f32x16 acc[8];
+  wn_f32x4 acc[16][2];
 #pragma unroll
-  for (int q = 0; q < 8; ++q)
+  for (int xi = 0; xi < 16; ++xi)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    for (int h = 0; h < 2; ++h) acc[xi][h] = wn_f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // ---- prologue: chunk 0 transformed into V[0], chunk 1 fetched
+  // ---- prologue: V[0] = chunk 0, Rs[1] = chunk 1, registers = chunk 2; operands of the first k-quad
+  set_group(0);
   xfetch(0);
-  aload(0, 0);
 #pragma unroll
-  for (int j = 0; j < NRAW; ++j) raw_step(j);
+  for (int xq = 0; xq < 4; ++xq) aload(xq, 0);
+#pragma unroll
+  for (int j = 0; j < NRAW; ++j) raw_step(0, j);
   __syncthreads();
-  if (n_chunks > 1) xfetch(IC);
+  if (VT > 1) fetch_chunk(1 / NC, 1 % NC);
 #pragma unroll
   for (int s = 0; s < NXF; ++s) xform_step(0, s);
-  __syncthreads();
-
-  constexpr int SLOTS = 8 * KP;                    // MFMA slots per chunk and wave
-  constexpr int HALF = SLOTS / 2;
-  static_assert(NRAW <= HALF && 1 + 4 * NIT <= HALF, "staging fits the slots of a chunk");
-  // One chunk.  MORE: another chunk follows -- its raw patch goes into Rs during the first half of the slots,
-  // barrier, the fetch of the chunk after it is issued, its transform into V[buf^1] rides on the second half.
-  auto chunk = [&](int c, auto more_tag) {
-    constexpr bool MORE = decltype(more_tag)::value != 0;
-    const int buf = c & 1;
-    const int cn2 = c + 2 < n_chunks ? c + 2 : n_chunks - 1;
+  if (VT > 1) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) bload1(0, buf, 0, q);
-#pragma unroll
-    for (int kp = 0; kp < KP; ++kp) {
-      const int cur = kp & 1, nxt = cur ^ 1;
-      // next k-pair's weights (for the last k-pair: the first of the next chunk; global memory, no barrier involved)
-      {
-        int kpg = c * KP + kp + 1;
-        if (kpg >= kpg_total) kpg = kpg_total - 1;
-        aload(nxt, kpg);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int slot = kp * 8 + q;
-        if (kp + 1 < KP) bload1(nxt, buf, kp + 1, q);          // B one k-pair ahead
-        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[cur][q >> 2][q & 3], breg[cur][q], acc[q], 0, 0, 0);
-        if (MORE) {
-          if (slot < HALF) {
-            if (slot < NRAW) raw_step(slot);
-          } else {
-            xform_slot(buf ^ 1, slot - HALF);
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (MORE && slot == HALF - 1) {
-          __syncthreads();                         // raw patch of chunk c+1 complete in Rs
-          xfetch(cn2 * IC);                        // registers free again: chunk c+2 (a redundant refill at the end)
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    }
-    if (MORE) __syncthreads();                     // V[buf^1] complete; Rs free
-  };
-  for (int c = 0; c + 1 < n_chunks; ++c) chunk(c, wn_int<1>());
-  chunk(n_chunks - 1, wn_int<0>());
-
-  // ---- output transform.  Row r of the accumulator tile is out-channel o_first + (r&3) + 8 (r>>2); this wave
-  // holds M[a][b] for a in {2 xh, 2 xh + 1}: acc[4 (a - 2 xh) + b].  Y = A^T M A is linear in M, so each wave of
-  // a pair forms its partial 2x2 outputs; the xh = 1 wave hands them over through LDS.
-  float part[16][4];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    float s0[4], s1[4];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const float m0 = acc[b][r], m1 = acc[4 + b][r];
-      if (xh == 0) { s0[b] = m0 + m1; s1[b] = m1; }            // rows a = 0, 1
-      else { s0[b] = m0; s1[b] = -m0 - m1; }                   // rows a = 2, 3
-    }
-    part[r][0] = s0[0] + s0[1] + s0[2];
-    part[r][1] = s0[1] - s0[2] - s0[3];
-    part[r][2] = s1[0] + s1[1] + s1[2];
-    part[r][3] = s1[1] - s1[2] - s1[3];
-  }
-  __syncthreads();                                 // every wave is done reading V
-  float* xch = &Vs[0][0][0][0] + pw * 64 * 64 + lane;          // [pair][r * 4 + j][lane]
-  if (xh == 1) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) xch[(r * 4 + j) * 64] = part[r][j];
+    for (int j = 0; j < NRAW; ++j) raw_step(1, j);
+    if (VT > 2) fetch_chunk(2 / NC, 2 % NC);
   }
   __syncthreads();
-  if (xh == 1) return;
 #pragma unroll
-  for (int r = 0; r < 16; ++r)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) part[r][j] += xch[(r * 4 + j) * 64];
+  for (int xi = 0; xi < 16; ++xi) bload(0, 0, xi);
 
-  // ---- epilogue: this lane holds the 2x2 outputs of tile (wn, fcol) for 16 out-channels
-  const int otr = (fcol >> 4) & 1, otc = fcol & 15;
-  const int oy = y0 + 4 * wn + 2 * otr, ox = x0 + 2 * otc;
-  const int o_first = o0 + 32 * wm + 4 * frow;
-  float nz[4] = {0.f, 0.f, 0.f, 0.f};
-  if (p.noise) {
-    const float nw = p.noise_w[0];
-    const float* np = p.noise + (int64_t)ib * hw + (int64_t)oy * p.w + ox;
-    const float2 n0 = *reinterpret_cast<const float2*>(np), n1 = *reinterpret_cast<const float2*>(np + p.w);
-    nz[0] = n0.x * nw; nz[1] = n0.y * nw; nz[2] = n1.x * nw; nz[3] = n1.y * nw;
-  }
-  float scale[16], bias[16];
-  if (p.demod) {
-    const float* dm = p.demod + (int64_t)ib * p.out_ch + o_first;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) scale[r] = dm[(r & 3) + 8 * (r >> 2)];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) scale[r] *= p.w_scale;
-  } else {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) scale[r] = p.w_scale;
-  }
-  if (p.act) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) bias[r] = p.bias[o_first + (r & 3) + 8 * (r >> 2)];
-  } else {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) bias[r] = 0.f;
-  }
-  float wr[3][16];
-  float rgbp[4][3];
-  if (RGB) {
-    float sr[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sr[r] = p.rgb_style[(int64_t)ib * p.out_ch + o_first + (r & 3) + 8 * (r >> 2)];
-#pragma unroll
-    for (int cc = 0; cc < 3; ++cc)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) wr[cc][r] = p.rgb_weight[cc * p.out_ch + o_first + (r & 3) + 8 * (r >> 2)];
-#pragma unroll
-    for (int cc = 0; cc < 3; ++cc)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) wr[cc][r] = p.rgb_scale * wr[cc][r] * sr[r];
+  // Epilogue of one group: lane-local output transform of this wave's 32 out-channels x 16 tiles.
+  // acc[4a + b][half][j] = M[a][b] of out-channel o0 + 32 wm + 16 half + 4 lk + j, tile column lt.
+  auto group_epilogue = [&](int g) __attribute__((always_inline)) {
+    const int x0 = (gx0 + g) * 32;
+    const int oy = y0 + 2 * wn, ox = x0 + 2 * lt;
+    const int o_first = o0 + 32 * wm + 4 * lk;            // + 16 half + j
+    float nz[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.noise) {
+      const float nw = p.noise_w[0];
+      const float* np = p.noise + (int64_t)ib * hw + (int64_t)oy * p.w + ox;
+      const float2 n0 = *reinterpret_cast<const float2*>(np), n1 = *reinterpret_cast<const float2*>(np + p.w);
+      nz[0] = n0.x * nw; nz[1] = n0.y * nw; nz[2] = n1.x * nw; nz[3] = n1.y * nw;
+    }
+    float rgbp[4][3];
 #pragma unroll
     for (int j = 0; j < 4; ++j) rgbp[j][0] = rgbp[j][1] = rgbp[j][2] = 0.f;
-  }
-  // Neighbouring lanes (tile columns 2m, 2m+1) exchange halves so that the even lane stores four consecutive
-  // pixels of output row oy and the odd lane four of row oy + 1: one aligned 16-byte store per lane and channel.
-  const bool odd = fcol & 1;
-  float* yb = p.y ? p.y + ((int64_t)ib * p.out_ch + o_first) * hw + (int64_t)(oy + (odd ? 1 : 0)) * p.w + (ox & ~3)
-                  : nullptr;
+    const float* dm = p.demod ? p.demod + (int64_t)ib * p.out_ch + o_first : nullptr;
+    // neighbouring lanes (tile columns 2m, 2m+1) exchange halves: the even lane stores four consecutive pixels of
+    // output row oy, the odd lane four of row oy + 1 -- one aligned 16-byte store per lane and channel
+    const bool odd = lt & 1;
+    float* yb = p.y ? p.y + ((int64_t)ib * p.out_ch + o_first) * hw + (int64_t)(oy + (odd ? 1 : 0)) * p.w + (ox & ~3)
+                    : nullptr;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    float v[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float t = part[r][j] * scale[r] + nz[j];
-      if (p.act) {
-        t += bias[r];
-        t = ((t > 0.f) ? t : t * 0.2f) * 1.4142135623730951f;
-      }
-      v[j] = t;
+    for (int q = 0; q < 8; ++q) {
+      const int half = q >> 2, j = q & 3;
+      // the per-channel constants are fetched here, one channel ahead of their use at most: keeping all eight
+      // channels' worth in registers next to 128 accumulators spills
+      const int oc = 16 * half + j;
+      const float scale = dm ? dm[oc] * p.w_scale : p.w_scale;
+      const float bias = p.act ? p.bias[o_first + oc] : 0.f;
+      float wr[3] = {0.f, 0.f, 0.f};
       if (RGB) {
+        const float sr = p.rgb_scale * p.rgb_style[(int64_t)ib * p.out_ch + o_first + oc];
 #pragma unroll
-        for (int cc = 0; cc < 3; ++cc) rgbp[j][cc] += t * wr[cc][r];
+        for (int cc = 0; cc < 3; ++cc) wr[cc] = sr * p.rgb_weight[cc * p.out_ch + o_first + oc];
       }
-    }
-    if (yb) {
-      // even lane keeps its row 0 (v0, v1) and takes the partner's row 0; odd lane keeps row 1, takes the partner's
-      const float g0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(odd ? v[0] : v[2]), 0xB1, 0xf, 0xf, true));
-      const float g1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(odd ? v[1] : v[3]), 0xB1, 0xf, 0xf, true));
-      rw_f32x4 o4;
-      o4[0] = odd ? g0 : v[0]; o4[1] = odd ? g1 : v[1];
-      o4[2] = odd ? v[2] : g0; o4[3] = odd ? v[3] : g1;
-      *reinterpret_cast<rw_f32x4*>(yb + (int64_t)((r & 3) + 8 * (r >> 2)) * hw) = o4;
-    }
-  }
-  if (RGB) {
-    // the partner half of the wave (frow) holds the other 16 of the 32 out-channels of the same pixels
+      float s0[4], s1[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int cc = 0; cc < 3; ++cc) rgbp[j][cc] += __shfl_xor(rgbp[j][cc], 32, 64);
-    if (frow == 0) {
-      float rb[3] = {0.f, 0.f, 0.f};
-      if (p.rgb_bias) {
-#pragma unroll
-        for (int cc = 0; cc < 3; ++cc) rb[cc] = p.rgb_bias[cc];
+      for (int b = 0; b < 4; ++b) {
+        const float m0 = acc[b][half][j], m1 = acc[4 + b][half][j], m2 = acc[8 + b][half][j], m3 = acc[12 + b][half][j];
+        s0[b] = m0 + m1 + m2;
+        s1[b] = m1 - m2 - m3;
       }
+      float v[4] = {s0[0] + s0[1] + s0[2], s0[1] - s0[2] - s0[3], s1[0] + s1[1] + s1[2], s1[1] - s1[2] - s1[3]};
 #pragma unroll
-      for (int cc = 0; cc < 3; ++cc) {
-        const int64_t base = ((int64_t)ib * 3 + cc) * hw + (int64_t)oy * p.w + ox;
-        float2 k0 = {0.f, 0.f}, k1 = {0.f, 0.f};
-        if (p.rgb_skip) {
-          k0 = *reinterpret_cast<const float2*>(p.rgb_skip + base);
-          k1 = *reinterpret_cast<const float2*>(p.rgb_skip + base + p.w);
+      for (int k = 0; k < 4; ++k) {
+        float t = v[k] * scale + nz[k];
+        if (p.act) {
+          t += bias;
+          t = ((t > 0.f) ? t : t * 0.2f) * 1.4142135623730951f;
         }
-        float2 r0 = {rgbp[0][cc] + rb[cc] + k0.x, rgbp[1][cc] + rb[cc] + k0.y};
-        float2 r1 = {rgbp[2][cc] + rb[cc] + k1.x, rgbp[3][cc] + rb[cc] + k1.y};
-        *reinterpret_cast<float2*>(p.rgb_out + base) = r0;
-        *reinterpret_cast<float2*>(p.rgb_out + base + p.w) = r1;
+        v[k] = t;
+        if (RGB) {
+#pragma unroll
+          for (int cc = 0; cc < 3; ++cc) rgbp[k][cc] += t * wr[cc];
+        }
+      }
+      if (yb) {
+        const float g0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(odd ? v[0] : v[2]), 0xB1, 0xf, 0xf, true));
+        const float g1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(odd ? v[1] : v[3]), 0xB1, 0xf, 0xf, true));
+        wn_f32x4 o4;
+        o4[0] = odd ? g0 : v[0]; o4[1] = odd ? g1 : v[1];
+        o4[2] = odd ? v[2] : g0; o4[3] = odd ? v[3] : g1;
+        *reinterpret_cast<wn_f32x4*>(yb + (int64_t)(16 * half + j) * hw) = o4;
       }
     }
-  }
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) acc[xi][h] = wn_f32x4{0.f, 0.f, 0.f, 0.f};
+    if (RGB) {
+      // the four 16-lane groups of the wave hold the other out-channels of the same pixels
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+          float t = rgbp[k][cc];
+          t += __shfl_xor(t, 16, 64);
+          t += __shfl_xor(t, 32, 64);
+          rgbp[k][cc] = t;
+        }
+      if (lk == 0) {
+        float rb[3] = {0.f, 0.f, 0.f};
+        if (p.rgb_bias) {
+#pragma unroll
+          for (int cc = 0; cc < 3; ++cc) rb[cc] = p.rgb_bias[cc];
+        }
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+          const int64_t base = ((int64_t)ib * 3 + cc) * hw + (int64_t)oy * p.w + ox;
+          float2 k0 = {0.f, 0.f}, k1 = {0.f, 0.f};
+          if (p.rgb_skip) {
+            k0 = *reinterpret_cast<const float2*>(p.rgb_skip + base);
+            k1 = *reinterpret_cast<const float2*>(p.rgb_skip + base + p.w);
+          }
+          float2 r0 = {rgbp[0][cc] + rb[cc] + k0.x, rgbp[1][cc] + rb[cc] + k0.y};
+          float2 r1 = {rgbp[2][cc] + rb[cc] + k1.x, rgbp[3][cc] + rb[cc] + k1.y};
+          *reinterpret_cast<float2*>(p.rgb_out + base) = r0;
+          *reinterpret_cast<float2*>(p.rgb_out + base + p.w) = r1;
+        }
+      }
+    }
+  };
+
+  // One virtual chunk.  STAGE: 2 = transform v+1, store v+2, fetch v+3; 1 = transform v+1 only; 0 = nothing.
+  // Slot = one MFMA; per k-quad the order is xi-quad, xi, 16-channel half (a B value feeds two MFMAs, an A
+  // register four), and a quad's registers are refilled for the next k-quad right behind its last MFMA.
+  auto chunk = [&](int v, int c, int fg, int fc, auto stage_tag) __attribute__((always_inline)) {
+    constexpr int STAGE = decltype(stage_tag)::value;
+    const int buf = v & 1;
+#pragma unroll
+    for (int kq = 0; kq < KQ; ++kq) {
+      int kqn = c * KQ + kq + 1;                   // next k-quad of the weight stream (wraps at the end of a group)
+      if (kqn >= kq_total) kqn = 0;
+#pragma unroll
+      for (int xq = 0; xq < 4; ++xq) {
+#pragma unroll
+        for (int xe = 0; xe < 4; ++xe) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int xi = 4 * xq + xe;
+            const int slot = kq * 32 + xq * 8 + xe * 2 + h;
+            acc[xi][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[xq][h][xe], breg[xi], acc[xi][h], 0, 0, 0);
+            if (STAGE >= 1 && !(WN_ABL & 1) && slot % STRIDE == 0) {
+              const int step = slot / STRIDE;
+              if (step < NXS) xform_slot(buf ^ 1, step);
+              else if (STAGE == 2 && step < NXS + NRAW) raw_step(buf, step - NXS);
+            }
+            if (h == 1 && !(WN_ABL & 8)) {
+              // this B value is consumed: next k-quad of the same chunk now; next chunk only behind the barrier
+              if (kq + 1 < KQ) bload(buf, kq + 1, xi);
+              else if (STAGE >= 1 && slot > BAR_SLOT) bload(buf ^ 1, 0, xi);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (STAGE >= 1 && kq == KQ - 1 && slot == BAR_SLOT) {
+              if (STAGE == 2 && !(WN_ABL & 4)) {
+                if (v + 3 < VT) fetch_chunk(fg, fc);   // uniform
+              }
+              if (!(WN_ABL & 2)) __syncthreads();  // V[buf^1] and Rs[buf] complete; nobody reads V[buf] any more
+              if (!(WN_ABL & 8)) {
+#pragma unroll
+                for (int x2 = 0; x2 < 16; ++x2)
+                  if (2 * x2 + 1 <= BAR_SLOT - 32 * (KQ - 1)) bload(buf ^ 1, 0, x2);   // consumed before the barrier
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }
+        if (!(WN_ABL & 16)) aload(xq, kqn);        // weights of this xi-quad for the next k-quad
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+  int v = 0, c = 0, g = 0;
+  int fg = 3 / NC, fc = 3 % NC;                     // (group, chunk) of virtual chunk v + 3
+  auto step = [&](auto stage_tag) __attribute__((always_inline)) {
+    chunk(v, c, fg, fc, stage_tag);
+    if (c == NC - 1) { group_epilogue(g); c = 0; ++g; } else { ++c; }
+    if (++fc == NC) { fc = 0; ++fg; }
+    ++v;
+  };
+  for (; v + 2 < VT;) step(wn_int<2>());
+  if (v + 1 < VT) step(wn_int<1>());
+  step(wn_int<0>());
 }
 
-// U = G g G^T in fragment order: uf[o/32][kpg][xi half][2][lane][4], value U[xi = 8 half + 4 q + e][o = 32 (o/32) +
-// (lane & 31)][i = 2 kpg + (lane >> 5)].  The weight scale 1/sqrt(9 Cin) is NOT folded in.
-__global__ void __launch_bounds__(256) pack_wino_kernel(const float* __restrict__ w, float* __restrict__ uf,
-                                                        int out_ch, int in_ch) {
+__global__ void __launch_bounds__(256) pack_wino16_kernel(const float* __restrict__ w, float* __restrict__ uf,
+                                                          int out_ch, int in_ch) {
   const int64_t total = (int64_t)out_ch * in_ch;       // one thread: the 16 values of one (o, i)
+  const int kqn = in_ch >> 2;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
     const int lane = (int)(idx & 63);
-    const int64_t rest = idx >> 6;
-    const int kpg = (int)(rest % (in_ch >> 1));
-    const int ob = (int)(rest / (in_ch >> 1));
-    const int o = 32 * ob + (lane & 31), i = 2 * kpg + (lane >> 5);
+    int64_t rest = idx >> 6;
+    const int half = (int)(rest & 1); rest >>= 1;
+    const int kq = (int)(rest % kqn);
+    const int ob = (int)(rest / kqn);
+    const int o = 32 * ob + 16 * half + (lane & 15), i = 4 * kq + (lane >> 4);
     const float* g = w + ((int64_t)o * in_ch + i) * 9;
-    float gg[4][3];                                      // G g
+    float gg[4][3];
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
       const float g0 = g[kx], g1 = g[3 + kx], g2 = g[6 + kx];
@@ -406,26 +437,16 @@ __global__ void __launch_bounds__(256) pack_wino_kernel(const float* __restrict_
       gg[2][kx] = 0.5f * (g0 - g1 + g2);
       gg[3][kx] = g2;
     }
-    float u[16];
+    float* dst = uf + ((int64_t)ob * kqn + kq) * 2048 + half * 256 + lane * 4;
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      u[4 * a + 0] = gg[a][0];
-      u[4 * a + 1] = 0.5f * (gg[a][0] + gg[a][1] + gg[a][2]);
-      u[4 * a + 2] = 0.5f * (gg[a][0] - gg[a][1] + gg[a][2]);
-      u[4 * a + 3] = gg[a][2];
-    }
-    float* dst = uf + ((int64_t)ob * (in_ch >> 1) + kpg) * 1024 + lane * 4;
-#pragma unroll
-    for (int half = 0; half < 2; ++half)
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-        *reinterpret_cast<rw_f32x4*>(dst + (half * 2 + q) * 256) =
-            rw_f32x4{u[8 * half + 4 * q], u[8 * half + 4 * q + 1], u[8 * half + 4 * q + 2], u[8 * half + 4 * q + 3]};
+    for (int a = 0; a < 4; ++a)
+      *reinterpret_cast<wn_f32x4*>(dst + a * 512) =
+          wn_f32x4{gg[a][0], 0.5f * (gg[a][0] + gg[a][1] + gg[a][2]), 0.5f * (gg[a][0] - gg[a][1] + gg[a][2]), gg[a][2]};
   }
 }
 
 static bool wino_shape_ok(int out_ch, int in_ch, int h, int w) {
-  return out_ch > 0 && in_ch > 0 && out_ch % 32 == 0 && in_ch % WN_IC == 0 && w % 32 == 0 && w >= 32 && h >= 8 &&
+  return out_ch > 0 && in_ch > 0 && out_ch % 32 == 0 && in_ch % 8 == 0 && w % 32 == 0 && w >= 32 && h >= 8 &&
          h % 8 == 0;
 }
 
@@ -438,30 +459,46 @@ extern "C" long long rw_packed_conv_weight_wino_elems(int out_ch, int in_ch) {
   return 16LL * out_ch * in_ch;
 }
 
+#include <stdlib.h>
+static int wn_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+
 extern "C" int rw_pack_conv_weight_wino_f32(const float* w, float* uf, int out_ch, int in_ch, rw_stream_t stream) {
   RW_CHECK_ARG(w && uf && out_ch > 0 && in_ch > 0);
-  if (out_ch % 32 || in_ch % 2) return RW_ERR_UNSUPPORTED;
+  if (out_ch % 32 || in_ch % 4) return RW_ERR_UNSUPPORTED;
   const int64_t total = (int64_t)out_ch * in_ch;
-  hipLaunchKernelGGL(pack_wino_kernel, dim3(rw_stream_grid(total, 256)), dim3(256), 0, rw_s(stream), w, uf, out_ch,
+  hipLaunchKernelGGL(pack_wino16_kernel, dim3(rw_stream_grid(total, 256)), dim3(256), 0, rw_s(stream), w, uf, out_ch,
                      in_ch);
   return RW_LAUNCH_RESULT();
 }
 
+// Workgroup = <2,2> 64 out-channels x 2 tile rows (4 x 32 pixels) or <1,4> 32 out-channels x 4 tile rows (8 x 32),
+// walking runs of gpw tile groups along x (RW_WINO_GPW overrides the run length: tuning).
 static int launch_wino(WinoProblem& p, bool rgb, hipStream_t s) {
-  const bool two_blocks = p.out_ch % 64 == 0;            // <2,1>: 64 out-channels x one tile group
-  const int wgn = two_blocks ? 1 : 2;
+  const bool wide = p.out_ch % 64 == 0;
+  const int wgn = wide ? 2 : 4;
   p.groups_x = p.w / 32;
-  p.groups_y = p.h / (4 * wgn);
-  const int64_t work = (int64_t)p.batch * p.groups_x * p.groups_y * (p.out_ch / (two_blocks ? 64 : 32));
+  p.groups_y = p.h / (2 * wgn);
+  const int o_tiles = p.out_ch / (wide ? 64 : 32);
+  int gpw = wn_env("RW_WINO_GPW", 8);
+  if (gpw < 1) gpw = 1;
+  if (gpw > p.groups_x) gpw = p.groups_x;
+  while (p.groups_x % gpw) --gpw;
+  // short launches: keep at least ~4 workgroups per CU
+  while (gpw > 1 && (int64_t)p.batch * p.groups_y * (p.groups_x / gpw) * o_tiles < 1024) {
+    --gpw;
+    while (p.groups_x % gpw) --gpw;
+  }
+  p.gpw = gpw;
+  const int64_t work = (int64_t)p.batch * p.groups_y * (p.groups_x / gpw) * o_tiles;
   if (work <= 0 || work > 0x7fffffff) return RW_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)work), block(256);
-  if (two_blocks) {
+  if (wide) {
     if (rgb) return RW_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((conv_wino_kernel<2, 1, false>), grid, block, 0, s, p);
+    hipLaunchKernelGGL((conv_wino16_kernel<2, 2, 8, false>), grid, block, 0, s, p);
   } else if (rgb) {
-    hipLaunchKernelGGL((conv_wino_kernel<1, 2, true>), grid, block, 0, s, p);
+    hipLaunchKernelGGL((conv_wino16_kernel<1, 4, 4, true>), grid, block, 0, s, p);
   } else {
-    hipLaunchKernelGGL((conv_wino_kernel<1, 2, false>), grid, block, 0, s, p);
+    hipLaunchKernelGGL((conv_wino16_kernel<1, 4, 4, false>), grid, block, 0, s, p);
   }
   return RW_LAUNCH_RESULT();
 }

@@ -173,7 +173,7 @@ def conv_algo():
     return os.environ.get('RW_CONV_ALGO', _DEFAULT_CONV_ALGO)
 
 
-_DEFAULT_CONV_ALGO = 'direct'
+_DEFAULT_CONV_ALGO = 'winograd'
 
 
 class DataBag(dict):

@@ -34,10 +34,19 @@ def main(batch=int(os.environ.get('RW_BATCH', '8')), iters=5, impl=int(os.enviro
         wp = hip.pack_conv_weight(w, 1 if up else 0)
         dm = hip.demod(hip.weight_sqsum(w, 1.0), style)
         split = os.environ.get('RW_PRECISION') == 'bf16x6' and not up and hip.bf16x6_supported(cout, cin, res)
+        wino = os.environ.get('RW_ALGO') == 'winograd' and not up and hip.wino_supported(cout, cin, res, res)
         if split:
             wb = hip.pack_conv_weight_bf16x3(w)
-        fn = (lambda: hip.conv3x3_bf16x6(x, wb, cout, 1.0, style=style, demod=dm)) if split else (lambda: hip.conv_transpose3x3s2(x, wp, cout, 1.0, style=style, demod=dm, impl=impl)) if up else \
-             (lambda: hip.conv3x3(x, wp, cout, 1.0, style=style, demod=dm, impl=impl))
+        ep = {}
+        if not up:          # the fused epilogue of a styled conv block, as the generator runs it
+            ep = dict(noise=torch.randn(batch, res * res, device=dev), noise_w=torch.tensor([0.1], device=dev),
+                      bias=torch.randn(cout, device=dev), act=True)
+        if wino:
+            uf = hip.pack_conv_weight_wino(w)
+        fn = (lambda: hip.conv3x3_wino(x, uf, cout, 1.0, style=style, demod=dm, **ep)) if wino else \
+             (lambda: hip.conv3x3_bf16x6(x, wb, cout, 1.0, style=style, demod=dm, **ep)) if split else \
+             (lambda: hip.conv_transpose3x3s2(x, wp, cout, 1.0, style=style, demod=dm, impl=impl)) if up else \
+             (lambda: hip.conv3x3(x, wp, cout, 1.0, style=style, demod=dm, impl=impl, **ep))
         fn()
         torch.cuda.synchronize()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -50,12 +59,12 @@ def main(batch=int(os.environ.get('RW_BATCH', '8')), iters=5, impl=int(os.enviro
         flops = 2.0 * 9 * cin * cout * res * res * batch
         out_res = 2 * res + 1 if up else res
         bytes_io = 4.0 * batch * (cin * res * res + cout * out_res * out_res)
-        rows.append(dict(layer=name, cin=cin, cout=cout, res=res, up=up, ms=round(ms, 4),
+        rows.append(dict(layer=name, cin=cin, cout=cout, res=res, up=up, wino=bool(wino), ms=round(ms, 4),
                          tflops=round(flops / ms / 1e9, 2), io_gbs=round(bytes_io / ms / 1e6, 1)))
         print(rows[-1])
         del x, w
     os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
-    with open(os.path.join(ROOT, 'gpurun_out', 'conv_bench.json'), 'w') as f:
+    with open(os.path.join(ROOT, 'gpurun_out', os.environ.get('RW_OUT', 'conv_bench.json')), 'w') as f:
         json.dump(dict(batch=batch, rows=rows), f, indent=1)
 
 
