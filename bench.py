@@ -104,7 +104,7 @@ class ConvTimer:
                 e.record()
                 b, i, h, w = x.shape
                 if wino is not None:
-                    name = 'conv_wino_kernel<%s, %s>' % ('2, 1' if out_ch % 64 == 0 else '1, 2', wino)
+                    name = 'conv_wino16_kernel<%s, %s>' % ('2, 2, 8' if out_ch % 64 == 0 else '1, 4, 4', wino)
                 else:
                     name = ('conv_halo_bf16x6_kernel<2, 2, %s>' % ('2, 2' if out_ch % 128 == 0 else '1, 4') if split
                             else conv_kernel_name(out_ch, i, w, upsample))
@@ -145,7 +145,7 @@ class ConvTimer:
                    all_conv_kernels=dict(achieved=round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
                                          frac=round(tot_fl / (tot_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
                                          ms_per_step=None))
-        if dom.startswith('conv_wino'):
+        if dom.startswith('conv_wino16'):
             # Winograd F(2x2,3x3): the matrix pipe issues 16/36 of the algorithmic (direct-sum) multiply-adds
             out['algorithm'] = 'winograd F(2x2,3x3), fp32: `achieved` counts the direct sum\'s FLOPs (SURVEY 8d); the matrix ' \
                                'pipe issues 1/2.25 of them'
@@ -474,7 +474,6 @@ def main():
     ap.add_argument('--size', type=int, default=1024)
     ap.add_argument('--layer', type=int, default=8)
     ap.add_argument('--seeds', type=int, default=1000)
-    ap.add_argument('--samples', type=int, default=1000, help='watermark: images per variant sample set')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='headline workload only')
     ap.add_argument('--precision', default='f32', choices=['f32', 'bf16x6'],

@@ -1,0 +1,175 @@
+"""BASELINE.json configs[4]: the watermark-removal experiment of the reference (``watermark.sh:11-24`` runs
+``metrics/make_watermark_images.py`` five times) as ONE job over the GPUs of a node.
+
+What shards: the five variants are independent edits of independent copies of the generator -- the part of the
+path SURVEY.md 8e calls "replicas only" (the 2001-step solve is sequential on 9.4 MB of state).  Variants are
+dealt round-robin to the ranks inside ``parallel.replicas()``, so every sweep a rewriter runs stays local to its
+rank and no collective is entered; the per-variant feature statistics of the generated sample sets are gathered
+once at the end (outside the timed region) for the Frechet distances between variants.
+
+Per variant (metrics/make_watermark_images.py:39-84, defaults :13-28): church-256 architecture, layer 6,
+1000-seed statistics computed with the truncation-1.0 model and re-used from the shared cache directory by the
+truncation-0.5 rewriter (quirk Q7), request multikey_markandbottom.json, then
+  'ours'        nreps x apply_erase(rank, drank, 2001 steps, low_rank_gradient=True)
+  'gandissect'  multi_key_from_selection(key_method='gandissect', rank=drank) + zero()
+  'none'        no edit
+and the sample set: the images of the statistics seeds in batches of 10 (:99-131 -- each image with the noise row
+of its position in its batch of 10, quirk Q1), reduced on the fly to float64 feature statistics.
+The reference's feature extractor (a TensorFlow Inception graph downloaded at run time, metrics/fid.py:16) is
+out of scope and pluggable; the default here is a fixed 8x8 average-pooled RGB descriptor (192 features).
+"""
+import json
+import os
+import shutil
+import tempfile
+import time
+
+import torch
+
+from . import parallel, samples, synthetic
+from .utils import zdataset
+from .utils.stylegan2 import models
+from .utils.stylegan2.models import noise_batch_period
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WATERMARK_VARIANTS = [                  # watermark.sh:11-24, in order
+    dict(erasemethod='ours', nreps=2, drank=60, rank=1),
+    dict(erasemethod='ours', nreps=2, drank=30, rank=1),
+    dict(erasemethod='gandissect', drank=30),
+    dict(erasemethod='gandissect', drank=60),
+    dict(erasemethod='none'),
+]
+
+
+def variant_name(v):
+    return '-'.join(str(v[k]) for k in ('erasemethod', 'drank', 'nreps') if k in v)
+
+
+def pooled_rgb_features(images):
+    """(B,3,S,S) -> (B,192): 8x8 average pooling.  A stand-in for the Inception pool3 features."""
+    return torch.nn.functional.adaptive_avg_pool2d(images, 8).reshape(images.shape[0], -1)
+
+
+def build_model(size, truncation, device, seed=0):
+    g = models.SeqStyleGAN2(size, 512, 8, truncation=truncation, mconv='seq')
+    synthetic.randomize_(g, seed=seed)
+    return g.eval().to(device)
+
+
+def sample_set_statistics(model, zds, batch=250, feature_fn=pooled_rgb_features, stats=None):
+    """metrics/make_watermark_images.py:99-131 without the PNG writer: model(z) over the dataset in index order,
+    launches of `batch` seeds = batch/10 reference batches of 10 (noise_batch_period keeps every image's row)."""
+    stats = stats or samples.FeatureStatistics()
+    device = next(model.parameters()).device
+    n = len(zds)
+    batch = max(10, batch // 10 * 10)
+    with torch.no_grad(), noise_batch_period(10):
+        for i in range(0, n - n % 10, batch):
+            z = torch.stack([zds[j][0] for j in range(i, min(i + batch, n - n % 10))]).to(device)
+            stats.add(feature_fn(model(z)))
+    if n % 10:
+        with torch.no_grad():           # the reference's last, short batch
+            z = torch.stack([zds[j][0] for j in range(n - n % 10, n)]).to(device)
+            stats.add(feature_fn(model(z)))
+    return stats
+
+
+def run_watermark_variant(variant, device, request, size=256, layer=6, sample_size=1000, niters=2001, piters=10,
+                          lr=0.05, cachedir=None, feature_fn=pooled_rgb_features, weight_seed=0):
+    """One invocation of metrics/make_watermark_images.py main(); returns (timings, FeatureStatistics, rewriter)."""
+    from .rewrite import ganrewrite
+    own_cache = cachedir is None
+    cachedir = cachedir or tempfile.mkdtemp(prefix='rw_watermark_')
+    t = {}
+    t0 = time.perf_counter()
+    model_for_covariance = build_model(size, 1.00, device, weight_seed)
+    model = build_model(size, 0.50, device, weight_seed)
+    zds = zdataset.z_dataset_for_model(model, size=sample_size)
+    gw = None
+    for m in (model_for_covariance, model):
+        gw = ganrewrite.SeqStyleGanRewriter(
+            m, zds, layer, cachedir=cachedir, low_rank_insert=True, low_rank_gradient=True,
+            key_method={'ours': 'zca', 'gandissect': 'gandissect', 'none': 'zca'}[variant['erasemethod']],
+            tight_paste=True)
+        if m is model_for_covariance:
+            gw.collect_2nd_moment()
+    torch.cuda.synchronize(device) if torch.device(device).type == 'cuda' else None
+    t['statistics_s'] = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    if variant['erasemethod'] == 'ours':
+        for _ in range(variant.get('nreps', 2)):
+            gw.apply_erase(request, rank=variant.get('rank', 1), drank=variant['drank'], niter=niters, piter=piters,
+                           lr=lr)
+    elif variant['erasemethod'] == 'gandissect':
+        mkey = gw.multi_key_from_selection(request['key'], rank=variant['drank'])
+        gw.zero(mkey)
+    else:
+        assert variant['erasemethod'] == 'none'
+    torch.cuda.synchronize(device) if torch.device(device).type == 'cuda' else None
+    t['edit_s'] = time.perf_counter() - t1
+    t2 = time.perf_counter()
+    stats = sample_set_statistics(gw.model, zds, feature_fn=feature_fn)
+    torch.cuda.synchronize(device) if torch.device(device).type == 'cuda' else None
+    t['sample_set_s'] = time.perf_counter() - t2
+    t['images'] = stats.count
+    if own_cache:
+        shutil.rmtree(cachedir, ignore_errors=True)
+    return t, stats, gw
+
+
+def load_request(name='multikey_markandbottom.json'):
+    with open(os.path.join(ROOT, 'tests', 'golden', 'masks', name)) as f:
+        return json.load(f)
+
+
+def watermark_job(device, rank=0, world=1, sample_size=1000, niters=2001, size=256, layer=6, variants=None):
+    """The five variants, variant i on rank i mod world.  Returns {variant name: (timings, stats)} of this rank."""
+    request = load_request()
+    variants = WATERMARK_VARIANTS if variants is None else variants
+    out = {}
+    with parallel.replicas():
+        for i, v in enumerate(variants):
+            if i % world != rank:
+                continue
+            t, stats, _ = run_watermark_variant(v, device, request, size=size, layer=layer, sample_size=sample_size,
+                                                niters=niters)
+            out[variant_name(v)] = (t, stats)
+    return out
+
+
+def watermark_bench(args, rank, world, device, timed):
+    """bench.py --workload watermark: one step = the whole five-variant job (strong scaling: the work is fixed)."""
+    import torch.distributed as dist
+    results = {}
+
+    def step():
+        results.clear()
+        results.update(watermark_job(device, rank, world, sample_size=args.seeds, niters=2001))
+    dt = timed(step, args.steps, args.warmup, world)
+    mine = {name: dict(t, mu_sigma=[a.tolist() for a in stats.mean_cov()]) for name, (t, stats) in results.items()}
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        mine = {k: v for part in gathered for k, v in part.items()}
+    frechet = {}
+    if rank == 0 and 'none' in mine:
+        import numpy
+        mu0, s0 = (numpy.array(a) for a in mine['none']['mu_sigma'])
+        for name, rec in mine.items():
+            mu, s = (numpy.array(a) for a in rec['mu_sigma'])
+            frechet[name] = float(samples.frechet_distance(mu, s, mu0, s0))
+    per_variant = {name: {k: (round(v, 4) if isinstance(v, float) else v) for k, v in rec.items() if k != 'mu_sigma'}
+                   for name, rec in mine.items()}
+    n = args.steps
+    images = sum(rec['images'] for rec in per_variant.values())
+    return dict(metric='watermark-removal job (watermark.sh: 5 erase variants + their %d-image sample sets), seconds'
+                       % args.seeds,
+                value=round(dt / n, 4), unit='s', n_gpus=world, steps=n, warmup=args.warmup,
+                ms_per_step=round(dt / n * 1e3, 2), higher_is_better=False, scaling='strong', vs_baseline=None,
+                dtype='f32', data='synthetic',
+                config=dict(workload='church-256 architecture, layer 6, %d-seed statistics, 2001-step erase solves '
+                                     '(low_rank_gradient), variants dealt round-robin to ranks as independent replicas'
+                                     % args.seeds,
+                            variants=per_variant, images_per_s=round(images / (dt / n), 1),
+                            frechet_vs_unedited_pooled_rgb=frechet))
