@@ -116,10 +116,13 @@ __global__ void __launch_bounds__(256, 2) conv_wino16_kernel(const WinoProblem p
   const int NC = p.in_ch / IC;
   const int VT = p.gpw * NC;
 
-  // ---- raw patch slots: position (r, c) = (pos / 34, pos % 34) of the patch; the global offset and the
-  // zero-padding mask are recomputed when the fetch cursor enters a new group of the run
+  // ---- raw patch slots: position (r, c) = (pos / 34, pos % 34) of the patch.  The fetch is a BUFFER load
+  // (descriptor = this image's feature maps, scalar channel offset, 32-bit lane offset): positions outside the
+  // image get an out-of-range offset and the hardware returns 0 -- the zero padding costs no instruction, and
+  // there is no 64-bit address arithmetic.  Lane offsets are recomputed when the fetch cursor enters a new group.
+  const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(xb), 0, (int)((int64_t)p.in_ch * hw * 4), 0x00020000);
   int xoff[PSLOT], xlds[PSLOT];
-  float xmask[PSLOT];
 #pragma unroll
   for (int sl = 0; sl < PSLOT; ++sl) {
     const int pos = tid + 256 * sl;
@@ -134,18 +137,18 @@ __global__ void __launch_bounds__(256, 2) conv_wino16_kernel(const WinoProblem p
       const int r = pos / WN_PC, c = pos - r * WN_PC;
       const int iy = y0 - 1 + r, ix = x0 - 1 + c;
       const bool ok = pos < NPOS && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
-      xoff[sl] = ok ? iy * p.w + ix : 0;
-      xmask[sl] = ok ? 1.0f : 0.0f;
+      xoff[sl] = ok ? (iy * p.w + ix) * 4 : 0x7fffffff;          // bytes; out of range -> 0
     }
   };
   float xreg[PSLOT][IC];
   float sty[IC];
+  const int hw4 = (int)hw * 4;
   auto xfetch = [&](int i0) __attribute__((always_inline)) {
-    const float* xc = xb + (int64_t)i0 * hw;
 #pragma unroll
     for (int ic = 0; ic < IC; ++ic)
 #pragma unroll
-      for (int sl = 0; sl < PSLOT; ++sl) xreg[sl][ic] = xc[(int64_t)ic * hw + xoff[sl]];
+      for (int sl = 0; sl < PSLOT; ++sl)
+        xreg[sl][ic] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xsrc, xoff[sl], (i0 + ic) * hw4, 0));
     if (st) {
 #pragma unroll
       for (int ic = 0; ic < IC; ++ic) sty[ic] = st[i0 + ic];
@@ -156,7 +159,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino16_kernel(const WinoProblem p
   };
   auto raw_step = [&](int rbuf, int j) __attribute__((always_inline)) {
     const int sl = j / IC, ic = j % IC;
-    (&Rs[0][0][0][0])[rbuf * IC * PR * WN_RS + ic * PR * WN_RS + xlds[sl]] = xreg[sl][ic] * (xmask[sl] * sty[ic]);
+    (&Rs[0][0][0][0])[rbuf * IC * PR * WN_RS + ic * PR * WN_RS + xlds[sl]] = xreg[sl][ic] * sty[ic];
   };
   // fetch of virtual chunk vf (uniform arguments, computed by the caller): chunk fc of group fg
   auto fetch_chunk = [&](int fg, int fc) __attribute__((always_inline)) {

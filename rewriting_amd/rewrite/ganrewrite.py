@@ -531,14 +531,21 @@ class ProgressiveGanRewriter(object):
         return renormalize.as_image(imgdata[0])
 
     def render_image_batch(self, imgnums, key=None, level=None, **kwargs):
-        if key is not None and level is not None:
-            return [self.render_image(n, key=key, level=level, **kwargs) for n in imgnums]
+        """Batches of three, as the reference renders them (rewrite/ganrewrite.py:626-650): an image's noise row is
+        its position in its batch of three (quirk Q1), for the picture and for the heat map alike."""
         results = []
         for i in range(0, len(imgnums), 3):
             with torch.no_grad():
                 zb = torch.cat([self.get_z(n) for n in imgnums[i:i + 3]])
                 batch = self.rendered_image(self.sample_image_from_latent(zb))
-            results.extend(renormalize.as_image(img) for img in batch)
+                if key is not None and level is not None:
+                    acts = self.context_acts(self.context_model(zb))
+                    heatmap = (acts * key.to(self.device)[None, :, None, None]).sum(dim=1)
+            if key is not None and level is not None:
+                iv = self._overlay().ImageVisualizer(batch.shape[2:])
+                results.extend(iv.masked_image(img, heatmap[j], level=level, **kwargs) for j, img in enumerate(batch))
+            else:
+                results.extend(renormalize.as_image(img) for img in batch)
         return results
 
 

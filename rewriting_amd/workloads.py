@@ -51,9 +51,22 @@ def pooled_rgb_features(images):
     return torch.nn.functional.adaptive_avg_pool2d(images, 8).reshape(images.shape[0], -1)
 
 
+_synthetic_states = {}
+
+
 def build_model(size, truncation, device, seed=0):
+    """The "checkpoint" of this offline build: seeded synthetic weights.  The state dict is generated once per
+    (size, seed) and kept on the host -- every variant then loads it like a driver loads its checkpoint file."""
     g = models.SeqStyleGAN2(size, 512, 8, truncation=truncation, mconv='seq')
-    synthetic.randomize_(g, seed=seed)
+    key = (size, seed)
+    if key not in _synthetic_states:
+        synthetic.randomize_(g, seed=seed)
+        _synthetic_states[key] = ({k: v.detach().clone() for k, v in g.state_dict().items()},
+                                  g.latents.latent_avg.detach().clone())
+    else:
+        sd, avg = _synthetic_states[key]
+        g.latents.latent_avg = avg.clone()
+        g.load_state_dict(sd)
     return g.eval().to(device)
 
 
