@@ -818,6 +818,7 @@ __global__ void __launch_bounds__(256, 2) conv_up_halo_kernel(const UpProblem p)
   constexpr int KP = IC / 2;
   static_assert(WGM * WGN == 4, "4 waves per workgroup");
   __shared__ float Xs[2][IC][XH][XW];
+  __shared__ float Sc[BM];                    // w_scale * demod of the workgroup's out-channels (see the epilogue)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm0 = (wave / WGN) * 32;
@@ -838,6 +839,9 @@ __global__ void __launch_bounds__(256, 2) conv_up_halo_kernel(const UpProblem p)
   // weights in fragment order (rw_pack_conv_weight_f32 mode 1): [chunk][o / 32][kp][576]
   const float* wf = p.wfrag + (int64_t)((o0 + wm0) >> 5) * KP * 576;    // uniform
   const int c_stride = (p.out_ch >> 5) * KP * 576;
+  // A global load in the epilogue would queue behind whatever the loop issued last (vmcnt retires in order) and cost
+  // a memory latency per workgroup: the per-channel factors go to LDS up front (visible after the first barrier).
+  if (tid < BM) Sc[tid] = p.demod ? p.demod[(int64_t)ib * p.out_ch + o0 + tid] * p.w_scale : p.w_scale;
 
   // Halo staging: this thread owns up to PSLOT fixed positions of the (TH+1) x 33 patch; positions
   // outside the image are loaded from a legal address and multiplied by 0, slots past the patch
@@ -923,7 +927,8 @@ __global__ void __launch_bounds__(256, 2) conv_up_halo_kernel(const UpProblem p)
       int nkp = kp + 1, nc = c;
       if (nkp == KP) { nkp = 0; nc = cn; }
       if (!RW_ABL(p, 2)) aload(anxt, nkp, nc);
-      if (kp == 0 && !RW_ABL(p, 4)) xfetch(cn * IC);       // after the weight load: its wait must not drain these
+      if (kp == 0 && c + 1 < n_chunks && !RW_ABL(p, 4)) xfetch(cn * IC);   // after the weight load: its wait must
+                                                                           // not drain these; nothing to fetch at the end
       if (kp + 1 < KP && !RW_ABL(p, 1)) {
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
@@ -970,17 +975,9 @@ __global__ void __launch_bounds__(256, 2) conv_up_halo_kernel(const UpProblem p)
   const int xx = x0 + lc;
   const bool odd_lane = fcol & 1;
   const bool pair_ok = (xx | 1) < p.w;        // both quads of the lane pair are inside the tiled area
-  float scale[16];                            // w_scale * demod of this lane's 16 out-channels, loaded at once
-  if (p.demod) {
-    const float* dm = p.demod + (int64_t)ib * p.out_ch + o0 + wm0 + 4 * frow;
+  float scale[16];                            // w_scale * demod of this lane's 16 out-channels (LDS table)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) scale[r] = dm[(r & 3) + 8 * (r >> 2)];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) scale[r] *= p.w_scale;
-  } else {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) scale[r] = p.w_scale;
-  }
+  for (int r = 0; r < 16; ++r) scale[r] = Sc[wm0 + 4 * frow + (r & 3) + 8 * (r >> 2)];
 #pragma unroll
   for (int b = 0; b < TN; ++b) {
     const int yy = y0 + wrow0 + b * RPT + lr;

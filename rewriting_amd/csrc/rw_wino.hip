@@ -23,7 +23,6 @@
 #define WN_ABL 0
 #endif
 
-#define WN_RS 48                // LDS row pitch of the raw patch (floats): 2 rows = 96 dwords = 32 mod 64 banks
 #define WN_PC 34                // patch columns
 
 struct WinoProblem {
@@ -65,8 +64,11 @@ template <int N> struct wn_int { static constexpr int value = N; };
 //   * operands are single buffered and streamed: the registers of a weight / V fragment are refilled for the next
 //     k-quad right after the MFMAs that consumed them (28 MFMAs ~ 900 cycles ahead of their next use); the weight
 //     stream wraps around at the end of a group (same out-channel tile for the whole run).
-// LDS: V rows are padded by 16 floats (the 16x16x4 B operand reads 16 tiles of 4 consecutive channels: without
-// the pad channels k and k+1 share banks).  IC = 8 input channels per chunk (4 for the 32-out-channel shape).
+// LDS banks: V channel rows are padded (the 16x16x4 B operand reads 16 tiles of 4 consecutive channels: unpadded,
+// channels k and k+1 share banks), and the raw patch has a row pitch of 48 floats (40 for the one-tile-row shape) so
+// that the two 16-lane halves of a transform read (tile rows r, r+1, or channels c, c+1) fall on disjoint banks.
+// Shapes: <4,1> 128 out-channels x 1 tile row, <2,2> 64 x 2, <1,4> 32 x 4; IC = 8 input channels per chunk (4 for
+// <1,4>, whose V is twice as wide).  The more out-channels share one transformed patch, the less staging per MFMA.
 //   weights: uf[o/32][i/4][xi/4][(o%32)/16][lane][xi%4], o = 32 (o/32) + 16 ((o%32)/16) + (lane & 15),
 //            i = 4 (i/4) + (lane >> 4)                                     (rw_pack_conv_weight_wino_f32)
 // ---------------------------------------------------------------------------------------
@@ -77,13 +79,17 @@ __global__ void __launch_bounds__(256, 2) conv_wino16_kernel(const WinoProblem p
   static_assert(WGM * WGN == 4, "4 waves per workgroup");
   constexpr int KQ = IC / 4;                       // k-quads per chunk
   constexpr int NT = 16 * WGN;                     // tiles per workgroup: WGN tile rows x 16 tile columns
-  constexpr int VP = NT + 16;                      // padded channel-row pitch of V
+  constexpr int VP = NT == 16 ? 48 : NT + 16;      // padded channel-row pitch of V (see the bank notes above)
+  constexpr int RS = NT == 16 ? 40 : 48;           // row pitch of the raw patch
   constexpr int PR = 2 * WGN + 2;                  // patch rows
   constexpr int NPOS = PR * WN_PC;
   constexpr int PSLOT = (NPOS + 255) / 256;
   constexpr int NRAW = PSLOT * IC;
-  constexpr int NIT = NT * IC / 256;
-  static_assert(NIT >= 1 && NT * IC % 256 == 0, "transform items");
+  // transform items (tile, channel) per thread and chunk; with fewer items than threads (<4,1>: 16 tiles x 8
+  // channels) only the first NT * IC threads transform
+  constexpr int NIT = NT * IC >= 256 ? NT * IC / 256 : 1;
+  constexpr bool XF_ALL = NT * IC >= 256;
+  static_assert(NT * IC % 256 == 0 || NT * IC == 128, "transform items");
   constexpr int CH_STEP = 256 / NT;
   constexpr int SLOTS = 32 * KQ;                   // MFMA slots per chunk and wave
   constexpr int NXS = 1 + 4 * NIT;                 // transform slots: the reads, then two compute steps per slot
@@ -92,8 +98,10 @@ __global__ void __launch_bounds__(256, 2) conv_wino16_kernel(const WinoProblem p
   constexpr int FETCH_SLOT = STRIDE * (NXS + NRAW);             // first slot after the last staging step
   constexpr int BAR_SLOT = FETCH_SLOT;                          // barrier right there; >= 5 MFMAs follow it
   static_assert(BAR_SLOT + 5 <= SLOTS, "room for the B prefetch behind the barrier");
-  __shared__ __attribute__((aligned(16))) float Rs[2][IC][PR][WN_RS];
+  __shared__ __attribute__((aligned(16))) float Rs[2][IC][PR][RS];
   __shared__ __attribute__((aligned(16))) float Vs[2][16][IC][VP];
+  // per-out-channel constants of the epilogue: [0] w_scale * demod, [1] bias, [2..4] ToRGB weights x style x scale
+  __shared__ float Ct[RGB ? 5 : 2][32 * WGM];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -116,6 +124,21 @@ __global__ void __launch_bounds__(256, 2) conv_wino16_kernel(const WinoProblem p
   const int NC = p.in_ch / IC;
   const int VT = p.gpw * NC;
 
+  // The epilogue runs once per tile group, in the middle of the load stream: a global load there queues behind the
+  // patch fetch just issued (vmcnt retires in order) and costs a full memory latency per group.  Everything it needs
+  // per out-channel is therefore put into LDS once per workgroup (visible after the prologue's first barrier); the
+  // per-pixel noise / running image are fetched at the start of a group's last chunk, ahead of that chunk's fetch.
+  if (tid < 32 * WGM) {
+    const int o = o0 + tid;
+    Ct[0][tid] = p.demod ? p.demod[(int64_t)ib * p.out_ch + o] * p.w_scale : p.w_scale;
+    Ct[1][tid] = p.act ? p.bias[o] : 0.f;
+    if (RGB) {
+      const float sr = p.rgb_scale * p.rgb_style[(int64_t)ib * p.out_ch + o];
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) Ct[2 + cc][tid] = sr * p.rgb_weight[cc * p.out_ch + o];
+    }
+  }
+
   // ---- raw patch slots: position (r, c) = (pos / 34, pos % 34) of the patch.  The fetch is a BUFFER load
   // (descriptor = this image's feature maps, scalar channel offset, 32-bit lane offset): positions outside the
   // image get an out-of-range offset and the hardware returns 0 -- the zero padding costs no instruction, and
@@ -127,7 +150,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino16_kernel(const WinoProblem p
   for (int sl = 0; sl < PSLOT; ++sl) {
     const int pos = tid + 256 * sl;
     const int r = pos / WN_PC, c = pos - r * WN_PC;
-    xlds[sl] = pos < NPOS ? r * WN_RS + c : WN_RS - 1;
+    xlds[sl] = pos < NPOS ? r * RS + c : RS - 1;
   }
   auto set_group = [&](int g) __attribute__((always_inline)) {
     const int x0 = (gx0 + g) * 32;
@@ -159,7 +182,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino16_kernel(const WinoProblem p
   };
   auto raw_step = [&](int rbuf, int j) __attribute__((always_inline)) {
     const int sl = j / IC, ic = j % IC;
-    (&Rs[0][0][0][0])[rbuf * IC * PR * WN_RS + ic * PR * WN_RS + xlds[sl]] = xreg[sl][ic] * sty[ic];
+    (&Rs[0][0][0][0])[rbuf * IC * PR * RS + ic * PR * RS + xlds[sl]] = xreg[sl][ic] * sty[ic];
   };
   // fetch of virtual chunk vf (uniform arguments, computed by the caller): chunk fc of group fg
   auto fetch_chunk = [&](int fg, int fc) __attribute__((always_inline)) {
@@ -175,12 +198,13 @@ __global__ void __launch_bounds__(256, 2) conv_wino16_kernel(const WinoProblem p
   float e[4][4];
   constexpr int NXF = 9 * NIT;
   auto xform_step = [&](int buf, int s) __attribute__((always_inline)) {          // Rs[buf] -> Vs[buf]
+    if (!XF_ALL && tid >= NT * IC) return;         // whole waves (NT * IC is a multiple of 64)
     if (s < NIT) {
-      const float* src = rsrc + buf * IC * PR * WN_RS + s * CH_STEP * PR * WN_RS;
+      const float* src = rsrc + buf * IC * PR * RS + s * CH_STEP * PR * RS;
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
-        drow[s][a][0] = *reinterpret_cast<const float2*>(src + a * WN_RS);
-        drow[s][a][1] = *reinterpret_cast<const float2*>(src + a * WN_RS + 2);
+        drow[s][a][0] = *reinterpret_cast<const float2*>(src + a * RS);
+        drow[s][a][1] = *reinterpret_cast<const float2*>(src + a * RS + 2);
       }
       return;
     }
@@ -254,21 +278,40 @@ __global__ void __launch_bounds__(256, 2) conv_wino16_kernel(const WinoProblem p
 
   // Epilogue of one group: lane-local output transform of this wave's 32 out-channels x 16 tiles.
   // acc[4a + b][half][j] = M[a][b] of out-channel o0 + 32 wm + 16 half + 4 lk + j, tile column lt.
+  float2 pre_nz[2];                                 // noise of this lane's 2x2 pixels (rows oy, oy + 1)
+  float2 pre_sk[RGB ? 3 : 1][2];                    // running RGB image, likewise
+  const float rgb_b0 = RGB && p.rgb_bias ? p.rgb_bias[0] : 0.f, rgb_b1 = RGB && p.rgb_bias ? p.rgb_bias[1] : 0.f,
+              rgb_b2 = RGB && p.rgb_bias ? p.rgb_bias[2] : 0.f;
+  const float noise_w = p.noise ? p.noise_w[0] : 0.f;
+  auto epilogue_prefetch = [&](int g) __attribute__((always_inline)) {
+    const int64_t pix = (int64_t)(y0 + 2 * wn) * p.w + (gx0 + g) * 32 + 2 * lt;
+    if (p.noise) {
+      const float* np = p.noise + (int64_t)ib * hw + pix;
+      pre_nz[0] = *reinterpret_cast<const float2*>(np);
+      pre_nz[1] = *reinterpret_cast<const float2*>(np + p.w);
+    }
+    if (RGB && p.rgb_skip) {
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) {
+        const float* sp = p.rgb_skip + ((int64_t)ib * 3 + cc) * hw + pix;
+        pre_sk[cc][0] = *reinterpret_cast<const float2*>(sp);
+        pre_sk[cc][1] = *reinterpret_cast<const float2*>(sp + p.w);
+      }
+    }
+  };
   auto group_epilogue = [&](int g) __attribute__((always_inline)) {
     const int x0 = (gx0 + g) * 32;
     const int oy = y0 + 2 * wn, ox = x0 + 2 * lt;
     const int o_first = o0 + 32 * wm + 4 * lk;            // + 16 half + j
     float nz[4] = {0.f, 0.f, 0.f, 0.f};
     if (p.noise) {
-      const float nw = p.noise_w[0];
-      const float* np = p.noise + (int64_t)ib * hw + (int64_t)oy * p.w + ox;
-      const float2 n0 = *reinterpret_cast<const float2*>(np), n1 = *reinterpret_cast<const float2*>(np + p.w);
-      nz[0] = n0.x * nw; nz[1] = n0.y * nw; nz[2] = n1.x * nw; nz[3] = n1.y * nw;
+      nz[0] = pre_nz[0].x * noise_w; nz[1] = pre_nz[0].y * noise_w;
+      nz[2] = pre_nz[1].x * noise_w; nz[3] = pre_nz[1].y * noise_w;
     }
     float rgbp[4][3];
 #pragma unroll
     for (int j = 0; j < 4; ++j) rgbp[j][0] = rgbp[j][1] = rgbp[j][2] = 0.f;
-    const float* dm = p.demod ? p.demod + (int64_t)ib * p.out_ch + o_first : nullptr;
+    const float* ct = &Ct[0][32 * wm + 4 * lk];
     // neighbouring lanes (tile columns 2m, 2m+1) exchange halves: the even lane stores four consecutive pixels of
     // output row oy, the odd lane four of row oy + 1 -- one aligned 16-byte store per lane and channel
     const bool odd = lt & 1;
@@ -277,16 +320,13 @@ __global__ void __launch_bounds__(256, 2) conv_wino16_kernel(const WinoProblem p
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int half = q >> 2, j = q & 3;
-      // the per-channel constants are fetched here, one channel ahead of their use at most: keeping all eight
-      // channels' worth in registers next to 128 accumulators spills
       const int oc = 16 * half + j;
-      const float scale = dm ? dm[oc] * p.w_scale : p.w_scale;
-      const float bias = p.act ? p.bias[o_first + oc] : 0.f;
+      const float scale = ct[oc];
+      const float bias = ct[32 * WGM + oc];
       float wr[3] = {0.f, 0.f, 0.f};
       if (RGB) {
-        const float sr = p.rgb_scale * p.rgb_style[(int64_t)ib * p.out_ch + o_first + oc];
 #pragma unroll
-        for (int cc = 0; cc < 3; ++cc) wr[cc] = sr * p.rgb_weight[cc * p.out_ch + o_first + oc];
+        for (int cc = 0; cc < 3; ++cc) wr[cc] = ct[(2 + cc) * 32 * WGM + oc];
       }
       float s0[4], s1[4];
 #pragma unroll
@@ -334,19 +374,12 @@ __global__ void __launch_bounds__(256, 2) conv_wino16_kernel(const WinoProblem p
           rgbp[k][cc] = t;
         }
       if (lk == 0) {
-        float rb[3] = {0.f, 0.f, 0.f};
-        if (p.rgb_bias) {
-#pragma unroll
-          for (int cc = 0; cc < 3; ++cc) rb[cc] = p.rgb_bias[cc];
-        }
+        const float rb[3] = {rgb_b0, rgb_b1, rgb_b2};
 #pragma unroll
         for (int cc = 0; cc < 3; ++cc) {
           const int64_t base = ((int64_t)ib * 3 + cc) * hw + (int64_t)oy * p.w + ox;
           float2 k0 = {0.f, 0.f}, k1 = {0.f, 0.f};
-          if (p.rgb_skip) {
-            k0 = *reinterpret_cast<const float2*>(p.rgb_skip + base);
-            k1 = *reinterpret_cast<const float2*>(p.rgb_skip + base + p.w);
-          }
+          if (p.rgb_skip) { k0 = pre_sk[cc][0]; k1 = pre_sk[cc][1]; }
           float2 r0 = {rgbp[0][cc] + rb[cc] + k0.x, rgbp[1][cc] + rb[cc] + k0.y};
           float2 r1 = {rgbp[2][cc] + rb[cc] + k1.x, rgbp[3][cc] + rb[cc] + k1.y};
           *reinterpret_cast<float2*>(p.rgb_out + base) = r0;
@@ -408,6 +441,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino16_kernel(const WinoProblem p
   int v = 0, c = 0, g = 0;
   int fg = 3 / NC, fc = 3 % NC;                     // (group, chunk) of virtual chunk v + 3
   auto step = [&](auto stage_tag) __attribute__((always_inline)) {
+    if (c == NC - 1) epilogue_prefetch(g);         // ahead of this chunk's patch fetch in the load queue
     chunk(v, c, fg, fc, stage_tag);
     if (c == NC - 1) { group_epilogue(g); c = 0; ++g; } else { ++c; }
     if (++fc == NC) { fc = 0; ++fg; }
@@ -474,14 +508,19 @@ extern "C" int rw_pack_conv_weight_wino_f32(const float* w, float* uf, int out_c
   return RW_LAUNCH_RESULT();
 }
 
-// Workgroup = <2,2> 64 out-channels x 2 tile rows (4 x 32 pixels) or <1,4> 32 out-channels x 4 tile rows (8 x 32),
-// walking runs of gpw tile groups along x (RW_WINO_GPW overrides the run length: tuning).
+// Workgroup shape by out-channel count: <4,1> 128 out-channels x 1 tile row (2 x 32 pixels), <2,2> 64 x 2 tile rows,
+// <1,4> 32 x 4 tile rows; each walks runs of gpw tile groups along x (RW_WINO_GPW / RW_WINO_TILE: tuning overrides).
 static int launch_wino(WinoProblem& p, bool rgb, hipStream_t s) {
-  const bool wide = p.out_ch % 64 == 0;
-  const int wgn = wide ? 2 : 4;
+  // (<4,1>: 128 out-channels x 1 tile row halves the staging per MFMA but gives each of the four waves its own weight
+  // stream: measured 195-222 vs 240 TFLOP/s effective -- the weight stream binds first; kept selectable for tuning)
+  int bm = p.out_ch % 64 == 0 ? 64 : 32;
+  const int force = wn_env("RW_WINO_TILE", 0);
+  if (force && p.out_ch % force == 0 && (force == 32 || force == 64 || force == 128)) bm = force;
+  const int wgn = 128 / bm;                       // tile rows per workgroup: 1, 2, 4
+  if (p.h % (2 * wgn)) return RW_ERR_UNSUPPORTED;
   p.groups_x = p.w / 32;
   p.groups_y = p.h / (2 * wgn);
-  const int o_tiles = p.out_ch / (wide ? 64 : 32);
+  const int o_tiles = p.out_ch / bm;
   int gpw = wn_env("RW_WINO_GPW", 8);
   if (gpw < 1) gpw = 1;
   if (gpw > p.groups_x) gpw = p.groups_x;
@@ -495,14 +534,11 @@ static int launch_wino(WinoProblem& p, bool rgb, hipStream_t s) {
   const int64_t work = (int64_t)p.batch * p.groups_y * (p.groups_x / gpw) * o_tiles;
   if (work <= 0 || work > 0x7fffffff) return RW_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)work), block(256);
-  if (wide) {
-    if (rgb) return RW_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((conv_wino16_kernel<2, 2, 8, false>), grid, block, 0, s, p);
-  } else if (rgb) {
-    hipLaunchKernelGGL((conv_wino16_kernel<1, 4, 4, true>), grid, block, 0, s, p);
-  } else {
-    hipLaunchKernelGGL((conv_wino16_kernel<1, 4, 4, false>), grid, block, 0, s, p);
-  }
+  if (rgb && bm != 32) return RW_ERR_UNSUPPORTED;
+  if (bm == 128) hipLaunchKernelGGL((conv_wino16_kernel<4, 1, 8, false>), grid, block, 0, s, p);
+  else if (bm == 64) hipLaunchKernelGGL((conv_wino16_kernel<2, 2, 8, false>), grid, block, 0, s, p);
+  else if (rgb) hipLaunchKernelGGL((conv_wino16_kernel<1, 4, 4, true>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((conv_wino16_kernel<1, 4, 4, false>), grid, block, 0, s, p);
   return RW_LAUNCH_RESULT();
 }
 
