@@ -290,8 +290,12 @@ def test_split_precision_switch_only_takes_eligible_stride1_layers(emulated_hip,
         return orig(x, wb, out_ch, *a, **k)
     monkeypatch.setattr(hip, 'conv3x3_bf16x6', spy)
     with torch.no_grad():
+        default = model(z)
+        monkeypatch.setenv('RW_CONV_ALGO', 'direct')               # the direct sum, which the split path restates
         base = model(z)
+        monkeypatch.delenv('RW_CONV_ALGO')
     assert seen == []                                              # default: exact fp32 kernels only
+    assert (default - base).abs().max().item() < 1e-4             # (default = Winograd on the same two layers)
     monkeypatch.setenv('RW_CONV_PRECISION', 'bf16x6')
     with torch.no_grad():
         img = model(z)
