@@ -19,7 +19,7 @@ import sys
 __version__ = '0.1.0'
 
 
-_ALIASED = ('nethook', 'tally', 'runningstats', 'zdataset', 'renormalize', 'pbar', 'sampler', 'proggan',
+_ALIASED = ('nethook', 'tally', 'runningstats', 'zdataset', 'renormalize', 'pbar', 'sampler', 'proggan', 'imgviz',
             'stylegan2', 'stylegan2.models', 'stylegan2.op')
 
 
@@ -30,7 +30,7 @@ def install_reference_aliases(force=False, reference_root=None):
     The reference's ``utils`` and ``rewrite`` are namespace packages (no ``__init__.py``).  They are registered
     here as packages whose ``__path__`` lists this package's directory FIRST and, when ``reference_root`` (or
     the environment variable RW_REFERENCE_ROOT) names a checkout of the reference, that checkout's directory
-    second: ``utils.imgviz``, ``utils.show``, ``utils.labwidget``, ``utils.paintwidget``, ``utils.pidfile``,
+    second: ``utils.show``, ``utils.labwidget``, ``utils.paintwidget``, ``utils.pidfile``,
     ``utils.imgsave``, ``utils.workerpool``, ``utils.segmenter`` and ``rewrite.rewriteapp`` -- consumers of the
     boundary that this package does not rebuild -- keep importing from the reference, on top of the kernels
     here.  The modules of the path itself are bound explicitly so that the reference's same-named files can
