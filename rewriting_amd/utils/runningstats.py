@@ -236,26 +236,43 @@ class RunningTopK:
 class RunningQuantile:
     """Per-unit quantiles of a stream of (samples, units) batches.
 
-    The reference keeps a randomised, resolution-``r`` reservoir sketch (utils/runningstats.py:
-    269-620) because a 2020 GPU could not hold the samples.  With 288 GB of HBM the samples of
-    every sweep on this path fit (1000 seeds x 32x32 x 512 units = 2 GB), so this class keeps them
-    and answers EXACTLY, with the reference's read-out convention (:550-575: midpoint cumulative
-    weights, the extremes pinned at 0 and 1).  ``r`` is accepted for call compatibility.  A
-    ``max_bytes`` guard raises instead of silently approximating."""
+    The reference keeps a randomised, resolution-``r`` reservoir sketch while it streams (utils/runningstats.py:
+    269-620) because a 2020 GPU could not hold the samples.  With 288 GB of HBM the samples of every sweep on
+    this path fit (1000 seeds x 32x32 x 512 units = 2 GB), so this class keeps them while the sweep runs, sorts
+    ONCE, and then holds the statistic in the reference's own form: levels of retained samples, a sample of
+    level l standing for 2^l samples, plus the exact extremes (:426-438).  ``compress_()`` reduces the exact
+    sorted sample to one such level -- every 2^L-th order statistic, taken at the middle of its stride, with L
+    the smallest level that retains at most 2r samples per unit (the reference's ``resolution``); for up to 2r
+    samples that is the sample itself and the answers are exact, beyond it the rank error is below 2^(L-1)/n
+    (6e-5 for 1000 seeds at 32x32), deterministic, where the reference's sketch is random with ~1e-3.
+
+    ``state_dict()`` / ``RunningQuantile(state=...)`` speak the reference's schema (keys resolution, depth,
+    buffersize, samplerate, data, sizes, extremes, size, batchcount), so a ``unit_rq.npz`` written by either
+    implementation loads in the other.  Read-out follows :550-575 and :598-620: piecewise linear through
+    (0, min), (midpoint cumulative weight, sample), (1, max).  A ``max_bytes`` guard raises instead of silently
+    approximating while samples are being collected."""
 
     def __init__(self, r=4096, buffersize=None, seed=None, state=None, max_bytes=64 << 30):
         if state is not None:
             self.set_state_dict(resolve_state_dict(state))
             return
-        self.resolution = r
+        self.resolution = 2 * r          # the reference's name for the retained-sample budget (:298-299)
+        self.buffersize = buffersize if buffersize is not None else min(128, (self.resolution + 7) // 8)
         self.max_bytes = max_bytes
         self.count = 0
         self.batchcount = 0
         self.depth = None
-        self._chunks = []
+        self._chunks = []               # exact samples, (units, n) pieces, while collecting
         self._sorted = None
+        self._levels = None             # after compress_() / a cache load: [(units, n_l)] with weight 2^l
+        self._extremes = None
+        self._table = None
 
+    # ------------------------------------------------------------------ collecting
     def add(self, incoming):
+        if self._levels is not None:
+            raise NotImplementedError('this RunningQuantile was compressed (or loaded from a cache); a finished '
+                                      'statistic does not take more samples')
         if incoming.dim() == 1:
             incoming = incoming[:, None]
         assert incoming.dim() == 2
@@ -279,40 +296,93 @@ class RunningQuantile:
             self._chunks = [self._sorted]
         return self._sorted
 
-    def _grid(self):
-        n = self.count
+    def compress_(self):
+        """Exact sorted sample -> one level of the reference's representation (see the class docstring)."""
+        if self._levels is not None or self.count == 0:
+            return self
         s = self._data()
-        pos = (torch.arange(n, device=s.device, dtype=torch.float64) + 0.5) / n
-        return s, pos
+        level = 0
+        while -(-self.count // (1 << level)) > self.resolution:
+            level += 1
+        stride = 1 << level
+        kept = s[:, stride // 2::stride].contiguous()
+        self._extremes = torch.stack([s[:, 0], s[:, -1]], dim=1)
+        self._levels = [s.new_zeros(self.depth, 0) for _ in range(level)] + [kept]
+        self._chunks, self._sorted, self._table = [], None, None
+        return self
+
+    # ------------------------------------------------------------------ read-out
+    def _weighted_table(self):
+        """(values, position): per unit the sorted retained samples between the extremes and the cumulative
+        weight at the middle of each, normalised to [0, 1] (utils/runningstats.py:530-563)."""
+        if self._table is None:
+            vals = torch.cat(self._levels, dim=1)
+            wts = torch.cat([torch.full((lv.shape[1],), 2.0 ** l, dtype=torch.float64, device=vals.device)
+                             for l, lv in enumerate(self._levels)])
+            vals, order = vals.sort(dim=1)
+            wts = wts[order]
+            ext = self._extremes.to(vals.device, vals.dtype)
+            zero = wts.new_zeros(self.depth, 1)
+            vals = torch.cat([ext[:, :1], vals, ext[:, 1:]], dim=1)
+            wts = torch.cat([zero, wts, zero], dim=1)
+            pos = (wts.cumsum(dim=1) - wts / 2) / wts.sum(dim=1, keepdim=True)
+            self._table = (vals.contiguous(), pos.contiguous())
+        return self._table
 
     def quantiles(self, quantiles, old_style=False):
+        """old_style is accepted for call compatibility: with the zero-weight extremes at both ends the
+        reference's two conventions (:556-561) coincide."""
         q = torch.as_tensor(quantiles, dtype=torch.float64)
         qshape = tuple(q.shape)
         if self.count == 0:
             return torch.full((self.depth or 0,) + qshape, float('nan'))
-        s, pos = self._grid()
-        qq = q.reshape(-1).to(s.device)
-        if old_style:                       # torch.percentile convention: min at 0, max at 1
-            lo, hi = pos[0], pos[-1]
-            qq = lo + qq * (hi - lo)
-        n = self.count
-        # piecewise linear through (0, min), ((i+.5)/n, s_i), (1, max)
-        t = (qq * n - 0.5).clamp(0, n - 1)
-        i0 = t.floor().long().clamp(0, n - 1)
-        i1 = (i0 + 1).clamp(0, n - 1)
-        frac = (t - i0.double()).to(s.dtype)
-        out = s[:, i0] * (1 - frac) + s[:, i1] * frac
+        if self._levels is None:
+            s = self._data()
+            n = self.count
+            # piecewise linear through (0, min), ((i+.5)/n, s_i), (1, max); s_0 and s_{n-1} ARE the extremes
+            t = (q.reshape(-1).to(s.device) * n - 0.5).clamp(0, n - 1)
+            i0 = t.floor().long().clamp(0, n - 1)
+            i1 = (i0 + 1).clamp(0, n - 1)
+            frac = (t - i0.double()).to(s.dtype)
+            out = s[:, i0] * (1 - frac) + s[:, i1] * frac
+            return out.reshape((self.depth,) + qshape)
+        vals, pos = self._weighted_table()
+        m = vals.shape[1]
+        qq = q.reshape(1, -1).to(vals.device).clamp(0, 1).expand(self.depth, -1).contiguous()
+        hi = torch.searchsorted(pos, qq, right=True).clamp(1, m - 1)
+        lo = hi - 1
+        p0, p1 = pos.gather(1, lo), pos.gather(1, hi)
+        frac = ((qq - p0) / (p1 - p0).clamp_min(1e-300)).clamp(0, 1).to(vals.dtype)
+        out = vals.gather(1, lo) * (1 - frac) + vals.gather(1, hi) * frac
         return out.reshape((self.depth,) + qshape)
 
+    def percentiles(self, percentiles):
+        return self.quantiles(percentiles, old_style=True)
+
     def minmax(self):
+        if self._levels is not None:
+            return self._extremes.clone()
         s = self._data()
         return torch.stack([s[:, 0], s[:, -1]], dim=1)
 
     def median(self):
         return self.quantiles([0.5])[:, 0]
 
+    def integrate(self, fun):
+        """sum over the represented samples of fun(sample) (utils/runningstats.py:577-591)."""
+        if self._levels is None:
+            return fun(self._data()).sum(dim=-1)
+        return sum(fun(lv).sum(dim=-1) * (2.0 ** l) for l, lv in enumerate(self._levels) if lv.shape[1])
+
     def mean(self):
-        return self._data().mean(dim=1)
+        return self.integrate(lambda x: x) / self.count
+
+    def variance(self):
+        mean = self.mean()[:, None]
+        return self.integrate(lambda x: (x - mean).pow(2)) / (self.count - 1)
+
+    def stdev(self):
+        return self.variance().sqrt()
 
     def readout(self, count=1001, old_style=True):
         return self.quantiles(torch.linspace(0.0, 1.0, count), old_style=old_style)
@@ -320,32 +390,73 @@ class RunningQuantile:
     def normalize(self, data):
         """data (units, ...) -> its quantile in [0, 1] within each unit's distribution."""
         assert self.count > 0 and data.shape[0] == self.depth
-        s, _ = self._grid()
-        n = self.count
-        flat = data.detach().reshape(self.depth, -1).to(s.device, s.dtype).contiguous()
-        hi = torch.searchsorted(s, flat, right=False).clamp(1, n - 1)      # s[hi-1] <= x <= s[hi] (interior)
+        if self._levels is None:
+            s = self._data()
+            n = self.count
+            flat = data.detach().reshape(self.depth, -1).to(s.device, s.dtype).contiguous()
+            hi = torch.searchsorted(s, flat, right=False).clamp(1, max(n - 1, 1))  # s[hi-1] <= x <= s[hi] (interior)
+            hi = hi.clamp(max=n - 1)
+            lo = (hi - 1).clamp(min=0)
+            x0, x1 = s.gather(1, lo), s.gather(1, hi)
+            frac = ((flat - x0) / (x1 - x0).clamp_min(1e-30)).clamp(0, 1)
+            q = ((lo.to(s.dtype) + 0.5) + frac) / n
+            q = torch.where(flat <= s[:, :1], torch.zeros_like(q), q)
+            q = torch.where(flat >= s[:, -1:], torch.ones_like(q), q)
+            return q.clamp_(0, 1).float().reshape(data.shape).to(data.device)
+        vals, pos = self._weighted_table()
+        m = vals.shape[1]
+        flat = data.detach().reshape(self.depth, -1).to(vals.device, vals.dtype).contiguous()
+        hi = torch.searchsorted(vals, flat, right=False).clamp(1, m - 1)
         lo = hi - 1
-        x0, x1 = s.gather(1, lo), s.gather(1, hi)
-        frac = ((flat - x0) / (x1 - x0).clamp_min(1e-30)).clamp(0, 1)
-        q = ((lo.to(s.dtype) + 0.5) + frac) / n
-        q = torch.where(flat <= s[:, :1], torch.zeros_like(q), q)
-        q = torch.where(flat >= s[:, -1:], torch.ones_like(q), q)
+        x0, x1 = vals.gather(1, lo), vals.gather(1, hi)
+        frac = ((flat - x0) / (x1 - x0).clamp_min(1e-30)).clamp(0, 1).double()
+        q = pos.gather(1, lo) * (1 - frac) + pos.gather(1, hi) * frac
+        q = torch.where(flat <= vals[:, :1], torch.zeros_like(q), q)
+        q = torch.where(flat >= vals[:, -1:], torch.ones_like(q), q)
         return q.clamp_(0, 1).float().reshape(data.shape).to(data.device)
 
     def to_(self, device):
         self._chunks = [c.to(device) for c in self._chunks]
         self._sorted = None if self._sorted is None else self._sorted.to(device)
+        if self._levels is not None:
+            self._levels = [lv.to(device) for lv in self._levels]
+            self._extremes = self._extremes.to(device)
+            self._table = None
 
+    # ------------------------------------------------------------------ the reference's cache schema
     def state_dict(self):
+        """utils/runningstats.py:422-437.  `data` holds one (retained, units) array per level; it is stored as an
+        object array because the levels differ in length."""
+        self.compress_()
+        levels = self._levels if self._levels is not None else []
+        data = numpy.empty(len(levels), dtype=object)
+        for l, lv in enumerate(levels):
+            data[l] = lv.t().contiguous().cpu().numpy()
+        extremes = (self._extremes.cpu().numpy() if self._extremes is not None
+                    else numpy.zeros((self.depth or 0, 2), dtype=numpy.float32))
         return dict(constructor=self.__module__ + '.' + self.__class__.__name__ + '()',
-                    resolution=self.resolution, depth=self.depth, size=self.count,
-                    batchcount=self.batchcount, exact_sorted=self._data().cpu().numpy())
+                    resolution=self.resolution, depth=self.depth, buffersize=self.buffersize, samplerate=1.0,
+                    data=data, sizes=[max(self.resolution, lv.shape[1]) for lv in levels],
+                    extremes=extremes, size=self.count, batchcount=self.batchcount)
 
     def set_state_dict(self, dic):
-        self.resolution = _item(dic['resolution'])
-        self.depth = _item(dic['depth'])
-        self.count = _item(dic['size'])
-        self.batchcount = _item(dic['batchcount'])
+        self.resolution = int(_item(dic['resolution']))
+        self.depth = int(_item(dic['depth']))
+        self.buffersize = int(_item(dic['buffersize']))
+        self.count = int(_item(dic['size']))
+        self.batchcount = int(_item(dic['batchcount'])) if 'batchcount' in dic else 0
         self.max_bytes = 64 << 30
-        self._sorted = torch.from_numpy(numpy.asarray(dic['exact_sorted']))
-        self._chunks = [self._sorted]
+        self._chunks, self._sorted, self._table = [], None, None
+        levels = []
+        for d in dic['data']:           # a list, an object array, or (equal lengths) one stacked 3-d array
+            d = numpy.asarray(d)
+            levels.append(torch.from_numpy(numpy.ascontiguousarray(d.reshape(-1, self.depth).T)))
+        self._levels = levels
+        # the reference folds the samples still in its level-0 buffer into the extremes lazily, at read-out
+        # (:527-528, :459-461); a saved state may not have seen them yet
+        ext = torch.from_numpy(numpy.asarray(dic['extremes'])).clone()
+        for lv in levels:
+            if lv.shape[1]:
+                ext[:, 0] = torch.minimum(ext[:, 0], lv.min(dim=1)[0].to(ext.dtype))
+                ext[:, 1] = torch.maximum(ext[:, 1], lv.max(dim=1)[0].to(ext.dtype))
+        self._extremes = ext

@@ -40,8 +40,9 @@ def make_loader(dataset, sample_size=None, batch_size=10, sampler=None, **kwargs
 
 def load_cached_state(cachefile, args, construct=None, shard=None):
     """The cached statistic, or None.  A cache counts only if its stored arguments match (utils/tally.py:703-718),
-    if `construct(state)` can rebuild the statistic from it -- a file of another schema (e.g. a unit_rq.npz
-    written by the reference's randomised RunningQuantile) is a miss, not an error -- and, in a sharded sweep,
+    if `construct(state)` can rebuild the statistic from it (a file of an unknown schema is a miss, not an error;
+    the statistics of this path -- c_matrix / unit_rq / mean caches -- use the reference's schemas both ways)
+    and, in a sharded sweep,
     if EVERY rank found it: the decision is collective, so no rank returns early while the others enter the
     sweep's all-reduce."""
     from .. import parallel
@@ -154,6 +155,7 @@ def tally_quantile(compute, dataset, sample_size=None, batch_size=10, r=4096, ca
     rq = runningstats.RunningQuantile(r=r)
     for batch in pbar(loader):
         rq.add(call_compute(compute, batch))
+    rq.compress_()          # sorted once on the device; fresh and cached answers are the same statistic
     rq.to_('cpu')
     save_cached_state(cachefile, rq, args, _replicated())
     return rq
@@ -179,6 +181,7 @@ def tally_topk_and_quantile(compute, dataset, sample_size=None, batch_size=10, k
         rtk.add(sample_tk)
         rq.add(sample_q)
     rtk.to_('cpu')
+    rq.compress_()
     rq.to_('cpu')
 
     class _Both:

@@ -232,3 +232,81 @@ def test_statistics_cache_interoperates_with_the_reference(tmp_path):
     numpy.savez(str(tmp_path / 'rs2.npz'), **ours.state_dict())
     back2 = ref.runningstats.RunningVariance(state=numpy.load(str(tmp_path / 'rs2.npz'), allow_pickle=True))
     assert torch.allclose(back2.mean(), rv.mean()) and torch.allclose(back2.variance(), rv.variance())
+
+
+@pytest.mark.skipif(not reference_shim.available(), reason='compares with the reference RunningQuantile')
+def test_quantile_cache_interoperates_with_the_reference(tmp_path):
+    """unit_rq.npz.  The reference's randomised sketch (utils/runningstats.py:269-620) written by
+    its own tally.tally_quantile loads here and reads out what the reference reads out of the same state; the
+    statistic computed here is written in the reference's schema (:422-437), loads into the reference's class
+    and through its tally cache branch, and answers within the bound of the class docstring of the exact
+    quantiles -- where the reference's own sketch is ~1e-3 away."""
+    import numpy
+    from rewriting_amd.utils import runningstats, tally
+    ref = reference_shim.load()
+    gen = torch.Generator().manual_seed(3)
+    units, n = 6, 40000
+    x = torch.randn(n, units, generator=gen) * torch.linspace(0.5, 3, units) + torch.linspace(-1, 1, units)
+    x[:, 2] = x[:, 2].exp()                                     # one skewed unit
+    data = torch.utils.data.TensorDataset(x)
+    qs = torch.tensor([0.0, 1e-4, 0.01, 0.25, 0.5, 0.9, 0.99, 0.999, 1.0])
+    exact = torch.from_numpy(numpy.quantile(x.double().numpy(), qs.numpy(), axis=0).T)
+    scale = x.std(dim=0)[:, None].double()
+
+    # --- theirs -> ours (r = 512: five levels of retained samples, weights 1 .. 16)
+    theirs_file = str(tmp_path / 'theirs' / 'unit_rq.npz')
+    theirs = ref.tally.tally_quantile(lambda b: b, data, batch_size=1000, r=512)
+    dat = dict(theirs.state_dict(), sample_size=None, r=512)    # what utils/tally.py:721-730 saves; the ragged list
+    ragged = numpy.empty(len(dat['data']), dtype=object)        # of levels became an object array under the numpy
+    ragged[:] = dat['data']                                     # of the reference's time (numpy 2 refuses to guess)
+    os.makedirs(os.path.dirname(theirs_file))
+    numpy.savez(theirs_file, **dict(dat, data=ragged))
+    st = numpy.load(theirs_file, allow_pickle=True)
+    assert len(st['data']) > 2
+    mine = tally.tally_quantile(lambda b: 1 / 0, data, batch_size=1000, r=512, cachefile=theirs_file)  # cache hit
+    assert mine.size() == n and mine.depth == units
+    # (the reference accumulates its cumulative weights in float32, this class in float64: ~1e-5 of the spread)
+    close = lambda a, b, tol=1e-4: bool(((a.double() - b.double()).abs() / scale.to(a.device)).max() < tol)
+    assert close(mine.quantiles(qs), theirs.quantiles(qs)), (mine.quantiles(qs) - theirs.quantiles(qs)).abs().max()
+    assert torch.equal(mine.minmax(), theirs.minmax())
+    probe = x[:500].t().contiguous()
+    assert torch.allclose(mine.normalize(probe), theirs.normalize(probe), rtol=0, atol=1e-5)
+    assert torch.allclose(mine.mean(), theirs.mean(), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(mine.stdev(), theirs.stdev(), rtol=1e-5)
+    # ... and written back out it is the same state
+    again = mine.state_dict()
+    assert sorted(again) == sorted(k for k in st.files if k not in ('sample_size', 'r'))
+    for a, b in zip(again['data'], st['data']):
+        assert numpy.array_equal(numpy.sort(a, axis=0), numpy.sort(numpy.asarray(b), axis=0))
+
+    # --- ours -> theirs
+    ours_file = str(tmp_path / 'ours' / 'unit_rq.npz')
+    ours = tally.tally_quantile(lambda b: b, data, batch_size=1000, r=512, cachefile=ours_file)
+    level = len(ours.state_dict()['data']) - 1
+    assert level == 6 and ours.state_dict()['data'][level].shape == (n // 64, units)   # 625 <= 2r retained
+    bound = 2.0 ** (level - 1) / n
+    ranks = ours.normalize(exact.float())                       # rank error of the answers, measured in rank
+    inner = (qs > 0) & (qs < 1)
+    assert (ranks[:, inner] - qs[inner]).abs().max() < bound + 1e-6
+    assert torch.equal(ours.quantiles(torch.tensor([0.0, 1.0])), torch.stack([x.min(0)[0], x.max(0)[0]], dim=1))
+    back = ref.tally.tally_quantile(lambda b: 1 / 0, data, batch_size=1000, r=512, cachefile=ours_file)
+    assert back.size() == n
+    assert close(back.quantiles(qs), ours.quantiles(qs))
+    assert torch.allclose(back.normalize(probe), ours.normalize(probe), rtol=0, atol=1e-5)
+    served = tally.tally_quantile(lambda b: 1 / 0, data, batch_size=1000, r=512, cachefile=ours_file)
+    assert torch.equal(served.quantiles(qs), ours.quantiles(qs))    # fresh == cached, bit for bit
+    # how far each is from the exact quantiles, measured in rank with the whole sample: ours within its bound
+    whole = runningstats.RunningQuantile(r=512)
+    whole.add(x)
+    rank_err = lambda rq: float((whole.normalize(rq.quantiles(qs[inner])).double() - qs[inner]).abs().max())
+    assert rank_err(ours) < bound + 1e-6 and rank_err(ours) <= rank_err(theirs), (rank_err(ours), rank_err(theirs))
+
+    # --- a sample below the retained budget is kept whole: answers exact, and the reference reads the same
+    small = runningstats.RunningQuantile(r=4096)
+    small.add(x[:3000])
+    want = small.quantiles(qs)
+    small.compress_()
+    assert torch.equal(small.quantiles(qs), want)
+    numpy.savez(str(tmp_path / 'small.npz'), **small.state_dict())
+    theirs_small = ref.runningstats.RunningQuantile(state=str(tmp_path / 'small.npz'))
+    assert close(theirs_small.quantiles(qs), want)
