@@ -58,8 +58,17 @@ def capture_stages(g):
     return store, handles
 
 
-def golden_generator(ref, name, size, truncation, cm, batch):
+def golden_generator(ref, name, size, truncation, cm, batch, mconv='seq'):
     g = build_stylegan(ref, size, truncation, cm)
+    if mconv == 'fast':
+        # the reference's other construction (utils/stylegan2/models.py:242-247: ModulatedConv2dF, one grouped
+        # convolution with per-sample modulated weights :427-433) holding the SAME weights, converted by the
+        # reference's own load_state_dict (:185-189)
+        fast = ref.models.SeqStyleGAN2(size, 512, 8, channel_multiplier=cm, truncation=truncation, mconv='fast')
+        fast.latents.latent_avg = g.latents.latent_avg.clone()
+        fast.load_state_dict(g.state_dict())      # strict: fails on the seq keys, converts, loads strictly
+        seq_image = g(ref.zdataset.standard_z_sample(batch, 512, seed=1)).detach()
+        g = fast.eval()
     z = ref.zdataset.standard_z_sample(batch, 512, seed=1)
     store, handles = capture_stages(g)
     with torch.no_grad():
@@ -68,7 +77,11 @@ def golden_generator(ref, name, size, truncation, cm, batch):
         h.remove()
     arrays = dict(z=z.numpy(), image=img.numpy(),
                   meta=json.dumps(dict(size=size, truncation=truncation, channel_multiplier=cm,
-                                       batch=batch, weight_seed=0)))
+                                       batch=batch, weight_seed=0, mconv=mconv)))
+    if mconv == 'fast':
+        arrays['seq_vs_fast_max'] = numpy.float64((seq_image - img).abs().max().item())
+        print('reference: mconv fast vs seq image, max abs %.3e (max |image| %.3f)' % (
+            arrays['seq_vs_fast_max'], img.abs().max().item()))
     for lname, out in store.items():
         if isinstance(out, dict):
             field = 'output' if (lname.startswith('to_rgb') and lname.endswith('.rgb')) or \
@@ -478,6 +491,114 @@ def golden_rewriter_extras(ref, name, size, layernum, maskfile, nseeds):
     save(name, **arrays)
 
 
+def golden_key_scatter(ref, name, size, layernum, maskfile, nseeds):
+    """The reference's own spread on the C^-1 key paths (covariance_adjusted_query_key, rewrite/ganrewrite.py:
+    700-706; key_method svd / mean :401-425; query_key_from_selection :427-436) and the float64 answer they
+    approximate.  C is ill conditioned, torch.lstsq runs in float32, so the reference's result depends on its
+    thread count and on the rounding of C; three runs of the reference -- 1 thread, 8 threads, and its arithmetic
+    on the float64-accumulated C rounded to float32 -- are compared with the same computation carried out in
+    float64 end to end.  Their largest deviation is the bar an implementation is held to (tests/common_checks.py)."""
+    g = build_stylegan(ref, size, 0.5)
+    zds = ref.zdataset.z_dataset_for_model(g, size=nseeds)
+    with open(os.path.join(MASKS, maskfile)) as f:
+        request = remap_request(json.load(f), nseeds)
+    keys = request['key']
+
+    def rewriter(threads):
+        torch.set_num_threads(threads)
+        return ref.ganrewrite.SeqStyleGanRewriter(g, zds, layernum, cachedir=None, key_method='zca')
+
+    def answers(gw):
+        return dict(svd=gw.multi_key_from_selection(keys, rank=2, key_method='svd').double(),
+                    mean=gw.multi_key_from_selection(keys, rank=1, key_method='mean').double(),
+                    query=gw.query_key_from_selection(*keys[0]).double()[None],
+                    zca=gw.zca_matrix.double())
+    runs = {}
+    gw1 = rewriter(1)
+    runs['t1'] = answers(gw1)
+    gw8 = rewriter(8)
+    runs['t8'] = answers(gw8)
+    # float64 statistics of the reference's own key maps
+    n = gw8.c_matrix.shape[0]
+    exact = torch.zeros(n, n, dtype=torch.float64)
+    count = 0
+    with torch.no_grad():
+        for b0 in range(0, nseeds, 10):
+            zb = torch.stack([zds[i][0] for i in range(b0, min(b0 + 10, nseeds))])
+            a = gw8.context_model(zb).fmap.permute(0, 2, 3, 1).reshape(-1, n).double()
+            exact += a.t() @ a
+            count += a.shape[0]
+    exact /= count
+    gwc = rewriter(8)
+    gwc.c_matrix = exact.float()
+    gwc.zca_matrix = ref.ganrewrite.zca_from_cov(gwc.c_matrix)
+    runs['c64'] = answers(gwc)
+    # the same definitions in float64 end to end
+    rows, means = [], []
+    with torch.no_grad():
+        for imgnum, mask in keys:
+            acts = gw8.context_model(gw8.get_z(imgnum)).fmap
+            area = ref.renormalize.from_url(mask, target='pt', size=gw8.k_shape[2:])[0]
+            wk = (acts[0] * area[None]).permute(1, 2, 0).reshape(-1, n)
+            rows.append(wk[wk.norm(2, dim=1) > 0].double())
+            means.append(((acts[0] * area[None]).double().sum(2).sum(1) / (1e-10 + area.double().sum())))
+    all_k = torch.linalg.solve(exact, torch.cat(rows).t()).t()
+    avg = all_k.mean(0)
+    u = torch.linalg.svd(all_k.t(), full_matrices=False)[0]
+    if (avg * u[:, 0]).sum() < 0:
+        u[:, 0] = -u[:, 0]
+    q = torch.linalg.solve(exact, means[0])
+    vals, vecs = torch.linalg.eigh(exact)
+    truth = dict(svd=u.t()[:2], mean=(avg / avg.norm())[None], query=(q / q.norm())[None],
+                 zca=(vecs * (1.0 / vals.sqrt().clamp(1e-20))[None, :]) @ vecs.t())
+
+    def angle(a, b, weight=None):
+        """1 - smallest principal cosine between the row spaces, optionally seen through C."""
+        a, b = a.t(), b.t()
+        if weight is not None:
+            a, b = weight @ a, weight @ b
+        return 1.0 - torch.linalg.svdvals(torch.linalg.qr(a)[0].t() @ torch.linalg.qr(b)[0]).min().item()
+    arrays = dict(meta=json.dumps(dict(size=size, layernum=layernum, mask=maskfile, nseeds=nseeds, weight_seed=0,
+                                       truncation=0.5, runs=sorted(runs))),
+                  c_exact=exact.float().numpy(), cond=numpy.float64((vals.max() / vals.min()).item()))
+    for m in ('svd', 'mean', 'query'):
+        arrays[m + '_exact'] = truth[m].numpy()
+        arrays[m + '_dev'] = numpy.array([angle(r[m], truth[m]) for r in runs.values()])
+        arrays[m + '_dev_lead'] = numpy.array([angle(r[m][:1], truth[m][:1]) for r in runs.values()])
+        arrays[m + '_dev_through_c'] = numpy.array([angle(r[m], truth[m], exact) for r in runs.values()])
+        arrays[m + '_between'] = numpy.array([angle(runs['t1'][m], runs['t8'][m]), angle(runs['t1'][m], runs['c64'][m]),
+                                              angle(runs['t8'][m], runs['c64'][m])])
+        print(m, 'reference runs vs float64:', arrays[m + '_dev'], 'lead', arrays[m + '_dev_lead'],
+              'through C', arrays[m + '_dev_through_c'], 'between runs', arrays[m + '_between'])
+    arrays['zca_exact'] = truth['zca'].float().numpy()[::4, ::4].copy()
+    arrays['zca_dev_max'] = numpy.array([(r['zca'] - truth['zca']).abs().max().item() for r in runs.values()])
+    arrays['zca_dev_rel'] = numpy.array([((r['zca'] - truth['zca']).norm() / truth['zca'].norm()).item()
+                                         for r in runs.values()])
+    print('zca vs float64: max abs', arrays['zca_dev_max'], 'rel', arrays['zca_dev_rel'], 'cond(C) %.3g' % arrays['cond'])
+    torch.set_num_threads(8)
+    # ranking_for_key (:582-594): the response quantiles of the UI search come out of the reference's randomised
+    # sketch -- three runs of it against the read-out of the whole sample (:550-575 applied to all responses)
+    qkey = torch.from_numpy(load_extras_query_key(name))
+    qs = [0.5, 0.99, 0.999]
+    arrays['ranking_q_runs'] = numpy.stack([gw8.ranking_for_key(qkey, k=8)[1].quantiles(qs)[0].numpy()
+                                            for _ in range(3)])
+    with torch.no_grad():
+        resp = torch.cat([(gw8.context_model(torch.stack([zds[i][0] for i in range(b0, min(b0 + 10, nseeds))])).fmap
+                           * qkey[None, :, None, None]).sum(1).reshape(-1) for b0 in range(0, nseeds, 10)])
+    srt = resp.sort()[0].double().numpy()
+    pos = (numpy.arange(len(srt)) + 0.5) / len(srt)
+    arrays['ranking_q_exact'] = numpy.interp(qs, numpy.concatenate([[0.0], pos, [1.0]]),
+                                             numpy.concatenate([srt[:1], srt, srt[-1:]]))
+    arrays['ranking_count'] = numpy.array(len(srt))
+    print('ranking quantiles: whole sample', arrays['ranking_q_exact'], 'reference runs', arrays['ranking_q_runs'])
+    save(name, **arrays)
+
+
+def load_extras_query_key(name):
+    """The query key of the companion fixture (rw_*_extras), so that the rankings are comparable."""
+    return numpy.load(os.path.join(GOLDEN, name.replace('keyscatter', 'extras') + '.npz'))['query_key']
+
+
 def golden_rewriter_variants(ref, name, size, layernum, maskfile, nseeds, tags=('tiny', 'pre')):
     """SeqTinyStyleGanRewriter (target = dconv alone) and SeqPreStyleGanRewriter (target starts at
     adain: the key is the UN-modulated feature map) on the same edit, a few solver steps each
@@ -574,6 +695,7 @@ def main():
         'ops': lambda: golden_ops(ref),
         'gen_s32_t05': lambda: golden_generator(ref, 'gen_s32_t05', 32, 0.5, 2, 3),
         'gen_s64_cm1': lambda: golden_generator(ref, 'gen_s64_cm1', 64, 1.0, 1, 2),
+        'gen_s32_fast': lambda: golden_generator(ref, 'gen_s32_fast', 32, 0.7, 2, 3, mconv='fast'),
         'rw_s64_l8_horsehat': lambda: golden_rewriter(
             ref, 'rw_s64_l8_horsehat', 64, 8, 'recorded_horse_hat.json', 60),
         'rw_s64_l7_horsehat': lambda: golden_rewriter(
@@ -583,6 +705,8 @@ def main():
         'rw_s64_l6_erase': lambda: golden_rewriter(
             ref, 'rw_s64_l6_erase', 64, 6, 'multikey_markandbottom.json', 20, mode='erase',
             low_rank_gradient=True),
+        'rw_s64_l8_keyscatter': lambda: golden_key_scatter(
+            ref, 'rw_s64_l8_keyscatter', 64, 8, 'recorded_horse_hat.json', 60),
         'rw_s64_l8_variants': lambda: golden_rewriter_variants(
             ref, 'rw_s64_l8_variants', 64, 8, 'recorded_horse_hat.json', 60),
         'rw_s64_l7_variants': lambda: golden_rewriter_variants(

@@ -240,11 +240,12 @@ class RunningQuantile:
     269-620) because a 2020 GPU could not hold the samples.  With 288 GB of HBM the samples of every sweep on
     this path fit (1000 seeds x 32x32 x 512 units = 2 GB), so this class keeps them while the sweep runs, sorts
     ONCE, and then holds the statistic in the reference's own form: levels of retained samples, a sample of
-    level l standing for 2^l samples, plus the exact extremes (:426-438).  ``compress_()`` reduces the exact
-    sorted sample to one such level -- every 2^L-th order statistic, taken at the middle of its stride, with L
-    the smallest level that retains at most 2r samples per unit (the reference's ``resolution``); for up to 2r
-    samples that is the sample itself and the answers are exact, beyond it the rank error is below 2^(L-1)/n
-    (6e-5 for 1000 seeds at 32x32), deterministic, where the reference's sketch is random with ~1e-3.
+    level l standing for 2^l samples, plus the exact extremes (:426-438).  ``compress_()`` picks the retained
+    samples deterministically (``retained_order_statistics``): at most 2r per unit (the reference's
+    ``resolution``), dense in the tails and strided in the body.  Up to 2r samples that is the sample itself and
+    the answers are exact; beyond it the rank error is below 2^(cap-1)/n in the body (1.2e-4 for 1000 seeds at
+    32x32) and at most 1/256 of the distance to the nearer end in the tails, where the reference's sketch is
+    random with ~1e-3 everywhere.
 
     ``state_dict()`` / ``RunningQuantile(state=...)`` speak the reference's schema (keys resolution, depth,
     buffersize, samplerate, data, sizes, extremes, size, batchcount), so a ``unit_rq.npz`` written by either
@@ -296,18 +297,61 @@ class RunningQuantile:
             self._chunks = [self._sorted]
         return self._sorted
 
+    @staticmethod
+    def retained_order_statistics(n, budget):
+        """Which order statistics of a sorted sample of n stand for it, per level: the sample is cut into
+        consecutive groups of 2^l ranks and the middle member of each group is retained at level l (weight 2^l,
+        so the weights sum to n exactly).  From each end: T = budget/32 groups of 1, T of 2, T of 4, ... up to
+        2^(cap-1); the body between the tails in groups of 2^cap (its remainder in binary, smaller groups); cap
+        is the smallest that keeps the retained count within the budget.  Rank error of a read-out: below
+        2^(cap-1) in the body, and in the tails at most 1/T of the distance to the nearer end (exact for the T
+        extreme values of each side) -- the tails are where -log(1 - rank) scores and the 0.99 / 0.999
+        thresholds of this path read."""
+        if n <= budget:
+            return [numpy.arange(n, dtype=numpy.int64)]
+        per = max(budget // 32, 1)
+        while True:
+            for cap in range(1, 62):
+                tail = per * ((1 << cap) - 1)
+                if 2 * tail > n:
+                    break
+                body = n - 2 * tail
+                if 2 * per * cap + (body >> cap) + bin(body & ((1 << cap) - 1)).count('1') <= budget:
+                    break
+            else:
+                cap = None
+            if cap is not None and 2 * per * ((1 << cap) - 1) <= n:
+                break
+            per //= 2
+            if per == 0:
+                raise ValueError('no retained set of %d order statistics for a sample of %d' % (budget, n))
+        levels = [[] for _ in range(cap + 1)]
+        steps = numpy.arange(per, dtype=numpy.int64)
+        pos = 0
+        for l in range(cap):                                   # low tail, upper-middle member
+            levels[l].append(pos + (1 << l) // 2 + (steps << l))
+            pos += per << l
+        body = n - 2 * per * ((1 << cap) - 1)
+        levels[cap].append(pos + (1 << cap) // 2 + (numpy.arange(body >> cap, dtype=numpy.int64) << cap))
+        pos += (body >> cap) << cap
+        for l in reversed(range(cap)):
+            if body & (1 << l):
+                levels[l].append(numpy.array([pos + (1 << l) // 2], dtype=numpy.int64))
+                pos += 1 << l
+        for l in reversed(range(cap)):                         # high tail, mirrored: lower-middle member
+            levels[l].append(pos + ((1 << l) - 1) // 2 + (steps << l))
+            pos += per << l
+        assert pos == n
+        return [numpy.concatenate(lv) for lv in levels]
+
     def compress_(self):
-        """Exact sorted sample -> one level of the reference's representation (see the class docstring)."""
+        """Exact sorted sample -> levels of the reference's representation (see retained_order_statistics)."""
         if self._levels is not None or self.count == 0:
             return self
         s = self._data()
-        level = 0
-        while -(-self.count // (1 << level)) > self.resolution:
-            level += 1
-        stride = 1 << level
-        kept = s[:, stride // 2::stride].contiguous()
         self._extremes = torch.stack([s[:, 0], s[:, -1]], dim=1)
-        self._levels = [s.new_zeros(self.depth, 0) for _ in range(level)] + [kept]
+        self._levels = [s[:, torch.from_numpy(idx).to(s.device)].contiguous()
+                        for idx in self.retained_order_statistics(self.count, self.resolution)]
         self._chunks, self._sorted, self._table = [], None, None
         return self
 
@@ -394,24 +438,24 @@ class RunningQuantile:
             s = self._data()
             n = self.count
             flat = data.detach().reshape(self.depth, -1).to(s.device, s.dtype).contiguous()
-            hi = torch.searchsorted(s, flat, right=False).clamp(1, max(n - 1, 1))  # s[hi-1] <= x <= s[hi] (interior)
-            hi = hi.clamp(max=n - 1)
+            # numpy.interp's bracket (:598-620): the LAST sample <= x on the left, so ties resolve upward
+            hi = torch.searchsorted(s, flat, right=True).clamp(1, max(n - 1, 1)).clamp(max=n - 1)
             lo = (hi - 1).clamp(min=0)
             x0, x1 = s.gather(1, lo), s.gather(1, hi)
             frac = ((flat - x0) / (x1 - x0).clamp_min(1e-30)).clamp(0, 1)
             q = ((lo.to(s.dtype) + 0.5) + frac) / n
-            q = torch.where(flat <= s[:, :1], torch.zeros_like(q), q)
+            q = torch.where(flat < s[:, :1], torch.zeros_like(q), q)
             q = torch.where(flat >= s[:, -1:], torch.ones_like(q), q)
             return q.clamp_(0, 1).float().reshape(data.shape).to(data.device)
         vals, pos = self._weighted_table()
         m = vals.shape[1]
         flat = data.detach().reshape(self.depth, -1).to(vals.device, vals.dtype).contiguous()
-        hi = torch.searchsorted(vals, flat, right=False).clamp(1, m - 1)
+        hi = torch.searchsorted(vals, flat, right=True).clamp(1, m - 1)
         lo = hi - 1
         x0, x1 = vals.gather(1, lo), vals.gather(1, hi)
         frac = ((flat - x0) / (x1 - x0).clamp_min(1e-30)).clamp(0, 1).double()
         q = pos.gather(1, lo) * (1 - frac) + pos.gather(1, hi) * frac
-        q = torch.where(flat <= vals[:, :1], torch.zeros_like(q), q)
+        q = torch.where(flat < vals[:, :1], torch.zeros_like(q), q)
         q = torch.where(flat >= vals[:, -1:], torch.ones_like(q), q)
         return q.clamp_(0, 1).float().reshape(data.shape).to(data.device)
 

@@ -299,7 +299,8 @@ def test_key_methods_linear_insert_and_rank3():
 
 def test_fast_mconv_equals_seq():
     from tests.common_checks import check_fast_mconv_equals_seq
-    check_fast_mconv_equals_seq(DEV)
+    report = check_fast_mconv_equals_seq(DEV)
+    json.dump(report, open('gpurun_out/fast_mconv_parity.json', 'w'))
 
 
 def test_odd_layer_solver_against_oracle_autograd():
