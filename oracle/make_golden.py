@@ -494,10 +494,12 @@ def golden_rewriter_extras(ref, name, size, layernum, maskfile, nseeds):
 def golden_key_scatter(ref, name, size, layernum, maskfile, nseeds):
     """The reference's own spread on the C^-1 key paths (covariance_adjusted_query_key, rewrite/ganrewrite.py:
     700-706; key_method svd / mean :401-425; query_key_from_selection :427-436) and the float64 answer they
-    approximate.  C is ill conditioned, torch.lstsq runs in float32, so the reference's result depends on its
-    thread count and on the rounding of C; three runs of the reference -- 1 thread, 8 threads, and its arithmetic
-    on the float64-accumulated C rounded to float32 -- are compared with the same computation carried out in
-    float64 end to end.  Their largest deviation is the bar an implementation is held to (tests/common_checks.py)."""
+    approximate.  C is ill conditioned (cond ~2e5) and torch.lstsq runs in float32 (gels, see reference_shim), so how
+    reproducible the reference's keys are is an empirical question: three runs of the reference -- 1 thread, 8
+    threads, and its arithmetic on the float64-accumulated C rounded to float32 -- are compared with the same
+    computation carried out in float64 end to end (they agree to 1 - cos ~ 3e-7; with torch.linalg.lstsq's
+    default gelsy driver they would be 0.8 apart).  Also: three runs of the randomised quantile sketch behind
+    ranking_for_key against the read-out of the whole sample."""
     g = build_stylegan(ref, size, 0.5)
     zds = ref.zdataset.z_dataset_for_model(g, size=nseeds)
     with open(os.path.join(MASKS, maskfile)) as f:

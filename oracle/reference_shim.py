@@ -20,7 +20,7 @@ in this container are stubbed before import:
    and ``transforms.functional.to_tensor`` (utils/renormalize.py:7,40,94).
 3. ``torch.symeig`` / ``torch.lstsq`` were removed from torch 2.x
    (rewrite/ganrewrite.py:104,822): mapped to ``torch.linalg.eigh(UPLO='U')`` and
-   ``torch.linalg.lstsq`` (symeig's default was upper=True).
+   ``torch.linalg.lstsq(driver='gels')`` (symeig's default was upper=True; lstsq was LAPACK gels).
 4. ``Tensor.cuda`` / ``Module.cuda`` -> identity for the hard-coded ``.cuda()`` calls
    (utils/stylegan2/models.py:545,652).
 5. No checkpoints offline: callers construct the models directly.
@@ -122,7 +122,10 @@ def _symeig(a, eigenvectors=False, upper=True):
 
 
 def _lstsq(b, a):
-    return (torch.linalg.lstsq(a, b).solution, None)
+    # torch 1.x ``torch.lstsq`` called LAPACK gels (QR, full rank assumed).  torch.linalg.lstsq defaults to gelsy,
+    # which truncates singular values below eps * max(m, n) * s_max -- for the key statistics of this path
+    # (cond ~2e5 in float32) that is a different, rank-truncated answer -- so the driver is pinned.
+    return (torch.linalg.lstsq(a, b, driver='gels').solution, None)
 
 
 _loaded = None

@@ -181,11 +181,13 @@ class ProgressiveGanRewriter(object):
     def covariance_adjusted_query_key(self, k):
         """C^-1 k by least squares (the reference's torch.lstsq, :101-105), in float32 LAPACK on the
         host like the reference's CPU configuration: C is ill-conditioned, so the precision of this
-        solve is part of the result."""
+        solve is part of the result -- and so is the driver: torch 1.x lstsq was gels (QR, no rank
+        truncation); torch.linalg.lstsq's default gelsy would drop the directions of C below
+        eps * 512 * lambda_max and return a different key."""
         c = self.c_matrix.cpu()
         rhs = (k[:, None] if k.dim() == 1 else k.permute(1, 0)).cpu()
         with host_linalg_threads():
-            sol = torch.linalg.lstsq(c, rhs).solution
+            sol = torch.linalg.lstsq(c, rhs, driver='gels').solution
         sol = sol.to(k.dtype).to(k.device)
         return sol[:, 0] if k.dim() == 1 else sol.permute(1, 0)
 
@@ -688,7 +690,7 @@ class SeqPreStyleGanRewriter(SeqStyleGanRewriter):
         cs = (self.c_matrix * kout.style[0][None, :]).cpu()
         rhs = (k[:, None] if k.dim() == 1 else k.permute(1, 0)).cpu()
         with host_linalg_threads():
-            sol = torch.linalg.lstsq(cs, rhs).solution
+            sol = torch.linalg.lstsq(cs, rhs, driver='gels').solution
         sol = sol.to(k.dtype).to(k.device)
         return sol[:, 0] if k.dim() == 1 else sol.permute(1, 0)
 

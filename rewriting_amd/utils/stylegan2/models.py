@@ -176,6 +176,17 @@ def conv_algo():
 _DEFAULT_CONV_ALGO = 'winograd'
 
 
+def micro_batch():
+    """(images per slice, first resolution run in slices) of SeqStyleGAN2._forward_micro, from
+    RW_MICRO_BATCH = "k" or "k:res" (0 = one launch per step for the whole batch)."""
+    spec = os.environ.get('RW_MICRO_BATCH', _DEFAULT_MICRO_BATCH)
+    k, _, res = spec.partition(':')
+    return int(k or 0), int(res or 256)
+
+
+_DEFAULT_MICRO_BATCH = '0'
+
+
 class DataBag(dict):
     """dict with attribute access, carrying latent / style / fmap / output / noise through the
     sequential generator (reference: utils/stylegan2/models.py:204-230)."""
@@ -464,6 +475,10 @@ class NoiseInjectionF(nn.Module):
     def noise_for(self, d, batch, height, width, device):
         noise = d.get('noise', None)
         if noise is None:
+            rows = d.get('batch_rows', None)
+            if rows is not None:        # a slice [start, start + batch) of a launch of `total` images keeps its rows
+                start, total = rows
+                return reference_noise(total, height * width, device)[start:start + batch]
             return reference_noise(batch, height * width, device)
         return noise.reshape(batch, height * width)
 
@@ -743,6 +758,11 @@ class SeqStyleGAN2(nn.Sequential):
         super().__init__(OrderedDict(steps))
 
     def forward(self, input):
+        mb, from_res = micro_batch()
+        if (mb and fusion_enabled() and torch.is_tensor(input) and not self.bag_output
+                and not self.bag_input and input.shape[0] > mb and 'up_rgb%d' % (int(math.log2(from_res)) - 2)
+                in self._modules and _rgb_branch.stream is None and _unhooked(*self.modules())):
+            return self._forward_micro(input, mb, from_res)
         side_ok = (fusion_enabled() and os.environ.get('RW_RGB_STREAM', '1') != '0' and torch.is_tensor(input)
                    and input.is_cuda and not self.bag_output and _rgb_branch.stream is None
                    and not torch.cuda.is_current_stream_capturing()
@@ -769,6 +789,37 @@ class SeqStyleGAN2(nn.Sequential):
             del _rgb_branch.keep[:]                      # freed to the trunk's pool AFTER the join is queued
         if torch.is_tensor(out):
             out.record_stream(main)
+        return out
+
+    def _forward_micro(self, z, mb, from_res):
+        """The un-hooked generator on a large batch: the low-resolution steps on the whole batch (their launches
+        need it to fill 256 CUs), the steps from resolution `from_res` up on `mb` images at a time, so that the
+        feature maps handed from one kernel to the next (134 MB per image at 1024^2) are still in the 256 MB
+        memory-side cache when the next kernel reads them instead of making a round trip through HBM.  The slices
+        reuse the same allocator blocks, image rows keep their noise rows (`batch_rows`), results are those of
+        the one-launch path."""
+        mods = list(self._modules.values())
+        k = list(self._modules).index('up_rgb%d' % (int(math.log2(from_res)) - 2))
+        d = z
+        for m in mods[:k]:
+            d = m(d)
+        total = d.latent.shape[0]
+        out = None
+        _rgb_branch.final = self._final_pair()
+        try:
+            for s in range(0, total, mb):
+                e = min(s + mb, total)
+                part = DataBag({key: (v[s:e] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == total else v)
+                                for key, v in d.items()})
+                part['batch_rows'] = (s, total)
+                for m in mods[k:]:
+                    part = m(part)
+                if out is None:
+                    out = part.new_empty((total,) + tuple(part.shape[1:]))
+                out[s:e] = part
+                del part
+        finally:
+            _rgb_branch.final = None
         return out
 
     def _final_pair(self):

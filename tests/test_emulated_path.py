@@ -231,3 +231,26 @@ def test_generator_with_winograd_convolutions_holds_the_golden_bars(emulated_hip
     for lname in ('layer8.sconv.mconv.dconv', 'layer10.sconv.mconv.dconv'):
         w = torch.from_numpy(g['stage/%s/sub' % lname])
         assert (subsample(store[lname].fmap) - w).abs().max() < 5e-5 * max(1.0, w.abs().max().item()), lname
+
+
+def test_micro_batched_forward_equals_one_launch(emulated_hip, monkeypatch):
+    """SeqStyleGAN2._forward_micro: high-resolution steps in slices of the batch -- same images, every image with
+    the noise row of its position in the whole batch (quirk Q1), also inside noise_batch_period."""
+    from rewriting_amd.utils.stylegan2.models import noise_batch_period
+    model = build_stylegan(64, 0.7)
+    z = torch.randn(6, 512, generator=torch.Generator().manual_seed(5))
+    with torch.no_grad():
+        want = model(z)
+        with noise_batch_period(3):
+            want_p = model(z)
+    for spec in ('2:16', '4:32', '1:64'):
+        monkeypatch.setenv('RW_MICRO_BATCH', spec)
+        with torch.no_grad():
+            got = model(z)
+            with noise_batch_period(3):
+                got_p = model(z)
+        assert (got - want).abs().max() < 1e-5, spec
+        assert (got_p - want_p).abs().max() < 1e-5, spec
+    monkeypatch.setenv('RW_MICRO_BATCH', '8:16')                 # not larger than the batch: the plain path
+    with torch.no_grad():
+        assert torch.equal(model(z), want)

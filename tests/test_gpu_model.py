@@ -395,3 +395,23 @@ def test_full_size_statistics_and_solve_properties():
     assert rel(ganrewrite.projected_conv(dW, mkey), dW) < 1e-4
     sv = torch.linalg.svdvals(dW[0].permute(0, 2, 3, 1).reshape(-1, 512).cpu())
     assert sv[1].item() < 1e-3 * sv[0].item()
+
+
+def test_micro_batched_forward_equals_one_launch(monkeypatch):
+    """SeqStyleGAN2._forward_micro (RW_MICRO_BATCH): slices of the batch through the high-resolution steps give
+    the images of the one-launch path, every image with the noise row of its position in the whole batch."""
+    from rewriting_amd.utils.stylegan2.models import noise_batch_period
+    model = build_stylegan(256, 0.7, device=DEV)
+    z = torch.randn(12, 512, generator=torch.Generator().manual_seed(5)).to(DEV)
+    with torch.no_grad():
+        want = model(z)
+        with noise_batch_period(3):
+            want_p = model(z)
+    for spec in ('2:64', '4:128', '1:256', '5:32'):
+        monkeypatch.setenv('RW_MICRO_BATCH', spec)
+        with torch.no_grad():
+            got = model(z)
+            with noise_batch_period(3):
+                got_p = model(z)
+        assert (got - want).abs().max().item() < 1e-5, spec
+        assert (got_p - want_p).abs().max().item() < 1e-5, spec
