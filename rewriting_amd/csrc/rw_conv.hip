@@ -884,8 +884,14 @@ __global__ void __launch_bounds__(256, 2) conv_up_halo_kernel(const UpProblem p)
   };
   // nine weight slabs of one k-pair: two 16-byte loads (slabs 0-3, 4-7; 1 KiB per wave each) and a
   // dword (slab 8) per lane
+  // The slabs are prefetched THREE k-pairs ahead through a ring of four register sets.  vmcnt retires in order: a
+  // weight load issued right behind the patch fetch of a chunk (48 loads from HBM, ~2 us) cannot be waited for before
+  // that fetch has landed, and with a one-ahead prefetch every wave stalled on it once per chunk (measured: loads
+  // cost 15 - 22 % of the kernel).  Three ahead, the first slab issued behind the fetch is consumed four k-pairs
+  // later -- when the staging steps need the patch anyway.
   struct ASlabs { rw_f32x4 v4[2]; float s8; };
-  ASlabs acur, anxt;
+  static_assert(KP % 4 == 0, "ring of four slab sets");
+  ASlabs aring[4];
   auto aload = [&](ASlabs& dst, int kp, int c) {
     const float* base = wf + (int64_t)c * c_stride + kp * 576;
     dst.v4[0] = *reinterpret_cast<const rw_f32x4*>(base + lane * 4);
@@ -903,7 +909,9 @@ __global__ void __launch_bounds__(256, 2) conv_up_halo_kernel(const UpProblem p)
 
   const int n_chunks = p.in_ch / IC;
   xfetch(0);
-  aload(acur, 0, 0);
+  aload(aring[0], 0, 0);
+  aload(aring[1], 1, 0);
+  aload(aring[2], 2, 0);
 #pragma unroll
   for (int j = 0; j < NST; ++j) stash_step(0, j);
   __syncthreads();
@@ -924,11 +932,13 @@ __global__ void __launch_bounds__(256, 2) conv_up_halo_kernel(const UpProblem p)
     }
 #pragma unroll
     for (int kp = 0; kp < KP; ++kp) {
-      int nkp = kp + 1, nc = c;
-      if (nkp == KP) { nkp = 0; nc = cn; }
-      if (!RW_ABL(p, 2)) aload(anxt, nkp, nc);
-      if (kp == 0 && c + 1 < n_chunks && !RW_ABL(p, 4)) xfetch(cn * IC);   // after the weight load: its wait must
-                                                                           // not drain these; nothing to fetch at the end
+      int nkp = kp + 3, nc = c;
+      if (nkp >= KP) { nkp -= KP; nc = cn; }
+      if (!RW_ABL(p, 2)) aload(aring[(kp + 3) & 3], nkp, nc);
+      // after the weight load (its wait must not drain these), and UNCONDITIONAL -- the last chunk re-fetches
+      // itself: with a branch around the fetch the compiler has to count vmcnt for the path without it, and
+      // every weight wait of the chunk then drains the fetch on the path with it
+      if (kp == 0 && !RW_ABL(p, 4)) xfetch(cn * IC);
       if (kp + 1 < KP && !RW_ABL(p, 1)) {
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
@@ -940,7 +950,7 @@ __global__ void __launch_bounds__(256, 2) conv_up_halo_kernel(const UpProblem p)
       // nine slabs x TN rows; consecutive MFMAs never accumulate into the same registers
 #define RW_UP_MFMA(m, q, sl, bv)                                                                        \
   _Pragma("unroll") for (int b = 0; b < TN; ++b) acc[q][b] =                                            \
-      __builtin_amdgcn_mfma_f32_32x32x2f32((sl) < 8 ? acur.v4[((sl) >> 2) & 1][(sl) & 3] : acur.s8, bv[b],  \
+      __builtin_amdgcn_mfma_f32_32x32x2f32((sl) < 8 ? aring[kp & 3].v4[((sl) >> 2) & 1][(sl) & 3] : aring[kp & 3].s8, bv[b],  \
                                            acc[q][b], 0, 0, 0);                                        \
   if (9 * kp + (m) >= SLOT0 && 9 * kp + (m) - SLOT0 < NST && !RW_ABL(p, 4)) {                                          \
     stash_step(buf ^ 1, 9 * kp + (m) - SLOT0);                                                          \
@@ -957,7 +967,6 @@ __global__ void __launch_bounds__(256, 2) conv_up_halo_kernel(const UpProblem p)
       RW_UP_MFMA(8, 2, 7, b0m)
 #undef RW_UP_MFMA
       __builtin_amdgcn_sched_barrier(0);
-      acur = anxt;
 #pragma unroll
       for (int b = 0; b < TN; ++b) { b00[b] = n00[b]; b0m[b] = n0m[b]; bm0[b] = nm0[b]; bmm[b] = nmm[b]; }
     }

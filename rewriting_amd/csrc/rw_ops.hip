@@ -553,48 +553,46 @@ extern "C" int rw_pack_conv_weight_f32(const float* w, float* wp, int out_ch, in
 // ---------------------------------------------------------------------------------------
 // Blur(pad 1,1) + noise + bias + leaky-ReLU for upsampling layers: one pass
 // ---------------------------------------------------------------------------------------
-// Workgroup = a persistent loop over 32 x 64 output tiles of (image, channel) planes.  The 35 x 67 input patch of a
-// tile is staged in LDS (double buffered) with 16-byte row loads (rows are 2W+1 floats long, so only 4-byte
-// aligned; the hardware takes unaligned vector loads); each thread then produces 4 horizontally adjacent outputs
-// of two rows, one 16-byte store each.  The pass is pure HBM streaming, and with one tile per workgroup the
-// bytes in flight per CU (Little's law: ~8 B/clk x ~2 us) were short: the loads of the NEXT tile are issued into
-// registers before the current tile is computed, so every resident workgroup always has 9 KB in flight.
+// Workgroup = 32 x 64 output tile of one (image, channel) plane: the 35 x 67 input patch is
+// staged in LDS with coalesced row loads (the odd row length 2W+1 rules out vector loads), each
+// thread then produces 4 horizontally adjacent outputs of two rows, one 16-byte store each.
 #define BL_TH 32
 #define BL_TW 64
 #define BL_PITCH (BL_TW + 4)
-#define BL_LPR (BL_TW / 4 + 1)                      /* lanes per patch row */
-#define BL_RPP (256 / BL_LPR)                       /* rows per pass */
-#define BL_NP ((BL_TH + 3 + BL_RPP - 1) / BL_RPP)
-__global__ void __launch_bounds__(256, 8) blur_noise_act_kernel(
+__global__ void __launch_bounds__(256) blur_noise_act_kernel(
     const float* __restrict__ x, const float* __restrict__ k4, const float* __restrict__ noise,
     const float* __restrict__ nw_ptr, const float* __restrict__ bias, float* __restrict__ y,
-    int batch, int channels, int out_h, int out_w, int tiles_x, int tiles_y, int total_tiles) {
-  typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+    int batch, int channels, int out_h, int out_w, int tiles_x, int tiles_y) {
   __shared__ float kf[16];
-  __shared__ __attribute__((aligned(16))) float tile[2][BL_TH + 3][BL_PITCH];
+  __shared__ __attribute__((aligned(16))) float tile[BL_TH + 3][BL_PITCH];
   const int tid = threadIdx.x;
   if (tid < 16) {
     const int a = tid >> 2, c = tid & 3;
     kf[tid] = k4[(3 - a) * 4 + (3 - c)];     // flipped, as upfirdn2d applies it
   }
+  int blk = blockIdx.x;
+  const int tx = blk % tiles_x; blk /= tiles_x;
+  const int ty = blk % tiles_y;
+  const int64_t bc = blk / tiles_y;
+  const int c = (int)(bc % channels);
+  const int64_t b = bc / channels;
   const int in_h = out_h + 1, in_w = out_w + 1;
-  const int rr = tid / BL_LPR, q4 = (tid - rr * BL_LPR) * 4;
-  const bool loader = rr < BL_RPP;
-  const float nw = noise ? nw_ptr[0] : 0.f;
-  const bool full = (out_w % 4 == 0);           // then ox + 3 < out_w and every row start is 16-byte aligned
-  const int lx = (tid & 15) * 4;
-
-  // patch rows oy0-1 .. oy0+BL_TH+1, cols ox0-1 .. ox0+BL_TW+2 (one spare) of tile t -> registers
-  auto fetch = [&](int t, rw_f32x4 (&v)[BL_NP]) __attribute__((always_inline)) {
-    const int tx = t % tiles_x; t /= tiles_x;
-    const int ty = t % tiles_y;
-    const int64_t bc = t / tiles_y;
-    const float* xp = x + bc * (int64_t)in_h * in_w;
-    const int oy0 = ty * BL_TH, ox0 = tx * BL_TW;
+  const int oy0 = ty * BL_TH, ox0 = tx * BL_TW;
+  const float* xp = x + bc * (int64_t)in_h * in_w;
+  // input patch rows oy0-1 .. oy0+BL_TH+1, cols ox0-1 .. ox0+BL_TW+2 (one spare): 17 lanes per row
+  // load four floats each as ONE 16-byte load (rows are 2W+1 floats long, so only 4-byte aligned;
+  // the hardware takes unaligned vector loads), all loads issued before the first LDS write.
+  {
+    typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+    constexpr int LPR = BL_TW / 4 + 1;                  // lanes per patch row
+    constexpr int RPP = 256 / LPR;                      // rows per pass
+    constexpr int NP = (BL_TH + 3 + RPP - 1) / RPP;
+    const int rr = tid / LPR, q4 = (tid - rr * LPR) * 4;
+    rw_f32x4 v[NP];
 #pragma unroll
-    for (int q = 0; q < BL_NP; ++q) {
-      const int r = rr + BL_RPP * q, iy = oy0 - 1 + r, ix = ox0 - 1 + q4;
-      const bool rok = loader && r < BL_TH + 3 && iy >= 0 && iy < in_h;
+    for (int q = 0; q < NP; ++q) {
+      const int r = rr + RPP * q, iy = oy0 - 1 + r, ix = ox0 - 1 + q4;
+      const bool rok = rr < RPP && r < BL_TH + 3 && iy >= 0 && iy < in_h;
       const float* src = xp + (int64_t)iy * in_w + ix;
       if (rok && ix >= 0 && ix + 3 < in_w) {
         v[q] = *reinterpret_cast<const f32x4_u*>(src);
@@ -603,79 +601,63 @@ __global__ void __launch_bounds__(256, 8) blur_noise_act_kernel(
         for (int e = 0; e < 4; ++e) v[q][e] = (rok && ix + e >= 0 && ix + e < in_w) ? src[e] : 0.f;
       }
     }
-  };
-  auto stage = [&](int buf, const rw_f32x4 (&v)[BL_NP]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int q = 0; q < BL_NP; ++q) {
-      const int r = rr + BL_RPP * q;
-      if (loader && r < BL_TH + 3) *reinterpret_cast<rw_f32x4*>(&tile[buf][r][q4]) = v[q];
+    for (int q = 0; q < NP; ++q) {
+      const int r = rr + RPP * q;
+      if (rr < RPP && r < BL_TH + 3) *reinterpret_cast<rw_f32x4*>(&tile[r][q4]) = v[q];
     }
-  };
-
-  int t = blockIdx.x;
-  rw_f32x4 v[BL_NP];
-  if (t < total_tiles) { fetch(t, v); stage(0, v); }
+  }
   __syncthreads();
-  for (int buf = 0; t < total_tiles; t += gridDim.x, buf ^= 1) {
-    const int tn = t + gridDim.x;
-    if (tn < total_tiles) fetch(tn, v);         // in flight while this tile is computed and stored
-    int tt = t;
-    const int tx = tt % tiles_x; tt /= tiles_x;
-    const int ty = tt % tiles_y;
-    const int64_t bc = tt / tiles_y;
-    const int c = (int)(bc % channels);
-    const int64_t b = bc / channels;
-    const int oy0 = ty * BL_TH, ox = tx * BL_TW + lx;
-    const float bv = bias ? bias[c] : 0.f;
-    // thread = 4 consecutive outputs of rows ly and ly + 16: two 16-byte LDS reads per tap row, one
-    // 16-byte noise load and one 16-byte store per output row -- the store tail is instruction-issue
-    // bound, so wide stores matter more than the (mild, 2-way) LDS bank overlap of this mapping
-    if (ox < out_w) {
+  // thread = 4 consecutive outputs of rows ly and ly + 16: two 16-byte LDS reads per tap row, one
+  // 16-byte noise load and one 16-byte store per output row -- the store tail is instruction-issue
+  // bound, so wide stores matter more than the (mild, 2-way) LDS bank overlap of this mapping
+  const int lx = (tid & 15) * 4;
+  const int ox = ox0 + lx;
+  if (ox >= out_w) return;
+  const float nw = noise ? nw_ptr[0] : 0.f;
+  const float bv = bias ? bias[c] : 0.f;
+  const bool full = (out_w % 4 == 0);           // then ox + 3 < out_w and every row start is 16-byte aligned
 #pragma unroll
-      for (int half = 0; half < BL_TH / 16; ++half) {
-        const int ly = (tid >> 4) + 16 * half;
-        const int oy = oy0 + ly;
-        if (oy >= out_h) continue;
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int half = 0; half < BL_TH / 16; ++half) {
+    const int ly = (tid >> 4) + 16 * half;
+    const int oy = oy0 + ly;
+    if (oy >= out_h) continue;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-          const float4 lo = *reinterpret_cast<const float4*>(&tile[buf][ly + a][lx]);
-          const float4 hi = *reinterpret_cast<const float4*>(&tile[buf][ly + a][lx + 4]);
-          const float rowv[7] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z};
+    for (int a = 0; a < 4; ++a) {
+      const float4 lo = *reinterpret_cast<const float4*>(&tile[ly + a][lx]);
+      const float4 hi = *reinterpret_cast<const float4*>(&tile[ly + a][lx + 4]);
+      const float rowv[7] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z};
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
+      for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) acc[q] += rowv[q + cc] * kf[a * 4 + cc];
-        }
-        float nzv[4] = {0.f, 0.f, 0.f, 0.f};
-        const int64_t noff = b * (int64_t)out_h * out_w + (int64_t)oy * out_w + ox;
-        if (noise) {
-          if (full) {
-            const float4 nz = *reinterpret_cast<const float4*>(noise + noff);
-            nzv[0] = nz.x; nzv[1] = nz.y; nzv[2] = nz.z; nzv[3] = nz.w;
-          } else {
+        for (int cc = 0; cc < 4; ++cc) acc[q] += rowv[q + cc] * kf[a * 4 + cc];
+    }
+    float nzv[4] = {0.f, 0.f, 0.f, 0.f};
+    const int64_t noff = b * (int64_t)out_h * out_w + (int64_t)oy * out_w + ox;
+    if (noise) {
+      if (full) {
+        const float4 nz = *reinterpret_cast<const float4*>(noise + noff);
+        nzv[0] = nz.x; nzv[1] = nz.y; nzv[2] = nz.z; nzv[3] = nz.w;
+      } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) if (ox + q < out_w) nzv[q] = noise[noff + q];
-          }
-        }
-        float res[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float r = acc[q] + nw * nzv[q];
-          if (bias) { r += bv; r = ((r > 0.f) ? r : r * 0.2f) * 1.4142135623730951f; }
-          res[q] = r;
-        }
-        float* yo = y + (bc * out_h + oy) * (int64_t)out_w + ox;
-        if (full) {
-          *reinterpret_cast<float4*>(yo) = make_float4(res[0], res[1], res[2], res[3]);
-        } else {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) if (ox + q < out_w) yo[q] = res[q];
-        }
+        for (int q = 0; q < 4; ++q) if (ox + q < out_w) nzv[q] = noise[noff + q];
       }
     }
-    if (tn < total_tiles) stage(buf ^ 1, v);    // nobody reads tile[buf ^ 1] any more (barrier of the last turn)
-    __syncthreads();
+    float res[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v = acc[q] + nw * nzv[q];
+      if (bias) { v += bv; v = ((v > 0.f) ? v : v * 0.2f) * 1.4142135623730951f; }
+      res[q] = v;
+    }
+    float* yo = y + (bc * out_h + oy) * (int64_t)out_w + ox;
+    if (full) {
+      *reinterpret_cast<float4*>(yo) = make_float4(res[0], res[1], res[2], res[3]);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) if (ox + q < out_w) yo[q] = res[q];
+    }
   }
 }
 
@@ -685,12 +667,10 @@ extern "C" int rw_blur_noise_act_f32(const float* x, const float* k4, const floa
   RW_CHECK_ARG(x && k4 && y && batch > 0 && channels > 0 && out_h > 0 && out_w > 0);
   RW_CHECK_ARG(!noise || noise_w);
   const int tiles_x = (int)rw_cdiv(out_w, BL_TW), tiles_y = (int)rw_cdiv(out_h, BL_TH);
-  const int64_t tiles = (int64_t)batch * channels * tiles_x * tiles_y;
-  if (tiles > 0x7fffffff) return RW_ERR_UNSUPPORTED;
-  const int64_t resident = 256 * 8;             // CUs x workgroups per CU (19 KB of LDS each)
-  hipLaunchKernelGGL(blur_noise_act_kernel, dim3((unsigned)(tiles < resident ? tiles : resident)), dim3(256), 0,
-                     rw_s(stream), x, k4, noise, noise_w, bias, y, batch, channels, out_h, out_w, tiles_x, tiles_y,
-                     (int)tiles);
+  const int64_t blocks = (int64_t)batch * channels * tiles_x * tiles_y;
+  if (blocks > 0x7fffffff) return RW_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(blur_noise_act_kernel, dim3((unsigned)blocks), dim3(256), 0, rw_s(stream), x, k4,
+                     noise, noise_w, bias, y, batch, channels, out_h, out_w, tiles_x, tiles_y);
   return RW_LAUNCH_RESULT();
 }
 

@@ -420,9 +420,10 @@ __global__ void __launch_bounds__(256, 2) conv_wino16_kernel(const WinoProblem p
             }
             __builtin_amdgcn_sched_barrier(0);
             if (STAGE >= 1 && kq == KQ - 1 && slot == BAR_SLOT) {
-              if (STAGE == 2 && !(WN_ABL & 4)) {
-                if (v + 3 < VT) fetch_chunk(fg, fc);   // uniform
-              }
+              // unconditional: the last turn of this loop fetches one virtual chunk past the run (a legal address,
+              // nobody reads it).  Behind a branch, the compiler must count vmcnt for the path WITHOUT the
+              // fetch, and every weight wait that follows then drains the fetch on the path with it.
+              if (STAGE == 2 && !(WN_ABL & 4)) fetch_chunk(fg, fc);
               if (!(WN_ABL & 2)) __syncthreads();  // V[buf^1] and Rs[buf] complete; nobody reads V[buf] any more
               if (!(WN_ABL & 8)) {
 #pragma unroll
