@@ -19,6 +19,7 @@
 #define SV_BM 64        // out channels per workgroup (both GEMMs)
 #define SV_BN 64        // pixels per workgroup in K1
 #define SV_BNK 128      // weight columns per workgroup in K3
+#define SV_DEPTH 4      // chunks of operands in flight per workgroup (K1, K3)
 
 static inline int sv_pp(int p) { return (int)rw_cdiv(p, 64) * 64; }
 
@@ -83,49 +84,63 @@ __global__ void __launch_bounds__(256) solve_fwd_kernel(const rw_solve_problem p
   const bool pix_ok = pix < P;
   const int py = pix_ok ? pix / CW : 0, px = pix_ok ? pix - py * CW : 0;
 
-  float4 areg;
-  float breg[4];
+  // Operands are fetched SV_DEPTH chunks ahead through a ring of register sets: the K range of a workgroup is
+  // only 9 - 18 chunks of 8 MFMAs, and with a one-ahead prefetch every chunk cost a full memory latency (13 us
+  // for 1.2 GFLOP).  Nothing touches a fetched value before its stash, SV_DEPTH - 1 chunks later.
+  float4 areg[SV_DEPTH];
+  float sreg[SV_DEPTH][4];
+  float breg[SV_DEPTH][4];
   float wsq_acc = 0.f;
-  auto fetch = [&](int c) {
+  auto fetch = [&](int c, int slot) __attribute__((always_inline)) {
     const int k0 = c * SV_KC;
-    areg = *reinterpret_cast<const float4*>(p.weight + (int64_t)(o0 + arow) * K + k0 + apart);
-    const float* av = &areg.x;
+    areg[slot] = *reinterpret_cast<const float4*>(p.weight + (int64_t)(o0 + arow) * K + k0 + apart);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int i = (k0 + apart + e) / 9;
-      const float t = p.w_scale * av[e] * p.style[i];
-      wsq_acc += t * t;
-    }
+    for (int e = 0; e < 4; ++e) sreg[slot][e] = p.style[(k0 + apart + e) / 9];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int k = k0 + bk0 + 4 * j;
       const int i = k / 9, tap = k - 9 * i;
-      breg[j] = pix_ok ? sv_gather(p, p.key + (int64_t)i * p.h * p.w, tap, py, px) : 0.f;
+      breg[slot][j] = pix_ok ? sv_gather(p, p.key + (int64_t)i * p.h * p.w, tap, py, px) : 0.f;
     }
   };
-  auto stash = [&](int buf) {
-    As[buf][apart + 0][arow] = areg.x; As[buf][apart + 1][arow] = areg.y;
-    As[buf][apart + 2][arow] = areg.z; As[buf][apart + 3][arow] = areg.w;
+  auto stash = [&](int buf, int slot) __attribute__((always_inline)) {
+    const float* av = &areg[slot].x;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) Bs[buf][bk0 + 4 * j][bn] = breg[j];
+    for (int e = 0; e < 4; ++e) {                  // demodulation partial, in chunk order
+      const float t = p.w_scale * av[e] * sreg[slot][e];
+      wsq_acc += t * t;
+    }
+    As[buf][apart + 0][arow] = areg[slot].x; As[buf][apart + 1][arow] = areg[slot].y;
+    As[buf][apart + 2][arow] = areg[slot].z; As[buf][apart + 3][arow] = areg[slot].w;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Bs[buf][bk0 + 4 * j][bn] = breg[slot][j];
   };
 
   rw_f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  if (cbeg < cend) { fetch(cbeg); stash(0); }
-  __syncthreads();
-  for (int c = cbeg; c < cend; ++c) {
-    const int buf = (c - cbeg) & 1;
-    if (c + 1 < cend) fetch(c + 1);
 #pragma unroll
-    for (int kp = 0; kp < SV_KC / 2; ++kp) {
-      const float af = As[buf][2 * kp + frow][wm0 + fcol];
-      const float bf = Bs[buf][2 * kp + frow][wn0 + fcol];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc, 0, 0, 0);
+  for (int d = 0; d < SV_DEPTH; ++d)
+    if (cbeg + d < cend) fetch(cbeg + d, d);
+  if (cbeg < cend) stash(0, 0);
+  __syncthreads();
+  for (int base = cbeg; base < cend; base += SV_DEPTH) {
+#pragma unroll
+    for (int d = 0; d < SV_DEPTH; ++d) {
+      const int c = base + d;
+      if (c < cend) {                                // uniform
+        const int buf = d & 1;                       // SV_DEPTH is even
+        if (c + SV_DEPTH < cend) fetch(c + SV_DEPTH, d);       // slot d was stashed one chunk ago
+#pragma unroll
+        for (int kp = 0; kp < SV_KC / 2; ++kp) {
+          const float af = As[buf][2 * kp + frow][wm0 + fcol];
+          const float bf = Bs[buf][2 * kp + frow][wn0 + fcol];
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc, 0, 0, 0);
+        }
+        if (c + 1 < cend) stash(buf ^ 1, (d + 1) % SV_DEPTH);
+        __syncthreads();
+      }
     }
-    if (c + 1 < cend) stash(buf ^ 1);
-    __syncthreads();
   }
   float* cpart = p.conv + (int64_t)ks * p.out_ch * pp;
 #pragma unroll
@@ -141,6 +156,19 @@ __global__ void __launch_bounds__(256) solve_fwd_kernel(const rw_solve_problem p
   }
 }
 
+// Sum of the split-K partials base[s * stride], s = 0 .. ksplit-1 (ksplit <= 32, rw_solve_ksplit), in that order:
+// all loads are issued before the first add -- a loop with a running sum serialises ksplit memory latencies
+// (measured: 17 us of the 57 us iteration went to K2 that way).
+__device__ __forceinline__ float sv_sum_partials(const float* base, int64_t stride, int ksplit) {
+  float v[32];
+#pragma unroll
+  for (int s = 0; s < 32; ++s) v[s] = s < ksplit ? base[s * stride] : 0.f;
+  float acc = 0.f;
+#pragma unroll
+  for (int s = 0; s < 32; ++s) acc += v[s];          // + 0.f past ksplit leaves the sum unchanged
+  return acc;
+}
+
 // ---------------------------------------------------------------------------------------
 // K2: one workgroup per out channel
 // ---------------------------------------------------------------------------------------
@@ -151,8 +179,7 @@ __global__ void __launch_bounds__(256) solve_mid_kernel(const rw_solve_problem p
   const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (o >= p.out_ch) return;
   const int P = sv_conv_h(p) * sv_conv_w(p);
-  float wsq = 0.f;
-  for (int s = 0; s < p.ksplit; ++s) wsq += p.wsq[(int64_t)s * p.out_ch + o];
+  const float wsq = sv_sum_partials(p.wsq + o, p.out_ch, p.ksplit);
   const float demod = rsqrtf(wsq + 1e-8f);
   // bias == NULL: the target is the demodulated convolution alone (SeqTinyStyleGanRewriter,
   // rewrite/ganrewrite.py:731-738): no noise, no bias, no activation between it and the loss
@@ -163,8 +190,7 @@ __global__ void __launch_bounds__(256) solve_mid_kernel(const rw_solve_problem p
   for (int n = lane; n < pp; n += 64) {
     float gdv = 0.f;
     if (n < P) {
-      float conv = 0.f;
-      for (int s = 0; s < p.ksplit; ++s) conv += p.conv[((int64_t)s * p.out_ch + o) * pp + n];
+      float conv = sv_sum_partials(p.conv + (int64_t)o * pp + n, (int64_t)p.out_ch * pp, p.ksplit);
       conv *= p.w_scale;
       float out, pre;
       if (plain) {
@@ -209,14 +235,10 @@ __global__ void __launch_bounds__(256) solve_mid_up_kernel(const rw_solve_proble
   float* conv = lds;
   float* gpre = lds + P;
   if (tid < 16) kf[tid] = p.blur_k[(3 - (tid >> 2)) * 4 + (3 - (tid & 3))];
-  float wsq = 0.f;
-  for (int s = 0; s < p.ksplit; ++s) wsq += p.wsq[(int64_t)s * p.out_ch + o];
+  const float wsq = sv_sum_partials(p.wsq + o, p.out_ch, p.ksplit);
   const float demod = rsqrtf(wsq + 1e-8f);
-  for (int n = tid; n < P; n += 256) {
-    float c = 0.f;
-    for (int s = 0; s < p.ksplit; ++s) c += p.conv[((int64_t)s * p.out_ch + o) * pp + n];
-    conv[n] = c * p.w_scale;
-  }
+  for (int n = tid; n < P; n += 256)
+    conv[n] = sv_sum_partials(p.conv + (int64_t)o * pp + n, (int64_t)p.out_ch * pp, p.ksplit) * p.w_scale;
   __syncthreads();
   const float nw = p.noise_w[0], bv = p.bias[o];
   const float inv_numel = 1.0f / ((float)p.out_ch * (float)PO);
@@ -318,11 +340,12 @@ __global__ void __launch_bounds__(256) solve_bwd_adam_kernel(const rw_solve_prob
   const int ci = col_ok ? kmine / 9 : 0, ctap = col_ok ? kmine - 9 * ci : 0;
   const float* kch = p.key + (int64_t)ci * p.h * p.w;
 
-  float4 areg;
-  float breg[8];
-  auto fetch = [&](int c) {
+  // operand ring as in K1 (the K dimension here is the crop: 4 - 16 chunks)
+  float4 areg[SV_DEPTH];
+  float breg[SV_DEPTH][8];
+  auto fetch = [&](int c, int slot) __attribute__((always_inline)) {
     const int p0 = c * SV_KC;
-    areg = *reinterpret_cast<const float4*>(p.gd + (int64_t)(o0 + arow) * pp + p0 + apart);
+    areg[slot] = *reinterpret_cast<const float4*>(p.gd + (int64_t)(o0 + arow) * pp + p0 + apart);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int n = p0 + bp0 + 2 * j;
@@ -331,14 +354,14 @@ __global__ void __launch_bounds__(256) solve_bwd_adam_kernel(const rw_solve_prob
         const int y = n / CW;
         v = sv_gather(p, kch, ctap, y, n - y * CW);
       }
-      breg[j] = v;
+      breg[slot][j] = v;
     }
   };
-  auto stash = [&](int buf) {
-    As[buf][apart + 0][arow] = areg.x; As[buf][apart + 1][arow] = areg.y;
-    As[buf][apart + 2][arow] = areg.z; As[buf][apart + 3][arow] = areg.w;
+  auto stash = [&](int buf, int slot) __attribute__((always_inline)) {
+    As[buf][apart + 0][arow] = areg[slot].x; As[buf][apart + 1][arow] = areg[slot].y;
+    As[buf][apart + 2][arow] = areg[slot].z; As[buf][apart + 3][arow] = areg[slot].w;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) Bs[buf][bp0 + 2 * j][bcol] = breg[j];
+    for (int j = 0; j < 8; ++j) Bs[buf][bp0 + 2 * j][bcol] = breg[slot][j];
   };
 
   rw_f32x16 acc[2];
@@ -347,28 +370,37 @@ __global__ void __launch_bounds__(256) solve_bwd_adam_kernel(const rw_solve_prob
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
   const int chunks = (P + SV_KC - 1) / SV_KC;
-  fetch(0);
-  stash(0);
+#pragma unroll
+  for (int d = 0; d < SV_DEPTH; ++d)
+    if (d < chunks) fetch(d, d);
+  stash(0, 0);
   __syncthreads();
-  for (int c = 0; c < chunks; ++c) {
-    const int buf = c & 1;
-    if (c + 1 < chunks) fetch(c + 1);
+  for (int base = 0; base < chunks; base += SV_DEPTH) {
 #pragma unroll
-    for (int kp = 0; kp < SV_KC / 2; ++kp) {
-      const float af = As[buf][2 * kp + frow][wm0 + fcol];
+    for (int d = 0; d < SV_DEPTH; ++d) {
+      const int c = base + d;
+      if (c < chunks) {                              // uniform
+        const int buf = d & 1;
+        if (c + SV_DEPTH < chunks) fetch(c + SV_DEPTH, d);
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const float bf = Bs[buf][2 * kp + frow][wn0 + 32 * b + fcol];
-        acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[b], 0, 0, 0);
+        for (int kp = 0; kp < SV_KC / 2; ++kp) {
+          const float af = As[buf][2 * kp + frow][wm0 + fcol];
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const float bf = Bs[buf][2 * kp + frow][wn0 + 32 * b + fcol];
+            acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[b], 0, 0, 0);
+          }
+        }
+        if (c + 1 < chunks) stash(buf ^ 1, (d + 1) % SV_DEPTH);
+        __syncthreads();
       }
     }
-    if (c + 1 < chunks) stash(buf ^ 1);
-    __syncthreads();
   }
 
   // Epilogue: gradient, then Adam in place.  W, m, v of the 16 rows a lane owns are fetched in one
   // batch (48 loads in flight) before anything is stored: weight/exp_avg/exp_avg_sq are read AND
   // written here, so element-by-element code serialises into 32 dependent L2 round trips per wave.
+  // (Requesting them before the GEMM instead -- they do not depend on it -- was measured slower: 30 vs 21 us.)
   const float step_size = p.step_size[it], bc2s = p.bc2_sqrt[it];
   float c2v[16];
 #pragma unroll
@@ -542,7 +574,7 @@ extern "C" int rw_solve_step_f32(const rw_solve_problem* pr, int project, rw_str
                p.exp_avg_sq && p.step_size && p.bc2_sqrt && p.step_counter && p.losses && p.conv &&
                p.wsq && p.gd && p.c2);
   RW_CHECK_ARG(!p.bias || (p.noise && p.noise_w));          // bias == NULL: plain dconv target
-  RW_CHECK_ARG(p.out_ch > 0 && p.in_ch > 0 && p.h > 0 && p.w > 0 && p.ksplit > 0);
+  RW_CHECK_ARG(p.out_ch > 0 && p.in_ch > 0 && p.h > 0 && p.w > 0 && p.ksplit > 0 && p.ksplit <= 32);
   RW_CHECK_ARG(!(project || p.low_rank_gradient || p.linear_insert) || (p.context && p.rank > 0));
   RW_CHECK_ARG(!(project || p.linear_insert) || p.ortho);
   RW_CHECK_ARG(!(p.low_rank_gradient || p.linear_insert) || p.grad);

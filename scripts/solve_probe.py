@@ -1,0 +1,45 @@
+"""Microseconds per iteration of the fused rank-constrained solve (GPU only) on a synthetic problem of the shape of
+BASELINE.json configs[2]: 512 -> 512 channels, a 5 x 8 key crop, rank-1 context, 2001 steps in HIP graphs of 10."""
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from rewriting_amd.rewrite import hipsolve          # noqa: E402
+
+
+def main(niter=int(os.environ.get('RW_NITER', '2001'))):
+    dev = 'cuda'
+    gen = torch.Generator().manual_seed(0)
+    rows = []
+    for (O, I, h, w) in [(512, 512, 5, 8), (512, 512, 12, 12), (256, 256, 8, 8)]:
+        weight = torch.nn.Parameter(torch.randn(1, O, I, 3, 3, generator=gen).to(dev))
+        key = torch.randn(1, I, h, w, generator=gen).to(dev)
+        style = (1 + 0.3 * torch.randn(1, I, generator=gen)).to(dev)
+        val = torch.randn(1, O, h, w, generator=gen).to(dev)
+        bias = torch.randn(O, generator=gen).to(dev)
+        noise_w = torch.tensor([0.1], device=dev)
+        ctx = torch.nn.functional.normalize(torch.randn(1, I, generator=gen), dim=1).to(dev)
+        best = None
+        for rep in range(3):
+            wt = torch.nn.Parameter(weight.detach().clone())
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            hipsolve.run(wt, key, style, val, bias, noise_w, ctx, niter=niter, piter=10, lr=0.05)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        rows.append(dict(out_ch=O, in_ch=I, crop=[h, w], steps=niter, seconds=round(best, 4),
+                         us_per_iter=round(best / niter * 1e6, 2), checksum=float(wt.detach().double().sum())))
+        print(rows[-1], flush=True)
+    os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+    with open(os.path.join(ROOT, 'gpurun_out', os.environ.get('RW_OUT', 'solve_probe.json')), 'w') as f:
+        json.dump(rows, f, indent=1)
+
+
+if __name__ == '__main__':
+    main()
