@@ -18,7 +18,11 @@
 #define SV_KC 16
 #define SV_BM 64        // out channels per workgroup (both GEMMs)
 #define SV_BN 64        // pixels per workgroup in K1
-#define SV_BNK 128      // weight columns per workgroup in K3
+#ifndef SV_BNK
+#define SV_BNK 64       // weight columns per workgroup in K3 (64 or 128: one or two 32-column tiles per wave)
+#endif
+#define SV_NB (SV_BNK / 64)
+#define SV_BJ (SV_KC * SV_BNK / 256)      // B elements a thread stages per chunk
 #define SV_DEPTH 4      // chunks of operands in flight per workgroup (K1, K3)
 
 static inline int sv_pp(int p) { return (int)rw_cdiv(p, 64) * 64; }
@@ -317,7 +321,7 @@ __global__ void __launch_bounds__(256) solve_bwd_adam_kernel(const rw_solve_prob
   __shared__ __attribute__((aligned(16))) float As[2][SV_KC][SV_BM + 4];
   __shared__ float Bs[2][SV_KC][SV_BNK];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 64;     // wave tile 32 (o) x 64 (k)
+  const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * (SV_BNK / 2);     // wave tile 32 (o) x SV_BNK/2 (k)
   const int frow = lane >> 5, fcol = lane & 31;
   const int o0 = blockIdx.x * SV_BM;
   const int k0 = blockIdx.y * SV_BNK;
@@ -334,7 +338,7 @@ __global__ void __launch_bounds__(256) solve_bwd_adam_kernel(const rw_solve_prob
   }
 
   const int arow = tid >> 2, apart = (tid & 3) * 4;
-  const int bcol = tid & 127, bp0 = tid >> 7;
+  const int bcol = tid & (SV_BNK - 1), bp0 = tid / SV_BNK;
   const int kmine = k0 + bcol;
   const bool col_ok = kmine < K;
   const int ci = col_ok ? kmine / 9 : 0, ctap = col_ok ? kmine - 9 * ci : 0;
@@ -342,13 +346,13 @@ __global__ void __launch_bounds__(256) solve_bwd_adam_kernel(const rw_solve_prob
 
   // operand ring as in K1 (the K dimension here is the crop: 4 - 16 chunks)
   float4 areg[SV_DEPTH];
-  float breg[SV_DEPTH][8];
+  float breg[SV_DEPTH][SV_BJ];
   auto fetch = [&](int c, int slot) __attribute__((always_inline)) {
     const int p0 = c * SV_KC;
     areg[slot] = *reinterpret_cast<const float4*>(p.gd + (int64_t)(o0 + arow) * pp + p0 + apart);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int n = p0 + bp0 + 2 * j;
+    for (int j = 0; j < SV_BJ; ++j) {
+      const int n = p0 + bp0 + (256 / SV_BNK) * j;
       float v = 0.f;
       if (n < P && col_ok) {
         const int y = n / CW;
@@ -361,12 +365,12 @@ __global__ void __launch_bounds__(256) solve_bwd_adam_kernel(const rw_solve_prob
     As[buf][apart + 0][arow] = areg[slot].x; As[buf][apart + 1][arow] = areg[slot].y;
     As[buf][apart + 2][arow] = areg[slot].z; As[buf][apart + 3][arow] = areg[slot].w;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) Bs[buf][bp0 + 2 * j][bcol] = breg[slot][j];
+    for (int j = 0; j < SV_BJ; ++j) Bs[buf][bp0 + (256 / SV_BNK) * j][bcol] = breg[slot][j];
   };
 
-  rw_f32x16 acc[2];
+  rw_f32x16 acc[SV_NB];
 #pragma unroll
-  for (int b = 0; b < 2; ++b)
+  for (int b = 0; b < SV_NB; ++b)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
   const int chunks = (P + SV_KC - 1) / SV_KC;
@@ -386,7 +390,7 @@ __global__ void __launch_bounds__(256) solve_bwd_adam_kernel(const rw_solve_prob
         for (int kp = 0; kp < SV_KC / 2; ++kp) {
           const float af = As[buf][2 * kp + frow][wm0 + fcol];
 #pragma unroll
-          for (int b = 0; b < 2; ++b) {
+          for (int b = 0; b < SV_NB; ++b) {
             const float bf = Bs[buf][2 * kp + frow][wn0 + 32 * b + fcol];
             acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[b], 0, 0, 0);
           }
@@ -406,7 +410,7 @@ __global__ void __launch_bounds__(256) solve_bwd_adam_kernel(const rw_solve_prob
 #pragma unroll
   for (int r = 0; r < 16; ++r) c2v[r] = p.c2[o0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * frow];
 #pragma unroll
-  for (int b = 0; b < 2; ++b) {
+  for (int b = 0; b < SV_NB; ++b) {
     const int k = k0 + wn0 + 32 * b + fcol;
     if (k >= K) continue;
     const int i = k / 9;
