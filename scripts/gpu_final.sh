@@ -36,3 +36,6 @@ RW_BATCH=64 RW_OUT=$TAG/cb_all.json python scripts/conv_bench.py 2>&1 | grep lay
 timeout 900 python bench.py --workload watermark --steps 1 --warmup 1 > $OUT/watermark.json 2> $OUT/watermark.err; echo "watermark exit $?"
 timeout 300 python bench.py --workload edit --steps 3 --warmup 1 > $OUT/edit.json 2> $OUT/edit.err; echo "edit exit $?"
 echo done
+python scripts/solve_probe.py > "$OUT/solve_probe.log" 2>&1; grep out_ch "$OUT/solve_probe.log"; cp gpurun_out/solve_probe.json "$OUT/" 2>/dev/null
+RW_OUT=$TAG/micro_probe.json RW_SPECS=0,8:256,4:512,2:1024 python scripts/micro_probe.py > "$OUT/micro.log" 2>&1; grep spec "$OUT/micro.log"
+echo final done
