@@ -194,6 +194,20 @@ int rw_conv3x3_wino_to_rgb_f32(const float* x, const float* uf, float* y, int ba
                                int h, int w, float w_scale, const rw_conv_epilogue* ep,
                                const rw_rgb_epilogue* rgb, rw_stream_t stream);
 
+/* The same convolution by Winograd F(4x4, 3x3) in fp32: 36 multiplications per 4x4 output tile and channel pair
+ * (4x fewer matrix FLOPs than the direct sum, 1.78x fewer than F(2x2,3x3)).  Its transforms carry the constants
+ * 4, 5, 8, 1/24: measured fp32 error 4e-6 .. 9e-6 of the output range per layer against 2e-7 .. 6e-7 for the two
+ * kernels above.  OPT-IN for image generation (the image tolerance of the path is 1e-3 L-inf); the statistics
+ * sweeps and the solve never use it.  Shapes: out_ch % 32 == 0, in_ch % 8 == 0, w % 64 == 0, h % 8 == 0.
+ *   uf: rw_packed_conv_weight_wino4_elems(out_ch, in_ch) = 36*out_ch*in_ch floats from
+ *       rw_pack_conv_weight_wino4_f32: uf[o / 16][i / 4][xi / 4][lane][xi % 4], o = 16 (o/16) + (lane & 15),
+ *       i = 4 (i/4) + (lane >> 4), xi = 6 a + b the transform point (row a, column b of G g G^T). */
+int rw_conv3x3_wino4_supported(int out_ch, int in_ch, int h, int w);
+long long rw_packed_conv_weight_wino4_elems(int out_ch, int in_ch);
+int rw_pack_conv_weight_wino4_f32(const float* w, float* uf, int out_ch, int in_ch, rw_stream_t stream);
+int rw_conv3x3_wino4_f32(const float* x, const float* uf, float* y, int batch, int in_ch, int out_ch, int h,
+                         int w, float w_scale, const rw_conv_epilogue* ep, rw_stream_t stream);
+
 /* F.conv_transpose2d(x, scale*W^T, stride=2, padding=0) [* demod]     (models.py:315-316,328)
  * x (B,Cin,H,W) -> y (B,Cout,2H+1,2W+1), wp from rw_pack_conv_weight_f32 mode 1. */
 int rw_conv_transpose3x3s2_f32(const float* x, const float* wp, float* y, int batch, int in_ch,

@@ -13,7 +13,9 @@ pids=()
 for src in "$HERE"/*.hip; do
   obj="$OBJ/$(basename "${src%.hip}").o"
   if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/rw_common.h" -nt "$obj" ] || [ "$HERE/../../include/rewriting_hip.h" -nt "$obj" ]; then
-    "$HIPCC" $FLAGS "$@" -c "$src" -o "$obj" &
+    # per-file flags: a leading comment line "// hipcc-flags: ..." in the source
+    extra="$(sed -n 's|^// hipcc-flags: ||p' "$src" | head -1)"
+    "$HIPCC" $FLAGS $extra "$@" -c "$src" -o "$obj" &
     pids+=($!)
   fi
 done

@@ -1,0 +1,422 @@
+// hipcc-flags: -fno-slp-vectorize
+// (the SLP vectoriser pairs the scalar row pass of the input transform and pays for it in register moves)
+// Stride-1 3x3 modulated convolution (DemodulatedConv2dF, utils/stylegan2/models.py:313-329) by Winograd
+// F(4x4, 3x3) in fp32: 36 multiplications per (in-channel, out-channel) pair and 4x4 output tile instead of 144 --
+// 4x fewer matrix FLOPs than the direct sum, 1.78x fewer than F(2x2,3x3) (rw_wino.hip).
+//
+// Accuracy: the transforms carry the constants 4, 5, 8 and 1/24, and fp32 rounding grows with them: measured 4e-6 to
+// 9e-6 of the output range per layer (32 - 512 channels) against 2e-7 to 6e-7 for F(2x2,3x3) and the direct sum.
+// That is inside the path's image tolerance (1e-3 L-inf) and outside what the key statistics and the solve are held
+// to, so this kernel is an OPT-IN for image generation (RW_CONV_ALGO=winograd4); it is never the default.
+//
+//   U[xi][o][i] = (G g G^T)[xi]      6x6 per (o, i), once per weight version      (rw_pack_conv_weight_wino4_f32)
+//   V[xi][i][t] = (B^T d B)[xi]      6x6 input tile d (stride 4)
+//   M[xi][o][t] = sum_i U[xi][o][i] V[xi][i][t]          36 independent GEMMs -> v_mfma_f32_16x16x4_f32
+//   Y[o][t]     = A^T M A            4x4 outputs, then the fused epilogue (demod, noise, bias, leaky-ReLU)
+//
+// Kernel design -- no V in LDS.  The B operand of v_mfma_f32_16x16x4_f32 puts element (k, n) in lane 16 k + n: with
+// k = input channel of the k-quad and n = tile, lane (k, n) needs V[all 36 xi][channel k][tile n] -- exactly the
+// output of the input transform of ONE (tile, channel) item.  So every lane transforms its own item in registers
+// (12 LDS reads of the raw patch, ~150 VALU instructions) and the results ARE the wave's B operands of that k-quad:
+// no transformed buffer, no second barrier, no LDS traffic for B.  A wave holds all 36 points of 16 out-channels x
+// 16 tiles (144 accumulator registers), so the output transform is lane-local too and a lane ends up with a 4x4
+// pixel block of four channels: 16-byte stores, 256 contiguous bytes per 16 lanes.  The two waves of a SIMD (two
+// workgroups per CU) alternate by themselves: while one transforms (VALU, LDS) the other issues its 36 MFMAs.
+// Waves of a workgroup that differ only in out-channels (WGM) repeat the transform; the VALU is otherwise idle.
+//
+// A workgroup = WGM out-channel blocks of 16 x WGN tile rows of 16 tiles (4 x 64 pixels each) and walks a run of
+// `gpw` 64-pixel groups along x as one pipeline of 4-channel intervals: interval v computes on Rs[v & 1], stores
+// the patch of interval v + 1 (fetched during v - 1, registers) into Rs[(v + 1) & 1] and fetches v + 2; one barrier
+// per interval.  Weights: uf[o / 16][i / 4][xi / 4][lane = 16 (i % 4) + o % 16][xi % 4], copied to LDS one interval
+// ahead by global_load_lds and read from there (one ds_read_b128 per four points).
+#include "rw_common.h"
+
+// Timing ablations (build a second library with -DW4_ABL=<bits>; results are WRONG when a bit is set): 1 = no input
+// transform arithmetic, 2 = no patch fetch / staging, 4 = no weight copies, 8 = no output transform / stores,
+// 16 = no barriers in the loop.
+#ifndef W4_ABL
+#define W4_ABL 0
+#endif
+
+typedef float w4_f32x4 __attribute__((ext_vector_type(4)));
+
+struct Wino4Problem {
+  const float* x; const float* uf; float* y;
+  const float* style; const float* demod; const float* noise; const float* noise_w; const float* bias;
+  int batch, in_ch, out_ch, h, w;
+  int groups_x, groups_y, gpw;
+  float w_scale;
+  int act;
+};
+
+#define W4_PC 66                // patch columns: 64 + 2
+#define W4_RS 72                // row pitch of the raw patch in LDS (floats)
+
+__device__ __forceinline__ int w4_xcd_remap(int id, int total) {
+  const int q = total >> 3, r = total & 7;
+  const int xcd = id & 7, slot = id >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + slot;
+}
+
+// 1-D input transform B^T (Lavin & Gray, points 0, +-1, +-2, inf), in place
+__device__ __forceinline__ void w4_bt(float& d0, float& d1, float& d2, float& d3, float& d4, float& d5) {
+  const float t0 = 4.f * d0 - 5.f * d2 + d4;
+  const float p = d4 - 4.f * d2, q = d3 - 4.f * d1;
+  const float r = d4 - d2, s = 2.f * (d3 - d1);
+  const float t5 = 4.f * d1 - 5.f * d3 + d5;
+  d0 = t0; d1 = p + q; d2 = p - q; d3 = r + s; d4 = r - s; d5 = t5;
+}
+
+// the same on two columns at once (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32: adjacent columns of a patch row come out
+// of the LDS reads as adjacent registers)
+typedef float w4_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void w4_bt2(w4_f32x2& d0, w4_f32x2& d1, w4_f32x2& d2, w4_f32x2& d3, w4_f32x2& d4,
+                                       w4_f32x2& d5) {
+  const w4_f32x2 t0 = 4.f * d0 - 5.f * d2 + d4;
+  const w4_f32x2 p = d4 - 4.f * d2, q = d3 - 4.f * d1;
+  const w4_f32x2 r = d4 - d2, s = 2.f * (d3 - d1);
+  const w4_f32x2 t5 = 4.f * d1 - 5.f * d3 + d5;
+  d0 = t0; d1 = p + q; d2 = p - q; d3 = r + s; d4 = r - s; d5 = t5;
+}
+
+// The same on ONE row held as three column pairs P0 = (e0,e1), P1 = (e2,e3), P2 = (e4,e5): six packed instructions
+// instead of thirteen scalar ones -- the packed operand selectors (op_sel) broadcast a half to both lanes, the
+// constants ride in register pairs:
+//   (t0,t5) = 4 P0 - 5 P1 + P2     (p,r) = e4 + (-4,-1) e2     (q,s) = e3 + (-4,-1) e1
+//   (t1,t2) = p + (q,-q)           (t3,t4) = r + (2,-2) s
+__device__ __forceinline__ void w4_bt_row(const w4_f32x2 P0, const w4_f32x2 P1, const w4_f32x2 P2, float (&t)[6]) {
+  const w4_f32x2 K1 = {-4.f, -1.f}, K2 = {2.f, -2.f}, K3 = {1.f, -1.f};
+  const w4_f32x2 t05 = 4.f * P0 + (P2 - 5.f * P1);
+  const w4_f32x2 pr = w4_f32x2{P2[0], P2[0]} + K1 * w4_f32x2{P1[0], P1[0]};
+  const w4_f32x2 qs = w4_f32x2{P1[1], P1[1]} + K1 * w4_f32x2{P0[1], P0[1]};
+  const w4_f32x2 t12 = w4_f32x2{pr[0], pr[0]} + K3 * w4_f32x2{qs[0], qs[0]};
+  const w4_f32x2 t34 = w4_f32x2{pr[1], pr[1]} + K2 * w4_f32x2{qs[1], qs[1]};
+  t[0] = t05[0]; t[1] = t12[0]; t[2] = t12[1]; t[3] = t34[0]; t[4] = t34[1]; t[5] = t05[1];
+}
+
+template <int WGM, int WGN>
+__global__ void __launch_bounds__(256, 2) conv_wino36_kernel(const Wino4Problem p) {
+  static_assert(WGM * WGN == 4, "4 waves per workgroup");
+  constexpr int IC = 4;                           // channels per interval = one k-quad
+  constexpr int PR = 4 * WGN + 2;                 // patch rows
+  constexpr int NPOS = PR * W4_PC;
+  constexpr int PSLOT = (NPOS + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float Rs[2][IC][PR][W4_RS];
+  __shared__ __attribute__((aligned(16))) float Us[3][WGM][9 * 256];      // weights of one k-quad, A-fragment order
+  __shared__ float Ct[2][16 * WGM];               // [0] w_scale * demod, [1] bias
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int lk = lane >> 4, lt = lane & 15;       // channel of the k-quad / tile column (A: k / out-channel row)
+
+  const int local = w4_xcd_remap(blockIdx.x, gridDim.x);
+  const int o_tiles = p.out_ch / (16 * WGM);
+  const int runs_x = p.groups_x / p.gpw;
+  const int ot = local % o_tiles;
+  int pg = local / o_tiles;
+  const int run = pg % runs_x; pg /= runs_x;
+  const int gy = pg % p.groups_y;
+  const int ib = pg / p.groups_y;
+  const int o0 = ot * 16 * WGM;
+  const int y0 = gy * 4 * WGN, gx0 = run * p.gpw;
+  const int64_t hw = (int64_t)p.h * p.w;
+  const float* xb = p.x + (int64_t)ib * p.in_ch * hw;
+  const float* st = p.style ? p.style + (int64_t)ib * p.in_ch : nullptr;
+  const int NC = p.in_ch / IC;
+  const int VT = p.gpw * NC;
+
+  if (tid < 16 * WGM) {
+    const int o = o0 + tid;
+    Ct[0][tid] = p.demod ? p.demod[(int64_t)ib * p.out_ch + o] * p.w_scale : p.w_scale;
+    Ct[1][tid] = p.act ? p.bias[o] : 0.f;
+  }
+
+  // ---- raw patch: buffer loads (out-of-image positions read 0), style applied on the way into LDS
+  const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(xb), 0, (int)((int64_t)p.in_ch * hw * 4), 0x00020000);
+  int xoff[PSLOT], xlds[PSLOT];
+#pragma unroll
+  for (int sl = 0; sl < PSLOT; ++sl) {
+    const int pos = tid + 256 * sl;
+    const int r = pos / W4_PC, c = pos - r * W4_PC;
+    xlds[sl] = pos < NPOS ? r * W4_RS + c : W4_RS - 1;      // spare slots land in a padding column
+  }
+  auto set_group = [&](int g) __attribute__((always_inline)) {
+    const int x0 = (gx0 + g) * 64;
+#pragma unroll
+    for (int sl = 0; sl < PSLOT; ++sl) {
+      const int pos = tid + 256 * sl;
+      const int r = pos / W4_PC, c = pos - r * W4_PC;
+      const int iy = y0 - 1 + r, ix = x0 - 1 + c;
+      const bool ok = pos < NPOS && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
+      xoff[sl] = ok ? (iy * p.w + ix) * 4 : 0x7fffffff;
+    }
+  };
+  float xreg[PSLOT][IC];
+  float sty[IC];
+  const int hw4 = (int)hw * 4;
+  auto fetch = [&](int fg, int fc) __attribute__((always_inline)) {       // interval (group fg, chunk fc); uniform
+    if (fc == 0) set_group(fg);
+    const int i0 = fc * IC;
+#pragma unroll
+    for (int ic = 0; ic < IC; ++ic)
+#pragma unroll
+      for (int sl = 0; sl < PSLOT; ++sl)
+        xreg[sl][ic] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xsrc, xoff[sl], (i0 + ic) * hw4, 0));
+#pragma unroll
+    for (int ic = 0; ic < IC; ++ic) sty[ic] = st ? st[(i0 + ic) < p.in_ch ? i0 + ic : 0] : 1.0f;
+  };
+  auto stash = [&](int rbuf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ic = 0; ic < IC; ++ic)
+#pragma unroll
+      for (int sl = 0; sl < PSLOT; ++sl)
+        (&Rs[0][0][0][0])[(rbuf * IC + ic) * PR * W4_RS + xlds[sl]] = xreg[sl][ic] * sty[ic];
+  };
+
+  // ---- operands
+  // Weights go global -> LDS directly (global_load_lds_dwordx4: no registers, and -- the point -- the A operands are
+  // then read with ds_read, which waits on lgkmcnt: a weight load in registers would queue behind the patch fetch in
+  // the in-order vmcnt FIFO and stall every interval on HBM latency).  9 KB per 16 out-channels and k-quad, the
+  // 9 * WGM one-KB pieces dealt round-robin to the four waves; LDS image = global image.
+  const int kq_total = p.in_ch >> 2;
+  const int a_lane = lane * 4;
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+  auto uload = [&](int ubuf, int kq) __attribute__((always_inline)) {
+    for (int j = wave; j < 9 * WGM; j += 4) {
+      const int ob = j / 9, q = j - 9 * ob;
+      const float* src = p.uf + ((int64_t)((o0 >> 4) + ob) * kq_total + kq) * (9 * 256) + q * 256 + a_lane;
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)&Us[ubuf][ob][q * 256], 16, 0, 0);
+    }
+  };
+  // this lane's item: channel lk of the k-quad, tile (row wn, column lt): patch rows 4 wn .., columns 4 lt ..
+  const float* item = &Rs[0][lk][4 * wn][4 * lt];
+
+  w4_f32x4 acc[36];
+#pragma unroll
+  for (int xi = 0; xi < 36; ++xi) acc[xi] = w4_f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const float noise_w = p.noise ? p.noise_w[0] : 0.f;
+
+  // one interval: transform this lane's item of Rs[buf], then the 36 MFMAs of k-quad kq
+  auto compute = [&](int buf, int ubuf) __attribute__((always_inline)) {
+    const float* base = &Us[ubuf][wm][a_lane];
+    // column pass on column pairs (packed), row pass scalar on the halves of the pairs: no register shuffles
+    w4_f32x2 c2[6][3];
+    const float* src = item + buf * IC * PR * W4_RS;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const w4_f32x4 lo = *reinterpret_cast<const w4_f32x4*>(src + r * W4_RS);
+      c2[r][0] = w4_f32x2{lo[0], lo[1]};
+      c2[r][1] = w4_f32x2{lo[2], lo[3]};
+      c2[r][2] = *reinterpret_cast<const w4_f32x2*>(src + r * W4_RS + 4);
+    }
+    float d[6][6];
+    if (!(W4_ABL & 1)) {
+#pragma unroll
+      for (int cp = 0; cp < 3; ++cp) w4_bt2(c2[0][cp], c2[1][cp], c2[2][cp], c2[3][cp], c2[4][cp], c2[5][cp]);
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      if (!(W4_ABL & 1)) {
+        w4_bt_row(c2[a][0], c2[a][1], c2[a][2], d[a]);                                            // rows: (B^T d) B
+      } else {
+        d[a][0] = c2[a][0][0]; d[a][1] = c2[a][0][1]; d[a][2] = c2[a][1][0]; d[a][3] = c2[a][1][1];
+        d[a][4] = c2[a][2][0]; d[a][5] = c2[a][2][1];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      const w4_f32x4 a = *reinterpret_cast<const w4_f32x4*>(base + q * 256);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int xi = 4 * q + e;
+        acc[xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], d[xi / 6][xi % 6], acc[xi], 0, 0, 0);
+      }
+    }
+  };
+
+  // epilogue of one group: lane-local output transform; acc[6 a + b][j] = M[a][b] of out-channel
+  // o0 + 16 wm + 4 lk + j, tile (row wn, column lt) -> pixels (y0 + 4 wn .. +3, x0 + 4 lt .. +3)
+  auto group_epilogue = [&](int g) __attribute__((always_inline)) {
+    const int oy = y0 + 4 * wn, ox = (gx0 + g) * 64 + 4 * lt;
+    w4_f32x4 nz[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) nz[r] = w4_f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.noise) {
+      const float* np = p.noise + (int64_t)ib * hw + (int64_t)oy * p.w + ox;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) nz[r] = *reinterpret_cast<const w4_f32x4*>(np + (int64_t)r * p.w) * noise_w;
+    }
+    const float* ct = &Ct[0][16 * wm + 4 * lk];
+    float* yb = p.y + ((int64_t)ib * p.out_ch + o0 + 16 * wm + 4 * lk) * hw + (int64_t)oy * p.w + ox;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float scale = ct[j], bias = ct[16 * WGM + j];
+      // A^T M: columns b = 0..5 -> 4 rows
+      float t[4][6];
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        const float m0 = acc[b][j], m1 = acc[6 + b][j], m2 = acc[12 + b][j], m3 = acc[18 + b][j], m4 = acc[24 + b][j],
+                    m5 = acc[30 + b][j];
+        const float s1 = m1 + m2, s2 = m1 - m2, s3 = m3 + m4, s4 = m3 - m4;
+        t[0][b] = m0 + s1 + s3;
+        t[1][b] = s2 + 2.f * s4;
+        t[2][b] = s1 + 4.f * s3;
+        t[3][b] = s2 + 8.f * s4 + m5;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float s1 = t[r][1] + t[r][2], s2 = t[r][1] - t[r][2], s3 = t[r][3] + t[r][4], s4 = t[r][3] - t[r][4];
+        w4_f32x4 v = {t[r][0] + s1 + s3, s2 + 2.f * s4, s1 + 4.f * s3, s2 + 8.f * s4 + t[r][5]};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float u = v[k] * scale + nz[r][k];
+          if (p.act) {
+            u += bias;
+            u = ((u > 0.f) ? u : u * 0.2f) * 1.4142135623730951f;
+          }
+          v[k] = u;
+        }
+        *reinterpret_cast<w4_f32x4*>(yb + (int64_t)j * hw + (int64_t)r * p.w) = v;
+      }
+    }
+#pragma unroll
+    for (int xi = 0; xi < 36; ++xi) acc[xi] = w4_f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+
+  // ---- prologue: Rs[0] = interval 0, registers = interval 1
+  fetch(0, 0);
+  uload(0, 0);
+  uload(1, 1 % NC);
+  stash(0);
+  fetch(1 / NC, 1 % NC);
+  __syncthreads();
+
+  // Synchronisation of an interval: the staging writes of this wave (lgkmcnt) and a raw s_barrier.  The loads issued
+  // in this interval -- the patch of v + 2 (registers) and the weights of v + 2 (LDS) -- stay in flight ACROSS the
+  // barrier: the first is waited for by the staging of the next interval (which, with LDS-direct loads pending,
+  // the compiler turns into vmcnt(0): it also retires this wave's weight pieces of v + 2, an interval before the
+  // barrier that publishes them).  __syncthreads() would drain both at every barrier (measured: 33 % + 14 %).
+  int c = 0, g = 0, ub = 0;                         // ub = v % 3
+  int fg = 2 / NC, fc = 2 % NC;                     // (group, chunk) of interval v + 2
+  for (int v = 0; v < VT; ++v) {
+    const int buf = v & 1;
+    const int ub2 = ub == 0 ? 2 : ub - 1;           // (v + 2) % 3
+    if (!(W4_ABL & 2)) {
+      stash(buf ^ 1);                               // interval v + 1 (the last one: a harmless refill)
+      fetch(fg, fc);                                // interval v + 2; past the run: legal addresses, never read
+    }
+    if (!(W4_ABL & 4)) uload(ub2, c + 2 < NC ? c + 2 : c + 2 - NC);   // weights of interval v + 2 (same slices for every group)
+    compute(buf, ub);
+    if (c == NC - 1) {
+      if (!(W4_ABL & 8) || acc[0][0] == 12345.f) group_epilogue(g);
+      c = 0; ++g;
+    } else { ++c; }
+    if (++fc == NC) { fc = 0; ++fg; }
+    ub = ub == 2 ? 0 : ub + 1;
+    if (!(W4_ABL & 16)) {
+      __builtin_amdgcn_s_waitcnt(0xC07F);           // lgkmcnt(0), vmcnt / expcnt untouched
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+}
+
+// One thread: the 36 values of one (o, i).  uf[o / 16][i / 4][xi / 4][16 (i % 4) + o % 16][xi % 4]
+__global__ void __launch_bounds__(256) pack_wino36_kernel(const float* __restrict__ w, float* __restrict__ uf,
+                                                          int out_ch, int in_ch) {
+  const int64_t total = (int64_t)out_ch * in_ch;
+  const int kqn = in_ch >> 2;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int lane = (int)(idx & 63);
+    int64_t rest = idx >> 6;
+    const int kq = (int)(rest % kqn);
+    const int ob = (int)(rest / kqn);
+    const int o = 16 * ob + (lane & 15), i = 4 * kq + (lane >> 4);
+    const float* g = w + ((int64_t)o * in_ch + i) * 9;
+    // G = [[1/4,0,0],[-1/6,-1/6,-1/6],[-1/6,1/6,-1/6],[1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]]
+    float gg[6][3];                                   // G g
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const float g0 = g[kx], g1 = g[3 + kx], g2 = g[6 + kx];
+      gg[0][kx] = 0.25f * g0;
+      gg[1][kx] = (-1.f / 6.f) * (g0 + g1 + g2);
+      gg[2][kx] = (-1.f / 6.f) * (g0 - g1 + g2);
+      gg[3][kx] = (1.f / 24.f) * g0 + (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
+      gg[4][kx] = (1.f / 24.f) * g0 - (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
+      gg[5][kx] = g2;
+    }
+    float u[36];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      const float g0 = gg[a][0], g1 = gg[a][1], g2 = gg[a][2];
+      u[6 * a + 0] = 0.25f * g0;
+      u[6 * a + 1] = (-1.f / 6.f) * (g0 + g1 + g2);
+      u[6 * a + 2] = (-1.f / 6.f) * (g0 - g1 + g2);
+      u[6 * a + 3] = (1.f / 24.f) * g0 + (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
+      u[6 * a + 4] = (1.f / 24.f) * g0 - (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
+      u[6 * a + 5] = g2;
+    }
+    float* dst = uf + ((int64_t)ob * kqn + kq) * (9 * 256) + lane * 4;
+#pragma unroll
+    for (int q = 0; q < 9; ++q)
+      *reinterpret_cast<w4_f32x4*>(dst + q * 256) = w4_f32x4{u[4 * q], u[4 * q + 1], u[4 * q + 2], u[4 * q + 3]};
+  }
+}
+
+static bool wino4_shape_ok(int out_ch, int in_ch, int h, int w) {
+  return out_ch > 0 && in_ch > 0 && out_ch % 32 == 0 && in_ch % 8 == 0 && w % 64 == 0 && h % 8 == 0;
+}
+
+extern "C" int rw_conv3x3_wino4_supported(int out_ch, int in_ch, int h, int w) {
+  return wino4_shape_ok(out_ch, in_ch, h, w) ? 1 : 0;
+}
+
+extern "C" long long rw_packed_conv_weight_wino4_elems(int out_ch, int in_ch) {
+  if (out_ch <= 0 || in_ch <= 0 || out_ch % 16 || in_ch % 4) return -1;
+  return 36LL * out_ch * in_ch;
+}
+
+extern "C" int rw_pack_conv_weight_wino4_f32(const float* w, float* uf, int out_ch, int in_ch, rw_stream_t stream) {
+  RW_CHECK_ARG(w && uf && out_ch > 0 && in_ch > 0);
+  if (out_ch % 16 || in_ch % 4) return RW_ERR_UNSUPPORTED;
+  const int64_t total = (int64_t)out_ch * in_ch;
+  hipLaunchKernelGGL(pack_wino36_kernel, dim3(rw_stream_grid(total, 256)), dim3(256), 0, rw_s(stream), w, uf, out_ch,
+                     in_ch);
+  return RW_LAUNCH_RESULT();
+}
+
+#include <stdlib.h>
+extern "C" int rw_conv3x3_wino4_f32(const float* x, const float* uf, float* y, int batch, int in_ch, int out_ch, int h,
+                                    int w, float w_scale, const rw_conv_epilogue* ep, rw_stream_t stream) {
+  RW_CHECK_ARG(x && uf && y && batch > 0 && in_ch > 0 && out_ch > 0 && h > 0 && w > 0);
+  RW_CHECK_ARG(!ep || ((!ep->noise || ep->noise_w) && (!ep->act || ep->bias)));
+  if (!wino4_shape_ok(out_ch, in_ch, h, w)) return RW_ERR_UNSUPPORTED;
+  Wino4Problem p;
+  p.x = x; p.uf = uf; p.y = y;
+  p.style = ep ? ep->style : nullptr; p.demod = ep ? ep->demod : nullptr; p.noise = ep ? ep->noise : nullptr;
+  p.noise_w = ep ? ep->noise_w : nullptr; p.bias = ep ? ep->bias : nullptr; p.act = ep ? ep->act : 0;
+  p.batch = batch; p.in_ch = in_ch; p.out_ch = out_ch; p.h = h; p.w = w; p.w_scale = w_scale;
+  // 32 out-channels x 2 tile rows (8 x 64 pixels) per workgroup
+  p.groups_x = w / 64;
+  p.groups_y = h / 8;
+  const int o_tiles = out_ch / 32;
+  const char* e = getenv("RW_WINO4_GPW");
+  int gpw = e ? atoi(e) : 4;
+  if (gpw < 1) gpw = 1;
+  if (gpw > p.groups_x) gpw = p.groups_x;
+  while (p.groups_x % gpw) --gpw;
+  while (gpw > 1 && (int64_t)batch * p.groups_y * (p.groups_x / gpw) * o_tiles < 1024) {
+    --gpw;
+    while (p.groups_x % gpw) --gpw;
+  }
+  p.gpw = gpw;
+  const int64_t work = (int64_t)batch * p.groups_y * (p.groups_x / gpw) * o_tiles;
+  if (work <= 0 || work > 0x7fffffff) return RW_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL((conv_wino36_kernel<2, 2>), dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
+  return RW_LAUNCH_RESULT();
+}

@@ -256,6 +256,37 @@ def conv3x3_wino(x, uf, out_ch, w_scale, style=None, demod=None, noise=None, noi
     return y
 
 
+def wino4_supported(out_ch, in_ch, height, width):
+    """Shapes the Winograd F(4x4,3x3) stride-1 convolution takes (rw_conv3x3_wino4_supported)."""
+    return bool(lib().rw_conv3x3_wino4_supported(int(out_ch), int(in_ch), int(height), int(width)))
+
+
+def pack_conv_weight_wino4(weight):
+    weight = _dev(weight, 'weight')
+    o, i = weight.shape[-4], weight.shape[-3]
+    n = lib().rw_packed_conv_weight_wino4_elems(o, i)
+    if n <= 0:
+        raise ValueError('no F(4x4,3x3) packing for a %d x %d weight' % (o, i))
+    uf = torch.empty(n, device=weight.device, dtype=torch.float32)
+    check(lib().rw_pack_conv_weight_wino4_f32(_p(weight), _p(uf), o, i, _stream()))
+    return uf
+
+
+def conv3x3_wino4(x, uf, out_ch, w_scale, style=None, demod=None, noise=None, noise_w=None, bias=None, act=False):
+    """Stride-1 3x3 convolution by Winograd F(4x4,3x3) in fp32 (opt-in: ~1e-5 relative error per layer); same
+    arguments and epilogue as conv3x3."""
+    x = _dev(x, 'fmap')
+    uf = _dev(uf, 'packed weight')
+    b, i, h, w = x.shape
+    if uf.numel() != lib().rw_packed_conv_weight_wino4_elems(out_ch, i):
+        raise ValueError('packed weight does not come from pack_conv_weight_wino4(%d x %d)' % (out_ch, i))
+    y = torch.empty(b, out_ch, h, w, device=x.device, dtype=x.dtype)
+    ep, keep = _epilogue(style, demod, noise, noise_w, bias, act)
+    check(lib().rw_conv3x3_wino4_f32(_p(x), _p(uf), _p(y), b, i, out_ch, h, w, float(w_scale), ctypes.byref(ep),
+                                     _stream()))
+    return y
+
+
 def conv3x3_wino_to_rgb(x, uf, out_ch, w_scale, rgb_weight, rgb_style, rgb_bias, rgb_skip, rgb_scale, style=None,
                         demod=None, noise=None, noise_w=None, bias=None, act=False, store_fmap=False):
     """conv3x3_wino with ToRGB in the epilogue (out_ch == 32): returns (fmap or None, rgb image)."""

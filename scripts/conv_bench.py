@@ -35,6 +35,7 @@ def main(batch=int(os.environ.get('RW_BATCH', '8')), iters=5, impl=int(os.enviro
         dm = hip.demod(hip.weight_sqsum(w, 1.0), style)
         split = os.environ.get('RW_PRECISION') == 'bf16x6' and not up and hip.bf16x6_supported(cout, cin, res)
         wino = os.environ.get('RW_ALGO') == 'winograd' and not up and hip.wino_supported(cout, cin, res, res)
+        wino4 = os.environ.get('RW_ALGO') == 'winograd4' and not up and hip.wino4_supported(cout, cin, res, res)
         if split:
             wb = hip.pack_conv_weight_bf16x3(w)
         ep = {}
@@ -43,7 +44,10 @@ def main(batch=int(os.environ.get('RW_BATCH', '8')), iters=5, impl=int(os.enviro
                       bias=torch.randn(cout, device=dev), act=True)
         if wino:
             uf = hip.pack_conv_weight_wino(w)
-        fn = (lambda: hip.conv3x3_wino(x, uf, cout, 1.0, style=style, demod=dm, **ep)) if wino else \
+        if wino4:
+            uf = hip.pack_conv_weight_wino4(w)
+        fn = (lambda: hip.conv3x3_wino4(x, uf, cout, 1.0, style=style, demod=dm, **ep)) if wino4 else \
+             (lambda: hip.conv3x3_wino(x, uf, cout, 1.0, style=style, demod=dm, **ep)) if wino else \
              (lambda: hip.conv3x3_bf16x6(x, wb, cout, 1.0, style=style, demod=dm, **ep)) if split else \
              (lambda: hip.conv_transpose3x3s2(x, wp, cout, 1.0, style=style, demod=dm, impl=impl)) if up else \
              (lambda: hip.conv3x3(x, wp, cout, 1.0, style=style, demod=dm, impl=impl, **ep))
@@ -59,7 +63,7 @@ def main(batch=int(os.environ.get('RW_BATCH', '8')), iters=5, impl=int(os.enviro
         flops = 2.0 * 9 * cin * cout * res * res * batch
         out_res = 2 * res + 1 if up else res
         bytes_io = 4.0 * batch * (cin * res * res + cout * out_res * out_res)
-        rows.append(dict(layer=name, cin=cin, cout=cout, res=res, up=up, wino=bool(wino), ms=round(ms, 4),
+        rows.append(dict(layer=name, cin=cin, cout=cout, res=res, up=up, wino=bool(wino) or ('f4' if wino4 else False), ms=round(ms, 4),
                          tflops=round(flops / ms / 1e9, 2), io_gbs=round(bytes_io / ms / 1e6, 1)))
         print(rows[-1])
         del x, w

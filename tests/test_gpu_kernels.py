@@ -287,6 +287,49 @@ def test_winograd_conv_matches_oracle_and_direct_kernel(case):
         assert y2 is None and rel(rgb2, want_rgb - skip - brgb.view(1, 3, 1, 1)) < 1e-5
 
 
+WINO4_CASES = [(1, 8, 32, 8, 64), (2, 64, 64, 16, 64), (1, 128, 128, 32, 64), (2, 32, 32, 16, 128), (1, 512, 512, 64, 64),
+               (3, 48, 96, 24, 192), (2, 24, 160, 8, 64), (1, 32, 32, 1024, 1024), (1, 64, 64, 512, 512),
+               (1, 128, 128, 256, 256)]
+
+
+@pytest.mark.parametrize('case', WINO4_CASES)
+def test_winograd_f4_conv_matches_oracle_within_its_error_class(case):
+    """hip.conv3x3_wino4 (F(4x4,3x3), opt-in) against the direct kernel, the oracle's convolution with the full
+    epilogue, and float64: the result of the same convolution, at the accuracy the algorithm has in fp32 -- 1e-5
+    relative (Frobenius) and 1e-4 of the output range, an order of magnitude looser than the default kernels."""
+    from rewriting_amd import hip
+    from oracle import restatement as R
+    b, i, o, h, w = case
+    assert hip.wino4_supported(o, i, h, w)
+    x, wt, style = _conv_inputs(*case, seed=41)
+    rs = numpy.random.RandomState(42)
+    x = x * torch.from_numpy(numpy.exp(1.5 * rs.randn(1, i, 1, 1)).astype('float32'))
+    bias = torch.from_numpy(rs.randn(o).astype('float32'))
+    nw = torch.tensor([0.2])
+    noise = torch.from_numpy(rs.randn(b, h * w).astype('float32'))
+    s = 1 / math.sqrt(i * 9)
+    dm = hip.demod(hip.weight_sqsum(wt.to(DEV), s), style.to(DEV))
+    uf = hip.pack_conv_weight_wino4(wt.to(DEV))
+    wp = hip.pack_conv_weight(wt.to(DEV), 0)
+    plain = hip.conv3x3_wino4(x.to(DEV), uf, o, s, style=style.to(DEV), demod=dm)
+    direct = hip.conv3x3(x.to(DEV), wp, o, s, style=style.to(DEV), demod=dm, impl=0 if i % 16 == 0 else 1)
+    scale = direct.abs().max().item()
+    assert (plain - direct).abs().max().item() < 1e-4 * scale, (plain - direct).abs().max().item() / scale
+    assert rel(plain, direct) < 2e-5, rel(plain, direct)
+    args = dict(style=style.to(DEV), demod=dm, noise=noise.to(DEV), noise_w=nw.to(DEV), bias=bias.to(DEV), act=True)
+    got = hip.conv3x3_wino4(x.to(DEV), uf, o, s, **args)
+    same = hip.conv3x3(x.to(DEV), wp, o, s, impl=0 if i % 16 == 0 else 1, **args)
+    assert (got - same).abs().max().item() < 1e-4 * max(1.0, same.abs().max().item())
+    if b * i * o * h * w <= 2 ** 32:
+        key = style[:, :, None, None] * x
+        conv = R.demod_conv(key, style, wt, upsample=False)
+        want = R.fused_leaky_relu(conv + nw * noise.view(b, 1, h, w), bias)
+        assert rel(got, want) < 2e-5
+        ref = torch.nn.functional.conv2d(key.double(), wt[0].double(), padding=1) * s * dm.cpu().double()[:, :, None, None]
+        e_w = ((plain.cpu().double() - ref).norm() / ref.norm()).item()
+        assert e_w < 2e-5, e_w
+
+
 def test_winograd_rejects_shapes_it_does_not_take():
     from rewriting_amd import hip
     assert not hip.wino_supported(32, 32, 16, 16) and not hip.wino_supported(48, 32, 32, 32)
