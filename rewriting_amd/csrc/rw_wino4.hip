@@ -39,6 +39,7 @@
 #endif
 
 typedef float w4_f32x4 __attribute__((ext_vector_type(4)));
+template <int N> struct w4_int { static constexpr int value = N; };
 
 struct Wino4Problem {
   const float* x; const float* uf; float* y;
@@ -325,6 +326,265 @@ __global__ void __launch_bounds__(256, 2) conv_wino36_kernel(const Wino4Problem 
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Second version: EVERYTHING the loop reads arrives by LDS-direct loads, two intervals ahead.
+//
+// The first version's interval time equals one memory latency: the patch of interval v + 1 is fetched into
+// registers during interval v - 1, and with LDS-direct loads pending the compiler turns the wait for any register
+// load into vmcnt(0) -- every interval drains the queue.  Worse, it orders every ds_read of an array that LDS-direct
+// loads write behind ALL of them (vmcnt(0) in front of the first read of an interval), and with one array per ring
+// slot it serialises the loads themselves.  So the loads are issued from inline assembly -- the compiler does not
+// know they exist -- and every vmcnt wait in the loop is written by hand.  The loop has no ordinary vector load:
+//   * patch: `buffer_load_dword ... lds` (out-of-image lanes write 0: the zero padding), the (4 WGN + 2) x 66 window
+//     of a channel as a flat image of pitch 68, 20 one-wave pieces per channel; wave w copies channel w / 2, pieces
+//     10 (w % 2) .. + 9.  The style factor is applied in the transform (packed multiplies of the 18 input pairs)
+//     from a table in LDS;
+//   * weights: `global_load_lds_dwordx4`, 18 one-KB pieces per interval dealt to the eight waves;
+//   * noise of a group: four dword pieces per wave into a wave-private strip, issued FIRST in the group's second-to-last
+//     interval, so the counted wait at the end of that interval retires them.
+// Rings of three buffers (interval v computes on ring[v % 3] while v + 1 is complete or landing and v + 2 is being
+// requested); synchronisation per interval = `s_waitcnt vmcnt(N) lgkmcnt(0)` with N = the pieces this wave issued in
+// THIS interval (they stay in flight across the barrier) + raw `s_barrier`.  Stores of a group's epilogue are younger
+// than the interval's pieces and count in vmcnt: + 16 in those intervals.
+// One workgroup of 512 threads per CU (117 KB of LDS): WGM = 2 out-channel blocks of 16 x WGN = 4 tile rows -- the
+// weights of an interval serve four waves, the patch halo is 2 rows in 18.
+// ---------------------------------------------------------------------------------------
+#define W4B_PITCH 68
+typedef int w4_i32x4 __attribute__((ext_vector_type(4)));
+// LDS-direct loads as inline assembly (see the note on the compiler above): M0 = LDS byte address of the wave's 64 x
+// size destination, lane L lands at + L * size.
+__device__ __forceinline__ void w4_dma_buffer_b32(unsigned lds_addr, int voffset, w4_i32x4 rsrc, int soffset) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+               :: "s"(lds_addr), "v"(voffset), "s"(rsrc), "s"(soffset) : "memory");
+}
+__device__ __forceinline__ void w4_dma_global_b128(unsigned lds_addr, const void* gptr) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(lds_addr), "v"(gptr) : "memory");
+}
+__device__ __forceinline__ void w4_dma_global_b32(unsigned lds_addr, const void* gptr) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" :: "s"(lds_addr), "v"(gptr) : "memory");
+}
+
+__global__ void __launch_bounds__(512) conv_wino36b_kernel(const Wino4Problem p) {
+  constexpr int WGM = 2, WGN = 4;
+  constexpr int PR = 4 * WGN + 2;                 // 18 patch rows
+  constexpr int PIECES = 20;                      // 64-float pieces per channel: 18 * 68 = 1224 <= 1280
+  constexpr int PSZ = 4 * PIECES * 64;            // floats per patch ring slot
+  constexpr int USZ = WGM * 9 * 256;              // floats per weight ring slot
+  __shared__ __attribute__((aligned(16))) float Ps[3 * PSZ];
+  __shared__ __attribute__((aligned(16))) float Us[3 * USZ];
+  __shared__ __attribute__((aligned(16))) float Ns[8 * 256];
+  __shared__ float St[512];
+  __shared__ float Ct[2][16 * WGM];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int lk = lane >> 4, lt = lane & 15;
+
+  const int local = w4_xcd_remap(blockIdx.x, gridDim.x);
+  const int o_tiles = p.out_ch / (16 * WGM);
+  const int runs_x = p.groups_x / p.gpw;
+  const int ot = local % o_tiles;
+  int pg = local / o_tiles;
+  const int run = pg % runs_x; pg /= runs_x;
+  const int gy = pg % p.groups_y;
+  const int ib = pg / p.groups_y;
+  const int o0 = ot * 16 * WGM;
+  const int y0 = gy * 4 * WGN, gx0 = run * p.gpw;
+  const int64_t hw = (int64_t)p.h * p.w;
+  const float* xb = p.x + (int64_t)ib * p.in_ch * hw;
+  const int NC = p.in_ch >> 2;
+  const int VT = p.gpw * NC;
+
+  for (int i = tid; i < p.in_ch; i += 512) St[i] = p.style ? p.style[(int64_t)ib * p.in_ch + i] : 1.0f;
+  if (tid < 16 * WGM) {
+    const int o = o0 + tid;
+    Ct[0][tid] = p.demod ? p.demod[(int64_t)ib * p.out_ch + o] * p.w_scale : p.w_scale;
+    Ct[1][tid] = p.act ? p.bias[o] : 0.f;
+  }
+  const float noise_w = p.noise ? p.noise_w[0] : 0.f;
+
+  typedef __attribute__((address_space(3))) float* lds_f;
+  const unsigned ps_base = (unsigned)(size_t)(lds_f)Ps, us_base = (unsigned)(size_t)(lds_f)Us,
+                 ns_base = (unsigned)(size_t)(lds_f)Ns;
+  const unsigned long long xaddr = (unsigned long long)xb;
+  const w4_i32x4 xsrc = {(int)(unsigned)xaddr, (int)(unsigned)(xaddr >> 32), (int)((int64_t)p.in_ch * hw * 4),
+                         0x00020000};
+  const int hw4 = (int)hw * 4;
+  // patch pieces of this wave: channel wave / 2 of the k-quad, pieces 10 (wave % 2) + s
+  const int pch = wave >> 1, piece0 = 10 * (wave & 1);
+  int xoff[10];
+  auto set_group = [&](int g) __attribute__((always_inline)) {
+    const int x0 = (gx0 + g) * 64;
+#pragma unroll
+    for (int s = 0; s < 10; ++s) {
+      const int f = 64 * (piece0 + s) + lane;
+      const int r = f / W4B_PITCH, c = f - r * W4B_PITCH;
+      const int iy = y0 - 1 + r, ix = x0 - 1 + c;
+      const bool ok = r < PR && c < W4_PC && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
+      xoff[s] = ok ? (iy * p.w + ix) * 4 : 0x7fffffff;
+    }
+  };
+  auto pload = [&](int ring, int fg, int fc) __attribute__((always_inline)) {     // interval (group fg, k-quad fc)
+    if (fc == 0) set_group(fg);
+    const int soff = (4 * fc + pch) * hw4;
+    const unsigned dst = ps_base + (unsigned)((ring * PSZ + pch * (PIECES * 64) + 64 * piece0) * 4);
+#pragma unroll
+    for (int s = 0; s < 10; ++s) w4_dma_buffer_b32(dst + 256 * s, xoff[s], xsrc, soff);
+  };
+  const int kq_total = p.in_ch >> 2;
+  const int a_lane = lane * 4;
+  auto uload = [&](int ring, int kq) __attribute__((always_inline)) {           // pieces wave, wave + 8, (wave + 16)
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int j = wave + 8 * t;
+      if (j < 9 * WGM) {
+        const int ob = j / 9, q = j - 9 * ob;
+        const float* src = p.uf + ((int64_t)((o0 >> 4) + ob) * kq_total + kq) * (9 * 256) + q * 256 + a_lane;
+        w4_dma_global_b128(us_base + (unsigned)((ring * USZ + ob * (9 * 256) + q * 256) * 4), src);
+      }
+    }
+  };
+  // noise rows y0 + 4 wn .. + 3, columns x0 .. x0 + 63 of this image -> Ns[wave][64 r + c]
+  auto nload = [&](int g) __attribute__((always_inline)) {
+    const float* np = p.noise + (int64_t)ib * hw + (int64_t)(y0 + 4 * wn) * p.w + (gx0 + g) * 64 + lane;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w4_dma_global_b32(ns_base + (unsigned)((wave * 256 + 64 * r) * 4), np + (int64_t)r * p.w);
+  };
+
+  w4_f32x4 acc[36];
+#pragma unroll
+  for (int xi = 0; xi < 36; ++xi) acc[xi] = w4_f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int item_off = lk * (PIECES * 64) + (4 * wn) * W4B_PITCH + 4 * lt;
+  auto compute = [&](int ring, int kq) __attribute__((always_inline)) {
+    const float* base = &Us[ring * USZ + wm * (9 * 256) + a_lane];
+    const float* src = &Ps[ring * PSZ + item_off];
+    const float sv = St[4 * kq + lk];
+    w4_f32x4 a4[3];
+    a4[0] = *reinterpret_cast<const w4_f32x4*>(base);
+    a4[1] = *reinterpret_cast<const w4_f32x4*>(base + 256);
+    a4[2] = *reinterpret_cast<const w4_f32x4*>(base + 512);
+    w4_f32x2 c2[6][3];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const w4_f32x4 lo = *reinterpret_cast<const w4_f32x4*>(src + r * W4B_PITCH);
+      c2[r][0] = w4_f32x2{lo[0], lo[1]} * sv;
+      c2[r][1] = w4_f32x2{lo[2], lo[3]} * sv;
+      c2[r][2] = *reinterpret_cast<const w4_f32x2*>(src + r * W4B_PITCH + 4) * sv;
+    }
+    float d[6][6];
+#pragma unroll
+    for (int cp = 0; cp < 3; ++cp)
+      if (!(W4_ABL & 1)) w4_bt2(c2[0][cp], c2[1][cp], c2[2][cp], c2[3][cp], c2[4][cp], c2[5][cp]);
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      if (!(W4_ABL & 1)) {
+        w4_bt_row(c2[a][0], c2[a][1], c2[a][2], d[a]);
+      } else {
+        d[a][0] = c2[a][0][0]; d[a][1] = c2[a][0][1]; d[a][2] = c2[a][1][0]; d[a][3] = c2[a][1][1];
+        d[a][4] = c2[a][2][0]; d[a][5] = c2[a][2][1];
+      }
+    }
+    // weights two quads ahead (an LDS read issued right in front of its MFMAs costs the wave its latency nine times
+    // per interval; two waves per SIMD do not hide that)
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      const w4_f32x4 a = a4[q % 3];
+      if (q + 3 < 9) a4[q % 3] = *reinterpret_cast<const w4_f32x4*>(base + (q + 3) * 256);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int xi = 4 * q + e;
+        acc[xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], d[xi / 6][xi % 6], acc[xi], 0, 0, 0);
+      }
+    }
+  };
+
+  auto group_epilogue = [&](int g) __attribute__((always_inline)) {
+    const int oy = y0 + 4 * wn, ox = (gx0 + g) * 64 + 4 * lt;
+    w4_f32x4 nz[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      nz[r] = p.noise ? *reinterpret_cast<const w4_f32x4*>(&Ns[wave * 256 + 64 * r + 4 * lt]) * noise_w
+                      : w4_f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* ct = &Ct[0][16 * wm + 4 * lk];
+    float* yb = p.y + ((int64_t)ib * p.out_ch + o0 + 16 * wm + 4 * lk) * hw + (int64_t)oy * p.w + ox;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float scale = ct[j], bias = ct[16 * WGM + j];
+      float t[4][6];
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        const float m0 = acc[b][j], m1 = acc[6 + b][j], m2 = acc[12 + b][j], m3 = acc[18 + b][j], m4 = acc[24 + b][j],
+                    m5 = acc[30 + b][j];
+        const float s1 = m1 + m2, s2 = m1 - m2, s3 = m3 + m4, s4 = m3 - m4;
+        t[0][b] = m0 + s1 + s3;
+        t[1][b] = s2 + 2.f * s4;
+        t[2][b] = s1 + 4.f * s3;
+        t[3][b] = s2 + 8.f * s4 + m5;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float s1 = t[r][1] + t[r][2], s2 = t[r][1] - t[r][2], s3 = t[r][3] + t[r][4], s4 = t[r][3] - t[r][4];
+        w4_f32x4 v = {t[r][0] + s1 + s3, s2 + 2.f * s4, s1 + 4.f * s3, s2 + 8.f * s4 + t[r][5]};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float u = v[k] * scale + nz[r][k];
+          if (p.act) {
+            u += bias;
+            u = ((u > 0.f) ? u : u * 0.2f) * 1.4142135623730951f;
+          }
+          v[k] = u;
+        }
+        *reinterpret_cast<w4_f32x4*>(yb + (int64_t)j * hw + (int64_t)r * p.w) = v;
+      }
+    }
+#pragma unroll
+    for (int xi = 0; xi < 36; ++xi) acc[xi] = w4_f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+
+  // pieces this wave issues per interval: 10 patch + 3 (waves 0, 1) or 2 weight pieces
+  const bool three = wave + 16 < 9 * WGM;
+  auto sync_interval = [&](bool stores) __attribute__((always_inline)) {
+    // s_waitcnt immediates (gfx9): vmcnt[3:0] | expcnt << 4 | lgkmcnt << 8 | vmcnt[5:4] << 14; expcnt 7 = no wait
+    if (three) {
+      if (stores) __builtin_amdgcn_s_waitcnt(0x407D); else __builtin_amdgcn_s_waitcnt(0x007D);    // vmcnt(29) / (13)
+    } else {
+      if (stores) __builtin_amdgcn_s_waitcnt(0x407C); else __builtin_amdgcn_s_waitcnt(0x007C);    // vmcnt(28) / (12)
+    }
+    if (!(W4_ABL & 16)) __builtin_amdgcn_s_barrier();
+  };
+
+  // ---- prologue: the tables (ordinary loads and LDS writes) are complete before any LDS-direct load is issued --
+  // from here on the compiler does not know about the loads in flight and every vmcnt wait is one of the two below
+  __builtin_amdgcn_s_waitcnt(0x0070);               // vmcnt(0) lgkmcnt(0)
+  pload(0, 0, 0);
+  uload(0, 0);
+  pload(1, 1 / NC, 1 % NC);
+  uload(1, 1 % NC);
+  sync_interval(false);                             // ring 0 landed; ring 1 may still be in flight
+
+  int c = 0, g = 0, ring = 0;
+  int fg = 2 / NC, fc = 2 % NC;                     // (group, k-quad) of interval v + 2
+  for (int v = 0; v < VT; ++v) {
+    const int ring2 = ring == 0 ? 2 : ring - 1;     // (v + 2) % 3
+    if (p.noise && c == NC - 2) nload(g);           // older than this interval's pieces: retired by its wait
+    if (!(W4_ABL & 2)) pload(ring2, fg, fc);        // past the run: legal addresses, never read
+    if (!(W4_ABL & 4)) uload(ring2, fc);
+    compute(ring, c);
+    const bool last = c == NC - 1;
+    if (last) {
+      if (!(W4_ABL & 8) || acc[0][0] == 12345.f) group_epilogue(g);
+      c = 0; ++g;
+    } else { ++c; }
+    if (++fc == NC) { fc = 0; ++fg; }
+    ring = ring == 2 ? 0 : ring + 1;
+    sync_interval(last);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0070);               // nothing in flight into LDS when the workgroup retires
+}
+
 // One thread: the 36 values of one (o, i).  uf[o / 16][i / 4][xi / 4][16 (i % 4) + o % 16][xi % 4]
 __global__ void __launch_bounds__(256) pack_wino36_kernel(const float* __restrict__ w, float* __restrict__ uf,
                                                           int out_ch, int in_ch) {
@@ -417,6 +677,24 @@ extern "C" int rw_conv3x3_wino4_f32(const float* x, const float* uf, float* y, i
   p.gpw = gpw;
   const int64_t work = (int64_t)batch * p.groups_y * (p.groups_x / gpw) * o_tiles;
   if (work <= 0 || work > 0x7fffffff) return RW_ERR_UNSUPPORTED;
+  const char* ver = getenv("RW_WINO4_V");
+  if (ver && atoi(ver) == 2 && h % 16 == 0 && in_ch <= 512) {
+    // 32 out-channels x 4 tile rows (16 x 64 pixels), 512 threads
+    p.groups_y = h / 16;
+    int gpw2 = e ? atoi(e) : 4;
+    if (gpw2 < 1) gpw2 = 1;
+    if (gpw2 > p.groups_x) gpw2 = p.groups_x;
+    while (p.groups_x % gpw2) --gpw2;
+    while (gpw2 > 1 && (int64_t)batch * p.groups_y * (p.groups_x / gpw2) * o_tiles < 512) {
+      --gpw2;
+      while (p.groups_x % gpw2) --gpw2;
+    }
+    p.gpw = gpw2;
+    const int64_t work2 = (int64_t)batch * p.groups_y * (p.groups_x / gpw2) * o_tiles;
+    if (work2 <= 0 || work2 > 0x7fffffff) return RW_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(conv_wino36b_kernel, dim3((unsigned)work2), dim3(512), 0, rw_s(stream), p);
+    return RW_LAUNCH_RESULT();
+  }
   hipLaunchKernelGGL((conv_wino36_kernel<2, 2>), dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
   return RW_LAUNCH_RESULT();
 }
