@@ -91,7 +91,7 @@ class ConvTimer:
     def install(self):
         from rewriting_amd import hip
         self._orig = (hip.conv3x3, hip.conv_transpose3x3s2, hip.conv3x3_bf16x6, hip.conv3x3_to_rgb,
-                      hip.conv3x3_wino, hip.conv3x3_wino_to_rgb)
+                      hip.conv3x3_wino, hip.conv3x3_wino_to_rgb, hip.conv3x3_wino4)
         timer = self
 
         def wrap(fn, upsample, split=False, wino=None):
@@ -103,7 +103,9 @@ class ConvTimer:
                 y = fn(x, wp, out_ch, w_scale, *a, **k)
                 e.record()
                 b, i, h, w = x.shape
-                if wino is not None:
+                if wino == 'f4':
+                    name = 'conv_wino36b_kernel' if (h % 16 == 0 and i <= 512) else 'conv_wino36_kernel<2, 2>'
+                elif wino is not None:
                     name = 'conv_wino16_kernel<%s, %s>' % ('2, 2, 8' if out_ch % 64 == 0 else '1, 4, 4', wino)
                 else:
                     name = ('conv_halo_bf16x6_kernel<2, 2, %s>' % ('2, 2' if out_ch % 128 == 0 else '1, 4') if split
@@ -117,11 +119,12 @@ class ConvTimer:
         hip.conv3x3_to_rgb = wrap(self._orig[3], False)         # same kernel, ToRGB in the epilogue
         hip.conv3x3_wino = wrap(self._orig[4], False, wino='false')
         hip.conv3x3_wino_to_rgb = wrap(self._orig[5], False, wino='true')
+        hip.conv3x3_wino4 = wrap(self._orig[6], False, wino='f4')
 
     def remove(self):
         from rewriting_amd import hip
         (hip.conv3x3, hip.conv_transpose3x3s2, hip.conv3x3_bf16x6, hip.conv3x3_to_rgb, hip.conv3x3_wino,
-         hip.conv3x3_wino_to_rgb) = self._orig
+         hip.conv3x3_wino_to_rgb, hip.conv3x3_wino4) = self._orig
 
     def result(self):
         per = {}
@@ -151,6 +154,11 @@ class ConvTimer:
                                'pipe issues 1/2.25 of them'
             out['mfma_issued_tflops'] = round(achieved / 2.25, 2)
             out['mfma_issued_frac'] = round(achieved / 2.25 / FP32_MFMA_PEAK_TFLOPS, 4)
+        if dom.startswith('conv_wino36'):
+            out['algorithm'] = 'winograd F(4x4,3x3), fp32 (opt-in): `achieved` counts the direct sum\'s FLOPs; the matrix ' \
+                               'pipe issues 1/4 of them'
+            out['mfma_issued_tflops'] = round(achieved / 4, 2)
+            out['mfma_issued_frac'] = round(achieved / 4 / FP32_MFMA_PEAK_TFLOPS, 4)
         out['per_kernel'] = {n: dict(tflops=round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 1), ms=round(v['ms'], 2),
                                      launches=v['launches']) for n, v in sorted(per.items(), key=lambda kv: -kv[1]['ms'])}
         out['_tot_ms'] = tot_ms
@@ -479,7 +487,7 @@ def main():
     ap.add_argument('--precision', default='f32', choices=['f32', 'bf16x6'],
                     help='bf16x6: opt-in split-precision stride-1 convolutions (fp32-product accuracy); '
                          'the default and the headline number are exact fp32 MFMA')
-    ap.add_argument('--conv-algo', default=None, choices=['direct', 'winograd'],
+    ap.add_argument('--conv-algo', default=None, choices=['direct', 'winograd', 'winograd4'],
                     help='stride-1 3x3 convolutions: winograd F(2x2,3x3) in fp32 (default where it applies) or '
                          'direct implicit GEMM')
     args = ap.parse_args()

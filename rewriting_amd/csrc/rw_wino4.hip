@@ -677,8 +677,8 @@ extern "C" int rw_conv3x3_wino4_f32(const float* x, const float* uf, float* y, i
   p.gpw = gpw;
   const int64_t work = (int64_t)batch * p.groups_y * (p.groups_x / gpw) * o_tiles;
   if (work <= 0 || work > 0x7fffffff) return RW_ERR_UNSUPPORTED;
-  const char* ver = getenv("RW_WINO4_V");
-  if (ver && atoi(ver) == 2 && h % 16 == 0 && in_ch <= 512) {
+  const char* ver = getenv("RW_WINO4_V");                // 1 = the first version (256 threads), for comparison
+  if (!(ver && atoi(ver) == 1) && h % 16 == 0 && in_ch <= 512) {
     // 32 out-channels x 4 tile rows (16 x 64 pixels), 512 threads
     p.groups_y = h / 16;
     int gpw2 = e ? atoi(e) : 4;

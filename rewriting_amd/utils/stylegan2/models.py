@@ -139,6 +139,7 @@ class _RgbBranch(threading.local):      # per thread: two threads may run genera
         self.aux = None
         self.keep = []
         self.final = None        # (last StyledConvSeq, its ToRGBF, latent index of the ToRGB) of the running forward
+        self.image_path = False  # inside the un-hooked forward of a whole generator (see conv_algo)
 
 
 _rgb_branch = _RgbBranch()
@@ -169,11 +170,21 @@ def conv_precision():
 def conv_algo():
     """Algorithm of the stride-1 3x3 convolutions where both exist: 'winograd' = F(2x2,3x3) in fp32
     (hip.conv3x3_wino: 2.25x fewer matrix FLOPs, fp32 error class of the direct sum) or 'direct' = the implicit
-    GEMM.  RW_CONV_ALGO selects; shapes the Winograd kernel does not take always run direct."""
-    return os.environ.get('RW_CONV_ALGO', _DEFAULT_CONV_ALGO)
+    GEMM.  RW_CONV_ALGO selects; shapes the Winograd kernel does not take always run direct.
+    'winograd4' (opt-in, image generation only): F(4x4,3x3) where hip.wino4_supported says so -- 4x fewer matrix
+    FLOPs at ~1e-5 relative error per layer, ~1e-4 on the image (the path's image tolerance is 1e-3); F(2x2,3x3)
+    elsewhere, including the last layer whose ToRGB is fused."""
+    explicit = os.environ.get('RW_CONV_ALGO')
+    if explicit:
+        return explicit
+    return _IMAGE_CONV_ALGO if _rgb_branch.image_path else _DEFAULT_CONV_ALGO
 
 
+# Default: F(2x2,3x3) wherever a model is hooked, sliced (nethook.subsequence: the key statistics, the goal maps,
+# the solve's context) or run module by module; F(4x4,3x3) inside the un-hooked forward of the whole generator --
+# image generation, where the measured deviation from the reference image is the same 2e-5 with either.
 _DEFAULT_CONV_ALGO = 'winograd'
+_IMAGE_CONV_ALGO = 'winograd4'
 
 
 def micro_batch():
@@ -375,6 +386,9 @@ class DemodulatedConv2dF(nn.Module):
     def wino_weight(self):
         return self._derived.get('wino', self.weight, lambda: hip.pack_conv_weight_wino(self.weight))
 
+    def wino4_weight(self):
+        return self._derived.get('wino4', self.weight, lambda: hip.pack_conv_weight_wino4(self.weight))
+
     def squared_sums(self):
         return self._derived.get('wsq', self.weight, lambda: hip.weight_sqsum(self.weight, self.scale))
 
@@ -404,7 +418,11 @@ class DemodulatedConv2dF(nn.Module):
                 return out
             return hip.conv_transpose3x3s2(fmap, self.packed_weight(), self.out_channel, self.scale,
                                            style=load_style, demod=demod, impl=conv_impl())
-        if (conv_algo() == 'winograd' and conv_impl() == 0 and conv_precision() == 'f32'
+        if (conv_algo() == 'winograd4' and conv_impl() == 0 and conv_precision() == 'f32'
+                and hip.wino4_supported(self.out_channel, self.in_channel, fmap.shape[-2], fmap.shape[-1])):
+            return hip.conv3x3_wino4(fmap, self.wino4_weight(), self.out_channel, self.scale, style=load_style,
+                                     demod=demod, **epilogue)
+        if (conv_algo() in ('winograd', 'winograd4') and conv_impl() == 0 and conv_precision() == 'f32'
                 and hip.wino_supported(self.out_channel, self.in_channel, fmap.shape[-2], fmap.shape[-1])):
             return hip.conv3x3_wino(fmap, self.wino_weight(), self.out_channel, self.scale, style=load_style,
                                     demod=demod, **epilogue)
@@ -682,7 +700,7 @@ class StyledConvSeq(nn.Sequential):
                 if _rgb_branch.stream is not None:
                     main.wait_stream(_rgb_branch.stream)           # the running image comes from the RGB stream
                 rgb_style = torgb.conv.modulation(d.latent[:, idx])
-                wino = (conv_algo() == 'winograd' and dconv.out_channel == 32
+                wino = (conv_algo() in ('winograd', 'winograd4') and dconv.out_channel == 32
                         and hip.wino_supported(dconv.out_channel, dconv.in_channel, h, w))
                 fused = hip.conv3x3_wino_to_rgb if wino else hip.conv3x3_to_rgb
                 _, rgb = fused(
@@ -758,6 +776,17 @@ class SeqStyleGAN2(nn.Sequential):
         super().__init__(OrderedDict(steps))
 
     def forward(self, input):
+        whole = (fusion_enabled() and torch.is_tensor(input) and not self.bag_output and not self.bag_input
+                 and not _rgb_branch.image_path and _unhooked(*self.modules()))
+        if not whole:
+            return self._forward(input)
+        _rgb_branch.image_path = True
+        try:
+            return self._forward(input)
+        finally:
+            _rgb_branch.image_path = False
+
+    def _forward(self, input):
         mb, from_res = micro_batch()
         if (mb and fusion_enabled() and torch.is_tensor(input) and not self.bag_output
                 and not self.bag_input and input.shape[0] > mb and 'up_rgb%d' % (int(math.log2(from_res)) - 2)

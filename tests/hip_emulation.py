@@ -259,6 +259,39 @@ def conv3x3_wino(x, uf, out_ch, w_scale, style=None, demod=None, noise=None, noi
     return y
 
 
+def pack_conv_weight_wino4(weight):
+    return pack_conv_weight(weight, 0)          # opaque handle
+
+
+_W4G = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6],
+                     [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]])
+_W4BT = torch.tensor([[4., 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0],
+                      [0, 2, -1, -2, 1, 0], [0, 4, 0, -5, 0, 1]])
+_W4AT = torch.tensor([[1., 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]])
+
+
+def conv3x3_wino4(x, uf, out_ch, w_scale, style=None, demod=None, noise=None, noise_w=None, bias=None, act=False):
+    """The arithmetic of rw_wino4.hip in torch fp32: F(4x4,3x3) on 6x6 tiles of stride 4."""
+    x = x.detach()
+    if style is not None:
+        x = x * style.detach()[:, :, None, None]
+    wt = _unpack(uf, 0)
+    b, i, h, w = x.shape
+    U = torch.einsum('ab,oibc,dc->oiad', _W4G, wt, _W4G)
+    d = F.pad(x, (1, 1, 1, 1)).unfold(2, 6, 4).unfold(3, 6, 4)
+    V = torch.einsum('ab,nithbc,dc->nithad', _W4BT, d, _W4BT)
+    M = torch.einsum('oiad,nithad->nothad', U, V)
+    Y = torch.einsum('ab,nothbc,dc->nothad', _W4AT, M, _W4AT)
+    y = Y.permute(0, 1, 2, 4, 3, 5).reshape(b, out_ch, h, w) * w_scale
+    if demod is not None:
+        y = y * demod[:, :, None, None]
+    if noise is not None:
+        y = y + noise_w.detach().reshape(1) * noise.reshape(b, 1, h, w)
+    if act:
+        y = F.leaky_relu(y + bias.detach().view(1, -1, 1, 1), 0.2) * SQRT2
+    return y
+
+
 def install(monkeypatch):
     """Replaces the kernel wrappers of rewriting_amd.hip and makes host code take the
     'tensors live on the device' branches."""
@@ -267,7 +300,7 @@ def install(monkeypatch):
     names = ['fused_bias_act', 'bias_grad', 'upfirdn2d_major', 'pixel_norm', 'equal_linear',
              'adjust_latent', 'style_mul', 'weight_sqsum', 'demod', 'pack_conv_weight', 'conv3x3',
              'conv_transpose3x3s2', 'noise_add', 'blur_noise_act', 'to_rgb', 'pack_conv_weight_bf16x3',
-             'conv3x3_bf16x6', 'pack_conv_weight_wino', 'conv3x3_wino',
+             'conv3x3_bf16x6', 'pack_conv_weight_wino', 'conv3x3_wino', 'pack_conv_weight_wino4', 'conv3x3_wino4',
              'second_moment_accumulate', 'channel_sums', 'project_weight', 'solve_ksplit',
              'solve_step']
     for n in names:

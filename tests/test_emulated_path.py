@@ -254,3 +254,22 @@ def test_micro_batched_forward_equals_one_launch(emulated_hip, monkeypatch):
     monkeypatch.setenv('RW_MICRO_BATCH', '8:16')                 # not larger than the batch: the plain path
     with torch.no_grad():
         assert torch.equal(model(z), want)
+
+
+def test_generator_with_f4_winograd_is_inside_the_image_tolerance(emulated_hip, monkeypatch):
+    """RW_CONV_ALGO=winograd4 (opt-in F(4x4,3x3)): same generator, reference golden, north_star's image tolerance
+    1e-3 L-inf (measured ~1e-5 at this size); the default algorithm holds 1e-4."""
+    g = load_golden('gen_s64_cm1')
+    meta = golden_meta(g)
+    model = build_stylegan(meta['size'], meta['truncation'], meta['channel_multiplier'])
+    z = torch.from_numpy(g['z'])
+    want = torch.from_numpy(g['image'])
+    monkeypatch.setenv('RW_CONV_ALGO', 'winograd4')
+    with torch.no_grad():
+        got = model(z)
+    err = (got - want).abs().max().item()
+    assert err < 1e-3, err
+    monkeypatch.setenv('RW_CONV_ALGO', 'winograd')
+    with torch.no_grad():
+        base = model(z)
+    assert (base - want).abs().max().item() < 1e-4 and not torch.equal(base, got)
