@@ -413,5 +413,7 @@ def test_micro_batched_forward_equals_one_launch(monkeypatch):
             got = model(z)
             with noise_batch_period(3):
                 got_p = model(z)
-        assert (got - want).abs().max().item() < 1e-5, spec
-        assert (got_p - want_p).abs().max().item() < 1e-5, spec
+        # (not bit-equal: the low-resolution kernels pick their split-K by batch size, and the F(4x4,3x3) layers
+        # turn a 1e-7 difference of their input into a fresh draw of their own 1e-5 rounding noise)
+        assert (got - want).abs().max().item() < 5e-5, spec
+        assert (got_p - want_p).abs().max().item() < 5e-5, spec
