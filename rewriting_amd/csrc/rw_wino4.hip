@@ -364,15 +364,24 @@ __device__ __forceinline__ void w4_dma_global_b32(unsigned lds_addr, const void*
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" :: "s"(lds_addr), "v"(gptr) : "memory");
 }
 
-__global__ void __launch_bounds__(512) conv_wino36b_kernel(const Wino4Problem p) {
-  constexpr int WGM = 2, WGN = 4;
-  constexpr int PR = 4 * WGN + 2;                 // 18 patch rows
-  constexpr int PIECES = 20;                      // 64-float pieces per channel: 18 * 68 = 1224 <= 1280
+// WGN tile rows per workgroup (2 WGN waves); UDEPTH = slots of the weight ring.  <4, 3>: one 512-thread workgroup per CU,
+// everything two intervals ahead -- but its eight waves pass one barrier per interval, so the two waves of a SIMD run
+// in lockstep (both transform, then both multiply).  <2, 2>: two 256-thread workgroups per CU (77 KB of LDS each)
+// that drift apart, patch two intervals ahead, weights one (they come from L2).
+template <int WGN, int UDEPTH>
+__global__ void __launch_bounds__(128 * WGN, 4 / WGN) conv_wino36b_kernel(const Wino4Problem p) {
+  constexpr int WGM = 2;
+  constexpr int WAVES = WGM * WGN, THREADS = 64 * WAVES;
+  constexpr int PR = 4 * WGN + 2;                 // patch rows
+  constexpr int PIECES = (PR * W4B_PITCH + 63) / 64;      // 64-float pieces per channel
+  constexpr int PPW = 4 * PIECES / WAVES;         // patch pieces per wave and interval
+  static_assert(4 * PIECES % WAVES == 0, "patch pieces divide among the waves");
+  constexpr int UPW = (9 * WGM + WAVES - 1) / WAVES;      // weight pieces per wave and interval (at most)
   constexpr int PSZ = 4 * PIECES * 64;            // floats per patch ring slot
   constexpr int USZ = WGM * 9 * 256;              // floats per weight ring slot
   __shared__ __attribute__((aligned(16))) float Ps[3 * PSZ];
-  __shared__ __attribute__((aligned(16))) float Us[3 * USZ];
-  __shared__ __attribute__((aligned(16))) float Ns[8 * 256];
+  __shared__ __attribute__((aligned(16))) float Us[UDEPTH * USZ];
+  __shared__ __attribute__((aligned(16))) float Ns[WAVES * 256];
   __shared__ float St[512];
   __shared__ float Ct[2][16 * WGM];
 
@@ -396,7 +405,7 @@ __global__ void __launch_bounds__(512) conv_wino36b_kernel(const Wino4Problem p)
   const int NC = p.in_ch >> 2;
   const int VT = p.gpw * NC;
 
-  for (int i = tid; i < p.in_ch; i += 512) St[i] = p.style ? p.style[(int64_t)ib * p.in_ch + i] : 1.0f;
+  for (int i = tid; i < p.in_ch; i += THREADS) St[i] = p.style ? p.style[(int64_t)ib * p.in_ch + i] : 1.0f;
   if (tid < 16 * WGM) {
     const int o = o0 + tid;
     Ct[0][tid] = p.demod ? p.demod[(int64_t)ib * p.out_ch + o] * p.w_scale : p.w_scale;
@@ -411,13 +420,14 @@ __global__ void __launch_bounds__(512) conv_wino36b_kernel(const Wino4Problem p)
   const w4_i32x4 xsrc = {(int)(unsigned)xaddr, (int)(unsigned)(xaddr >> 32), (int)((int64_t)p.in_ch * hw * 4),
                          0x00020000};
   const int hw4 = (int)hw * 4;
-  // patch pieces of this wave: channel wave / 2 of the k-quad, pieces 10 (wave % 2) + s
-  const int pch = wave >> 1, piece0 = 10 * (wave & 1);
-  int xoff[10];
+  // patch pieces of this wave: flat pieces [wave * PPW, + PPW) of the 4 * PIECES of a k-quad (never across a channel)
+  static_assert(PIECES % PPW == 0, "a wave's pieces lie in one channel");
+  const int pch = (wave * PPW) / PIECES, piece0 = (wave * PPW) % PIECES;
+  int xoff[PPW];
   auto set_group = [&](int g) __attribute__((always_inline)) {
     const int x0 = (gx0 + g) * 64;
 #pragma unroll
-    for (int s = 0; s < 10; ++s) {
+    for (int s = 0; s < PPW; ++s) {
       const int f = 64 * (piece0 + s) + lane;
       const int r = f / W4B_PITCH, c = f - r * W4B_PITCH;
       const int iy = y0 - 1 + r, ix = x0 - 1 + c;
@@ -425,19 +435,28 @@ __global__ void __launch_bounds__(512) conv_wino36b_kernel(const Wino4Problem p)
       xoff[s] = ok ? (iy * p.w + ix) * 4 : 0x7fffffff;
     }
   };
-  auto pload = [&](int ring, int fg, int fc) __attribute__((always_inline)) {     // interval (group fg, k-quad fc)
+  // the pieces of interval (group fg, k-quad fc) -> ring slot: all at once (prologue), or piece by piece from
+  // inside the MFMA loop -- a wave that issues its eleven loads in one burst sits in the issue stage while the
+  // address unit works them off, with its MFMAs waiting behind
+  int p_soff = 0;
+  unsigned p_dst = 0;
+  auto pload_begin = [&](int ring, int fg, int fc) __attribute__((always_inline)) {
     if (fc == 0) set_group(fg);
-    const int soff = (4 * fc + pch) * hw4;
-    const unsigned dst = ps_base + (unsigned)((ring * PSZ + pch * (PIECES * 64) + 64 * piece0) * 4);
+    p_soff = (4 * fc + pch) * hw4;
+    p_dst = ps_base + (unsigned)((ring * PSZ + pch * (PIECES * 64) + 64 * piece0) * 4);
+  };
+  auto pload_piece = [&](int s) __attribute__((always_inline)) { w4_dma_buffer_b32(p_dst + 256 * s, xoff[s], xsrc, p_soff); };
+  auto pload = [&](int ring, int fg, int fc) __attribute__((always_inline)) {
+    pload_begin(ring, fg, fc);
 #pragma unroll
-    for (int s = 0; s < 10; ++s) w4_dma_buffer_b32(dst + 256 * s, xoff[s], xsrc, soff);
+    for (int s = 0; s < PPW; ++s) pload_piece(s);
   };
   const int kq_total = p.in_ch >> 2;
   const int a_lane = lane * 4;
-  auto uload = [&](int ring, int kq) __attribute__((always_inline)) {           // pieces wave, wave + 8, (wave + 16)
+  auto uload = [&](int ring, int kq) __attribute__((always_inline)) {           // pieces wave, wave + WAVES, ...
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      const int j = wave + 8 * t;
+    for (int t = 0; t < UPW; ++t) {
+      const int j = wave + WAVES * t;
       if (j < 9 * WGM) {
         const int ob = j / 9, q = j - 9 * ob;
         const float* src = p.uf + ((int64_t)((o0 >> 4) + ob) * kq_total + kq) * (9 * 256) + q * 256 + a_lane;
@@ -457,8 +476,9 @@ __global__ void __launch_bounds__(512) conv_wino36b_kernel(const Wino4Problem p)
   for (int xi = 0; xi < 36; ++xi) acc[xi] = w4_f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int item_off = lk * (PIECES * 64) + (4 * wn) * W4B_PITCH + 4 * lt;
-  auto compute = [&](int ring, int kq) __attribute__((always_inline)) {
-    const float* base = &Us[ring * USZ + wm * (9 * 256) + a_lane];
+  auto compute = [&](int ring, int uring, int kq, auto spread_tag) __attribute__((always_inline)) {
+    constexpr bool SPREAD = decltype(spread_tag)::value != 0;
+    const float* base = &Us[uring * USZ + wm * (9 * 256) + a_lane];
     const float* src = &Ps[ring * PSZ + item_off];
     const float sv = St[4 * kq + lk];
     w4_f32x4 a4[3];
@@ -492,6 +512,10 @@ __global__ void __launch_bounds__(512) conv_wino36b_kernel(const Wino4Problem p)
     for (int q = 0; q < 9; ++q) {
       const w4_f32x4 a = a4[q % 3];
       if (q + 3 < 9) a4[q % 3] = *reinterpret_cast<const w4_f32x4*>(base + (q + 3) * 256);
+      if (SPREAD && !(W4_ABL & 2)) {
+        if (2 * q < PPW) pload_piece(2 * q);
+        if (2 * q + 1 < PPW) pload_piece(2 * q + 1);
+      }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -544,35 +568,53 @@ __global__ void __launch_bounds__(512) conv_wino36b_kernel(const Wino4Problem p)
     for (int xi = 0; xi < 36; ++xi) acc[xi] = w4_f32x4{0.f, 0.f, 0.f, 0.f};
   };
 
-  // pieces this wave issues per interval: 10 patch + 3 (waves 0, 1) or 2 weight pieces
-  const bool three = wave + 16 < 9 * WGM;
+  // s_waitcnt immediates (gfx9): vmcnt[3:0] | expcnt << 4 | lgkmcnt << 8 | vmcnt[5:4] << 14; expcnt 7 = no wait
+#define W4_WAIT(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (((n) >> 4) << 14) | 0x70)
+  // Pieces that may stay in flight across the barrier of an interval = what this wave issued for interval v + 2:
+  // UDEPTH 3: its patch and weight pieces (PPW + UPW or UPW - 1); UDEPTH 2: the patch pieces only (the weights of
+  // v + 1 are issued FIRST in the interval and must have landed).  + 16 stores after a group's epilogue.
+  const bool full_u = wave + WAVES * (UPW - 1) < 9 * WGM;
   auto sync_interval = [&](bool stores) __attribute__((always_inline)) {
-    // s_waitcnt immediates (gfx9): vmcnt[3:0] | expcnt << 4 | lgkmcnt << 8 | vmcnt[5:4] << 14; expcnt 7 = no wait
-    if (three) {
-      if (stores) __builtin_amdgcn_s_waitcnt(0x407D); else __builtin_amdgcn_s_waitcnt(0x007D);    // vmcnt(29) / (13)
+    if (UDEPTH == 2) {
+      if (stores) W4_WAIT(PPW + 16); else W4_WAIT(PPW);
+    } else if (full_u) {
+      if (stores) W4_WAIT(PPW + UPW + 16); else W4_WAIT(PPW + UPW);
     } else {
-      if (stores) __builtin_amdgcn_s_waitcnt(0x407C); else __builtin_amdgcn_s_waitcnt(0x007C);    // vmcnt(28) / (12)
+      if (stores) W4_WAIT(PPW + UPW - 1 + 16); else W4_WAIT(PPW + UPW - 1);
     }
     if (!(W4_ABL & 16)) __builtin_amdgcn_s_barrier();
   };
 
   // ---- prologue: the tables (ordinary loads and LDS writes) are complete before any LDS-direct load is issued --
-  // from here on the compiler does not know about the loads in flight and every vmcnt wait is one of the two below
+  // from here on the compiler does not know about the loads in flight and every vmcnt wait is one of the above
   __builtin_amdgcn_s_waitcnt(0x0070);               // vmcnt(0) lgkmcnt(0)
-  pload(0, 0, 0);
-  uload(0, 0);
-  pload(1, 1 / NC, 1 % NC);
-  uload(1, 1 % NC);
-  sync_interval(false);                             // ring 0 landed; ring 1 may still be in flight
+  if (UDEPTH == 2) {
+    uload(0, 0);
+    pload(0, 0, 0);
+    pload(1, 1 / NC, 1 % NC);
+  } else {
+    pload(0, 0, 0);
+    uload(0, 0);
+    pload(1, 1 / NC, 1 % NC);
+    uload(1, 1 % NC);
+  }
+  sync_interval(false);                             // slot 0 landed; slot 1 may still be in flight
 
   int c = 0, g = 0, ring = 0;
   int fg = 2 / NC, fc = 2 % NC;                     // (group, k-quad) of interval v + 2
   for (int v = 0; v < VT; ++v) {
     const int ring2 = ring == 0 ? 2 : ring - 1;     // (v + 2) % 3
     if (p.noise && c == NC - 2) nload(g);           // older than this interval's pieces: retired by its wait
-    if (!(W4_ABL & 2)) pload(ring2, fg, fc);        // past the run: legal addresses, never read
-    if (!(W4_ABL & 4)) uload(ring2, fc);
-    compute(ring, c);
+    static_assert(2 * 9 >= PPW, "two patch pieces per weight quad cover the wave's share");
+    if (UDEPTH == 2) {
+      if (!(W4_ABL & 4)) uload((v + 1) & 1, c + 1 < NC ? c + 1 : 0);      // weights of interval v + 1
+      pload_begin(ring2, fg, fc);                   // past the run: legal addresses, never read
+      compute(ring, v & 1, c, w4_int<1>());         // ... issues the patch pieces of v + 2 between its MFMAs
+    } else {
+      if (!(W4_ABL & 2)) pload(ring2, fg, fc);
+      if (!(W4_ABL & 4)) uload(ring2, fc);
+      compute(ring, ring, c, w4_int<0>());
+    }
     const bool last = c == NC - 1;
     if (last) {
       if (!(W4_ABL & 8) || acc[0][0] == 12345.f) group_epilogue(g);
@@ -583,6 +625,7 @@ __global__ void __launch_bounds__(512) conv_wino36b_kernel(const Wino4Problem p)
     sync_interval(last);
   }
   __builtin_amdgcn_s_waitcnt(0x0070);               // nothing in flight into LDS when the workgroup retires
+#undef W4_WAIT
 }
 
 // One thread: the 36 values of one (o, i).  uf[o / 16][i / 4][xi / 4][16 (i % 4) + o % 16][xi % 4]
@@ -677,9 +720,11 @@ extern "C" int rw_conv3x3_wino4_f32(const float* x, const float* uf, float* y, i
   p.gpw = gpw;
   const int64_t work = (int64_t)batch * p.groups_y * (p.groups_x / gpw) * o_tiles;
   if (work <= 0 || work > 0x7fffffff) return RW_ERR_UNSUPPORTED;
-  const char* ver = getenv("RW_WINO4_V");                // 1 = the first version (256 threads), for comparison
-  if (!(ver && atoi(ver) == 1) && h % 16 == 0 && in_ch <= 512) {
-    // 32 out-channels x 4 tile rows (16 x 64 pixels), 512 threads
+  // versions: 1 = registers / compiler-scheduled loads (256 threads); 2 = <4,3> 512-thread workgroups;
+  // 3 (default) = <2,2> two 256-thread workgroups per CU.  RW_WINO4_V overrides for comparison.
+  const char* ver = getenv("RW_WINO4_V");
+  const int version = ver ? atoi(ver) : 3;
+  if (version == 2 && h % 16 == 0 && in_ch <= 512) {
     p.groups_y = h / 16;
     int gpw2 = e ? atoi(e) : 4;
     if (gpw2 < 1) gpw2 = 1;
@@ -692,7 +737,11 @@ extern "C" int rw_conv3x3_wino4_f32(const float* x, const float* uf, float* y, i
     p.gpw = gpw2;
     const int64_t work2 = (int64_t)batch * p.groups_y * (p.groups_x / gpw2) * o_tiles;
     if (work2 <= 0 || work2 > 0x7fffffff) return RW_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(conv_wino36b_kernel, dim3((unsigned)work2), dim3(512), 0, rw_s(stream), p);
+    hipLaunchKernelGGL((conv_wino36b_kernel<4, 3>), dim3((unsigned)work2), dim3(512), 0, rw_s(stream), p);
+    return RW_LAUNCH_RESULT();
+  }
+  if (version == 3 && in_ch <= 512) {
+    hipLaunchKernelGGL((conv_wino36b_kernel<2, 2>), dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
     return RW_LAUNCH_RESULT();
   }
   hipLaunchKernelGGL((conv_wino36_kernel<2, 2>), dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
