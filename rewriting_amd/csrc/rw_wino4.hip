@@ -350,6 +350,9 @@ __global__ void __launch_bounds__(256, 2) conv_wino36_kernel(const Wino4Problem 
 // weights of an interval serve four waves, the patch halo is 2 rows in 18.
 // ---------------------------------------------------------------------------------------
 #define W4B_PITCH 68
+#ifndef W4C_PREFETCH
+#define W4C_PREFETCH 0        // raw window of the next interval read during the MFMAs (36 more live registers)
+#endif
 typedef int w4_i32x4 __attribute__((ext_vector_type(4)));
 // LDS-direct loads as inline assembly (see the note on the compiler above): M0 = LDS byte address of the wave's 64 x
 // size destination, lane L lands at + L * size.
@@ -359,6 +362,11 @@ __device__ __forceinline__ void w4_dma_buffer_b32(unsigned lds_addr, int voffset
 }
 __device__ __forceinline__ void w4_dma_global_b128(unsigned lds_addr, const void* gptr) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(lds_addr), "v"(gptr) : "memory");
+}
+// the same with a scalar base and a 32-bit lane offset: no 64-bit vector address arithmetic per piece
+__device__ __forceinline__ void w4_dma_global_b128_s(unsigned lds_addr, int voffset, const void* sbase) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(lds_addr), "v"(voffset), "s"(sbase)
+               : "memory");
 }
 __device__ __forceinline__ void w4_dma_global_b32(unsigned lds_addr, const void* gptr) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" :: "s"(lds_addr), "v"(gptr) : "memory");
@@ -459,8 +467,8 @@ __global__ void __launch_bounds__(128 * WGN, 4 / WGN) conv_wino36b_kernel(const 
       const int j = wave + WAVES * t;
       if (j < 9 * WGM) {
         const int ob = j / 9, q = j - 9 * ob;
-        const float* src = p.uf + ((int64_t)((o0 >> 4) + ob) * kq_total + kq) * (9 * 256) + q * 256 + a_lane;
-        w4_dma_global_b128(us_base + (unsigned)((ring * USZ + ob * (9 * 256) + q * 256) * 4), src);
+        const float* src = p.uf + ((int64_t)((o0 >> 4) + ob) * kq_total + kq) * (9 * 256) + q * 256;     // uniform
+        w4_dma_global_b128_s(us_base + (unsigned)((ring * USZ + ob * (9 * 256) + q * 256) * 4), a_lane * 4, src);
       }
     }
   };
@@ -628,6 +636,15 @@ __global__ void __launch_bounds__(128 * WGN, 4 / WGN) conv_wino36b_kernel(const 
 #undef W4_WAIT
 }
 
+// ---------------------------------------------------------------------------------------
+// What bounds these kernels (scripts/probe/mfma_valu_probe): on gfx950 an fp32 MFMA and vector-ALU work do NOT
+// overlap.  v_mfma_f32_16x16x4_f32 alone runs at 145 TFLOP/s (the clock under load: 2.2 GHz); every v_fma_f32
+// placed between two of them costs ~2.7 of the 32 MFMA cycles, every v_pk_fma_f32 ~6 -- from the same wave or
+// from the other wave of the SIMD.  What counts is therefore VALU instructions per MFMA: 4.9 here (2.6 of them
+// packed) = ~22 cycles per 32-cycle MFMA, i.e. the 45 - 47 % matrix-pipe occupancy that PMC shows.  A variant with
+// one wave per SIMD holding 32 out-channels (each transformed value feeding two MFMAs, 288 accumulators) halves
+// that ratio on paper; the register allocator spills it (1 KB of scratch per lane), so it is not in the tree.
+// ---------------------------------------------------------------------------------------
 // One thread: the 36 values of one (o, i).  uf[o / 16][i / 4][xi / 4][16 (i % 4) + o % 16][xi % 4]
 __global__ void __launch_bounds__(256) pack_wino36_kernel(const float* __restrict__ w, float* __restrict__ uf,
                                                           int out_ch, int in_ch) {
