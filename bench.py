@@ -104,7 +104,7 @@ class ConvTimer:
                 e.record()
                 b, i, h, w = x.shape
                 if wino == 'f4':
-                    name = 'conv_wino36b_kernel' if (h % 16 == 0 and i <= 512) else 'conv_wino36_kernel<2, 2>'
+                    name = 'conv_wino36b_kernel<2, 2>' if i <= 512 else 'conv_wino36_kernel<2, 2>'
                 elif wino is not None:
                     name = 'conv_wino16_kernel<%s, %s>' % ('2, 2, 8' if out_ch % 64 == 0 else '1, 4, 4', wino)
                 else:
