@@ -214,6 +214,21 @@ int rw_conv_transpose3x3s2_f32(const float* x, const float* wp, float* y, int ba
                                int out_ch, int h, int w, float w_scale, const rw_conv_epilogue* ep,
                                int impl, rw_stream_t stream);
 
+/* The quads y < H, x < W of the same transposed convolution (everything but output row 2H and column 2W, which
+ * rw_conv_transpose3x3s2_f32 impl 8 writes) by the minimal-filtering algorithm F(2,2) in fp32: 25 instead of 36
+ * multiplications per 2x2 block of quads and channel pair; coefficients 0, +-1 (the direct sum's error class).
+ * Shapes: out_ch % 32 == 0, 16 <= in_ch <= 512, in_ch % 8 == 0, w % 32 == 0, h % 4 == 0.
+ *   uf: rw_packed_conv_transpose_wino_elems(out_ch, in_ch) = 28*out_ch*in_ch floats from
+ *       rw_pack_conv_transpose_wino_f32 (w = the (1,out_ch,in_ch,3,3) parameter as rw_pack_conv_weight_f32 takes it):
+ *       uf[o / 16][i / 4][q][lane][xi % 4], xi = 4 q + e < 25 the point (rw_upwino.hip lists them), 25..27 zero.
+ *   style (batch x in_ch) and demod (batch x out_ch) as in rw_conv_epilogue, either may be NULL. */
+int rw_conv_transpose3x3s2_wino_supported(int out_ch, int in_ch, int h, int w);
+long long rw_packed_conv_transpose_wino_elems(int out_ch, int in_ch);
+int rw_pack_conv_transpose_wino_f32(const float* w, float* uf, int out_ch, int in_ch, rw_stream_t stream);
+int rw_conv_transpose3x3s2_wino_f32(const float* x, const float* uf, float* y, int batch, int in_ch, int out_ch,
+                                    int h, int w, float w_scale, const float* style, const float* demod,
+                                    rw_stream_t stream);
+
 /* NoiseInjectionF (models.py:535-546): y[b][c][p] = x[b][c][p] + noise_w[0] * noise[b][p] */
 int rw_noise_add_f32(const float* x, const float* noise, const float* noise_w, float* y,
                      int batch, int channels, int64_t hw, rw_stream_t stream);

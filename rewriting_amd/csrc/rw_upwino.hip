@@ -1,0 +1,364 @@
+// hipcc-flags: -fno-slp-vectorize
+// Stride-2 transposed 3x3 modulated convolution (DemodulatedConv2dF with upsample, utils/stylegan2/models.py:313-329:
+// F.conv_transpose2d(x, W^T, stride=2) -> (2H+1) x (2W+1)) by the minimal-filtering algorithm F(2,2) in fp32.
+//
+// Along one axis  y[2i] = w0 x[i] + w2 x[i-1]  (a 2-tap filter over the input) and  y[2i+1] = w1 x[i]  (1 tap).  Two
+// consecutive even outputs come from three inputs with THREE multiplications instead of four (F(2,2): points
+// d0-d1, d1, d2-d1 against w2, w2+w0, w0; y[2i] = m0+m1, y[2i+2] = m1+m2), the odd ones take two.  In 2-D a block
+// of 2x2 quads (4x4 output pixels) from a 3x3 input window costs 9 + 6 + 6 + 4 = 25 multiplications per channel
+// pair for its four output-parity phases instead of 36 -- 1.44x fewer matrix FLOPs than rw_conv.hip's
+// conv_up_halo_kernel, which already skips the inserted zeros.  The 25 points use only 16 distinct transformed
+// inputs (vertical d0-d1, d1, d2-d1, d2 x the same horizontally): 14 subtractions per window and channel.  The
+// transforms have coefficients 0, +-1 only: the error class of the direct sum.
+//
+//   xi =  0.. 8  phase (0,0): rows (d0-d1, d1, d2-d1) x cols (same)      weights (w2, w2+w0, w0) x (same)
+//   xi =  9..14  phase (0,1): rows (d0-d1, d1, d2-d1) x cols (d1, d2)    weights (w2, w2+w0, w0) x (w1, w1)
+//   xi = 15..20  phase (1,0): rows (d1, d2) x cols (d0-d1, d1, d2-d1)
+//   xi = 21..24  phase (1,1): rows (d1, d2) x cols (d1, d2)
+//
+// Kernel: the design of rw_wino4.hip's conv_wino36b_kernel<2,2> (see there).  The B operand of
+// v_mfma_f32_16x16x4_f32 puts element (k, n) in lane 16 k + n; with k = channel of the k-quad and n = block, a
+// lane transforms the window of ITS (block, channel) in registers and the results are its B operands -- here at
+// 0.9 VALU instructions per MFMA (9 style multiplies + 14 subtractions for 25 MFMAs), which matters because fp32
+// MFMA and VALU do not overlap on gfx950.  A wave holds the 25 points of 16 out-channels x 16
+// blocks (100 accumulator registers); the output transform is lane-local and a lane ends with a 4x4 pixel block of
+// four channels.  Patch (5 rows x 33 columns per channel, `buffer_load_dword ... lds`, out-of-image lanes write 0)
+// and weights (`global_load_lds_dwordx4`) arrive by LDS-direct loads issued from inline assembly, the patch two
+// 8-channel intervals ahead, the weights one; waits are hand-written (vmcnt(N) + raw s_barrier).
+// Workgroup = 4 waves = 32 out-channels x 2 block rows of 16 blocks (4 x 32 quads = 8 x 64 output pixels); it
+// walks a run of groups along x.  Quads y < H, x < W only (H % 4 == 0, W % 32 == 0): output row 2H and column 2W
+// are the strip problems of rw_conv.hip (rw_conv_transpose3x3s2_f32 impl 8), as for conv_up_halo_kernel.
+//   weights: uf[o / 16][i / 4][q = 0..6][lane = 16 (i % 4) + o % 16][xi % 4], xi = 4 q + e (25..27 are zero)
+#include "rw_common.h"
+
+typedef float uw_f32x4 __attribute__((ext_vector_type(4)));
+typedef float uw_f32x2 __attribute__((ext_vector_type(2)));
+typedef int uw_i32x4 __attribute__((ext_vector_type(4)));
+
+struct UpWinoProblem {
+  const float* x; const float* uf; float* y;
+  const float* style; const float* demod;
+  int batch, in_ch, out_ch, h, w;
+  int groups_x, groups_y, gpw;
+  float w_scale;
+};
+
+#define UW_PITCH 36             // row pitch of a patch channel in LDS: 33 columns + 3
+#define UW_PIECES 3             // 5 rows x 36 = 180 floats -> three 64-float pieces
+
+__device__ __forceinline__ int uw_xcd_remap(int id, int total) {
+  const int q = total >> 3, r = total & 7;
+  const int xcd = id & 7, slot = id >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + slot;
+}
+__device__ __forceinline__ void uw_dma_buffer_b32(unsigned lds_addr, int voffset, uw_i32x4 rsrc, int soffset) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+               :: "s"(lds_addr), "v"(voffset), "s"(rsrc), "s"(soffset) : "memory");
+}
+__device__ __forceinline__ void uw_dma_global_b128_s(unsigned lds_addr, int voffset, const void* sbase) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(lds_addr), "v"(voffset), "s"(sbase)
+               : "memory");
+}
+
+__global__ void __launch_bounds__(256, 2) conv_up_wino_kernel(const UpWinoProblem p) {
+  constexpr int IC = 8;                           // channels per interval: two k-quads
+  constexpr int PSZ = IC * UW_PIECES * 64;        // floats per patch ring slot
+  constexpr int USZ = 2 * 2 * 7 * 256;            // floats per weight ring slot: [16-channel half][k-quad][7][256]
+  __shared__ __attribute__((aligned(16))) float Ps[3 * PSZ];
+  __shared__ __attribute__((aligned(16))) float Us[2 * USZ];
+  __shared__ float St[512];
+  __shared__ float Sc[32];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;        // out-channel half / block row
+  const int lk = lane >> 4, lt = lane & 15;       // channel of the k-quad / block column
+
+  const int local = uw_xcd_remap(blockIdx.x, gridDim.x);
+  const int o_tiles = p.out_ch / 32;
+  const int runs_x = p.groups_x / p.gpw;
+  const int ot = local % o_tiles;
+  int pg = local / o_tiles;
+  const int run = pg % runs_x; pg /= runs_x;
+  const int gy = pg % p.groups_y;
+  const int ib = pg / p.groups_y;
+  const int o0 = ot * 32;
+  const int q0y = 4 * gy, gx0 = run * p.gpw;      // first quad row; groups of 32 quad columns
+  const int64_t hw = (int64_t)p.h * p.w;
+  const float* xb = p.x + (int64_t)ib * p.in_ch * hw;
+  const int NC = p.in_ch / IC;
+  const int VT = p.gpw * NC;
+
+  for (int i = tid; i < p.in_ch; i += 256) St[i] = p.style ? p.style[(int64_t)ib * p.in_ch + i] : 1.0f;
+  if (tid < 32) Sc[tid] = p.demod ? p.demod[(int64_t)ib * p.out_ch + o0 + tid] * p.w_scale : p.w_scale;
+
+  typedef __attribute__((address_space(3))) float* lds_f;
+  const unsigned ps_base = (unsigned)(size_t)(lds_f)Ps, us_base = (unsigned)(size_t)(lds_f)Us;
+  const unsigned long long xaddr = (unsigned long long)xb;
+  const uw_i32x4 xsrc = {(int)(unsigned)xaddr, (int)(unsigned)(xaddr >> 32), (int)((int64_t)p.in_ch * hw * 4),
+                         0x00020000};
+  const int hw4 = (int)hw * 4;
+  // patch pieces of this wave: channels 2 wave, 2 wave + 1 of the interval, three pieces each.  Patch row r = input
+  // row q0y - 1 + r (r = 0..4), column c = input column 32 (gx0 + g) - 1 + c (c = 0..32).
+  int xoff[UW_PIECES];
+  auto set_group = [&](int g) __attribute__((always_inline)) {
+    const int x0 = (gx0 + g) * 32;
+#pragma unroll
+    for (int s = 0; s < UW_PIECES; ++s) {
+      const int f = 64 * s + lane;
+      const int r = f / UW_PITCH, c = f - r * UW_PITCH;
+      const int iy = q0y - 1 + r, ix = x0 - 1 + c;
+      const bool ok = r < 5 && c < 33 && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
+      xoff[s] = ok ? (iy * p.w + ix) * 4 : 0x7fffffff;
+    }
+  };
+  int p_soff = 0;
+  unsigned p_dst = 0;
+  auto pload_begin = [&](int ring, int fg, int fc) __attribute__((always_inline)) {
+    if (fc == 0) set_group(fg);
+    p_soff = (IC * fc + 2 * wave) * hw4;
+    p_dst = ps_base + (unsigned)((ring * PSZ + 2 * wave * (UW_PIECES * 64)) * 4);
+  };
+  // piece s = 0..5: channel 2 wave + s / 3, piece s % 3
+  auto pload_piece = [&](int s) __attribute__((always_inline)) {
+    uw_dma_buffer_b32(p_dst + 256 * s, xoff[s % UW_PIECES], xsrc, p_soff + (s / UW_PIECES) * hw4);
+  };
+  // weights of an interval: 28 one-KB pieces [half 2][k-quad 2][7]; wave w copies pieces 7 w .. 7 w + 6
+  const int kq_total = p.in_ch >> 2;
+  const int a_lane = lane * 4;
+  auto uload = [&](int slot, int fc) __attribute__((always_inline)) {
+    const int hf = wave >> 1, kql = wave & 1;
+    const float* src = p.uf + ((int64_t)((o0 >> 4) + hf) * kq_total + 2 * fc + kql) * (7 * 256);       // uniform
+    const unsigned dst = us_base + (unsigned)((slot * USZ + (hf * 2 + kql) * (7 * 256)) * 4);
+#pragma unroll
+    for (int q = 0; q < 7; ++q) uw_dma_global_b128_s(dst + q * 1024, a_lane * 4, src + q * 256);
+  };
+
+  uw_f32x4 acc[25];
+#pragma unroll
+  for (int xi = 0; xi < 25; ++xi) acc[xi] = uw_f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // this lane's window: patch rows 2 wn .. 2 wn + 2, columns 2 lt .. 2 lt + 2 of channel lk (+ 4 per k-quad)
+  const int item_off = lk * (UW_PIECES * 64) + (2 * wn) * UW_PITCH + 2 * lt;
+  auto compute = [&](int ring, int uslot, int c, bool spread) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kql = 0; kql < 2; ++kql) {
+      const float* src = &Ps[ring * PSZ + kql * 4 * (UW_PIECES * 64) + item_off];
+      const float sv = St[IC * c + 4 * kql + lk];
+      float d[3][3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const uw_f32x2 lo = *reinterpret_cast<const uw_f32x2*>(src + r * UW_PITCH);
+        d[r][0] = lo[0] * sv; d[r][1] = lo[1] * sv; d[r][2] = src[r * UW_PITCH + 2] * sv;
+      }
+      // T[v][h]: v, h in (d0-d1, d1, d2-d1, d2)
+      float t[4][3];
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) {
+        t[0][cc] = d[0][cc] - d[1][cc]; t[1][cc] = d[1][cc]; t[2][cc] = d[2][cc] - d[1][cc]; t[3][cc] = d[2][cc];
+      }
+      float T[4][4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        T[v][0] = t[v][0] - t[v][1]; T[v][1] = t[v][1]; T[v][2] = t[v][2] - t[v][1]; T[v][3] = t[v][2];
+      }
+      const float* ub = &Us[uslot * USZ + (wm * 2 + kql) * (7 * 256) + a_lane];
+      uw_f32x4 a4[3];
+      a4[0] = *reinterpret_cast<const uw_f32x4*>(ub);
+      a4[1] = *reinterpret_cast<const uw_f32x4*>(ub + 256);
+#pragma unroll
+      for (int q = 0; q < 7; ++q) {
+        if (q + 2 < 7) a4[(q + 2) % 3] = *reinterpret_cast<const uw_f32x4*>(ub + (q + 2) * 256);
+        if (spread && q < 3) pload_piece(3 * kql + q);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int xi = 4 * q + e;
+          if (xi < 25) {
+            // the transformed input of point xi (see the table in the header)
+            const int vr = xi < 9 ? xi / 3 : (xi < 15 ? (xi - 9) / 2 : (xi < 21 ? 1 + 2 * ((xi - 15) / 3) : 1 + 2 * ((xi - 21) / 2)));
+            const int hc = xi < 9 ? xi % 3 : (xi < 15 ? 1 + 2 * ((xi - 9) % 2) : (xi < 21 ? (xi - 15) % 3 : 1 + 2 * ((xi - 21) % 2)));
+            acc[xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[q % 3][e], T[vr][hc], acc[xi], 0, 0, 0);
+          }
+        }
+      }
+    }
+  };
+
+  // epilogue of one group: acc[xi][j] = M[xi] of out-channel o0 + 16 wm + 4 lk + j, block (row wn, column lt):
+  // quads (q0y + 2 wn + a, 32 (gx0 + g) + 2 lt + b), pixels (2 quad + phase)
+  typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+  const int oh = 2 * p.h + 1, ow = 2 * p.w + 1;
+  const int64_t ohw = (int64_t)oh * ow;
+  auto group_epilogue = [&](int g) __attribute__((always_inline)) {
+    const int Y0 = 2 * (q0y + 2 * wn), X0 = 2 * (32 * (gx0 + g) + 2 * lt);
+    float* yb = p.y + ((int64_t)ib * p.out_ch + o0 + 16 * wm + 4 * lk) * ohw + (int64_t)Y0 * ow + X0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float sc = Sc[16 * wm + 4 * lk + j];
+      float px[4][4];                              // [2 a + py][2 b + px]
+      // phase (0,0): 3 x 3 -> 2 x 2
+      {
+        float cs[3][2];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { cs[a][0] = acc[3 * a][j] + acc[3 * a + 1][j]; cs[a][1] = acc[3 * a + 1][j] + acc[3 * a + 2][j]; }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) { px[0][2 * b] = cs[0][b] + cs[1][b]; px[2][2 * b] = cs[1][b] + cs[2][b]; }
+      }
+      // phase (0,1): 3 x 2 -> 2 x 2
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        px[0][2 * b + 1] = acc[9 + b][j] + acc[11 + b][j];
+        px[2][2 * b + 1] = acc[11 + b][j] + acc[13 + b][j];
+      }
+      // phase (1,0): 2 x 3 -> 2 x 2
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        px[2 * a + 1][0] = acc[15 + 3 * a][j] + acc[16 + 3 * a][j];
+        px[2 * a + 1][2] = acc[16 + 3 * a][j] + acc[17 + 3 * a][j];
+      }
+      // phase (1,1)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) px[2 * a + 1][2 * b + 1] = acc[21 + 2 * a + b][j];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        f32x4_u v = {px[r][0] * sc, px[r][1] * sc, px[r][2] * sc, px[r][3] * sc};
+        *reinterpret_cast<f32x4_u*>(yb + (int64_t)j * ohw + (int64_t)r * ow) = v;
+      }
+    }
+#pragma unroll
+    for (int xi = 0; xi < 25; ++xi) acc[xi] = uw_f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+
+#define UW_WAIT(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (((n) >> 4) << 14) | 0x70)
+  // in flight across the barrier of an interval: the 6 patch pieces issued in it (the weights of v + 1 go first
+  // and have landed); + 16 stores after a group's epilogue
+  auto sync_interval = [&](bool stores) __attribute__((always_inline)) {
+    if (stores) UW_WAIT(6 + 16); else UW_WAIT(6);
+    __builtin_amdgcn_s_barrier();
+  };
+
+  int fg = 0, fc = 0;                               // (group, chunk) of the next interval to fetch
+  auto advance = [&]() __attribute__((always_inline)) { if (++fc == NC) { fc = 0; ++fg; } };
+  // ---- prologue: tables complete before any LDS-direct load; then U(0), patch 0, patch 1
+  __builtin_amdgcn_s_waitcnt(0x0070);
+  uload(0, 0);
+  pload_begin(0, fg, fc);
+#pragma unroll
+  for (int s = 0; s < 6; ++s) pload_piece(s);
+  advance();
+  pload_begin(1, fg, fc);
+#pragma unroll
+  for (int s = 0; s < 6; ++s) pload_piece(s);
+  advance();
+  sync_interval(false);                             // U(0), patch 0 landed; patch 1 may be in flight
+
+  int c = 0, g = 0, ring = 0;
+  for (int v = 0; v < VT; ++v) {
+    const int ring2 = ring == 0 ? 2 : ring - 1;     // (v + 2) % 3
+    uload((v + 1) & 1, c + 1 < NC ? c + 1 : 0);     // weights of interval v + 1 (same slices for every group)
+    pload_begin(ring2, fg, fc);                     // patch of interval v + 2: pieces issued between the MFMAs
+    advance();
+    compute(ring, v & 1, c, true);
+    const bool last = c == NC - 1;
+    if (last) { group_epilogue(g); c = 0; ++g; } else { ++c; }
+    ring = ring == 2 ? 0 : ring + 1;
+    sync_interval(last);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0070);
+#undef UW_WAIT
+}
+
+// One thread: the 25 (+3 zero) values of one (o, i).  W[o][i][ky][kx] as rw_conv_transpose3x3s2_f32 sees it.
+__global__ void __launch_bounds__(256) pack_up_wino_kernel(const float* __restrict__ w, float* __restrict__ uf,
+                                                           int out_ch, int in_ch) {
+  const int64_t total = (int64_t)out_ch * in_ch;
+  const int kqn = in_ch >> 2;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int lane = (int)(idx & 63);
+    int64_t rest = idx >> 6;
+    const int kq = (int)(rest % kqn);
+    const int ob = (int)(rest / kqn);
+    const int o = 16 * ob + (lane & 15), i = 4 * kq + (lane >> 4);
+    const float* g = w + ((int64_t)o * in_ch + i) * 9;          // g[3 ky + kx]
+    // vertical transforms of the three kernel rows: E -> (w[2], w[2] + w[0], w[0]); O -> (w[1], w[1])
+    float ve[3][3], vo[2][3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      ve[0][kx] = g[6 + kx]; ve[1][kx] = g[6 + kx] + g[kx]; ve[2][kx] = g[kx];
+      vo[0][kx] = g[3 + kx]; vo[1][kx] = g[3 + kx];
+    }
+    float u[28];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      u[3 * a + 0] = ve[a][2]; u[3 * a + 1] = ve[a][2] + ve[a][0]; u[3 * a + 2] = ve[a][0];       // E x E
+      u[9 + 2 * a + 0] = ve[a][1]; u[9 + 2 * a + 1] = ve[a][1];                                   // E x O
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      u[15 + 3 * a + 0] = vo[a][2]; u[15 + 3 * a + 1] = vo[a][2] + vo[a][0]; u[15 + 3 * a + 2] = vo[a][0];   // O x E
+      u[21 + 2 * a + 0] = vo[a][1]; u[21 + 2 * a + 1] = vo[a][1];                                  // O x O
+    }
+    u[25] = u[26] = u[27] = 0.f;
+    float* dst = uf + ((int64_t)ob * kqn + kq) * (7 * 256) + lane * 4;
+#pragma unroll
+    for (int q = 0; q < 7; ++q)
+      *reinterpret_cast<uw_f32x4*>(dst + q * 256) = uw_f32x4{u[4 * q], u[4 * q + 1], u[4 * q + 2], u[4 * q + 3]};
+  }
+}
+
+static bool up_wino_shape_ok(int out_ch, int in_ch, int h, int w) {
+  return out_ch > 0 && in_ch >= 16 && in_ch <= 512 && out_ch % 32 == 0 && in_ch % 8 == 0 && w % 32 == 0 && h % 4 == 0;
+}
+
+extern "C" int rw_conv_transpose3x3s2_wino_supported(int out_ch, int in_ch, int h, int w) {
+  return up_wino_shape_ok(out_ch, in_ch, h, w) ? 1 : 0;
+}
+
+extern "C" long long rw_packed_conv_transpose_wino_elems(int out_ch, int in_ch) {
+  if (out_ch <= 0 || in_ch <= 0 || out_ch % 16 || in_ch % 4) return -1;
+  return 28LL * out_ch * in_ch;
+}
+
+extern "C" int rw_pack_conv_transpose_wino_f32(const float* w, float* uf, int out_ch, int in_ch, rw_stream_t stream) {
+  RW_CHECK_ARG(w && uf && out_ch > 0 && in_ch > 0);
+  if (out_ch % 16 || in_ch % 4) return RW_ERR_UNSUPPORTED;
+  const int64_t total = (int64_t)out_ch * in_ch;
+  hipLaunchKernelGGL(pack_up_wino_kernel, dim3(rw_stream_grid(total, 256)), dim3(256), 0, rw_s(stream), w, uf, out_ch,
+                     in_ch);
+  return RW_LAUNCH_RESULT();
+}
+
+#include <stdlib.h>
+// The quads y < H, x < W of the transposed convolution (everything but output row 2H and column 2W, which
+// rw_conv_transpose3x3s2_f32 impl 8 writes): y (B, out_ch, 2H+1, 2W+1).
+extern "C" int rw_conv_transpose3x3s2_wino_f32(const float* x, const float* uf, float* y, int batch, int in_ch,
+                                               int out_ch, int h, int w, float w_scale, const float* style,
+                                               const float* demod, rw_stream_t stream) {
+  RW_CHECK_ARG(x && uf && y && batch > 0 && in_ch > 0 && out_ch > 0 && h > 0 && w > 0);
+  if (!up_wino_shape_ok(out_ch, in_ch, h, w)) return RW_ERR_UNSUPPORTED;
+  UpWinoProblem p;
+  p.x = x; p.uf = uf; p.y = y; p.style = style; p.demod = demod;
+  p.batch = batch; p.in_ch = in_ch; p.out_ch = out_ch; p.h = h; p.w = w; p.w_scale = w_scale;
+  p.groups_x = w / 32;
+  p.groups_y = h / 4;
+  const int o_tiles = out_ch / 32;
+  const char* e = getenv("RW_UPWINO_GPW");
+  int gpw = e ? atoi(e) : 4;
+  if (gpw < 1) gpw = 1;
+  if (gpw > p.groups_x) gpw = p.groups_x;
+  while (p.groups_x % gpw) --gpw;
+  while (gpw > 1 && (int64_t)batch * p.groups_y * (p.groups_x / gpw) * o_tiles < 1024) {
+    --gpw;
+    while (p.groups_x % gpw) --gpw;
+  }
+  p.gpw = gpw;
+  const int64_t work = (int64_t)batch * p.groups_y * (p.groups_x / gpw) * o_tiles;
+  if (work <= 0 || work > 0x7fffffff) return RW_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(conv_up_wino_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
+  return RW_LAUNCH_RESULT();
+}

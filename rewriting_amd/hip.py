@@ -366,6 +366,40 @@ def conv_transpose3x3s2(x, wp, out_ch, w_scale, style=None, demod=None, impl=0, 
     return y
 
 
+def conv_transpose_wino_supported(out_ch, in_ch, height, width):
+    """Shapes the F(2,2) transposed convolution takes (rw_conv_transpose3x3s2_wino_supported)."""
+    return bool(lib().rw_conv_transpose3x3s2_wino_supported(int(out_ch), int(in_ch), int(height), int(width)))
+
+
+def pack_conv_transpose_weight_wino(weight):
+    weight = _dev(weight, 'weight')
+    o, i = weight.shape[-4], weight.shape[-3]
+    n = lib().rw_packed_conv_transpose_wino_elems(o, i)
+    if n <= 0:
+        raise ValueError('no F(2,2) packing for a %d x %d transposed-conv weight' % (o, i))
+    uf = torch.empty(n, device=weight.device, dtype=torch.float32)
+    check(lib().rw_pack_conv_transpose_wino_f32(_p(weight), _p(uf), o, i, _stream()))
+    return uf
+
+
+def conv_transpose3x3s2_wino(x, uf, out_ch, w_scale, style=None, demod=None, out=None):
+    """The quads y < H, x < W of conv_transpose3x3s2 by F(2,2) (25 instead of 36 multiplies per 2x2 block of quads);
+    output row 2H and column 2W are left to conv_transpose3x3s2(..., impl=8, out=...)."""
+    x = _dev(x, 'fmap')
+    uf = _dev(uf, 'packed weight')
+    b, i, h, w = x.shape
+    if uf.numel() != lib().rw_packed_conv_transpose_wino_elems(out_ch, i):
+        raise ValueError('packed weight does not come from pack_conv_transpose_weight_wino(%d x %d)' % (out_ch, i))
+    y = out if out is not None else torch.empty(b, out_ch, 2 * h + 1, 2 * w + 1, device=x.device, dtype=x.dtype)
+    if tuple(y.shape) != (b, out_ch, 2 * h + 1, 2 * w + 1) or not y.is_contiguous():
+        raise ValueError('out has the wrong shape')
+    style = _opt(style, 'style')
+    demod = _opt(demod, 'demod')
+    check(lib().rw_conv_transpose3x3s2_wino_f32(_p(x), _p(uf), _p(y), b, i, out_ch, h, w, float(w_scale), _p(style),
+                                                _p(demod), _stream()))
+    return y
+
+
 def noise_add(x, noise, noise_w):
     x = _dev(x, 'fmap')
     noise = _dev(noise, 'noise')

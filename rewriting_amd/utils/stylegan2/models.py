@@ -180,6 +180,13 @@ def conv_algo():
     return _IMAGE_CONV_ALGO if _rgb_branch.image_path else _DEFAULT_CONV_ALGO
 
 
+def up_conv_algo():
+    """Algorithm of the stride-2 transposed convolutions: 'winograd' = F(2,2) on the four output-parity phases
+    (hip.conv_transpose3x3s2_wino: 25 instead of 36 multiplies per 2x2 block of quads; coefficients 0, +-1, the direct
+    sum's error class -- the default everywhere it applies) or 'direct'.  RW_UP_ALGO selects."""
+    return os.environ.get('RW_UP_ALGO', 'winograd')
+
+
 # Default: F(2x2,3x3) wherever a model is hooked, sliced (nethook.subsequence: the key statistics, the goal maps,
 # the solve's context) or run module by module; F(4x4,3x3) inside the un-hooked forward of the whole generator --
 # image generation, where the measured deviation from the reference image is the same 2e-5 with either.
@@ -386,6 +393,9 @@ class DemodulatedConv2dF(nn.Module):
     def wino_weight(self):
         return self._derived.get('wino', self.weight, lambda: hip.pack_conv_weight_wino(self.weight))
 
+    def up_wino_weight(self):
+        return self._derived.get('upwino', self.weight, lambda: hip.pack_conv_transpose_weight_wino(self.weight))
+
     def wino4_weight(self):
         return self._derived.get('wino4', self.weight, lambda: hip.pack_conv_weight_wino4(self.weight))
 
@@ -400,21 +410,35 @@ class DemodulatedConv2dF(nn.Module):
         load_style = style if style_on_load else None
         if self.upsample:
             aux = _rgb_branch.aux
-            if (aux is not None and conv_impl() == 0
-                    and hip.up_halo_applicable(self.out_channel, self.in_channel, fmap.shape[-1])):
-                # un-hooked full forward: the border row/column strips (latency-bound, 2 % of the step) go to
-                # a third stream beside the quad tiles; they write disjoint elements of the same map
-                b, _, h, w = fmap.shape
+            b, _, h, w = fmap.shape
+            f22 = (up_conv_algo() == 'winograd' and conv_impl() == 0
+                   and hip.up_halo_applicable(self.out_channel, self.in_channel, w)
+                   and hip.conv_transpose_wino_supported(self.out_channel, self.in_channel, h, w))
+            if conv_impl() == 0 and hip.up_halo_applicable(self.out_channel, self.in_channel, w) and (
+                    aux is not None or f22):
+                # quad tiles (F(2,2) where it applies, else the direct kernel) and the border row / column strips
+                # write disjoint elements of the same map; in the un-hooked full forward the strips
+                # (latency-bound, 2 % of the step) go to a third stream beside the tiles
                 out = torch.empty(b, self.out_channel, 2 * h + 1, 2 * w + 1, device=fmap.device, dtype=fmap.dtype)
                 wp = self.packed_weight()      # (re)packed on the trunk's stream BEFORE the fork
-                main = torch.cuda.current_stream()
-                aux.wait_stream(main)
-                with torch.cuda.stream(aux):
+                uf = self.up_wino_weight() if f22 else None
+                main = torch.cuda.current_stream() if aux is not None else None
+                if aux is not None:
+                    aux.wait_stream(main)
+                    with torch.cuda.stream(aux):
+                        hip.conv_transpose3x3s2(fmap, wp, self.out_channel, self.scale,
+                                                style=load_style, demod=demod, impl=8, out=out)
+                else:
                     hip.conv_transpose3x3s2(fmap, wp, self.out_channel, self.scale,
                                             style=load_style, demod=demod, impl=8, out=out)
-                hip.conv_transpose3x3s2(fmap, wp, self.out_channel, self.scale,
-                                        style=load_style, demod=demod, impl=7, out=out)
-                main.wait_stream(aux)          # queued while fmap / style / demod / out are still referenced
+                if f22:
+                    hip.conv_transpose3x3s2_wino(fmap, uf, self.out_channel, self.scale, style=load_style,
+                                                 demod=demod, out=out)
+                else:
+                    hip.conv_transpose3x3s2(fmap, wp, self.out_channel, self.scale,
+                                            style=load_style, demod=demod, impl=7, out=out)
+                if aux is not None:
+                    main.wait_stream(aux)      # queued while fmap / style / demod / out are still referenced
                 return out
             return hip.conv_transpose3x3s2(fmap, self.packed_weight(), self.out_channel, self.scale,
                                            style=load_style, demod=demod, impl=conv_impl())

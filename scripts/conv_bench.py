@@ -46,7 +46,12 @@ def main(batch=int(os.environ.get('RW_BATCH', '8')), iters=5, impl=int(os.enviro
             uf = hip.pack_conv_weight_wino(w)
         if wino4:
             uf = hip.pack_conv_weight_wino4(w)
-        fn = (lambda: hip.conv3x3_wino4(x, uf, cout, 1.0, style=style, demod=dm, **ep)) if wino4 else \
+        upw = os.environ.get('RW_UP_ALGO') == 'wino' and up and hip.conv_transpose_wino_supported(cout, cin, res, res)
+        if upw:
+            ufu = hip.pack_conv_transpose_weight_wino(w)
+            yout = torch.empty(batch, cout, 2 * res + 1, 2 * res + 1, device=dev)
+        fn = (lambda: hip.conv_transpose3x3s2_wino(x, ufu, cout, 1.0, style=style, demod=dm, out=yout)) if upw else \
+             (lambda: hip.conv3x3_wino4(x, uf, cout, 1.0, style=style, demod=dm, **ep)) if wino4 else \
              (lambda: hip.conv3x3_wino(x, uf, cout, 1.0, style=style, demod=dm, **ep)) if wino else \
              (lambda: hip.conv3x3_bf16x6(x, wb, cout, 1.0, style=style, demod=dm, **ep)) if split else \
              (lambda: hip.conv_transpose3x3s2(x, wp, cout, 1.0, style=style, demod=dm, impl=impl)) if up else \

@@ -103,7 +103,7 @@ def conv3x3(x, wp, out_ch, w_scale, style=None, demod=None, noise=None, noise_w=
     return y
 
 
-def conv_transpose3x3s2(x, wp, out_ch, w_scale, style=None, demod=None, impl=0):
+def conv_transpose3x3s2(x, wp, out_ch, w_scale, style=None, demod=None, impl=0, out=None):
     x = x.detach()
     if style is not None:
         x = x * style.detach()[:, :, None, None]
@@ -111,6 +111,58 @@ def conv_transpose3x3s2(x, wp, out_ch, w_scale, style=None, demod=None, impl=0):
     y = F.conv_transpose2d(x, w.transpose(0, 1), stride=2) * w_scale
     if demod is not None:
         y = y * demod[:, :, None, None]
+    if out is None:
+        return y
+    if impl == 8:                                        # the border row / column strips only
+        out[:, :, -1, :] = y[:, :, -1, :]
+        out[:, :, :, -1] = y[:, :, :, -1]
+    elif impl == 7:                                      # the quad tiles only
+        out[:, :, :-1, :-1] = y[:, :, :-1, :-1]
+    else:
+        out.copy_(y)
+    return out
+
+
+def pack_conv_transpose_weight_wino(weight):
+    return pack_conv_weight(weight, 1)                   # opaque handle
+
+
+def conv_transpose3x3s2_wino(x, uf, out_ch, w_scale, style=None, demod=None, out=None):
+    """The arithmetic of rw_upwino.hip in torch fp32: per axis the even outputs by F(2,2) (points d0-d1, d1, d2-d1
+    against w2, w2+w0, w0), the odd ones by their single tap; 25 products per 2x2 block of quads.  Writes the
+    quads y < H, x < W of `out` only."""
+    x = x.detach()
+    if style is not None:
+        x = x * style.detach()[:, :, None, None]
+    w = _unpack(uf, 1)                                   # [o][i][ky][kx]
+    b, c, h, wd = x.shape
+    y = out if out is not None else torch.zeros(b, out_ch, 2 * h + 1, 2 * wd + 1)
+    xp = F.pad(x, (1, 1, 1, 1))
+    d = [[xp[:, :, r:r + h:2, cc:cc + wd:2] for cc in range(3)] for r in range(3)]      # windows of the 2x2 blocks
+
+    def pts(kind, a0, a1, a2):
+        return [a0 - a1, a1, a2 - a1] if kind == 'E' else [a1, a2]
+
+    def wts(kind, g0, g1, g2):
+        return [g2, g2 + g0, g0] if kind == 'E' else [g1, g1]
+
+    def outs(kind, m):
+        return [m[0] + m[1], m[1] + m[2]] if kind == 'E' else [m[0], m[1]]
+    for py, kv in ((0, 'E'), (1, 'O')):
+        for px, kh in ((0, 'E'), (1, 'O')):
+            rows = [pts(kv, d[0][cc], d[1][cc], d[2][cc]) for cc in range(3)]            # rows[cc][a]
+            V = [pts(kh, rows[0][a], rows[1][a], rows[2][a]) for a in range(len(rows[0]))]   # V[a][b]
+            gv = wts(kv, w[:, :, 0], w[:, :, 1], w[:, :, 2])                              # [a] -> (o,i,kx)
+            U = [wts(kh, g[:, :, 0], g[:, :, 1], g[:, :, 2]) for g in gv]                  # U[a][b] (o,i)
+            M = [[torch.einsum('oi,nihw->nohw', U[a][bb], V[a][bb]) for bb in range(len(V[0]))] for a in range(len(V))]
+            cols = [outs(kh, M[a]) for a in range(len(M))]
+            for bq in range(2):
+                col = outs(kv, [cols[a][bq] for a in range(len(M))])
+                for aq in range(2):
+                    val = col[aq] * w_scale
+                    if demod is not None:
+                        val = val * demod[:, :, None, None]
+                    y[:, :, 2 * aq + py:2 * h:4, 2 * bq + px:2 * wd:4] = val
     return y
 
 
@@ -300,7 +352,7 @@ def install(monkeypatch):
     names = ['fused_bias_act', 'bias_grad', 'upfirdn2d_major', 'pixel_norm', 'equal_linear',
              'adjust_latent', 'style_mul', 'weight_sqsum', 'demod', 'pack_conv_weight', 'conv3x3',
              'conv_transpose3x3s2', 'noise_add', 'blur_noise_act', 'to_rgb', 'pack_conv_weight_bf16x3',
-             'conv3x3_bf16x6', 'pack_conv_weight_wino', 'conv3x3_wino', 'pack_conv_weight_wino4', 'conv3x3_wino4',
+             'conv3x3_bf16x6', 'pack_conv_weight_wino', 'conv3x3_wino', 'pack_conv_weight_wino4', 'conv3x3_wino4', 'pack_conv_transpose_weight_wino', 'conv_transpose3x3s2_wino',
              'second_moment_accumulate', 'channel_sums', 'project_weight', 'solve_ksplit',
              'solve_step']
     for n in names:

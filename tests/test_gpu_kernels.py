@@ -330,6 +330,47 @@ def test_winograd_f4_conv_matches_oracle_within_its_error_class(case):
         assert e_w < 2e-5, e_w
 
 
+UP_WINO_CASES = [(2, 16, 32, 4, 32), (1, 64, 64, 8, 32), (1, 128, 64, 16, 64), (3, 32, 32, 12, 96), (1, 512, 512, 32, 32),
+                 (1, 24, 96, 8, 64), (1, 64, 32, 512, 512), (1, 128, 64, 256, 256), (1, 512, 256, 64, 64)]
+
+
+@pytest.mark.parametrize('case', UP_WINO_CASES)
+def test_transposed_conv_f22_matches_direct_kernel_and_oracle(case):
+    """hip.conv_transpose3x3s2_wino (F(2,2): 25 instead of 36 multiplies per 2x2 block of quads) + the border strips
+    against the direct transposed-conv kernels and the oracle, at the direct kernels' bars (its transforms have
+    coefficients 0, +-1); asymmetric random weights, channel scales spread over two decades."""
+    from rewriting_amd import hip
+    from oracle import restatement as R
+    b, i, o, h, w = case
+    assert hip.conv_transpose_wino_supported(o, i, h, w)
+    x, wt, style = _conv_inputs(*case, seed=51)
+    rs = numpy.random.RandomState(52)
+    x = x * torch.from_numpy(numpy.exp(1.5 * rs.randn(1, i, 1, 1)).astype('float32'))
+    s = 1 / math.sqrt(i * 9)
+    dm = hip.demod(hip.weight_sqsum(wt.to(DEV), s), style.to(DEV))
+    wp = hip.pack_conv_weight(wt.to(DEV), 1)
+    uf = hip.pack_conv_transpose_weight_wino(wt.to(DEV))
+    direct = hip.conv_transpose3x3s2(x.to(DEV), wp, o, s, style=style.to(DEV), demod=dm,
+                                     impl=0 if i % 16 == 0 else 1)
+    out = torch.full_like(direct, float('nan'))
+    hip.conv_transpose3x3s2_wino(x.to(DEV), uf, o, s, style=style.to(DEV), demod=dm, out=out)
+    assert torch.isnan(out[:, :, -1, :]).all() and torch.isnan(out[:, :, :, -1]).all()      # strips untouched
+    assert torch.isfinite(out[:, :, :-1, :-1]).all()
+    if i % 16 == 0:
+        hip.conv_transpose3x3s2(x.to(DEV), wp, o, s, style=style.to(DEV), demod=dm, impl=8, out=out)
+    else:
+        out[:, :, -1, :] = direct[:, :, -1, :]
+        out[:, :, :, -1] = direct[:, :, :, -1]
+    scale = direct.abs().max().item()
+    assert (out - direct).abs().max().item() < 2e-5 * scale, (out - direct).abs().max().item() / scale
+    assert rel(out, direct) < 3e-6
+    if b * i * o * h * w <= 2 ** 31:
+        key = style[:, :, None, None] * x
+        want = R.demod_conv(key, style, wt, upsample=True)
+        assert rel(out, want) < 1e-5
+        assert (out.cpu() - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())
+
+
 def test_winograd_rejects_shapes_it_does_not_take():
     from rewriting_amd import hip
     assert not hip.wino_supported(32, 32, 16, 16) and not hip.wino_supported(48, 32, 32, 32)
