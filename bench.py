@@ -91,7 +91,8 @@ class ConvTimer:
     def install(self):
         from rewriting_amd import hip
         self._orig = (hip.conv3x3, hip.conv_transpose3x3s2, hip.conv3x3_bf16x6, hip.conv3x3_to_rgb,
-                      hip.conv3x3_wino, hip.conv3x3_wino_to_rgb, hip.conv3x3_wino4, hip.conv_transpose3x3s2_wino)
+                      hip.conv3x3_wino, hip.conv3x3_wino_to_rgb, hip.conv3x3_wino4, hip.conv_transpose3x3s2_wino,
+                      hip.conv_transpose3x3s2_blur_wino4)
         timer = self
 
         def wrap(fn, upsample, split=False, wino=None):
@@ -105,6 +106,8 @@ class ConvTimer:
                 b, i, h, w = x.shape
                 if wino == 'up':
                     name = 'conv_up_wino_kernel'
+                elif wino == 'up4':           # transposed conv + blur + noise + activation in one pass
+                    name = 'conv_up_wino36_kernel'
                 elif wino == 'f4':
                     name = 'conv_wino36b_kernel<2, 2>' if i <= 512 else 'conv_wino36_kernel<2, 2>'
                 elif wino is not None:
@@ -123,11 +126,13 @@ class ConvTimer:
         hip.conv3x3_wino_to_rgb = wrap(self._orig[5], False, wino='true')
         hip.conv3x3_wino4 = wrap(self._orig[6], False, wino='f4')
         hip.conv_transpose3x3s2_wino = wrap(self._orig[7], True, wino='up')
+        hip.conv_transpose3x3s2_blur_wino4 = wrap(self._orig[8], True, wino='up4')
 
     def remove(self):
         from rewriting_amd import hip
         (hip.conv3x3, hip.conv_transpose3x3s2, hip.conv3x3_bf16x6, hip.conv3x3_to_rgb, hip.conv3x3_wino,
-         hip.conv3x3_wino_to_rgb, hip.conv3x3_wino4, hip.conv_transpose3x3s2_wino) = self._orig
+         hip.conv3x3_wino_to_rgb, hip.conv3x3_wino4, hip.conv_transpose3x3s2_wino,
+         hip.conv_transpose3x3s2_blur_wino4) = self._orig
 
     def result(self):
         per = {}
@@ -157,7 +162,10 @@ class ConvTimer:
                                'pipe issues 1/2.25 of them'
             out['mfma_issued_tflops'] = round(achieved / 2.25, 2)
             out['mfma_issued_frac'] = round(achieved / 2.25 / FP32_MFMA_PEAK_TFLOPS, 4)
-        if dom.startswith('conv_up_wino'):
+        if dom.startswith('conv_up_wino36'):
+            out['algorithm'] = 'transposed conv (*) blur as four F(4x4,3x3) phase convolutions, fp32: `achieved` counts the ' \
+                               'transposed conv\'s direct-sum FLOPs, which is also what the matrix pipe issues'
+        elif dom.startswith('conv_up_wino'):
             out['algorithm'] = 'transposed conv by F(2,2) on the four output-parity phases, fp32: `achieved` counts the ' \
                                'direct sum\'s FLOPs (2.25 MACs per output); the matrix pipe issues 25/36 of them'
             out['mfma_issued_tflops'] = round(achieved * 25 / 36, 2)

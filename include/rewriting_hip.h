@@ -229,6 +229,26 @@ int rw_conv_transpose3x3s2_wino_f32(const float* x, const float* uf, float* y, i
                                     int h, int w, float w_scale, const float* style, const float* demod,
                                     rw_stream_t stream);
 
+/* An upsampling StyledConv in ONE pass: F.conv_transpose2d(x, scale*W^T, stride=2) [* demod] -> Blur(pad 1,1) ->
+ * NoiseInjectionF -> FusedLeakyReLUF  (models.py:315-316,328; 277-281; 539-546; 622-626):
+ * x (B,Cin,H,W) -> y (B,Cout,2H,2W).  A stride-2 transposed 3x3 convolution followed by the 4x4 FIR is a stride-2
+ * transposed convolution with their 6x6 composition, and each of its four output-parity phases is a 3x3 'same'
+ * convolution of x: the phases run as 4*Cout virtual channels of the F(4x4,3x3) kernel above (its error class:
+ * opt-in for image generation), the (2H+1)x(2W+1) map is never written, there are no border strips.
+ * Shapes: out_ch % 8 == 0, 8 <= in_ch <= 512, in_ch % 8 == 0, w % 64 == 0, h % 8 == 0.
+ *   uf: rw_packed_conv_transpose_blur_wino4_elems(out_ch, in_ch) = 144*out_ch*in_ch floats from
+ *       rw_pack_conv_transpose_blur_weight_wino4_f32(w, k4): w = the (1,out_ch,in_ch,3,3) parameter, k4 = the 4x4
+ *       FIR buffer of the layer's Blur (already multiplied by 4); layout of rw_pack_conv_weight_wino4_f32 with
+ *       virtual channel 4 o + 2 py + px.
+ *   ep: style / demod / noise (B x 2H x 2W) + noise_w / bias + act as in rw_conv_epilogue. */
+int rw_conv_transpose_blur_wino4_supported(int out_ch, int in_ch, int h, int w);
+long long rw_packed_conv_transpose_blur_wino4_elems(int out_ch, int in_ch);
+int rw_pack_conv_transpose_blur_weight_wino4_f32(const float* w, const float* k4, float* uf, int out_ch, int in_ch,
+                                                 rw_stream_t stream);
+int rw_conv_transpose3x3s2_blur_wino4_f32(const float* x, const float* uf, float* y, int batch, int in_ch,
+                                          int out_ch, int h, int w, float w_scale, const rw_conv_epilogue* ep,
+                                          rw_stream_t stream);
+
 /* NoiseInjectionF (models.py:535-546): y[b][c][p] = x[b][c][p] + noise_w[0] * noise[b][p] */
 int rw_noise_add_f32(const float* x, const float* noise, const float* noise_w, float* y,
                      int batch, int channels, int64_t hw, rw_stream_t stream);

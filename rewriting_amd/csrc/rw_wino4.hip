@@ -376,8 +376,20 @@ __device__ __forceinline__ void w4_dma_global_b32(unsigned lds_addr, const void*
 // everything two intervals ahead -- but its eight waves pass one barrier per interval, so the two waves of a SIMD run
 // in lockstep (both transform, then both multiply).  <2, 2>: two 256-thread workgroups per CU (77 KB of LDS each)
 // that drift apart, patch two intervals ahead, weights one (they come from L2).
-template <int WGN, int UDEPTH>
-__global__ void __launch_bounds__(128 * WGN, 4 / WGN) conv_wino36b_kernel(const Wino4Problem p) {
+//
+// UP = the same machinery computing a stride-2 transposed 3x3 convolution FOLLOWED BY the 4x4 blur (pad 1,1), noise,
+// bias and leaky ReLU of an upsampling StyledConv in one pass (conv_up_wino36_kernel).  conv_transpose (stride 2)
+// then a 4-tap FIR is a stride-2 transposed convolution with the 6x6 kernel w (*) k, and each of its four
+// output-parity phases is a 3x3 'same' convolution of the INPUT map: out[2m + p] = sum_a x[m - 1 + a] g[2 - 2a + p],
+// g[t] = sum_b k'[b] w[t - 1 + b].  The four phases are virtual out-channels v = 4 o + 2 py + px of a stride-1
+// F(4x4,3x3) problem (rw_pack_conv_transpose_blur_weight_wino4_f32 composes and transforms the weights); a lane's
+// four accumulator components j are then the four phases of ONE channel, its 4x4 tile an 8x8 block of output pixels
+// stored as 32-byte row segments.  The (2H+1) x (2W+1) map between transposed convolution and blur is never
+// written or read (8.6 GB each way at 32 x 1024^2 x 64 images), there are no border strips (the composed phases are
+// exact 'same' convolutions), and the blur pass disappears -- at 1.44x the matrix work of rw_upwino.hip's F(2,2),
+// which pays where the blur's traffic outweighs it: few channels, large maps.
+template <int WGN, int UDEPTH, bool UP>
+__device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
   constexpr int WGM = 2;
   constexpr int WAVES = WGM * WGN, THREADS = 64 * WAVES;
   constexpr int PR = 4 * WGN + 2;                 // patch rows
@@ -415,8 +427,9 @@ __global__ void __launch_bounds__(128 * WGN, 4 / WGN) conv_wino36b_kernel(const 
 
   for (int i = tid; i < p.in_ch; i += THREADS) St[i] = p.style ? p.style[(int64_t)ib * p.in_ch + i] : 1.0f;
   if (tid < 16 * WGM) {
-    const int o = o0 + tid;
-    Ct[0][tid] = p.demod ? p.demod[(int64_t)ib * p.out_ch + o] * p.w_scale : p.w_scale;
+    const int o = UP ? (o0 + tid) >> 2 : o0 + tid;          // UP: four phases per real channel
+    const int real_ch = UP ? p.out_ch >> 2 : p.out_ch;
+    Ct[0][tid] = p.demod ? p.demod[(int64_t)ib * real_ch + o] * p.w_scale : p.w_scale;
     Ct[1][tid] = p.act ? p.bias[o] : 0.f;
   }
   const float noise_w = p.noise ? p.noise_w[0] : 0.f;
@@ -533,7 +546,70 @@ __global__ void __launch_bounds__(128 * WGN, 4 / WGN) conv_wino36b_kernel(const 
     }
   };
 
+  // UP: lane (lk, lt) of wave (wm, wn) holds the four phases j = 2 py + px of channel o0 / 4 + 4 wm + lk on the tile
+  // rows oy .. oy + 3, columns ox .. ox + 3 of the INPUT grid = output rows 2 oy .. + 7, columns 2 ox .. + 7.
+  auto up_epilogue = [&](int g) __attribute__((always_inline)) {
+    const int oy = y0 + 4 * wn, ox = (gx0 + g) * 64 + 4 * lt;
+    const int W2 = 2 * p.w;
+    const int64_t hw2 = 4 * hw;
+    const int ch = (o0 >> 2) + 4 * wm + lk;
+    float* yb = p.y + ((int64_t)ib * (p.out_ch >> 2) + ch) * hw2 + (int64_t)(2 * oy) * W2 + 2 * ox;
+    const float* nb = p.noise ? p.noise + (int64_t)ib * hw2 + (int64_t)(2 * oy) * W2 + 2 * ox : nullptr;
+    const float scale = Ct[0][16 * wm + 4 * lk], bias = Ct[1][16 * wm + 4 * lk];
+#pragma unroll
+    for (int py = 0; py < 2; ++py) {
+      float v[2][4][4];
+#pragma unroll
+      for (int px = 0; px < 2; ++px) {
+        const int j = 2 * py + px;
+        float t[4][6];
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+          const float m0 = acc[b][j], m1 = acc[6 + b][j], m2 = acc[12 + b][j], m3 = acc[18 + b][j], m4 = acc[24 + b][j],
+                      m5 = acc[30 + b][j];
+          const float s1 = m1 + m2, s2 = m1 - m2, s3 = m3 + m4, s4 = m3 - m4;
+          t[0][b] = m0 + s1 + s3;
+          t[1][b] = s2 + 2.f * s4;
+          t[2][b] = s1 + 4.f * s3;
+          t[3][b] = s2 + 8.f * s4 + m5;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float s1 = t[r][1] + t[r][2], s2 = t[r][1] - t[r][2], s3 = t[r][3] + t[r][4], s4 = t[r][3] - t[r][4];
+          v[px][r][0] = t[r][0] + s1 + s3; v[px][r][1] = s2 + 2.f * s4; v[px][r][2] = s1 + 4.f * s3;
+          v[px][r][3] = s2 + 8.f * s4 + t[r][5];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t off = (int64_t)(2 * r + py) * W2;
+        w4_f32x4 n0 = {0.f, 0.f, 0.f, 0.f}, n1 = n0;
+        if (p.noise) {
+          n0 = *reinterpret_cast<const w4_f32x4*>(nb + off) * noise_w;
+          n1 = *reinterpret_cast<const w4_f32x4*>(nb + off + 4) * noise_w;
+        }
+        w4_f32x4 q0 = {v[0][r][0], v[1][r][0], v[0][r][1], v[1][r][1]};
+        w4_f32x4 q1 = {v[0][r][2], v[1][r][2], v[0][r][3], v[1][r][3]};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float u0 = q0[k] * scale + n0[k], u1 = q1[k] * scale + n1[k];
+          if (p.act) {
+            u0 += bias; u1 += bias;
+            u0 = ((u0 > 0.f) ? u0 : u0 * 0.2f) * 1.4142135623730951f;
+            u1 = ((u1 > 0.f) ? u1 : u1 * 0.2f) * 1.4142135623730951f;
+          }
+          q0[k] = u0; q1[k] = u1;
+        }
+        *reinterpret_cast<w4_f32x4*>(yb + off) = q0;
+        *reinterpret_cast<w4_f32x4*>(yb + off + 4) = q1;
+      }
+    }
+#pragma unroll
+    for (int xi = 0; xi < 36; ++xi) acc[xi] = w4_f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+
   auto group_epilogue = [&](int g) __attribute__((always_inline)) {
+    if (UP) { up_epilogue(g); return; }
     const int oy = y0 + 4 * wn, ox = (gx0 + g) * 64 + 4 * lt;
     w4_f32x4 nz[4];
 #pragma unroll
@@ -612,7 +688,7 @@ __global__ void __launch_bounds__(128 * WGN, 4 / WGN) conv_wino36b_kernel(const 
   int fg = 2 / NC, fc = 2 % NC;                     // (group, k-quad) of interval v + 2
   for (int v = 0; v < VT; ++v) {
     const int ring2 = ring == 0 ? 2 : ring - 1;     // (v + 2) % 3
-    if (p.noise && c == NC - 2) nload(g);           // older than this interval's pieces: retired by its wait
+    if (!UP && p.noise && c == NC - 2) nload(g);    // older than this interval's pieces: retired by its wait
     static_assert(2 * 9 >= PPW, "two patch pieces per weight quad cover the wave's share");
     if (UDEPTH == 2) {
       if (!(W4_ABL & 4)) uload((v + 1) & 1, c + 1 < NC ? c + 1 : 0);      // weights of interval v + 1
@@ -636,6 +712,15 @@ __global__ void __launch_bounds__(128 * WGN, 4 / WGN) conv_wino36b_kernel(const 
 #undef W4_WAIT
 }
 
+template <int WGN, int UDEPTH>
+__global__ void __launch_bounds__(128 * WGN, 4 / WGN) conv_wino36b_kernel(const Wino4Problem p) {
+  conv_wino36b_body<WGN, UDEPTH, false>(p);
+}
+// transposed convolution + blur + noise + bias + leaky ReLU (see UP above): <2, 2> only
+__global__ void __launch_bounds__(256, 2) conv_up_wino36_kernel(const Wino4Problem p) {
+  conv_wino36b_body<2, 2, true>(p);
+}
+
 // ---------------------------------------------------------------------------------------
 // What bounds these kernels (scripts/probe/mfma_valu_probe): on gfx950 an fp32 MFMA and vector-ALU work do NOT
 // overlap.  v_mfma_f32_16x16x4_f32 alone runs at 145 TFLOP/s (the clock under load: 2.2 GHz); every v_fma_f32
@@ -645,21 +730,11 @@ __global__ void __launch_bounds__(128 * WGN, 4 / WGN) conv_wino36b_kernel(const 
 // one wave per SIMD holding 32 out-channels (each transformed value feeding two MFMAs, 288 accumulators) halves
 // that ratio on paper; the register allocator spills it (1 KB of scratch per lane), so it is not in the tree.
 // ---------------------------------------------------------------------------------------
-// One thread: the 36 values of one (o, i).  uf[o / 16][i / 4][xi / 4][16 (i % 4) + o % 16][xi % 4]
-__global__ void __launch_bounds__(256) pack_wino36_kernel(const float* __restrict__ w, float* __restrict__ uf,
-                                                          int out_ch, int in_ch) {
-  const int64_t total = (int64_t)out_ch * in_ch;
-  const int kqn = in_ch >> 2;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    const int lane = (int)(idx & 63);
-    int64_t rest = idx >> 6;
-    const int kq = (int)(rest % kqn);
-    const int ob = (int)(rest / kqn);
-    const int o = 16 * ob + (lane & 15), i = 4 * kq + (lane >> 4);
-    const float* g = w + ((int64_t)o * in_ch + i) * 9;
+// G g G^T of one 3x3 kernel g[3 ky + kx] -> the 36 values of lane `dst` (stride 256 floats per point quad)
+__device__ __forceinline__ void w4_pack_store(const float* g, float* dst) {
     // G = [[1/4,0,0],[-1/6,-1/6,-1/6],[-1/6,1/6,-1/6],[1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]]
     float gg[6][3];                                   // G g
+
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
       const float g0 = g[kx], g1 = g[3 + kx], g2 = g[6 + kx];
@@ -681,10 +756,61 @@ __global__ void __launch_bounds__(256) pack_wino36_kernel(const float* __restric
       u[6 * a + 4] = (1.f / 24.f) * g0 - (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
       u[6 * a + 5] = g2;
     }
-    float* dst = uf + ((int64_t)ob * kqn + kq) * (9 * 256) + lane * 4;
 #pragma unroll
     for (int q = 0; q < 9; ++q)
       *reinterpret_cast<w4_f32x4*>(dst + q * 256) = w4_f32x4{u[4 * q], u[4 * q + 1], u[4 * q + 2], u[4 * q + 3]};
+}
+
+// One thread: the 36 values of one (o, i).  uf[o / 16][i / 4][xi / 4][16 (i % 4) + o % 16][xi % 4]
+__global__ void __launch_bounds__(256) pack_wino36_kernel(const float* __restrict__ w, float* __restrict__ uf,
+                                                          int out_ch, int in_ch) {
+  const int64_t total = (int64_t)out_ch * in_ch;
+  const int kqn = in_ch >> 2;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int lane = (int)(idx & 63);
+    int64_t rest = idx >> 6;
+    const int kq = (int)(rest % kqn);
+    const int ob = (int)(rest / kqn);
+    const int o = 16 * ob + (lane & 15), i = 4 * kq + (lane >> 4);
+    w4_pack_store(w + ((int64_t)o * in_ch + i) * 9, uf + ((int64_t)ob * kqn + kq) * (9 * 256) + lane * 4);
+  }
+}
+
+// The same for the transposed convolution + blur problem: virtual channel v = 4 o + 2 py + px carries the phase
+// kernel h[a][b] = g6[2 - 2a + py][2 - 2b + px], g6[ty][tx] = sum_{c,d} k'[c][d] w[ty - 1 + c][tx - 1 + d] (t = -2..3),
+// k' = the blur kernel as upfirdn2d applies it (flipped).  w[o][i][ky][kx] as rw_conv_transpose3x3s2_f32 sees it.
+__global__ void __launch_bounds__(256) pack_up_wino36_kernel(const float* __restrict__ w, const float* __restrict__ k4,
+                                                             float* __restrict__ uf, int out_ch, int in_ch) {
+  const int vch = 4 * out_ch;
+  const int64_t total = (int64_t)vch * in_ch;
+  const int kqn = in_ch >> 2;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int lane = (int)(idx & 63);
+    int64_t rest = idx >> 6;
+    const int kq = (int)(rest % kqn);
+    const int ob = (int)(rest / kqn);
+    const int v = 16 * ob + (lane & 15), i = 4 * kq + (lane >> 4);
+    const int o = v >> 2, py = (v >> 1) & 1, px = v & 1;
+    const float* g = w + ((int64_t)o * in_ch + i) * 9;
+    float h[9];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        const int ty = 2 - 2 * a + py, tx = 2 - 2 * b + px;        // -2 .. 3
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            const int ky = ty - 1 + c, kx = tx - 1 + d;
+            if (ky >= 0 && ky < 3 && kx >= 0 && kx < 3) sum += k4[(3 - c) * 4 + (3 - d)] * g[3 * ky + kx];
+          }
+        h[3 * a + b] = sum;
+      }
+    w4_pack_store(h, uf + ((int64_t)ob * kqn + kq) * (9 * 256) + lane * 4);
   }
 }
 
@@ -762,5 +888,63 @@ extern "C" int rw_conv3x3_wino4_f32(const float* x, const float* uf, float* y, i
     return RW_LAUNCH_RESULT();
   }
   hipLaunchKernelGGL((conv_wino36_kernel<2, 2>), dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
+  return RW_LAUNCH_RESULT();
+}
+
+// ---------------------------------------------------------------------------------------
+// Transposed convolution + blur + noise + bias + leaky ReLU of an upsampling StyledConv in one pass
+// (utils/stylegan2/models.py:313-329 F.conv_transpose2d(stride=2), then Blur(pad 1,1) :289-291, NoiseInjection
+// :259-270, FusedLeakyReLU :232-257): y (B, out_ch, 2H, 2W).  See UP in conv_wino36b_body.
+// ---------------------------------------------------------------------------------------
+static bool up_wino4_shape_ok(int out_ch, int in_ch, int h, int w) {
+  return out_ch > 0 && out_ch % 8 == 0 && in_ch >= 8 && in_ch <= 512 && in_ch % 8 == 0 && w % 64 == 0 && h % 8 == 0;
+}
+
+extern "C" int rw_conv_transpose_blur_wino4_supported(int out_ch, int in_ch, int h, int w) {
+  return up_wino4_shape_ok(out_ch, in_ch, h, w) ? 1 : 0;
+}
+
+extern "C" long long rw_packed_conv_transpose_blur_wino4_elems(int out_ch, int in_ch) {
+  if (out_ch <= 0 || in_ch <= 0 || out_ch % 4 || in_ch % 4) return -1;
+  return 144LL * out_ch * in_ch;
+}
+
+extern "C" int rw_pack_conv_transpose_blur_weight_wino4_f32(const float* w, const float* k4, float* uf, int out_ch,
+                                                            int in_ch, rw_stream_t stream) {
+  RW_CHECK_ARG(w && k4 && uf && out_ch > 0 && in_ch > 0);
+  if (out_ch % 4 || in_ch % 4) return RW_ERR_UNSUPPORTED;
+  const int64_t total = 4LL * out_ch * in_ch;
+  hipLaunchKernelGGL(pack_up_wino36_kernel, dim3(rw_stream_grid(total, 256)), dim3(256), 0, rw_s(stream), w, k4, uf,
+                     out_ch, in_ch);
+  return RW_LAUNCH_RESULT();
+}
+
+extern "C" int rw_conv_transpose3x3s2_blur_wino4_f32(const float* x, const float* uf, float* y, int batch, int in_ch,
+                                                     int out_ch, int h, int w, float w_scale,
+                                                     const rw_conv_epilogue* ep, rw_stream_t stream) {
+  RW_CHECK_ARG(x && uf && y && batch > 0 && in_ch > 0 && out_ch > 0 && h > 0 && w > 0);
+  RW_CHECK_ARG(!ep || ((!ep->noise || ep->noise_w) && (!ep->act || ep->bias)));
+  if (!up_wino4_shape_ok(out_ch, in_ch, h, w)) return RW_ERR_UNSUPPORTED;
+  Wino4Problem p;
+  p.x = x; p.uf = uf; p.y = y;
+  p.style = ep ? ep->style : nullptr; p.demod = ep ? ep->demod : nullptr; p.noise = ep ? ep->noise : nullptr;
+  p.noise_w = ep ? ep->noise_w : nullptr; p.bias = ep ? ep->bias : nullptr; p.act = ep ? ep->act : 0;
+  p.batch = batch; p.in_ch = in_ch; p.out_ch = 4 * out_ch; p.h = h; p.w = w; p.w_scale = w_scale;
+  p.groups_x = w / 64;
+  p.groups_y = h / 8;
+  const int o_tiles = p.out_ch / 32;
+  const char* e = getenv("RW_WINO4_GPW");
+  int gpw = e ? atoi(e) : 4;
+  if (gpw < 1) gpw = 1;
+  if (gpw > p.groups_x) gpw = p.groups_x;
+  while (p.groups_x % gpw) --gpw;
+  while (gpw > 1 && (int64_t)batch * p.groups_y * (p.groups_x / gpw) * o_tiles < 1024) {
+    --gpw;
+    while (p.groups_x % gpw) --gpw;
+  }
+  p.gpw = gpw;
+  const int64_t work = (int64_t)batch * p.groups_y * (p.groups_x / gpw) * o_tiles;
+  if (work <= 0 || work > 0x7fffffff) return RW_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(conv_up_wino36_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
   return RW_LAUNCH_RESULT();
 }

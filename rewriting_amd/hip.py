@@ -400,6 +400,43 @@ def conv_transpose3x3s2_wino(x, uf, out_ch, w_scale, style=None, demod=None, out
     return y
 
 
+def conv_transpose_blur_wino4_supported(out_ch, in_ch, height, width):
+    """Shapes the one-pass upsampling StyledConv takes (rw_conv_transpose_blur_wino4_supported)."""
+    return bool(lib().rw_conv_transpose_blur_wino4_supported(int(out_ch), int(in_ch), int(height), int(width)))
+
+
+def pack_conv_transpose_blur_weight_wino4(weight, k4):
+    """F(4x4,3x3) weights of the four output-parity phases of conv_transpose(stride 2) followed by the 4x4 FIR k4."""
+    weight = _dev(weight, 'weight')
+    k4 = _dev(k4, 'blur kernel').contiguous()
+    if tuple(k4.shape) != (4, 4):
+        raise ValueError('the blur kernel must be 4 x 4')
+    o, i = weight.shape[-4], weight.shape[-3]
+    n = lib().rw_packed_conv_transpose_blur_wino4_elems(o, i)
+    if n <= 0:
+        raise ValueError('no F(4x4,3x3) phase packing for a %d x %d transposed-conv weight' % (o, i))
+    uf = torch.empty(n, device=weight.device, dtype=torch.float32)
+    check(lib().rw_pack_conv_transpose_blur_weight_wino4_f32(_p(weight), _p(k4), _p(uf), o, i, _stream()))
+    return uf
+
+
+def conv_transpose3x3s2_blur_wino4(x, uf, out_ch, w_scale, style=None, demod=None, noise=None, noise_w=None,
+                                   bias=None, act=False):
+    """conv_transpose3x3s2 -> blur(pad 1,1) -> noise -> bias + leaky ReLU in one pass: (B,Cin,H,W) -> (B,Cout,2H,2W),
+    the four output-parity phases as virtual channels of the F(4x4,3x3) kernel (its error class: image generation)."""
+    x = _dev(x, 'fmap')
+    uf = _dev(uf, 'packed weight')
+    b, i, h, w = x.shape
+    if uf.numel() != lib().rw_packed_conv_transpose_blur_wino4_elems(out_ch, i):
+        raise ValueError('packed weight does not come from pack_conv_transpose_blur_weight_wino4(%d x %d)'
+                         % (out_ch, i))
+    y = torch.empty(b, out_ch, 2 * h, 2 * w, device=x.device, dtype=x.dtype)
+    ep, keep = _epilogue(style, demod, noise, noise_w, bias, act)
+    check(lib().rw_conv_transpose3x3s2_blur_wino4_f32(_p(x), _p(uf), _p(y), b, i, out_ch, h, w, float(w_scale),
+                                                      ctypes.byref(ep), _stream()))
+    return y
+
+
 def noise_add(x, noise, noise_w):
     x = _dev(x, 'fmap')
     noise = _dev(noise, 'noise')

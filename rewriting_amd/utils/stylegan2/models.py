@@ -192,6 +192,7 @@ def up_conv_algo():
 # image generation, where the measured deviation from the reference image is the same 2e-5 with either.
 _DEFAULT_CONV_ALGO = 'winograd'
 _IMAGE_CONV_ALGO = 'winograd4'
+_ONE_PASS_UP_MAX_IN = 64       # see DemodulatedConv2dF.one_pass_upsample
 
 
 def micro_batch():
@@ -395,6 +396,29 @@ class DemodulatedConv2dF(nn.Module):
 
     def up_wino_weight(self):
         return self._derived.get('upwino', self.weight, lambda: hip.pack_conv_transpose_weight_wino(self.weight))
+
+    def up_blur_wino4_weight(self, k4):
+        return self._derived.get('upblur4', self.weight,
+                                 lambda: hip.pack_conv_transpose_blur_weight_wino4(self.weight, k4))
+
+    def one_pass_upsample(self, fmap, blur):
+        """Transposed conv + blur + noise + activation in ONE pass (hip.conv_transpose3x3s2_blur_wino4: the four
+        output-parity phases as virtual channels of the F(4x4,3x3) kernel) -- where F(4x4,3x3) runs at all (the
+        un-hooked whole-generator forward, conv_algo() == 'winograd4') and where it pays: it does 1.44x the matrix work
+        of the F(2,2) kernel and saves writing + reading the (2H+1)x(2W+1) map and the blur pass, which wins at
+        <= 64 input channels (layer 17 of the 1024 model: 12.4 -> 9.x ms).  RW_UP_ALGO=winograd4 forces it wherever
+        the shape allows, RW_UP_ALGO=direct / RW_UP_FUSED=0 turn it off."""
+        algo = up_conv_algo()
+        if not self.upsample or conv_impl() != 0 or conv_precision() != 'f32' or algo == 'direct':
+            return False
+        if os.environ.get('RW_UP_FUSED', '1') == '0' or tuple(blur.pad) != (1, 1) or tuple(blur.kernel.shape) != (4, 4):
+            return False
+        if not hip.conv_transpose_blur_wino4_supported(self.out_channel, self.in_channel, fmap.shape[-2],
+                                                       fmap.shape[-1]):
+            return False
+        if algo == 'winograd4':
+            return True
+        return conv_algo() == 'winograd4' and self.in_channel <= _ONE_PASS_UP_MAX_IN
 
     def wino4_weight(self):
         return self._derived.get('wino4', self.weight, lambda: hip.pack_conv_weight_wino4(self.weight))
@@ -706,8 +730,13 @@ class StyledConvSeq(nn.Sequential):
         if mconv.upsample:
             h, w = 2 * fmap.shape[2], 2 * fmap.shape[3]
             noise = self.noise.noise_for(d, b, h, w, fmap.device)
-            wide = dconv.run(fmap, style, style_on_load=True)
-            out = hip.blur_noise_act(wide, mconv.blur.kernel, noise, self.noise.weight, act.bias)
+            if dconv.one_pass_upsample(fmap, mconv.blur):
+                out = hip.conv_transpose3x3s2_blur_wino4(
+                    fmap, dconv.up_blur_wino4_weight(mconv.blur.kernel), dconv.out_channel, dconv.scale, style=style,
+                    demod=dconv.demod_factors(style), noise=noise, noise_w=self.noise.weight, bias=act.bias, act=True)
+            else:
+                wide = dconv.run(fmap, style, style_on_load=True)
+                out = hip.blur_noise_act(wide, mconv.blur.kernel, noise, self.noise.weight, act.bias)
         else:
             h, w = fmap.shape[2:]
             noise = self.noise.noise_for(d, b, h, w, fmap.device)

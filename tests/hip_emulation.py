@@ -344,6 +344,40 @@ def conv3x3_wino4(x, uf, out_ch, w_scale, style=None, demod=None, noise=None, no
     return y
 
 
+def pack_conv_transpose_blur_weight_wino4(weight, k4):
+    return (pack_conv_weight(weight, 1), k4.detach().clone())          # opaque handle
+
+
+def conv_transpose3x3s2_blur_wino4(x, uf, out_ch, w_scale, style=None, demod=None, noise=None, noise_w=None,
+                                   bias=None, act=False):
+    """The arithmetic of rw_wino4.hip's conv_up_wino36_kernel in torch fp32: the four output-parity phases of
+    conv_transpose(stride 2) (*) blur as 4 * out_ch virtual channels of the F(4x4,3x3) convolution, pixel-shuffled."""
+    wp, k4 = uf
+    w = _unpack(wp, 1)                                   # [o][i][3][3]
+    o, i = w.shape[:2]
+    kf = torch.flip(k4, [0, 1])
+    g6 = torch.zeros(o, i, 6, 6)
+    for c in range(4):
+        for d in range(4):
+            # g6[t + 2] += k'[c] w[t - 1 + c]  ->  w[ky] lands at t = ky + 1 - c
+            g6[:, :, 3 - c:6 - c, 3 - d:6 - d] += kf[c, d] * w
+    wv = torch.zeros(4 * o, i, 3, 3)
+    for py in range(2):
+        for px in range(2):
+            for a in range(3):
+                for b in range(3):
+                    wv[2 * py + px::4, :, a, b] = g6[:, :, 4 - 2 * a + py, 4 - 2 * b + px]
+    z = conv3x3_wino4(x, pack_conv_weight(wv.reshape(1, 4 * o, i, 3, 3), 0), 4 * o, w_scale, style=style,
+                      demod=None if demod is None else demod.repeat_interleave(4, dim=1))
+    n, _, h, wd = z.shape
+    y = z.reshape(n, o, 2, 2, h, wd).permute(0, 1, 4, 2, 5, 3).reshape(n, o, 2 * h, 2 * wd)
+    if noise is not None:
+        y = y + noise_w.detach().reshape(1) * noise.reshape(n, 1, 2 * h, 2 * wd)
+    if act:
+        y = F.leaky_relu(y + bias.detach().view(1, -1, 1, 1), 0.2) * SQRT2
+    return y
+
+
 def install(monkeypatch):
     """Replaces the kernel wrappers of rewriting_amd.hip and makes host code take the
     'tensors live on the device' branches."""
@@ -353,6 +387,7 @@ def install(monkeypatch):
              'adjust_latent', 'style_mul', 'weight_sqsum', 'demod', 'pack_conv_weight', 'conv3x3',
              'conv_transpose3x3s2', 'noise_add', 'blur_noise_act', 'to_rgb', 'pack_conv_weight_bf16x3',
              'conv3x3_bf16x6', 'pack_conv_weight_wino', 'conv3x3_wino', 'pack_conv_weight_wino4', 'conv3x3_wino4', 'pack_conv_transpose_weight_wino', 'conv_transpose3x3s2_wino',
+             'pack_conv_transpose_blur_weight_wino4', 'conv_transpose3x3s2_blur_wino4',
              'second_moment_accumulate', 'channel_sums', 'project_weight', 'solve_ksplit',
              'solve_step']
     for n in names:

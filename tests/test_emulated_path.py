@@ -273,3 +273,40 @@ def test_generator_with_f4_winograd_is_inside_the_image_tolerance(emulated_hip, 
     with torch.no_grad():
         base = model(z)
     assert (base - want).abs().max().item() < 1e-4 and not torch.equal(base, got)
+
+
+def test_one_pass_upsampling_layers_stay_inside_the_image_tolerance(emulated_hip, monkeypatch):
+    """RW_UP_ALGO=winograd4: the upsampling StyledConvs as ONE pass (transposed conv (*) blur as four F(4x4,3x3) phase
+    convolutions, noise + bias + activation in the epilogue) instead of conv -> (2H+1)^2 map -> blur pass: same
+    generator, reference golden, image tolerance; a hooked layer falls back to the module-by-module route."""
+    from rewriting_amd import hip
+    from rewriting_amd.utils import nethook
+    g = load_golden('gen_s64_cm1')
+    meta = golden_meta(g)
+    model = build_stylegan(meta['size'], meta['truncation'], meta['channel_multiplier'])
+    z = torch.from_numpy(g['z'])
+    want = torch.from_numpy(g['image'])
+    calls = []
+    real = hip.conv_transpose3x3s2_blur_wino4
+    monkeypatch.setattr(hip, 'conv_transpose_blur_wino4_supported', lambda o, i, h, w: True)
+    monkeypatch.setattr(hip, 'conv_transpose3x3s2_blur_wino4', lambda *a, **k: (calls.append(a[0].shape), real(*a, **k))[1])
+    monkeypatch.setenv('RW_UP_ALGO', 'winograd4')
+    with torch.no_grad():
+        got = model(z)
+    assert len(calls) == 4                              # 4 -> 8 -> 16 -> 32 -> 64
+    assert (got - want).abs().max().item() < 1e-3
+    monkeypatch.setenv('RW_UP_ALGO', 'winograd')
+    del calls[:]
+    with torch.no_grad():
+        base = model(z)
+    assert not calls and (base - want).abs().max().item() < 1e-4
+    assert (got - base).abs().max().item() < 1e-4 and not torch.equal(got, base)
+    # a hooked blur inside one layer: that layer runs child by child, the others in one pass
+    monkeypatch.setenv('RW_UP_ALGO', 'winograd4')
+    with nethook.InstrumentedModel(model) as inst:
+        inst.retain_layer('layer5.sconv.mconv.blur', detach=False)
+        with torch.no_grad():
+            hooked = inst(z)
+        assert inst.retained_layer('layer5.sconv.mconv.blur') is not None
+    assert len(calls) == 3
+    assert (hooked - want).abs().max().item() < 1e-3

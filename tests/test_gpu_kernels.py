@@ -371,6 +371,48 @@ def test_transposed_conv_f22_matches_direct_kernel_and_oracle(case):
         assert (out.cpu() - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())
 
 
+UP_BLUR_CASES = [(2, 16, 8, 8, 64), (1, 64, 32, 16, 64), (1, 128, 64, 8, 128), (3, 32, 16, 24, 64), (1, 512, 64, 8, 64),
+                 (1, 24, 40, 8, 64), (1, 64, 32, 512, 512)]
+
+
+@pytest.mark.parametrize('case', UP_BLUR_CASES)
+def test_one_pass_upsampling_conv_matches_conv_then_blur(case):
+    """hip.conv_transpose3x3s2_blur_wino4 (the four output-parity phases of conv_transpose (*) blur as virtual channels
+    of the F(4x4,3x3) kernel, noise + bias + leaky ReLU in its epilogue) against the two-pass route of the same library
+    (direct transposed conv -> blur_noise_act) and the oracle, at the F(4x4,3x3) bars."""
+    from rewriting_amd import hip
+    from oracle import restatement as R
+    b, i, o, h, w = case
+    assert hip.conv_transpose_blur_wino4_supported(o, i, h, w)
+    x, wt, style = _conv_inputs(*case, seed=61)
+    rs = numpy.random.RandomState(62)
+    x = x * torch.from_numpy(numpy.exp(1.0 * rs.randn(1, i, 1, 1)).astype('float32'))
+    s = 1 / math.sqrt(i * 9)
+    k1 = torch.tensor([1., 3., 3., 1.])
+    k4 = k1[:, None] * k1[None, :]
+    k4 = (k4 / k4.sum() * 4).to(DEV)
+    noise = torch.from_numpy(rs.randn(b, 1, 2 * h, 2 * w).astype('float32')).to(DEV)
+    nw = torch.tensor([0.37], device=DEV)
+    bias = torch.from_numpy(rs.randn(o).astype('float32')).to(DEV)
+    dm = hip.demod(hip.weight_sqsum(wt.to(DEV), s), style.to(DEV))
+    wp = hip.pack_conv_weight(wt.to(DEV), 1)
+    wide = hip.conv_transpose3x3s2(x.to(DEV), wp, o, s, style=style.to(DEV), demod=dm,
+                                   impl=0 if i % 16 == 0 and o % 32 == 0 else 1)
+    uf = hip.pack_conv_transpose_blur_weight_wino4(wt.to(DEV), k4)
+    for kw in (dict(noise=noise, noise_w=nw, bias=bias, act=True), dict()):
+        want = hip.blur_noise_act(wide, k4, kw.get('noise'), kw.get('noise_w'), kw.get('bias'))
+        got = hip.conv_transpose3x3s2_blur_wino4(x.to(DEV), uf, o, s, style=style.to(DEV), demod=dm, **kw)
+        assert got.shape == want.shape == (b, o, 2 * h, 2 * w)
+        scale = want.abs().max().item()
+        assert (got - want).abs().max().item() < 1e-4 * scale, (got - want).abs().max().item() / scale
+        assert rel(got, want) < 3e-5, rel(got, want)
+    if b * i * o * h * w <= 2 ** 28:
+        key = style[:, :, None, None] * x
+        pre = R.demod_conv(key, style, wt, upsample=True)
+        ref = R.upfirdn2d(pre, k4.cpu(), pad=(1, 1))
+        assert rel(got, ref) < 3e-5
+
+
 def test_winograd_rejects_shapes_it_does_not_take():
     from rewriting_amd import hip
     assert not hip.wino_supported(32, 32, 16, 16) and not hip.wino_supported(48, 32, 32, 32)
