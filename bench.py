@@ -92,7 +92,7 @@ class ConvTimer:
         from rewriting_amd import hip
         self._orig = (hip.conv3x3, hip.conv_transpose3x3s2, hip.conv3x3_bf16x6, hip.conv3x3_to_rgb,
                       hip.conv3x3_wino, hip.conv3x3_wino_to_rgb, hip.conv3x3_wino4, hip.conv_transpose3x3s2_wino,
-                      hip.conv_transpose3x3s2_blur_wino4)
+                      hip.conv_transpose3x3s2_blur_wino4, hip.conv3x3_wino4_to_rgb)
         timer = self
 
         def wrap(fn, upsample, split=False, wino=None):
@@ -108,6 +108,8 @@ class ConvTimer:
                     name = 'conv_up_wino_kernel'
                 elif wino == 'up4':           # transposed conv + blur + noise + activation in one pass
                     name = 'conv_up_wino36_kernel'
+                elif wino == 'f4rgb':
+                    name = 'conv_wino36_rgb_kernel'
                 elif wino == 'f4':
                     name = 'conv_wino36b_kernel<2, 2>' if i <= 512 else 'conv_wino36_kernel<2, 2>'
                 elif wino is not None:
@@ -127,12 +129,13 @@ class ConvTimer:
         hip.conv3x3_wino4 = wrap(self._orig[6], False, wino='f4')
         hip.conv_transpose3x3s2_wino = wrap(self._orig[7], True, wino='up')
         hip.conv_transpose3x3s2_blur_wino4 = wrap(self._orig[8], True, wino='up4')
+        hip.conv3x3_wino4_to_rgb = wrap(self._orig[9], False, wino='f4rgb')
 
     def remove(self):
         from rewriting_amd import hip
         (hip.conv3x3, hip.conv_transpose3x3s2, hip.conv3x3_bf16x6, hip.conv3x3_to_rgb, hip.conv3x3_wino,
          hip.conv3x3_wino_to_rgb, hip.conv3x3_wino4, hip.conv_transpose3x3s2_wino,
-         hip.conv_transpose3x3s2_blur_wino4) = self._orig
+         hip.conv_transpose3x3s2_blur_wino4, hip.conv3x3_wino4_to_rgb) = self._orig
 
     def result(self):
         per = {}

@@ -208,6 +208,15 @@ int rw_pack_conv_weight_wino4_f32(const float* w, float* uf, int out_ch, int in_
 int rw_conv3x3_wino4_f32(const float* x, const float* uf, float* y, int batch, int in_ch, int out_ch, int h,
                          int w, float w_scale, const rw_conv_epilogue* ep, rw_stream_t stream);
 
+/* rw_conv3x3_wino4_f32 with ToRGB in its epilogue, as rw_conv3x3_wino_to_rgb_f32 (models.py:639-655): the last styled
+ * convolution of the generator; rgb->out = ToRGB(act(conv + noise + bias)) + rgb bias + skip, the feature map is not
+ * written.  Shapes: out_ch == 32, in_ch % 8 == 0, in_ch <= 512, w % 64 == 0, h % 8 == 0; uf from
+ * rw_pack_conv_weight_wino4_f32. */
+int rw_conv3x3_wino4_to_rgb_supported(int out_ch, int in_ch, int h, int w);
+int rw_conv3x3_wino4_to_rgb_f32(const float* x, const float* uf, int batch, int in_ch, int out_ch, int h, int w,
+                                float w_scale, const rw_conv_epilogue* ep, const rw_rgb_epilogue* rgb,
+                                rw_stream_t stream);
+
 /* F.conv_transpose2d(x, scale*W^T, stride=2, padding=0) [* demod]     (models.py:315-316,328)
  * x (B,Cin,H,W) -> y (B,Cout,2H+1,2W+1), wp from rw_pack_conv_weight_f32 mode 1. */
 int rw_conv_transpose3x3s2_f32(const float* x, const float* wp, float* y, int batch, int in_ch,

@@ -48,6 +48,9 @@ struct Wino4Problem {
   int groups_x, groups_y, gpw;
   float w_scale;
   int act;
+  // ToRGB in the epilogue (conv_wino36_rgb_kernel, out_ch == 32): see rw_rgb_epilogue
+  const float* rgb_weight; const float* rgb_style; const float* rgb_bias; const float* rgb_skip; float* rgb_out;
+  float rgb_scale;
 };
 
 #define W4_PC 66                // patch columns: 64 + 2
@@ -388,8 +391,18 @@ __device__ __forceinline__ void w4_dma_global_b32(unsigned lds_addr, const void*
 // written or read (8.6 GB each way at 32 x 1024^2 x 64 images), there are no border strips (the composed phases are
 // exact 'same' convolutions), and the blur pass disappears -- at 1.44x the matrix work of rw_upwino.hip's F(2,2),
 // which pays where the blur's traffic outweighs it: few channels, large maps.
-template <int WGN, int UDEPTH, bool UP>
+//
+// MODE 2 (conv_wino36_rgb_kernel) = the last styled convolution of the generator with ToRGB in its epilogue
+// (models.py:639-655; out_ch == 32 = one workgroup tile): every lane multiplies its activated outputs by the
+// modulated 1x1 ToRGB weights of its four channels, the sums over the wave's 16 channels go by a reduce-scatter over
+// the four 16-lane groups (lane (lk, lt) ends with row lk of its tile), the two waves that hold the other 16
+// channels of the same pixels exchange halves through LDS, and the feature map -- which nothing else reads -- is
+// never written.
+template <int WGN, int UDEPTH, int MODE>
 __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
+  constexpr bool UP = MODE == 1, RGB = MODE == 2;
+  constexpr int NSZ = RGB ? 384 : 256;            // floats of a wave's noise strip (RGB: also the exchange buffer)
+  constexpr int NST = RGB ? 3 : 16;               // stores of a group's epilogue per wave
   constexpr int WGM = 2;
   constexpr int WAVES = WGM * WGN, THREADS = 64 * WAVES;
   constexpr int PR = 4 * WGN + 2;                 // patch rows
@@ -401,9 +414,10 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
   constexpr int USZ = WGM * 9 * 256;              // floats per weight ring slot
   __shared__ __attribute__((aligned(16))) float Ps[3 * PSZ];
   __shared__ __attribute__((aligned(16))) float Us[UDEPTH * USZ];
-  __shared__ __attribute__((aligned(16))) float Ns[WAVES * 256];
+  __shared__ __attribute__((aligned(16))) float Ns[WAVES * NSZ];
   __shared__ float St[512];
   __shared__ float Ct[2][16 * WGM];
+  __shared__ float Cr[3][16 * WGM];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -431,6 +445,11 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
     const int real_ch = UP ? p.out_ch >> 2 : p.out_ch;
     Ct[0][tid] = p.demod ? p.demod[(int64_t)ib * real_ch + o] * p.w_scale : p.w_scale;
     Ct[1][tid] = p.act ? p.bias[o] : 0.f;
+    if (RGB) {
+      const float sr = p.rgb_scale * p.rgb_style[(int64_t)ib * p.out_ch + o];
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) Cr[cc][tid] = sr * p.rgb_weight[cc * p.out_ch + o];
+    }
   }
   const float noise_w = p.noise ? p.noise_w[0] : 0.f;
 
@@ -489,7 +508,7 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
   auto nload = [&](int g) __attribute__((always_inline)) {
     const float* np = p.noise + (int64_t)ib * hw + (int64_t)(y0 + 4 * wn) * p.w + (gx0 + g) * 64 + lane;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) w4_dma_global_b32(ns_base + (unsigned)((wave * 256 + 64 * r) * 4), np + (int64_t)r * p.w);
+    for (int r = 0; r < 4; ++r) w4_dma_global_b32(ns_base + (unsigned)((wave * NSZ + 64 * r) * 4), np + (int64_t)r * p.w);
   };
 
   w4_f32x4 acc[36];
@@ -608,13 +627,106 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
     for (int xi = 0; xi < 36; ++xi) acc[xi] = w4_f32x4{0.f, 0.f, 0.f, 0.f};
   };
 
-  auto group_epilogue = [&](int g) __attribute__((always_inline)) {
-    if (UP) { up_epilogue(g); return; }
+  auto rgb_epilogue = [&](int g) __attribute__((always_inline)) {
     const int oy = y0 + 4 * wn, ox = (gx0 + g) * 64 + 4 * lt;
     w4_f32x4 nz[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      nz[r] = p.noise ? *reinterpret_cast<const w4_f32x4*>(&Ns[wave * 256 + 64 * r + 4 * lt]) * noise_w
+      nz[r] = p.noise ? *reinterpret_cast<const w4_f32x4*>(&Ns[wave * NSZ + 64 * r + 4 * lt]) * noise_w
+                      : w4_f32x4{0.f, 0.f, 0.f, 0.f};
+    float rp[4][4][3];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) rp[r][k][0] = rp[r][k][1] = rp[r][k][2] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int oc = 16 * wm + 4 * lk + j;
+      const float scale = Ct[0][oc], bias = Ct[1][oc];
+      const float cr[3] = {Cr[0][oc], Cr[1][oc], Cr[2][oc]};
+      float t[4][6];
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        const float m0 = acc[b][j], m1 = acc[6 + b][j], m2 = acc[12 + b][j], m3 = acc[18 + b][j], m4 = acc[24 + b][j],
+                    m5 = acc[30 + b][j];
+        const float s1 = m1 + m2, s2 = m1 - m2, s3 = m3 + m4, s4 = m3 - m4;
+        t[0][b] = m0 + s1 + s3;
+        t[1][b] = s2 + 2.f * s4;
+        t[2][b] = s1 + 4.f * s3;
+        t[3][b] = s2 + 8.f * s4 + m5;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float s1 = t[r][1] + t[r][2], s2 = t[r][1] - t[r][2], s3 = t[r][3] + t[r][4], s4 = t[r][3] - t[r][4];
+        const float v[4] = {t[r][0] + s1 + s3, s2 + 2.f * s4, s1 + 4.f * s3, s2 + 8.f * s4 + t[r][5]};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float u = v[k] * scale + nz[r][k];
+          if (p.act) {
+            u += bias;
+            u = ((u > 0.f) ? u : u * 0.2f) * 1.4142135623730951f;
+          }
+#pragma unroll
+          for (int cc = 0; cc < 3; ++cc) rp[r][k][cc] += u * cr[cc];
+        }
+      }
+    }
+#pragma unroll
+    for (int xi = 0; xi < 36; ++xi) acc[xi] = w4_f32x4{0.f, 0.f, 0.f, 0.f};
+    // sum over the wave's 16 channels = over its four 16-lane groups, as a reduce-scatter: lane (lk, lt) ends with
+    // row lk of the tile
+    const bool hi = (lk & 2) != 0, odd = (lk & 1) != 0;
+    float q[2][4][3];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+          const float send = hi ? rp[a][k][cc] : rp[a + 2][k][cc];
+          q[a][k][cc] = (hi ? rp[a + 2][k][cc] : rp[a][k][cc]) + __shfl_xor(send, 32, 64);
+        }
+    w4_f32x4 sum[3];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) {
+        const float send = odd ? q[0][k][cc] : q[1][k][cc];
+        sum[cc][k] = (odd ? q[1][k][cc] : q[0][k][cc]) + __shfl_xor(send, 16, 64);
+      }
+    // the other 16 channels of the same pixels are in wave (1 - wm, wn): wave wm finishes rows 2 wm, 2 wm + 1 and
+    // hands the other two over
+    const bool mine = (lk >> 1) == wm;
+    const int slot = ((lk & 1) * 16 + lt) * 4;
+    asm volatile("" ::: "memory");
+    if (!mine) {
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) *reinterpret_cast<w4_f32x4*>(&Ns[wave * NSZ + cc * 128 + slot]) = sum[cc];
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);             // lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (mine) {
+      const int64_t pix = (int64_t)(oy + lk) * p.w + ox;
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) {
+        const w4_f32x4 other = *reinterpret_cast<const w4_f32x4*>(&Ns[(wave ^ WGN) * NSZ + cc * 128 + slot]);
+        const int64_t off = ((int64_t)ib * 3 + cc) * hw + pix;
+        w4_f32x4 o4 = sum[cc] + other + (p.rgb_bias ? p.rgb_bias[cc] : 0.f);
+        if (p.rgb_skip) o4 += *reinterpret_cast<const w4_f32x4*>(p.rgb_skip + off);
+        *reinterpret_cast<w4_f32x4*>(p.rgb_out + off) = o4;
+      }
+    }
+  };
+
+  auto group_epilogue = [&](int g) __attribute__((always_inline)) {
+    if (UP) { up_epilogue(g); return; }
+    if (RGB) { rgb_epilogue(g); return; }
+    const int oy = y0 + 4 * wn, ox = (gx0 + g) * 64 + 4 * lt;
+    w4_f32x4 nz[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      nz[r] = p.noise ? *reinterpret_cast<const w4_f32x4*>(&Ns[wave * NSZ + 64 * r + 4 * lt]) * noise_w
                       : w4_f32x4{0.f, 0.f, 0.f, 0.f};
     const float* ct = &Ct[0][16 * wm + 4 * lk];
     float* yb = p.y + ((int64_t)ib * p.out_ch + o0 + 16 * wm + 4 * lk) * hw + (int64_t)oy * p.w + ox;
@@ -660,11 +772,11 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
   const bool full_u = wave + WAVES * (UPW - 1) < 9 * WGM;
   auto sync_interval = [&](bool stores) __attribute__((always_inline)) {
     if (UDEPTH == 2) {
-      if (stores) W4_WAIT(PPW + 16); else W4_WAIT(PPW);
+      if (stores) W4_WAIT(PPW + NST); else W4_WAIT(PPW);
     } else if (full_u) {
-      if (stores) W4_WAIT(PPW + UPW + 16); else W4_WAIT(PPW + UPW);
+      if (stores) W4_WAIT(PPW + UPW + NST); else W4_WAIT(PPW + UPW);
     } else {
-      if (stores) W4_WAIT(PPW + UPW - 1 + 16); else W4_WAIT(PPW + UPW - 1);
+      if (stores) W4_WAIT(PPW + UPW - 1 + NST); else W4_WAIT(PPW + UPW - 1);
     }
     if (!(W4_ABL & 16)) __builtin_amdgcn_s_barrier();
   };
@@ -714,11 +826,15 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
 
 template <int WGN, int UDEPTH>
 __global__ void __launch_bounds__(128 * WGN, 4 / WGN) conv_wino36b_kernel(const Wino4Problem p) {
-  conv_wino36b_body<WGN, UDEPTH, false>(p);
+  conv_wino36b_body<WGN, UDEPTH, 0>(p);
 }
 // transposed convolution + blur + noise + bias + leaky ReLU (see UP above): <2, 2> only
 __global__ void __launch_bounds__(256, 2) conv_up_wino36_kernel(const Wino4Problem p) {
-  conv_wino36b_body<2, 2, true>(p);
+  conv_wino36b_body<2, 2, 1>(p);
+}
+// the last styled convolution with ToRGB in its epilogue (MODE 2 above): <2, 2> only
+__global__ void __launch_bounds__(256, 2) conv_wino36_rgb_kernel(const Wino4Problem p) {
+  conv_wino36b_body<2, 2, 2>(p);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -842,7 +958,7 @@ extern "C" int rw_conv3x3_wino4_f32(const float* x, const float* uf, float* y, i
   RW_CHECK_ARG(x && uf && y && batch > 0 && in_ch > 0 && out_ch > 0 && h > 0 && w > 0);
   RW_CHECK_ARG(!ep || ((!ep->noise || ep->noise_w) && (!ep->act || ep->bias)));
   if (!wino4_shape_ok(out_ch, in_ch, h, w)) return RW_ERR_UNSUPPORTED;
-  Wino4Problem p;
+  Wino4Problem p = {};
   p.x = x; p.uf = uf; p.y = y;
   p.style = ep ? ep->style : nullptr; p.demod = ep ? ep->demod : nullptr; p.noise = ep ? ep->noise : nullptr;
   p.noise_w = ep ? ep->noise_w : nullptr; p.bias = ep ? ep->bias : nullptr; p.act = ep ? ep->act : 0;
@@ -925,7 +1041,7 @@ extern "C" int rw_conv_transpose3x3s2_blur_wino4_f32(const float* x, const float
   RW_CHECK_ARG(x && uf && y && batch > 0 && in_ch > 0 && out_ch > 0 && h > 0 && w > 0);
   RW_CHECK_ARG(!ep || ((!ep->noise || ep->noise_w) && (!ep->act || ep->bias)));
   if (!up_wino4_shape_ok(out_ch, in_ch, h, w)) return RW_ERR_UNSUPPORTED;
-  Wino4Problem p;
+  Wino4Problem p = {};
   p.x = x; p.uf = uf; p.y = y;
   p.style = ep ? ep->style : nullptr; p.demod = ep ? ep->demod : nullptr; p.noise = ep ? ep->noise : nullptr;
   p.noise_w = ep ? ep->noise_w : nullptr; p.bias = ep ? ep->bias : nullptr; p.act = ep ? ep->act : 0;
@@ -946,5 +1062,44 @@ extern "C" int rw_conv_transpose3x3s2_blur_wino4_f32(const float* x, const float
   const int64_t work = (int64_t)batch * p.groups_y * (p.groups_x / gpw) * o_tiles;
   if (work <= 0 || work > 0x7fffffff) return RW_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(conv_up_wino36_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
+  return RW_LAUNCH_RESULT();
+}
+
+// ---------------------------------------------------------------------------------------
+// The last styled convolution of the generator with ToRGB in the epilogue (models.py:639-655), F(4x4,3x3):
+// rgb->out (B, 3, H, W) = ToRGB(act(conv(x) + noise + bias)) + rgb bias + skip; the feature map is not written.
+// ---------------------------------------------------------------------------------------
+extern "C" int rw_conv3x3_wino4_to_rgb_supported(int out_ch, int in_ch, int h, int w) {
+  return out_ch == 32 && in_ch <= 512 && wino4_shape_ok(out_ch, in_ch, h, w) ? 1 : 0;
+}
+
+extern "C" int rw_conv3x3_wino4_to_rgb_f32(const float* x, const float* uf, int batch, int in_ch, int out_ch, int h,
+                                           int w, float w_scale, const rw_conv_epilogue* ep,
+                                           const rw_rgb_epilogue* rgb, rw_stream_t stream) {
+  RW_CHECK_ARG(x && uf && rgb && rgb->weight && rgb->style && rgb->out && batch > 0 && in_ch > 0 && out_ch > 0);
+  RW_CHECK_ARG(!ep || ((!ep->noise || ep->noise_w) && (!ep->act || ep->bias)));
+  if (!rw_conv3x3_wino4_to_rgb_supported(out_ch, in_ch, h, w)) return RW_ERR_UNSUPPORTED;
+  Wino4Problem p = {};
+  p.x = x; p.uf = uf; p.y = nullptr;
+  p.style = ep ? ep->style : nullptr; p.demod = ep ? ep->demod : nullptr; p.noise = ep ? ep->noise : nullptr;
+  p.noise_w = ep ? ep->noise_w : nullptr; p.bias = ep ? ep->bias : nullptr; p.act = ep ? ep->act : 0;
+  p.rgb_weight = rgb->weight; p.rgb_style = rgb->style; p.rgb_bias = rgb->bias; p.rgb_skip = rgb->skip;
+  p.rgb_out = rgb->out; p.rgb_scale = rgb->scale;
+  p.batch = batch; p.in_ch = in_ch; p.out_ch = out_ch; p.h = h; p.w = w; p.w_scale = w_scale;
+  p.groups_x = w / 64;
+  p.groups_y = h / 8;
+  const char* e = getenv("RW_WINO4_GPW");
+  int gpw = e ? atoi(e) : 4;
+  if (gpw < 1) gpw = 1;
+  if (gpw > p.groups_x) gpw = p.groups_x;
+  while (p.groups_x % gpw) --gpw;
+  while (gpw > 1 && (int64_t)batch * p.groups_y * (p.groups_x / gpw) < 1024) {
+    --gpw;
+    while (p.groups_x % gpw) --gpw;
+  }
+  p.gpw = gpw;
+  const int64_t work = (int64_t)batch * p.groups_y * (p.groups_x / gpw);
+  if (work <= 0 || work > 0x7fffffff) return RW_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(conv_wino36_rgb_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
   return RW_LAUNCH_RESULT();
 }

@@ -314,6 +314,38 @@ def conv3x3_wino_to_rgb(x, uf, out_ch, w_scale, rgb_weight, rgb_style, rgb_bias,
     return y, rgb
 
 
+def wino4_to_rgb_supported(out_ch, in_ch, height, width):
+    """Shapes conv3x3_wino4_to_rgb takes (rw_conv3x3_wino4_to_rgb_supported: out_ch == 32)."""
+    return bool(lib().rw_conv3x3_wino4_to_rgb_supported(int(out_ch), int(in_ch), int(height), int(width)))
+
+
+def conv3x3_wino4_to_rgb(x, uf, out_ch, w_scale, rgb_weight, rgb_style, rgb_bias, rgb_skip, rgb_scale, style=None,
+                         demod=None, noise=None, noise_w=None, bias=None, act=False):
+    """conv3x3_wino4 with ToRGB in the epilogue (out_ch == 32): returns (None, rgb image); the feature map is not
+    written."""
+    x = _dev(x, 'fmap')
+    uf = _dev(uf, 'packed weight')
+    rgb_weight = _dev(rgb_weight, 'rgb weight').contiguous()
+    rgb_style = _dev(rgb_style, 'rgb style').contiguous()
+    rgb_bias = _opt(rgb_bias, 'rgb bias')
+    rgb_skip = _opt(rgb_skip, 'rgb skip')
+    b, i, h, w = x.shape
+    if tuple(rgb_weight.shape) != (3, out_ch) or tuple(rgb_style.shape) != (b, out_ch):
+        raise ValueError('rgb weight / style shapes')
+    if rgb_skip is not None and tuple(rgb_skip.shape) != (b, 3, h, w):
+        raise ValueError('rgb skip shape')
+    if uf.numel() != lib().rw_packed_conv_weight_wino4_elems(out_ch, i):
+        raise ValueError('packed weight does not come from pack_conv_weight_wino4(%d x %d)' % (out_ch, i))
+    rgb = torch.empty(b, 3, h, w, device=x.device, dtype=x.dtype)
+    ep, keep = _epilogue(style, demod, noise, noise_w, bias, act)
+    from ._lib import RgbEpilogue
+    re = RgbEpilogue(_p(rgb_weight).value, _p(rgb_style).value, _p(rgb_bias).value, _p(rgb_skip).value,
+                     _p(rgb).value, float(rgb_scale))
+    check(lib().rw_conv3x3_wino4_to_rgb_f32(_p(x), _p(uf), b, i, out_ch, h, w, float(w_scale), ctypes.byref(ep),
+                                            ctypes.byref(re), _stream()))
+    return None, rgb
+
+
 def bf16x6_supported(out_ch, in_ch, width):
     """Shapes the opt-in split-precision convolution takes (rw_conv3x3_bf16x6_f32)."""
     return width >= 24 and in_ch % 16 == 0 and in_ch <= 1024 and out_ch % 64 == 0

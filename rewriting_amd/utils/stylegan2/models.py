@@ -755,9 +755,13 @@ class StyledConvSeq(nn.Sequential):
                 rgb_style = torgb.conv.modulation(d.latent[:, idx])
                 wino = (conv_algo() in ('winograd', 'winograd4') and dconv.out_channel == 32
                         and hip.wino_supported(dconv.out_channel, dconv.in_channel, h, w))
-                fused = hip.conv3x3_wino_to_rgb if wino else hip.conv3x3_to_rgb
+                wino4 = (conv_algo() == 'winograd4' and os.environ.get('RW_RGB_F4', '1') != '0'
+                         and hip.wino4_to_rgb_supported(dconv.out_channel, dconv.in_channel, h, w))
+                fused = (hip.conv3x3_wino4_to_rgb if wino4 else
+                         hip.conv3x3_wino_to_rgb if wino else hip.conv3x3_to_rgb)
                 _, rgb = fused(
-                    fmap, dconv.wino_weight() if wino else dconv.packed_weight(), dconv.out_channel, dconv.scale,
+                    fmap, dconv.wino4_weight() if wino4 else dconv.wino_weight() if wino else dconv.packed_weight(),
+                    dconv.out_channel, dconv.scale,
                     torgb.conv.weight.view(3, torgb.conv.in_channel), rgb_style, torgb.bias.view(3), skip,
                     torgb.conv.scale, style=style, demod=dconv.demod_factors(style), noise=noise,
                     noise_w=self.noise.weight, bias=act.bias, act=True)

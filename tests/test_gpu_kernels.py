@@ -328,6 +328,21 @@ def test_winograd_f4_conv_matches_oracle_within_its_error_class(case):
         ref = torch.nn.functional.conv2d(key.double(), wt[0].double(), padding=1) * s * dm.cpu().double()[:, :, None, None]
         e_w = ((plain.cpu().double() - ref).norm() / ref.norm()).item()
         assert e_w < 2e-5, e_w
+    if o == 32:                                             # ToRGB in the epilogue (the feature map is not written)
+        assert hip.wino4_to_rgb_supported(o, i, h, w)
+        wrgb = torch.from_numpy(rs.randn(3, o).astype('float32')).to(DEV)
+        srgb = torch.from_numpy((1 + 0.3 * rs.randn(b, o)).astype('float32')).to(DEV)
+        brgb = torch.from_numpy(rs.randn(3).astype('float32')).to(DEV)
+        skip = torch.from_numpy(rs.randn(b, 3, h, w).astype('float32')).to(DEV)
+        want_rgb = hip.to_rgb(got, wrgb, srgb, brgb, skip, 1 / math.sqrt(o))
+        y, rgb = hip.conv3x3_wino4_to_rgb(x.to(DEV), uf, o, s, wrgb, srgb, brgb, skip, 1 / math.sqrt(o), **args)
+        assert y is None and rel(rgb, want_rgb) < 2e-6, rel(rgb, want_rgb)
+        _, rgb2 = hip.conv3x3_wino4_to_rgb(x.to(DEV), uf, o, s, wrgb, srgb, None, None, 1 / math.sqrt(o), **args)
+        assert rel(rgb2, want_rgb - skip - brgb.view(1, 3, 1, 1)) < 1e-5
+        plain_rgb = hip.to_rgb(plain, wrgb, srgb, None, None, 1 / math.sqrt(o))
+        _, rgb3 = hip.conv3x3_wino4_to_rgb(x.to(DEV), uf, o, s, wrgb, srgb, None, None, 1 / math.sqrt(o),
+                                           style=style.to(DEV), demod=dm)
+        assert rel(rgb3, plain_rgb) < 1e-5
 
 
 UP_WINO_CASES = [(2, 16, 32, 4, 32), (1, 64, 64, 8, 32), (1, 128, 64, 16, 64), (3, 32, 32, 12, 96), (1, 512, 512, 32, 32),
