@@ -574,7 +574,10 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
     const int ch = (o0 >> 2) + 4 * wm + lk;
     float* yb = p.y + ((int64_t)ib * (p.out_ch >> 2) + ch) * hw2 + (int64_t)(2 * oy) * W2 + 2 * ox;
     const float* nb = p.noise ? p.noise + (int64_t)ib * hw2 + (int64_t)(2 * oy) * W2 + 2 * ox : nullptr;
-    const float scale = Ct[0][16 * wm + 4 * lk], bias = Ct[1][16 * wm + 4 * lk];
+    // leaky ReLU and its gain as max(t, 0.2 t) on values that already carry the gain (act off: slope 1, gain 1)
+    const float gain = p.act ? 1.4142135623730951f : 1.f, slope = p.act ? 0.2f : 1.f;
+    const float scale = Ct[0][16 * wm + 4 * lk] * gain, bias = Ct[1][16 * wm + 4 * lk] * gain;
+    const float nwg = noise_w * gain;
 #pragma unroll
     for (int py = 0; py < 2; ++py) {
       float v[2][4][4];
@@ -604,20 +607,15 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
         const int64_t off = (int64_t)(2 * r + py) * W2;
         w4_f32x4 n0 = {0.f, 0.f, 0.f, 0.f}, n1 = n0;
         if (p.noise) {
-          n0 = *reinterpret_cast<const w4_f32x4*>(nb + off) * noise_w;
-          n1 = *reinterpret_cast<const w4_f32x4*>(nb + off + 4) * noise_w;
+          n0 = *reinterpret_cast<const w4_f32x4*>(nb + off) * nwg;
+          n1 = *reinterpret_cast<const w4_f32x4*>(nb + off + 4) * nwg;
         }
         w4_f32x4 q0 = {v[0][r][0], v[1][r][0], v[0][r][1], v[1][r][1]};
         w4_f32x4 q1 = {v[0][r][2], v[1][r][2], v[0][r][3], v[1][r][3]};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          float u0 = q0[k] * scale + n0[k], u1 = q1[k] * scale + n1[k];
-          if (p.act) {
-            u0 += bias; u1 += bias;
-            u0 = ((u0 > 0.f) ? u0 : u0 * 0.2f) * 1.4142135623730951f;
-            u1 = ((u1 > 0.f) ? u1 : u1 * 0.2f) * 1.4142135623730951f;
-          }
-          q0[k] = u0; q1[k] = u1;
+          const float u0 = q0[k] * scale + n0[k] + bias, u1 = q1[k] * scale + n1[k] + bias;
+          q0[k] = fmaxf(u0, u0 * slope); q1[k] = fmaxf(u1, u1 * slope);
         }
         *reinterpret_cast<w4_f32x4*>(yb + off) = q0;
         *reinterpret_cast<w4_f32x4*>(yb + off + 4) = q1;
@@ -629,10 +627,11 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
 
   auto rgb_epilogue = [&](int g) __attribute__((always_inline)) {
     const int oy = y0 + 4 * wn, ox = (gx0 + g) * 64 + 4 * lt;
+    const float gain = p.act ? 1.4142135623730951f : 1.f, slope = p.act ? 0.2f : 1.f;
     w4_f32x4 nz[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      nz[r] = p.noise ? *reinterpret_cast<const w4_f32x4*>(&Ns[wave * NSZ + 64 * r + 4 * lt]) * noise_w
+      nz[r] = p.noise ? *reinterpret_cast<const w4_f32x4*>(&Ns[wave * NSZ + 64 * r + 4 * lt]) * (noise_w * gain)
                       : w4_f32x4{0.f, 0.f, 0.f, 0.f};
     float rp[4][4][3];
 #pragma unroll
@@ -642,7 +641,7 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int oc = 16 * wm + 4 * lk + j;
-      const float scale = Ct[0][oc], bias = Ct[1][oc];
+      const float scale = Ct[0][oc] * gain, bias = Ct[1][oc] * gain;
       const float cr[3] = {Cr[0][oc], Cr[1][oc], Cr[2][oc]};
       float t[4][6];
 #pragma unroll
@@ -661,11 +660,8 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
         const float v[4] = {t[r][0] + s1 + s3, s2 + 2.f * s4, s1 + 4.f * s3, s2 + 8.f * s4 + t[r][5]};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          float u = v[k] * scale + nz[r][k];
-          if (p.act) {
-            u += bias;
-            u = ((u > 0.f) ? u : u * 0.2f) * 1.4142135623730951f;
-          }
+          float u = v[k] * scale + nz[r][k] + bias;
+          u = fmaxf(u, u * slope);
 #pragma unroll
           for (int cc = 0; cc < 3; ++cc) rp[r][k][cc] += u * cr[cc];
         }
@@ -723,16 +719,17 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
     if (UP) { up_epilogue(g); return; }
     if (RGB) { rgb_epilogue(g); return; }
     const int oy = y0 + 4 * wn, ox = (gx0 + g) * 64 + 4 * lt;
+    const float gain = p.act ? 1.4142135623730951f : 1.f, slope = p.act ? 0.2f : 1.f;
     w4_f32x4 nz[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      nz[r] = p.noise ? *reinterpret_cast<const w4_f32x4*>(&Ns[wave * NSZ + 64 * r + 4 * lt]) * noise_w
+      nz[r] = p.noise ? *reinterpret_cast<const w4_f32x4*>(&Ns[wave * NSZ + 64 * r + 4 * lt]) * (noise_w * gain)
                       : w4_f32x4{0.f, 0.f, 0.f, 0.f};
     const float* ct = &Ct[0][16 * wm + 4 * lk];
     float* yb = p.y + ((int64_t)ib * p.out_ch + o0 + 16 * wm + 4 * lk) * hw + (int64_t)oy * p.w + ox;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float scale = ct[j], bias = ct[16 * WGM + j];
+      const float scale = ct[j] * gain, bias = ct[16 * WGM + j] * gain;
       float t[4][6];
 #pragma unroll
       for (int b = 0; b < 6; ++b) {
@@ -750,12 +747,8 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
         w4_f32x4 v = {t[r][0] + s1 + s3, s2 + 2.f * s4, s1 + 4.f * s3, s2 + 8.f * s4 + t[r][5]};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          float u = v[k] * scale + nz[r][k];
-          if (p.act) {
-            u += bias;
-            u = ((u > 0.f) ? u : u * 0.2f) * 1.4142135623730951f;
-          }
-          v[k] = u;
+          const float u = v[k] * scale + nz[r][k] + bias;
+          v[k] = fmaxf(u, u * slope);
         }
         *reinterpret_cast<w4_f32x4*>(yb + (int64_t)j * hw + (int64_t)r * p.w) = v;
       }
