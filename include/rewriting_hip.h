@@ -249,14 +249,16 @@ int rw_conv_transpose3x3s2_wino_f32(const float* x, const float* uf, float* y, i
  *       rw_pack_conv_transpose_blur_weight_wino4_f32(w, k4): w = the (1,out_ch,in_ch,3,3) parameter, k4 = the 4x4
  *       FIR buffer of the layer's Blur (already multiplied by 4); layout of rw_pack_conv_weight_wino4_f32 with
  *       virtual channel 4 o + 2 py + px.
- *   ep: style / demod / noise (B x 2H x 2W) + noise_w / bias + act as in rw_conv_epilogue. */
+ *   ep: style / demod / noise (B x 2H x 2W) + noise_w / bias + act as in rw_conv_epilogue.
+ *   post_scale (batch x out_ch, nullable): a factor on the finished result -- the style of the convolution that
+ *       consumes y, which then runs with style == NULL (the F(4x4,3x3) kernels skip the multiply in their loop). */
 int rw_conv_transpose_blur_wino4_supported(int out_ch, int in_ch, int h, int w);
 long long rw_packed_conv_transpose_blur_wino4_elems(int out_ch, int in_ch);
 int rw_pack_conv_transpose_blur_weight_wino4_f32(const float* w, const float* k4, float* uf, int out_ch, int in_ch,
                                                  rw_stream_t stream);
 int rw_conv_transpose3x3s2_blur_wino4_f32(const float* x, const float* uf, float* y, int batch, int in_ch,
                                           int out_ch, int h, int w, float w_scale, const rw_conv_epilogue* ep,
-                                          rw_stream_t stream);
+                                          const float* post_scale, rw_stream_t stream);
 
 /* NoiseInjectionF (models.py:535-546): y[b][c][p] = x[b][c][p] + noise_w[0] * noise[b][p] */
 int rw_noise_add_f32(const float* x, const float* noise, const float* noise_w, float* y,
@@ -268,6 +270,11 @@ int rw_noise_add_f32(const float* x, const float* noise, const float* noise_w, f
 int rw_blur_noise_act_f32(const float* x, const float* k4, const float* noise, const float* noise_w,
                           const float* bias, float* y, int batch, int channels, int out_h, int out_w,
                           rw_stream_t stream);
+/* The same with a per (image, channel) factor on the result (batch x channels, nullable): the style of the
+ * convolution that consumes y, handed over pre-multiplied. */
+int rw_blur_noise_act_scaled_f32(const float* x, const float* k4, const float* noise, const float* noise_w,
+                                 const float* bias, const float* post_scale, float* y, int batch, int channels,
+                                 int out_h, int out_w, rw_stream_t stream);
 
 /* ToRGBF (models.py:628-655): y[b][c][p] = sum_i (W[c][i]*style[b][i]*w_scale) x[b][i][p]
  * + bias[c] + skip[b][c][p]; out channels = 3, skip nullable. */

@@ -562,7 +562,7 @@ extern "C" int rw_pack_conv_weight_f32(const float* w, float* wp, int out_ch, in
 __global__ void __launch_bounds__(256) blur_noise_act_kernel(
     const float* __restrict__ x, const float* __restrict__ k4, const float* __restrict__ noise,
     const float* __restrict__ nw_ptr, const float* __restrict__ bias, float* __restrict__ y,
-    int batch, int channels, int out_h, int out_w, int tiles_x, int tiles_y) {
+    int batch, int channels, int out_h, int out_w, int tiles_x, int tiles_y, const float* __restrict__ post) {
   __shared__ float kf[16];
   __shared__ __attribute__((aligned(16))) float tile[BL_TH + 3][BL_PITCH];
   const int tid = threadIdx.x;
@@ -616,6 +616,7 @@ __global__ void __launch_bounds__(256) blur_noise_act_kernel(
   if (ox >= out_w) return;
   const float nw = noise ? nw_ptr[0] : 0.f;
   const float bv = bias ? bias[c] : 0.f;
+  const float ps = post ? post[bc] : 1.f;       // per (image, channel) factor on the result: the NEXT layer's style
   const bool full = (out_w % 4 == 0);           // then ox + 3 < out_w and every row start is 16-byte aligned
 #pragma unroll
   for (int half = 0; half < BL_TH / 16; ++half) {
@@ -649,7 +650,7 @@ __global__ void __launch_bounds__(256) blur_noise_act_kernel(
     for (int q = 0; q < 4; ++q) {
       float v = acc[q] + nw * nzv[q];
       if (bias) { v += bv; v = ((v > 0.f) ? v : v * 0.2f) * 1.4142135623730951f; }
-      res[q] = v;
+      res[q] = post ? v * ps : v;
     }
     float* yo = y + (bc * out_h + oy) * (int64_t)out_w + ox;
     if (full) {
@@ -661,17 +662,24 @@ __global__ void __launch_bounds__(256) blur_noise_act_kernel(
   }
 }
 
-extern "C" int rw_blur_noise_act_f32(const float* x, const float* k4, const float* noise,
-                                     const float* noise_w, const float* bias, float* y, int batch,
-                                     int channels, int out_h, int out_w, rw_stream_t stream) {
+extern "C" int rw_blur_noise_act_scaled_f32(const float* x, const float* k4, const float* noise,
+                                            const float* noise_w, const float* bias, const float* post_scale,
+                                            float* y, int batch, int channels, int out_h, int out_w,
+                                            rw_stream_t stream) {
   RW_CHECK_ARG(x && k4 && y && batch > 0 && channels > 0 && out_h > 0 && out_w > 0);
   RW_CHECK_ARG(!noise || noise_w);
   const int tiles_x = (int)rw_cdiv(out_w, BL_TW), tiles_y = (int)rw_cdiv(out_h, BL_TH);
   const int64_t blocks = (int64_t)batch * channels * tiles_x * tiles_y;
   if (blocks > 0x7fffffff) return RW_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(blur_noise_act_kernel, dim3((unsigned)blocks), dim3(256), 0, rw_s(stream), x, k4,
-                     noise, noise_w, bias, y, batch, channels, out_h, out_w, tiles_x, tiles_y);
+                     noise, noise_w, bias, y, batch, channels, out_h, out_w, tiles_x, tiles_y, post_scale);
   return RW_LAUNCH_RESULT();
+}
+
+extern "C" int rw_blur_noise_act_f32(const float* x, const float* k4, const float* noise,
+                                     const float* noise_w, const float* bias, float* y, int batch,
+                                     int channels, int out_h, int out_w, rw_stream_t stream) {
+  return rw_blur_noise_act_scaled_f32(x, k4, noise, noise_w, bias, nullptr, y, batch, channels, out_h, out_w, stream);
 }
 
 // ---------------------------------------------------------------------------------------

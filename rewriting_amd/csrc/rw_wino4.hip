@@ -51,6 +51,7 @@ struct Wino4Problem {
   // ToRGB in the epilogue (conv_wino36_rgb_kernel, out_ch == 32): see rw_rgb_epilogue
   const float* rgb_weight; const float* rgb_style; const float* rgb_bias; const float* rgb_skip; float* rgb_out;
   float rgb_scale;
+  const float* post;            // UP: (batch x real out_ch) factor on the result (the next layer's style), nullable
 };
 
 #define W4_PC 66                // patch columns: 64 + 2
@@ -398,7 +399,9 @@ __device__ __forceinline__ void w4_dma_global_b32(unsigned lds_addr, const void*
 // the four 16-lane groups (lane (lk, lt) ends with row lk of its tile), the two waves that hold the other 16
 // channels of the same pixels exchange halves through LDS, and the feature map -- which nothing else reads -- is
 // never written.
-template <int WGN, int UDEPTH, int MODE>
+// STYLE = false: the input map already carries this layer's style (its producer multiplied it in: `post` of the
+// UP epilogue, rw_blur_noise_act_scaled_f32) -- 18 packed multiplies per item less in the loop.
+template <int WGN, int UDEPTH, int MODE, bool STYLE>
 __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
   constexpr bool UP = MODE == 1, RGB = MODE == 2;
   constexpr int NSZ = RGB ? 384 : 256;            // floats of a wave's noise strip (RGB: also the exchange buffer)
@@ -529,9 +532,15 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
       const w4_f32x4 lo = *reinterpret_cast<const w4_f32x4*>(src + r * W4B_PITCH);
-      c2[r][0] = w4_f32x2{lo[0], lo[1]} * sv;
-      c2[r][1] = w4_f32x2{lo[2], lo[3]} * sv;
-      c2[r][2] = *reinterpret_cast<const w4_f32x2*>(src + r * W4B_PITCH + 4) * sv;
+      if (STYLE) {
+        c2[r][0] = w4_f32x2{lo[0], lo[1]} * sv;
+        c2[r][1] = w4_f32x2{lo[2], lo[3]} * sv;
+        c2[r][2] = *reinterpret_cast<const w4_f32x2*>(src + r * W4B_PITCH + 4) * sv;
+      } else {
+        c2[r][0] = w4_f32x2{lo[0], lo[1]};
+        c2[r][1] = w4_f32x2{lo[2], lo[3]};
+        c2[r][2] = *reinterpret_cast<const w4_f32x2*>(src + r * W4B_PITCH + 4);
+      }
     }
     float d[6][6];
 #pragma unroll
@@ -578,6 +587,7 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
     const float gain = p.act ? 1.4142135623730951f : 1.f, slope = p.act ? 0.2f : 1.f;
     const float scale = Ct[0][16 * wm + 4 * lk] * gain, bias = Ct[1][16 * wm + 4 * lk] * gain;
     const float nwg = noise_w * gain;
+    const float post = p.post ? p.post[(int64_t)ib * (p.out_ch >> 2) + ch] : 1.f;
 #pragma unroll
     for (int py = 0; py < 2; ++py) {
       float v[2][4][4];
@@ -615,7 +625,7 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const float u0 = q0[k] * scale + n0[k] + bias, u1 = q1[k] * scale + n1[k] + bias;
-          q0[k] = fmaxf(u0, u0 * slope); q1[k] = fmaxf(u1, u1 * slope);
+          q0[k] = fmaxf(u0, u0 * slope) * post; q1[k] = fmaxf(u1, u1 * slope) * post;
         }
         *reinterpret_cast<w4_f32x4*>(yb + off) = q0;
         *reinterpret_cast<w4_f32x4*>(yb + off + 4) = q1;
@@ -819,26 +829,27 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
 
 template <int WGN, int UDEPTH>
 __global__ void __launch_bounds__(128 * WGN, 4 / WGN) conv_wino36b_kernel(const Wino4Problem p) {
-  conv_wino36b_body<WGN, UDEPTH, 0>(p);
+  conv_wino36b_body<WGN, UDEPTH, 0, true>(p);
 }
 // transposed convolution + blur + noise + bias + leaky ReLU (see UP above): <2, 2> only
 __global__ void __launch_bounds__(256, 2) conv_up_wino36_kernel(const Wino4Problem p) {
-  conv_wino36b_body<2, 2, 1>(p);
+  conv_wino36b_body<2, 2, 1, true>(p);
 }
 // the last styled convolution with ToRGB in its epilogue (MODE 2 above): <2, 2> only
 __global__ void __launch_bounds__(256, 2) conv_wino36_rgb_kernel(const Wino4Problem p) {
-  conv_wino36b_body<2, 2, 2>(p);
+  conv_wino36b_body<2, 2, 2, true>(p);
+}
+// the same three on an input map that already carries the style (STYLE = false; chosen when the style pointer is null)
+__global__ void __launch_bounds__(256, 2) conv_wino36b_ns_kernel(const Wino4Problem p) {
+  conv_wino36b_body<2, 2, 0, false>(p);
+}
+__global__ void __launch_bounds__(256, 2) conv_up_wino36_ns_kernel(const Wino4Problem p) {
+  conv_wino36b_body<2, 2, 1, false>(p);
+}
+__global__ void __launch_bounds__(256, 2) conv_wino36_rgb_ns_kernel(const Wino4Problem p) {
+  conv_wino36b_body<2, 2, 2, false>(p);
 }
 
-// ---------------------------------------------------------------------------------------
-// What bounds these kernels (scripts/probe/mfma_valu_probe): on gfx950 an fp32 MFMA and vector-ALU work do NOT
-// overlap.  v_mfma_f32_16x16x4_f32 alone runs at 145 TFLOP/s (the clock under load: 2.2 GHz); every v_fma_f32
-// placed between two of them costs ~2.7 of the 32 MFMA cycles, every v_pk_fma_f32 ~6 -- from the same wave or
-// from the other wave of the SIMD.  What counts is therefore VALU instructions per MFMA: 4.9 here (2.6 of them
-// packed) = ~22 cycles per 32-cycle MFMA, i.e. the 45 - 47 % matrix-pipe occupancy that PMC shows.  A variant with
-// one wave per SIMD holding 32 out-channels (each transformed value feeding two MFMAs, 288 accumulators) halves
-// that ratio on paper; the register allocator spills it (1 KB of scratch per lane), so it is not in the tree.
-// ---------------------------------------------------------------------------------------
 // G g G^T of one 3x3 kernel g[3 ky + kx] -> the 36 values of lane `dst` (stride 256 floats per point quad)
 __device__ __forceinline__ void w4_pack_store(const float* g, float* dst) {
     // G = [[1/4,0,0],[-1/6,-1/6,-1/6],[-1/6,1/6,-1/6],[1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]]
@@ -993,7 +1004,8 @@ extern "C" int rw_conv3x3_wino4_f32(const float* x, const float* uf, float* y, i
     return RW_LAUNCH_RESULT();
   }
   if (version == 3 && in_ch <= 512) {
-    hipLaunchKernelGGL((conv_wino36b_kernel<2, 2>), dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
+    if (p.style) hipLaunchKernelGGL((conv_wino36b_kernel<2, 2>), dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
+    else hipLaunchKernelGGL(conv_wino36b_ns_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
     return RW_LAUNCH_RESULT();
   }
   hipLaunchKernelGGL((conv_wino36_kernel<2, 2>), dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
@@ -1030,7 +1042,8 @@ extern "C" int rw_pack_conv_transpose_blur_weight_wino4_f32(const float* w, cons
 
 extern "C" int rw_conv_transpose3x3s2_blur_wino4_f32(const float* x, const float* uf, float* y, int batch, int in_ch,
                                                      int out_ch, int h, int w, float w_scale,
-                                                     const rw_conv_epilogue* ep, rw_stream_t stream) {
+                                                     const rw_conv_epilogue* ep, const float* post_scale,
+                                                     rw_stream_t stream) {
   RW_CHECK_ARG(x && uf && y && batch > 0 && in_ch > 0 && out_ch > 0 && h > 0 && w > 0);
   RW_CHECK_ARG(!ep || ((!ep->noise || ep->noise_w) && (!ep->act || ep->bias)));
   if (!up_wino4_shape_ok(out_ch, in_ch, h, w)) return RW_ERR_UNSUPPORTED;
@@ -1038,6 +1051,7 @@ extern "C" int rw_conv_transpose3x3s2_blur_wino4_f32(const float* x, const float
   p.x = x; p.uf = uf; p.y = y;
   p.style = ep ? ep->style : nullptr; p.demod = ep ? ep->demod : nullptr; p.noise = ep ? ep->noise : nullptr;
   p.noise_w = ep ? ep->noise_w : nullptr; p.bias = ep ? ep->bias : nullptr; p.act = ep ? ep->act : 0;
+  p.post = post_scale;
   p.batch = batch; p.in_ch = in_ch; p.out_ch = 4 * out_ch; p.h = h; p.w = w; p.w_scale = w_scale;
   p.groups_x = w / 64;
   p.groups_y = h / 8;
@@ -1054,7 +1068,8 @@ extern "C" int rw_conv_transpose3x3s2_blur_wino4_f32(const float* x, const float
   p.gpw = gpw;
   const int64_t work = (int64_t)batch * p.groups_y * (p.groups_x / gpw) * o_tiles;
   if (work <= 0 || work > 0x7fffffff) return RW_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(conv_up_wino36_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
+  if (p.style) hipLaunchKernelGGL(conv_up_wino36_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
+  else hipLaunchKernelGGL(conv_up_wino36_ns_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
   return RW_LAUNCH_RESULT();
 }
 
@@ -1093,6 +1108,7 @@ extern "C" int rw_conv3x3_wino4_to_rgb_f32(const float* x, const float* uf, int 
   p.gpw = gpw;
   const int64_t work = (int64_t)batch * p.groups_y * (p.groups_x / gpw);
   if (work <= 0 || work > 0x7fffffff) return RW_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(conv_wino36_rgb_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
+  if (p.style) hipLaunchKernelGGL(conv_wino36_rgb_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
+  else hipLaunchKernelGGL(conv_wino36_rgb_ns_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
   return RW_LAUNCH_RESULT();
 }

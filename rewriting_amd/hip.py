@@ -453,7 +453,7 @@ def pack_conv_transpose_blur_weight_wino4(weight, k4):
 
 
 def conv_transpose3x3s2_blur_wino4(x, uf, out_ch, w_scale, style=None, demod=None, noise=None, noise_w=None,
-                                   bias=None, act=False):
+                                   bias=None, act=False, post_scale=None):
     """conv_transpose3x3s2 -> blur(pad 1,1) -> noise -> bias + leaky ReLU in one pass: (B,Cin,H,W) -> (B,Cout,2H,2W),
     the four output-parity phases as virtual channels of the F(4x4,3x3) kernel (its error class: image generation)."""
     x = _dev(x, 'fmap')
@@ -464,8 +464,11 @@ def conv_transpose3x3s2_blur_wino4(x, uf, out_ch, w_scale, style=None, demod=Non
                          % (out_ch, i))
     y = torch.empty(b, out_ch, 2 * h, 2 * w, device=x.device, dtype=x.dtype)
     ep, keep = _epilogue(style, demod, noise, noise_w, bias, act)
+    post_scale = _opt(post_scale, 'post scale')
+    if post_scale is not None and tuple(post_scale.shape) != (b, out_ch):
+        raise ValueError('post_scale must be batch x out_ch')
     check(lib().rw_conv_transpose3x3s2_blur_wino4_f32(_p(x), _p(uf), _p(y), b, i, out_ch, h, w, float(w_scale),
-                                                      ctypes.byref(ep), _stream()))
+                                                      ctypes.byref(ep), _p(post_scale), _stream()))
     return y
 
 
@@ -479,7 +482,9 @@ def noise_add(x, noise, noise_w):
     return y
 
 
-def blur_noise_act(x, k4, noise, noise_w, bias):
+def blur_noise_act(x, k4, noise, noise_w, bias, post_scale=None):
+    """Blur(pad 1,1) + noise + bias + leaky ReLU of an upsampling layer in one pass; post_scale (B x C, optional):
+    a factor on the result -- the style of the convolution that consumes it."""
     x = _dev(x, 'fmap')
     k4 = _dev(k4, 'blur kernel')
     noise = _opt(noise, 'noise')
@@ -487,8 +492,11 @@ def blur_noise_act(x, k4, noise, noise_w, bias):
     bias = _opt(bias, 'bias')
     b, c, ih, iw = x.shape
     y = torch.empty(b, c, ih - 1, iw - 1, device=x.device, dtype=x.dtype)
-    check(lib().rw_blur_noise_act_f32(_p(x), _p(k4), _p(noise), _p(noise_w), _p(bias), _p(y), b, c,
-                                      ih - 1, iw - 1, _stream()))
+    post_scale = _opt(post_scale, 'post scale')
+    if post_scale is not None and tuple(post_scale.shape) != (b, c):
+        raise ValueError('post_scale must be batch x channels')
+    check(lib().rw_blur_noise_act_scaled_f32(_p(x), _p(k4), _p(noise), _p(noise_w), _p(bias), _p(post_scale), _p(y),
+                                             b, c, ih - 1, iw - 1, _stream()))
     return y
 
 

@@ -140,6 +140,7 @@ class _RgbBranch(threading.local):      # per thread: two threads may run genera
         self.keep = []
         self.final = None        # (last StyledConvSeq, its ToRGBF, latent index of the ToRGB) of the running forward
         self.image_path = False  # inside the un-hooked forward of a whole generator (see conv_algo)
+        self.successor = {}      # id(upsampling StyledConvSeq) -> (the StyledConvSeq that reads its result, latent index)
 
 
 _rgb_branch = _RgbBranch()
@@ -717,26 +718,55 @@ class StyledConvSeq(nn.Sequential):
             return False
         return _unhooked(mconv, self.noise, self.activate, *mconv._modules.values())
 
+    def _hands_over_prescaled(self, h, w):
+        """Would this (stride-1) layer, fed a map of h x w, run an F(4x4,3x3) kernel with the style applied on load?
+        Then the layer in front may multiply the style into its own result (see forward)."""
+        mconv, act = self.mconv, self.activate
+        if (os.environ.get('RW_PRESCALE', '1') == '0' or not self._fusable() or mconv.upsample
+                or act.negative_slope != 0.2 or abs(act.scale - 2 ** 0.5) > 1e-12):
+            return False
+        dconv = mconv.dconv
+        return (conv_algo() == 'winograd4' and conv_impl() == 0 and conv_precision() == 'f32'
+                and hip.wino4_supported(dconv.out_channel, dconv.in_channel, h, w))
+
     def forward(self, d):
+        pre = d.get('prescaled')
         if not self._fusable():
+            if pre is not None:
+                raise RuntimeError('a pre-scaled feature map reached a layer that runs module by module')
             return super().forward(d)
         mconv, act = self.mconv, self.activate
-        style = mconv.modulation(DataBag(style=d.style)).style
+        # `pre`: the layer in front already multiplied this layer's style into fmap (and computed it)
+        style = pre if pre is not None else mconv.modulation(DataBag(style=d.style)).style
+        on_load = pre is None
         fmap = d.fmap
         b = fmap.shape[0]
         dconv = mconv.dconv
         if act.negative_slope != 0.2 or abs(act.scale - 2 ** 0.5) > 1e-12:
+            if pre is not None:
+                raise RuntimeError('a pre-scaled feature map reached a layer that runs module by module')
             return super().forward(d)
+        if pre is not None:
+            d = DataBag(d)
+            del d['prescaled']
+        post = None
         if mconv.upsample:
+            # inside the un-hooked whole-generator forward the result is read by exactly one consumer, the next
+            # styled convolution: where that one runs F(4x4,3x3) -- whose loop is bound by vector instructions beside
+            # the MFMAs -- its style multiply (18 packed multiplies per 6x6 item) moves into this layer's epilogue
+            nxt = _rgb_branch.successor.get(id(self)) if _rgb_branch.image_path and pre is None else None
+            if nxt is not None and nxt[0]._hands_over_prescaled(2 * fmap.shape[2], 2 * fmap.shape[3]):
+                post = nxt[0].mconv.modulation(DataBag(style=d.latent[:, nxt[1]])).style
             h, w = 2 * fmap.shape[2], 2 * fmap.shape[3]
             noise = self.noise.noise_for(d, b, h, w, fmap.device)
             if dconv.one_pass_upsample(fmap, mconv.blur):
                 out = hip.conv_transpose3x3s2_blur_wino4(
                     fmap, dconv.up_blur_wino4_weight(mconv.blur.kernel), dconv.out_channel, dconv.scale, style=style,
-                    demod=dconv.demod_factors(style), noise=noise, noise_w=self.noise.weight, bias=act.bias, act=True)
+                    demod=dconv.demod_factors(style), noise=noise, noise_w=self.noise.weight, bias=act.bias, act=True,
+                    post_scale=post)
             else:
                 wide = dconv.run(fmap, style, style_on_load=True)
-                out = hip.blur_noise_act(wide, mconv.blur.kernel, noise, self.noise.weight, act.bias)
+                out = hip.blur_noise_act(wide, mconv.blur.kernel, noise, self.noise.weight, act.bias, post_scale=post)
         else:
             h, w = fmap.shape[2:]
             noise = self.noise.noise_for(d, b, h, w, fmap.device)
@@ -763,11 +793,13 @@ class StyledConvSeq(nn.Sequential):
                     fmap, dconv.wino4_weight() if wino4 else dconv.wino_weight() if wino else dconv.packed_weight(),
                     dconv.out_channel, dconv.scale,
                     torgb.conv.weight.view(3, torgb.conv.in_channel), rgb_style, torgb.bias.view(3), skip,
-                    torgb.conv.scale, style=style, demod=dconv.demod_factors(style), noise=noise,
+                    torgb.conv.scale, style=style if on_load else None, demod=dconv.demod_factors(style), noise=noise,
                     noise_w=self.noise.weight, bias=act.bias, act=True)
                 return DataBag(d, style=style, fmap=None, fused_rgb=rgb)
-            out = dconv.run(fmap, style, style_on_load=True, noise=noise,
+            out = dconv.run(fmap, style, style_on_load=on_load, noise=noise,
                             noise_w=self.noise.weight, bias=act.bias, act=True)
+        if post is not None:        # only inside the un-hooked forward: bags that callers see never carry the key
+            return DataBag(d, style=style, fmap=out, prescaled=post)
         return DataBag(d, style=style, fmap=out)
 
     def _unfused_final(self, d):
@@ -838,10 +870,12 @@ class SeqStyleGAN2(nn.Sequential):
         if not whole:
             return self._forward(input)
         _rgb_branch.image_path = True
+        _rgb_branch.successor = self._successors()
         try:
             return self._forward(input)
         finally:
             _rgb_branch.image_path = False
+            _rgb_branch.successor = {}
 
     def _forward(self, input):
         mb, from_res = micro_batch()
@@ -906,6 +940,23 @@ class SeqStyleGAN2(nn.Sequential):
                 del part
         finally:
             _rgb_branch.final = None
+        return out
+
+    def _successors(self):
+        """{id(upsampling StyledConvSeq): (next StyledConvSeq, its latent index)} for the layer pairs
+        'layer(2j+1)' (upsample) -> 'layer(2j+2)' that follow each other directly in this sequence."""
+        out = {}
+        names = list(self._modules)
+        for a, b in zip(names, names[1:]):
+            ma, mb = self._modules[a], self._modules[b]
+            sa, sb = getattr(ma, 'sconv', None), getattr(mb, 'sconv', None)
+            if not (isinstance(sa, StyledConvSeq) and isinstance(sb, StyledConvSeq)):
+                continue
+            if not getattr(sa.mconv, 'upsample', False) or getattr(sb.mconv, 'upsample', False):
+                continue
+            picks = [m for m in mb.children() if isinstance(m, PickLatent)]
+            if len(picks) == 1 and list(mb.children())[0] is picks[0]:
+                out[id(sa)] = (sb, picks[0].index)
         return out
 
     def _final_pair(self):

@@ -171,13 +171,15 @@ def noise_add(x, noise, noise_w):
     return x.detach() + noise_w.detach().reshape(1) * noise.reshape(b, 1, h, w)
 
 
-def blur_noise_act(x, k4, noise, noise_w, bias):
+def blur_noise_act(x, k4, noise, noise_w, bias, post_scale=None):
     y = R.upfirdn2d(x.detach(), k4, pad=(1, 1))
     b, c, h, w = y.shape
     if noise is not None:
         y = y + noise_w.detach().reshape(1) * noise.reshape(b, 1, h, w)
     if bias is not None:
         y = F.leaky_relu(y + bias.detach().view(1, -1, 1, 1), 0.2) * SQRT2
+    if post_scale is not None:
+        y = y * post_scale.detach()[:, :, None, None]
     return y
 
 
@@ -349,7 +351,7 @@ def pack_conv_transpose_blur_weight_wino4(weight, k4):
 
 
 def conv_transpose3x3s2_blur_wino4(x, uf, out_ch, w_scale, style=None, demod=None, noise=None, noise_w=None,
-                                   bias=None, act=False):
+                                   bias=None, act=False, post_scale=None):
     """The arithmetic of rw_wino4.hip's conv_up_wino36_kernel in torch fp32: the four output-parity phases of
     conv_transpose(stride 2) (*) blur as 4 * out_ch virtual channels of the F(4x4,3x3) convolution, pixel-shuffled."""
     wp, k4 = uf
@@ -375,6 +377,8 @@ def conv_transpose3x3s2_blur_wino4(x, uf, out_ch, w_scale, style=None, demod=Non
         y = y + noise_w.detach().reshape(1) * noise.reshape(n, 1, 2 * h, 2 * wd)
     if act:
         y = F.leaky_relu(y + bias.detach().view(1, -1, 1, 1), 0.2) * SQRT2
+    if post_scale is not None:
+        y = y * post_scale.detach()[:, :, None, None]
     return y
 
 

@@ -310,3 +310,35 @@ def test_one_pass_upsampling_layers_stay_inside_the_image_tolerance(emulated_hip
         assert inst.retained_layer('layer5.sconv.mconv.blur') is not None
     assert len(calls) == 3
     assert (hooked - want).abs().max().item() < 1e-3
+
+
+def test_style_handed_over_premultiplied_changes_nothing(emulated_hip, monkeypatch):
+    """Inside the un-hooked forward an upsampling layer multiplies the NEXT layer's style into its own result where
+    that layer runs F(4x4,3x3) (one multiply per element instead of one per 6x6 item and out-channel tile): the same
+    products in the same precision, so the image is bit-identical with RW_PRESCALE=0, and bags seen by hooks never
+    carry the hand-over key."""
+    from rewriting_amd import hip
+    from rewriting_amd.utils import nethook
+    g = load_golden('gen_s64_cm1')
+    meta = golden_meta(g)
+    model = build_stylegan(meta['size'], meta['truncation'], meta['channel_multiplier'])
+    z = torch.from_numpy(g['z'])
+    seen = []
+    real = hip.blur_noise_act
+    monkeypatch.setattr(hip, 'blur_noise_act',
+                        lambda *a, **k: (seen.append(k.get('post_scale') is not None), real(*a, **k))[1])
+    with torch.no_grad():
+        got = model(z)
+    assert any(seen)                                     # the 64 x 64 layer takes F(4x4,3x3)
+    monkeypatch.setenv('RW_PRESCALE', '0')
+    del seen[:]
+    with torch.no_grad():
+        base = model(z)
+    assert not any(seen) and torch.equal(got, base)
+    monkeypatch.delenv('RW_PRESCALE')
+    with nethook.InstrumentedModel(model) as inst:
+        inst.retain_layer('layer7', detach=False)
+        with torch.no_grad():
+            hooked = inst(z)
+        assert 'prescaled' not in inst.retained_layer('layer7')
+    assert (hooked - got).abs().max().item() < 1e-4

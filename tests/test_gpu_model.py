@@ -417,3 +417,25 @@ def test_micro_batched_forward_equals_one_launch(monkeypatch):
         # turn a 1e-7 difference of their input into a fresh draw of their own 1e-5 rounding noise)
         assert (got - want).abs().max().item() < 5e-5, spec
         assert (got_p - want_p).abs().max().item() < 5e-5, spec
+
+
+def test_premultiplied_style_and_one_pass_layers_on_the_image_path(monkeypatch):
+    """The un-hooked forward's extra fusions against the same forward without them: the next layer's style multiplied
+    into an upsampling layer's result (RW_PRESCALE: the same products, up to the FMA contraction of the in-loop
+    multiply, which the F(4x4,3x3) layers turn into a fresh draw of their 1e-5 rounding noise), the last
+    upsampling layer in one pass and the last conv + ToRGB by F(4x4,3x3) (RW_UP_FUSED, RW_RGB_F4: the F(4x4,3x3)
+    error class)."""
+    model = build_stylegan(256, 0.7, device=DEV)
+    z = torch.randn(4, 512, generator=torch.Generator().manual_seed(9)).to(DEV)
+    with torch.no_grad():
+        got = model(z)
+        monkeypatch.setenv('RW_PRESCALE', '0')
+        same = model(z)
+        assert (got - same).abs().max().item() < 5e-5
+        monkeypatch.setenv('RW_UP_FUSED', '0')
+        monkeypatch.setenv('RW_RGB_F4', '0')
+        base = model(z)
+        monkeypatch.setenv('RW_CONV_ALGO', 'winograd')
+        exact = model(z)
+    assert (got - base).abs().max().item() < 5e-5
+    assert (got - exact).abs().max().item() < 1e-4
