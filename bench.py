@@ -106,12 +106,17 @@ class ConvTimer:
                 b, i, h, w = x.shape
                 if wino == 'up':
                     name = 'conv_up_wino_kernel'
-                elif wino == 'up4':           # transposed conv + blur + noise + activation in one pass
-                    name = 'conv_up_wino36_kernel'
-                elif wino == 'f4rgb':
-                    name = 'conv_wino36_rgb_kernel'
-                elif wino == 'f4':
-                    name = 'conv_wino36b_kernel<2, 2>' if i <= 512 else 'conv_wino36_kernel<2, 2>'
+                elif wino in ('up4', 'f4rgb', 'f4'):
+                    # rw_wino4.hip picks the no-style variants when the input map already carries the style
+                    ns = k.get('style') is None
+                    if wino == 'up4':         # transposed conv + blur + noise + activation in one pass
+                        name = 'conv_up_wino36_ns_kernel' if ns else 'conv_up_wino36_kernel'
+                    elif wino == 'f4rgb':
+                        name = 'conv_wino36_rgb_ns_kernel' if ns else 'conv_wino36_rgb_kernel'
+                    elif i > 512:
+                        name = 'conv_wino36_kernel<2, 2>'
+                    else:
+                        name = 'conv_wino36b_ns_kernel' if ns else 'conv_wino36b_kernel<2, 2>'
                 elif wino is not None:
                     name = 'conv_wino16_kernel<%s, %s>' % ('2, 2, 8' if out_ch % 64 == 0 else '1, 4, 4', wino)
                 else:
