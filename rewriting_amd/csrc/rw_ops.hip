@@ -6,6 +6,8 @@
 // matter are coalesced 16-byte accesses along W (NCHW => W is the fast axis), one pass over
 // each feature map, and >> 256 workgroups.  Nothing here is reshaped into a GEMM.
 #include "rw_common.h"
+#include <stdlib.h>
+#include <stdint.h>
 
 extern "C" int rw_abi_version(void) { return 1; }
 
@@ -321,11 +323,69 @@ __global__ void __launch_bounds__(256) equal_linear_kernel(
   }
 }
 
+// The same on the matrix pipe for the shapes the generator uses (in_dim % 16 == 0, out_dim % 16 == 0): one wave =
+// a 16 (batch) x 16 (out) tile, v_mfma_f32_16x16x4_f32 over K.  Lane (m | n = lane & 15, q = lane >> 4) loads
+// x[b0 + m][16 c + 4 q .. + 3] and w[o0 + n][16 c + 4 q .. + 3] as one 16-byte load each per 16-wide K block c and feeds
+// component j to MFMA j of the block (k = 16 c + 4 q + j on both operands: every k exactly once).  The butterfly
+// kernel above is one memory latency + six shuffle rounds per four batch rows (18 us at batch 64, 51 us at 250 --
+// 7 % of a key-statistics sweep); this one is 128 MFMAs behind 8-deep load batches.
+typedef float rw_lin_f32x4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(64) equal_linear_mfma_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+    float* __restrict__ y, int batch, int in_dim, int out_dim, int64_t x_stride, float w_scale,
+    float b_scale, int act, float alpha, float act_scale) {
+  const int lane = threadIdx.x, mn = lane & 15, q = lane >> 4;
+  const int o0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+  const int brow = min(b0 + mn, batch - 1);                 // rows past the batch: a legal row, results dropped
+  const float* xp = x + (int64_t)brow * x_stride + 4 * q;
+  const float* wp = w + (int64_t)(o0 + mn) * in_dim + 4 * q;
+  rw_lin_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int blocks = in_dim >> 4;
+  constexpr int DEPTH = 8;
+  for (int c0 = 0; c0 < blocks; c0 += DEPTH) {
+    rw_lin_f32x4 a[DEPTH], b[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      const int c = min(c0 + d, blocks - 1);
+      a[d] = *reinterpret_cast<const rw_lin_f32x4*>(xp + 16 * c);
+      b[d] = *reinterpret_cast<const rw_lin_f32x4*>(wp + 16 * c);
+    }
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      if (c0 + d < blocks) {
+        const rw_lin_f32x4 bs = b[d] * w_scale;            // the reference scales the weight before F.linear
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[d][j], bs[j], acc, 0, 0, 0);
+      }
+    }
+  }
+  // acc[j] = y[b0 + 4 q + j][o0 + mn]   (C/D layout: row = 4 (lane >> 4) + j, column = lane & 15)
+  const int o = o0 + mn;
+  const float bv = bias ? bias[o] * b_scale : 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int b = b0 + 4 * q + j;
+    if (b < batch) {
+      float v = acc[j] + bv;
+      if (act) v = ((v > 0.f) ? v : v * alpha) * act_scale;
+      y[(int64_t)b * out_dim + o] = v;
+    }
+  }
+}
+
 extern "C" int rw_equal_linear_f32(const float* x, const float* w, const float* bias, float* y,
                                    int batch, int in_dim, int out_dim, int64_t x_stride,
                                    float w_scale, float b_scale, int act, float alpha,
                                    float act_scale, rw_stream_t stream) {
   RW_CHECK_ARG(x && w && y && batch > 0 && in_dim > 0 && out_dim > 0 && x_stride >= in_dim);
+  const char* impl = getenv("RW_LINEAR_IMPL");              // 1 = the butterfly kernel (A/B runs, tests)
+  const bool butterfly = impl && atoi(impl) == 1;
+  if (!butterfly && in_dim % 16 == 0 && out_dim % 16 == 0 && x_stride % 4 == 0 && ((uintptr_t)x & 15) == 0 &&
+      ((uintptr_t)w & 15) == 0) {
+    hipLaunchKernelGGL(equal_linear_mfma_kernel, dim3(out_dim / 16, (batch + 15) / 16), dim3(64), 0, rw_s(stream), x,
+                       w, bias, y, batch, in_dim, out_dim, x_stride, w_scale, b_scale, act, alpha, act_scale);
+    return RW_LAUNCH_RESULT();
+  }
   if (in_dim > 64 * RW_LINEAR_MAX_PER_LANE) return RW_ERR_UNSUPPORTED;
   int gy = (batch + RW_LINEAR_ROWS - 1) / RW_LINEAR_ROWS;
   if (gy > 64) gy = 64;

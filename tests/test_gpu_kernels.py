@@ -104,6 +104,19 @@ def test_mapping_network_pieces():
     lat = torch.randn(3, 14, 512)
     got = hip.equal_linear(lat.to(DEV)[:, 5], w.to(DEV), b.to(DEV), 1 / math.sqrt(512), 1.0).cpu()   # strided rows
     assert rel(got, R.equal_linear(lat[:, 5], w, b)) < 1e-6
+    # the MFMA kernel (in/out multiples of 16) against the butterfly kernel and float64, ragged batches, 32..512 outputs
+    for batch, out_dim in ((1, 512), (64, 512), (250, 512), (37, 32), (64, 64), (10, 256)):
+        zz = torch.randn(batch, 512)
+        ww, bb = torch.randn(out_dim, 512), torch.randn(out_dim)
+        got = hip.equal_linear(zz.to(DEV), ww.to(DEV), bb.to(DEV), 1 / math.sqrt(512), 1.0).cpu()
+        os.environ['RW_LINEAR_IMPL'] = '1'
+        try:
+            other = hip.equal_linear(zz.to(DEV), ww.to(DEV), bb.to(DEV), 1 / math.sqrt(512), 1.0).cpu()
+        finally:
+            del os.environ['RW_LINEAR_IMPL']
+        exact = (zz.double() @ (ww.double() / math.sqrt(512)).t() + bb.double())
+        assert got.shape == (batch, out_dim) and rel(got, other) < 1e-6
+        assert rel(got.double(), exact) < 5e-7 and rel(other.double(), exact) < 5e-7
     avg = torch.randn(512)
     got = hip.adjust_latent(z.to(DEV), avg.to(DEV), 6, 0.5).cpu()
     assert torch.allclose(got, (avg + 0.5 * (z - avg)).unsqueeze(1).repeat(1, 6, 1), atol=1e-6)
