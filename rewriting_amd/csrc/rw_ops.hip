@@ -519,9 +519,53 @@ __global__ void __launch_bounds__(256) demod_kernel(const float* __restrict__ ws
   if (lane == 0) demod[idx] = rsqrtf(acc + eps);
 }
 
+// the same on the matrix pipe (in_ch % 16 == 0, out_ch % 16 == 0): a 16 (batch) x 16 (out) tile per wave, operands and
+// k mapping as in equal_linear_mfma_kernel, A = style^2
+__global__ void __launch_bounds__(64) demod_mfma_kernel(const float* __restrict__ wsq, const float* __restrict__ style,
+                                                        float* __restrict__ demod, int batch, int out_ch, int in_ch,
+                                                        float eps) {
+  const int lane = threadIdx.x, mn = lane & 15, q = lane >> 4;
+  const int o0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+  const int brow = min(b0 + mn, batch - 1);
+  const float* sp = style + (int64_t)brow * in_ch + 4 * q;
+  const float* wp = wsq + (int64_t)(o0 + mn) * in_ch + 4 * q;
+  rw_lin_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int blocks = in_ch >> 4;
+  constexpr int DEPTH = 8;
+  for (int c0 = 0; c0 < blocks; c0 += DEPTH) {
+    rw_lin_f32x4 a[DEPTH], b[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      const int c = min(c0 + d, blocks - 1);
+      a[d] = *reinterpret_cast<const rw_lin_f32x4*>(sp + 16 * c);
+      b[d] = *reinterpret_cast<const rw_lin_f32x4*>(wp + 16 * c);
+    }
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      if (c0 + d < blocks) {
+        const rw_lin_f32x4 a2 = a[d] * a[d];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[j], b[d][j], acc, 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int b = b0 + 4 * q + j;
+    if (b < batch) demod[(int64_t)b * out_ch + o0 + mn] = rsqrtf(acc[j] + eps);
+  }
+}
+
 extern "C" int rw_demod_f32(const float* wsq, const float* style, float* demod, int batch,
                             int out_ch, int in_ch, float eps, rw_stream_t stream) {
   RW_CHECK_ARG(wsq && style && demod && batch > 0 && out_ch > 0 && in_ch > 0);
+  const char* impl = getenv("RW_LINEAR_IMPL");              // 1 = the butterfly kernel (A/B runs, tests)
+  if (!(impl && atoi(impl) == 1) && in_ch % 16 == 0 && out_ch % 16 == 0 && ((uintptr_t)wsq & 15) == 0 &&
+      ((uintptr_t)style & 15) == 0) {
+    hipLaunchKernelGGL(demod_mfma_kernel, dim3(out_ch / 16, (batch + 15) / 16), dim3(64), 0, rw_s(stream), wsq, style,
+                       demod, batch, out_ch, in_ch, eps);
+    return RW_LAUNCH_RESULT();
+  }
   const int64_t waves = (int64_t)batch * out_ch;
   hipLaunchKernelGGL(demod_kernel, dim3((unsigned)rw_cdiv(waves, 4)), dim3(256), 0, rw_s(stream),
                      wsq, style, demod, batch, out_ch, in_ch, eps);

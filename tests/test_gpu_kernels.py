@@ -117,6 +117,18 @@ def test_mapping_network_pieces():
         exact = (zz.double() @ (ww.double() / math.sqrt(512)).t() + bb.double())
         assert got.shape == (batch, out_dim) and rel(got, other) < 1e-6
         assert rel(got.double(), exact) < 5e-7 and rel(other.double(), exact) < 5e-7
+    # demodulation factors: the MFMA kernel against the butterfly kernel and float64
+    for batch, out_dim, in_dim in ((1, 512, 512), (64, 32, 64), (250, 512, 512), (7, 256, 128)):
+        st = (1 + 0.5 * torch.randn(batch, in_dim)).to(DEV)
+        wsq = torch.rand(out_dim, in_dim).to(DEV)
+        got = hip.demod(wsq, st).cpu()
+        os.environ['RW_LINEAR_IMPL'] = '1'
+        try:
+            other = hip.demod(wsq, st).cpu()
+        finally:
+            del os.environ['RW_LINEAR_IMPL']
+        exact = torch.rsqrt((st.cpu().double() ** 2) @ wsq.cpu().double().t() + 1e-8)
+        assert got.shape == (batch, out_dim) and rel(got, other) < 1e-6 and rel(got.double(), exact) < 5e-7
     avg = torch.randn(512)
     got = hip.adjust_latent(z.to(DEV), avg.to(DEV), 6, 0.5).cpu()
     assert torch.allclose(got, (avg + 0.5 * (z - avg)).unsqueeze(1).repeat(1, 6, 1), atol=1e-6)
