@@ -17,6 +17,7 @@
 // stride-1 layers -- noise, bias and leaky-ReLU, so a styled-conv block reads its input once
 // and writes its output once.
 #include "rw_common.h"
+#include <stdlib.h>
 
 __host__ __device__ __forceinline__ int rw_tap_off(unsigned bits, int t) {
   return (int)((bits >> (2 * t)) & 3u) - 1;
@@ -320,9 +321,12 @@ __global__ void __launch_bounds__(256) conv_mfma_ksplit_kernel(const ConvBatch c
   const int chunks_per_tap = p.in_ch / KC;
   const int n_chunks = chunks_per_tap * p.ntaps;
 
-  float breg[B_ELEMS];
-  rw_f32x4 areg[A_VEC];
-  auto gather = [&](int c) {
+  // Chunks are fetched DEPTH ahead into a ring of register sets: a chunk is only 16 MFMAs per wave (~0.5 us), one
+  // chunk of look-ahead left the loop at one memory latency per chunk (260 us for layer 2's 144 chunks)
+  constexpr int DEPTH = 4;
+  float bring[DEPTH][B_ELEMS];
+  rw_f32x4 aring[DEPTH][A_VEC];
+  auto gather = [&](int c, float (&breg)[B_ELEMS], rw_f32x4 (&areg)[A_VEC]) __attribute__((always_inline)) {
     const int t = c % p.ntaps;
     const int i0 = (c / p.ntaps) * KC;
     const int iy = gy + rw_tap_off(p.dy_bits, t), ix = gx + rw_tap_off(p.dx_bits, t);
@@ -344,7 +348,7 @@ __global__ void __launch_bounds__(256) conv_mfma_ksplit_kernel(const ConvBatch c
       areg[j] = *reinterpret_cast<const rw_f32x4*>(wrow + (int64_t)kk * p.out_ch + o4 * 4);
     }
   };
-  auto stash = [&](int buf) {
+  auto stash = [&](int buf, const float (&breg)[B_ELEMS], const rw_f32x4 (&areg)[A_VEC]) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < B_ELEMS; ++j) Bs[buf][kk0 + j * B_KSTEP][nl] = breg[j];
 #pragma unroll
@@ -363,29 +367,40 @@ __global__ void __launch_bounds__(256) conv_mfma_ksplit_kernel(const ConvBatch c
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  gather(0);
-  stash(0);
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d)
+    if (d < n_chunks) gather(d, bring[d], aring[d]);
+  stash(0, bring[0], aring[0]);
   __syncthreads();
   const int frow = lane >> 5, fcol = lane & 31;
-  for (int c = 0; c < n_chunks; ++c) {
-    const int buf = c & 1;
-    if (c + 1 < n_chunks) gather(c + 1);
+  for (int c0 = 0; c0 < n_chunks; c0 += DEPTH) {
 #pragma unroll
-    for (int kp = 0; kp < KW / 2; ++kp) {
-      const int kr = wave * KW + 2 * kp + frow;
-      float af[T], bf[T];
+    for (int d = 0; d < DEPTH; ++d) {
+      const int c = c0 + d;
+      if (c < n_chunks) {
+        const int buf = c & 1;
+        // ring slot d held chunk c, which the previous iteration stored to LDS: free for chunk c + DEPTH
+        if (c > 0 && c - 1 + DEPTH < n_chunks) gather(c - 1 + DEPTH, bring[(d + DEPTH - 1) % DEPTH], aring[(d + DEPTH - 1) % DEPTH]);
 #pragma unroll
-      for (int a = 0; a < T; ++a) af[a] = As[buf][kr][32 * a + fcol];
+        for (int kp = 0; kp < KW / 2; ++kp) {
+          const int kr = wave * KW + 2 * kp + frow;
+          float af[T], bf[T];
 #pragma unroll
-      for (int b = 0; b < T; ++b) bf[b] = Bs[buf][kr][32 * b + fcol];
+          for (int a = 0; a < T; ++a) af[a] = As[buf][kr][32 * a + fcol];
 #pragma unroll
-      for (int a = 0; a < T; ++a)
+          for (int b = 0; b < T; ++b) bf[b] = Bs[buf][kr][32 * b + fcol];
 #pragma unroll
-        for (int b = 0; b < T; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+          for (int a = 0; a < T; ++a)
+#pragma unroll
+            for (int b = 0; b < T; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+        if (c + 1 < n_chunks) stash(buf ^ 1, bring[(d + 1) % DEPTH], aring[(d + 1) % DEPTH]);
+        // LDS writes complete + barrier; NOT __syncthreads(), whose vmcnt(0) would drain the ring every chunk
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();
+      }
     }
-    if (c + 1 < n_chunks) stash(buf ^ 1);
-    __syncthreads();
   }
 
   // ---- cross-wave reduction tree through LDS: (2,3) -> (0,1), then 1 -> 0
@@ -1203,11 +1218,18 @@ static int launch_batch(const ConvProblem* ps, int n, int impl, hipStream_t s) {
   cb.n = n;
   int ksplit = 0;   // 0 = off, 1 = 32x32 tiles (chunks of 64 k), 2 = 64x64 tiles (chunks of 32 k)
   if (impl == 6 || (impl != 5 && blocks < 192)) {      // 6: force split-K (A/B measurements)
-    if (c.out_ch % 64 == 0 && c.in_ch % 32 == 0 && blocks64 >= 128) ksplit = 2;
+    // 64x64 tiles only when they still give two workgroups per CU (one wave per SIMD leaves every LDS read ->
+    // MFMA dependency exposed: layer 2 of the 1024 model at batch 64 runs 0.19 ms on 32x32 tiles, 0.31 ms on 64x64)
+    if (c.out_ch % 64 == 0 && c.in_ch % 32 == 0 && (blocks64 >= 512 || c.in_ch % 64)) ksplit = 2;
     else if (c.in_ch % 64 == 0) ksplit = 1;
     else if (c.out_ch % 64 == 0 && c.in_ch % 32 == 0) ksplit = 2;
   }
-  if (ksplit) { bm = bn = (ksplit == 2) ? 64 : 32; }
+  if (ksplit) {
+    const char* ek = getenv("RW_KSPLIT");             // experiment: force the 32x32 (1) or 64x64 (2) tile
+    if (ek && atoi(ek) == 1 && c.in_ch % 64 == 0) ksplit = 1;
+    if (ek && atoi(ek) == 2 && c.out_ch % 64 == 0 && c.in_ch % 32 == 0) ksplit = 2;
+    bm = bn = (ksplit == 2) ? 64 : 32;
+  }
   int64_t work = 0;
   for (int q = 0; q < 4; ++q) {
     cb.p[q] = ps[q < n ? q : 0];

@@ -7,7 +7,8 @@
 // Accuracy: the transforms carry the constants 4, 5, 8 and 1/24, and fp32 rounding grows with them: measured 4e-6 to
 // 9e-6 of the output range per layer (32 - 512 channels) against 2e-7 to 6e-7 for F(2x2,3x3) and the direct sum.
 // That is inside the path's image tolerance (1e-3 L-inf) and outside what the key statistics and the solve are held
-// to, so this kernel is an OPT-IN for image generation (RW_CONV_ALGO=winograd4); it is never the default.
+// to, so the host side selects these kernels for image generation only -- inside the un-hooked forward of a whole
+// generator, or with RW_CONV_ALGO=winograd4 -- and never for a hooked or sliced model.
 //
 //   U[xi][o][i] = (G g G^T)[xi]      6x6 per (o, i), once per weight version      (rw_pack_conv_weight_wino4_f32)
 //   V[xi][i][t] = (B^T d B)[xi]      6x6 input tile d (stride 4)

@@ -55,8 +55,8 @@ def main(batch=int(os.environ.get('RW_BATCH', '8')), iters=5, impl=int(os.enviro
             k1 = torch.tensor([1., 3., 3., 1.], device=dev)
             k4 = k1[:, None] * k1[None, :]
             k4 = k4 / k4.sum() * 4
-            epu = dict(noise=torch.randn(batch, 4 * res * res, device=dev), noise_w=torch.tensor([0.1], device=dev),
-                       bias=torch.randn(cout, device=dev))
+            epu = dict(noise=None if os.environ.get('RW_NO_NOISE') else torch.randn(batch, 4 * res * res, device=dev),
+                       noise_w=torch.tensor([0.1], device=dev), bias=torch.randn(cout, device=dev))
         upf = upmode == 'fused' and hip.conv_transpose_blur_wino4_supported(cout, cin, res, res)
         upb = upmode == 'wino+blur' and hip.conv_transpose_wino_supported(cout, cin, res, res)
         if upf:
