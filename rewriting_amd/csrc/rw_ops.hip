@@ -657,10 +657,12 @@ extern "C" int rw_pack_conv_weight_f32(const float* w, float* wp, int out_ch, in
 // ---------------------------------------------------------------------------------------
 // Blur(pad 1,1) + noise + bias + leaky-ReLU for upsampling layers: one pass
 // ---------------------------------------------------------------------------------------
-// Workgroup = 32 x 64 output tile of one (image, channel) plane: the 35 x 67 input patch is
+// Workgroup = 64 x 64 output tile of one (image, channel) plane: the 67 x 67 input patch is
 // staged in LDS with coalesced row loads (the odd row length 2W+1 rules out vector loads), each
-// thread then produces 4 horizontally adjacent outputs of two rows, one 16-byte store each.
-#define BL_TH 32
+// thread then produces 4 horizontally adjacent outputs of four rows, one 16-byte store each.
+#ifndef BL_TH
+#define BL_TH 64        // 16 / 32 / 64 / 96 / 128 rows measured: 3.1 / 3.5 / 3.9 / 3.6 / 3.3 TB/s at 32 x 1024^2 x 64
+#endif
 #define BL_TW 64
 #define BL_PITCH (BL_TW + 4)
 __global__ void __launch_bounds__(256) blur_noise_act_kernel(
@@ -712,7 +714,7 @@ __global__ void __launch_bounds__(256) blur_noise_act_kernel(
     }
   }
   __syncthreads();
-  // thread = 4 consecutive outputs of rows ly and ly + 16: two 16-byte LDS reads per tap row, one
+  // thread = 4 consecutive outputs of rows ly, ly + 16, ...: two 16-byte LDS reads per tap row, one
   // 16-byte noise load and one 16-byte store per output row -- the store tail is instruction-issue
   // bound, so wide stores matter more than the (mild, 2-way) LDS bank overlap of this mapping
   const int lx = (tid & 15) * 4;
