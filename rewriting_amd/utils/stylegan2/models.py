@@ -746,6 +746,7 @@ class StyledConvSeq(nn.Sequential):
             if pre is not None:
                 raise RuntimeError('a pre-scaled feature map reached a layer that runs module by module')
             return super().forward(d)
+        d_in = d                    # as received (with the hand-over key, if any): what a re-entry must see
         if pre is not None:
             d = DataBag(d)
             del d['prescaled']
@@ -778,7 +779,7 @@ class StyledConvSeq(nn.Sequential):
                 torgb, idx = fin[1], fin[2]
                 skip = d.output if torgb.skip else None
                 if skip is not None and tuple(skip.shape[2:]) != (h, w):
-                    return self._unfused_final(d)
+                    return self._unfused_final(d_in)
                 main = torch.cuda.current_stream()
                 if _rgb_branch.stream is not None:
                     main.wait_stream(_rgb_branch.stream)           # the running image comes from the RGB stream
