@@ -751,6 +751,8 @@ class StyledConvSeq(nn.Sequential):
             d = DataBag(d)
             del d['prescaled']
         post = None
+        if mconv.upsample and pre is not None:
+            raise RuntimeError('a pre-scaled feature map reached an upsampling layer')
         if mconv.upsample:
             # inside the un-hooked whole-generator forward the result is read by exactly one consumer, the next
             # styled convolution: where that one runs F(4x4,3x3) -- whose loop is bound by vector instructions beside
