@@ -38,4 +38,5 @@ timeout 300 python bench.py --workload edit --steps 3 --warmup 1 > $OUT/edit.jso
 echo done
 python scripts/solve_probe.py > "$OUT/solve_probe.log" 2>&1; grep out_ch "$OUT/solve_probe.log"; cp gpurun_out/solve_probe.json "$OUT/" 2>/dev/null
 RW_OUT=$TAG/micro_probe.json RW_SPECS=0,8:256,4:512,2:1024 python scripts/micro_probe.py > "$OUT/micro.log" 2>&1; grep spec "$OUT/micro.log"
+bash scripts/gpu_sweep_prof.sh > "$OUT/sweep_prof.log" 2>&1; mkdir -p "$OUT/sweep_prof"; cp gpurun_out/sweep_prof/prof/sweep_kernel_stats.csv gpurun_out/sweep_prof/prof_edit/edit_kernel_stats.csv gpurun_out/sweep_prof/sweep.json "$OUT/sweep_prof/" 2>/dev/null
 echo final done
