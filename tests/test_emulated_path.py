@@ -342,3 +342,36 @@ def test_style_handed_over_premultiplied_changes_nothing(emulated_hip, monkeypat
             hooked = inst(z)
         assert 'prescaled' not in inst.retained_layer('layer7')
     assert (hooked - got).abs().max().item() < 1e-4
+
+
+def test_successor_pairs_and_hand_over_guards(emulated_hip):
+    """SeqStyleGAN2._successors pairs every upsampling layer with the styled convolution that follows it directly,
+    and a pre-scaled map can only be consumed by a fused stride-1 layer: anything else refuses it loudly."""
+    from rewriting_amd.utils.stylegan2 import models
+    g = load_golden('gen_s64_cm1')
+    meta = golden_meta(g)
+    model = build_stylegan(meta['size'], meta['truncation'], meta['channel_multiplier'])
+    succ = model._successors()
+    ups = [m.sconv for n, m in model.named_children() if n.startswith('layer') and getattr(m, 'sconv', None) is not None
+           and m.sconv.mconv.upsample]
+    assert len(ups) == 4 and set(succ) == {id(u) for u in ups}
+    for name, idx in (('layer3', 2), ('layer5', 4), ('layer7', 6), ('layer9', 8)):
+        nxt, lat = succ[id(getattr(model, name).sconv)]
+        assert nxt is getattr(model, 'layer%d' % (int(name[5:]) + 1)).sconv and lat == idx
+    # a bag carrying the hand-over key in front of an upsampling layer, or of a layer that runs module by module
+    z = torch.from_numpy(g['z'])
+    with torch.no_grad():
+        bag = model.bag_from_z(z)
+        for n, m in model.named_children():
+            if n == 'layer5':
+                break
+            if n != 'bag_in':
+                bag = m(bag)
+        bad = models.DataBag(bag, prescaled=torch.ones(z.shape[0], 512))
+        with pytest.raises(RuntimeError, match='pre-scaled'):
+            model.layer5(bad)                            # upsampling
+        from rewriting_amd.utils import nethook
+        with nethook.InstrumentedModel(model) as inst:
+            inst.retain_layer('layer4.sconv.mconv.adain', detach=False)
+            with pytest.raises(RuntimeError, match='pre-scaled'):
+                model.layer4(models.DataBag(bag, prescaled=torch.ones(z.shape[0], 512)))
