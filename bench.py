@@ -11,12 +11,14 @@ itself under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --ma
 partitioned rank-wise (no data-path collective, weak scaling); the timed region is bracketed by barrier +
 synchronize and the MAX over ranks is reported.
 
-Rank 0 prints ONE JSON line with `roofline` (the dominant conv kernel: algorithmic conv FLOPs of
-its launches / their HIP-event time, against the 157.3 TFLOP/s fp32-MFMA peak) and
+Rank 0 prints ONE JSON line with `roofline` (the dominant conv kernel: the matrix FLOPs its launches ISSUE /
+their HIP-event time, against the 157.3 TFLOP/s fp32-MFMA peak; the direct-sum figure beside it) and
 `cpu_baseline` (the reference's own files when /root/reference is present, else the oracle restatement, timed
 on the host cores on a bounded sample at the best of several thread counts; N=1 only) and `extra`: the other
 half of BASELINE.json's metric (seconds per rank-1 edit = 1000-seed key statistics + 2001-step solve), the
-256^2 forward (configs[1]) and the key-statistics sweep (configs[3]), each timed in this process.
+256^2 forward (configs[1]), the key-statistics sweeps at layers 8/10/14 (configs[3]) and the five-variant
+watermark job (configs[4]), each timed in this process; `step` (the whole step against the MFMA-issue and HBM
+roofs) and `parity` (the output of the last timed step against the reference-generated fixture).
 
 Other workloads (parity-test configurations of BASELINE.json, not the headline line):
   ffhq256   StyleGANv2-256 forward, batch 64         (configs[1])
@@ -153,40 +155,57 @@ class ConvTimer:
             return None
         dom = max(per, key=lambda n: per[n]['ms'])
         d = per[dom]
-        achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
+        factor, algorithm = issued_fraction(dom)
+        effective = d['flops'] / (d['ms'] * 1e-3) / 1e12          # direct-sum FLOPs per second
+        issued = effective * factor                                  # what the matrix pipe executes
         tot_ms = sum(v['ms'] for v in per.values())
         tot_fl = sum(v['flops'] for v in per.values())
-        out = dict(bound='mfma', achieved=round(achieved, 2), peak=FP32_MFMA_PEAK_TFLOPS,
-                   unit='TFLOP/s', frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
+        tot_issued = sum(v['flops'] * issued_fraction(n)[0] for n, v in per.items())
+        out = dict(bound='mfma-issue (fp32 MFMA shares the SIMD lanes with the VALU)',
+                   achieved=round(issued, 2), peak=FP32_MFMA_PEAK_TFLOPS,
+                   unit='TFLOP/s', frac=round(issued / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
                    kernel=dom, launches=d['launches'],
                    avg_launch_us=round(d['ms'] * 1e3 / d['launches'], 2),
-                   flops_per_launch=round(d['flops'] / d['launches']),
-                   all_conv_kernels=dict(achieved=round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
-                                         frac=round(tot_fl / (tot_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                   algorithm=algorithm, mfma_flops_issued_over_direct_sum=round(factor, 4),
+                   flops_per_launch=round(d['flops'] / d['launches'] * factor),
+                   direct_sum_flops_per_launch=round(d['flops'] / d['launches']),
+                   effective_tflops=round(effective, 2),
+                   effective_over_direct_roof=round(effective / FP32_MFMA_PEAK_TFLOPS, 4),
+                   note='`achieved` = matrix FLOPs the kernel ISSUES per second (direct-sum FLOPs of SURVEY 8d x the '
+                        'algorithm\'s multiply count / the direct sum\'s) -- a fraction of the fp32 MFMA peak that cannot '
+                        'exceed 1; `effective_tflops` = the direct sum\'s FLOPs per second, which can',
+                   all_conv_kernels=dict(issued_tflops=round(tot_issued / (tot_ms * 1e-3) / 1e12, 2),
+                                         issued_frac=round(tot_issued / (tot_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                                         effective_tflops=round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
+                                         effective_over_direct_roof=round(
+                                             tot_fl / (tot_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
                                          ms_per_step=None))
-        if dom.startswith('conv_wino16'):
-            # Winograd F(2x2,3x3): the matrix pipe issues 16/36 of the algorithmic (direct-sum) multiply-adds
-            out['algorithm'] = 'winograd F(2x2,3x3), fp32: `achieved` counts the direct sum\'s FLOPs (SURVEY 8d); the matrix ' \
-                               'pipe issues 1/2.25 of them'
-            out['mfma_issued_tflops'] = round(achieved / 2.25, 2)
-            out['mfma_issued_frac'] = round(achieved / 2.25 / FP32_MFMA_PEAK_TFLOPS, 4)
-        if dom.startswith('conv_up_wino36'):
-            out['algorithm'] = 'transposed conv (*) blur as four F(4x4,3x3) phase convolutions, fp32: `achieved` counts the ' \
-                               'transposed conv\'s direct-sum FLOPs, which is also what the matrix pipe issues'
-        elif dom.startswith('conv_up_wino'):
-            out['algorithm'] = 'transposed conv by F(2,2) on the four output-parity phases, fp32: `achieved` counts the ' \
-                               'direct sum\'s FLOPs (2.25 MACs per output); the matrix pipe issues 25/36 of them'
-            out['mfma_issued_tflops'] = round(achieved * 25 / 36, 2)
-            out['mfma_issued_frac'] = round(achieved * 25 / 36 / FP32_MFMA_PEAK_TFLOPS, 4)
-        if dom.startswith('conv_wino36'):
-            out['algorithm'] = 'winograd F(4x4,3x3), fp32 (opt-in): `achieved` counts the direct sum\'s FLOPs; the matrix ' \
-                               'pipe issues 1/4 of them'
-            out['mfma_issued_tflops'] = round(achieved / 4, 2)
-            out['mfma_issued_frac'] = round(achieved / 4 / FP32_MFMA_PEAK_TFLOPS, 4)
-        out['per_kernel'] = {n: dict(tflops=round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 1), ms=round(v['ms'], 2),
-                                     launches=v['launches']) for n, v in sorted(per.items(), key=lambda kv: -kv[1]['ms'])}
+        out['per_kernel'] = {n: dict(effective_tflops=round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 1),
+                                     issued_tflops=round(v['flops'] * issued_fraction(n)[0] / (v['ms'] * 1e-3) / 1e12, 1),
+                                     issued_frac=round(v['flops'] * issued_fraction(n)[0] / (v['ms'] * 1e-3) / 1e12
+                                                       / FP32_MFMA_PEAK_TFLOPS, 3),
+                                     ms=round(v['ms'], 2), launches=v['launches'])
+                             for n, v in sorted(per.items(), key=lambda kv: -kv[1]['ms'])}
         out['_tot_ms'] = tot_ms
+        out['_issued_flops'] = tot_issued
         return out
+
+
+def issued_fraction(kernel):
+    """(matrix FLOPs a kernel issues / direct-sum FLOPs of the convolution it computes, what the algorithm is).
+    The minimal-filtering kernels multiply less than the direct sum; the roofline fraction is priced on what they
+    issue (rw_wino.hip, rw_wino4.hip, rw_upwino.hip headers)."""
+    if kernel.startswith('conv_up_wino36'):
+        return 1.0, ('transposed conv (*) blur as four F(4x4,3x3) phase convolutions, fp32: issues the transposed '
+                     'conv\'s direct-sum FLOP count')
+    if kernel.startswith('conv_up_wino'):
+        return 25.0 / 36.0, ('transposed conv by F(2,2) on the four output-parity phases, fp32: 25 multiplies per 2x2 '
+                             'block of quads where the direct sum has 36')
+    if kernel.startswith('conv_wino36'):
+        return 0.25, 'winograd F(4x4,3x3), fp32: 36 multiplies per 4x4 output tile where the direct sum has 144'
+    if kernel.startswith('conv_wino16'):
+        return 1.0 / 2.25, 'winograd F(2x2,3x3), fp32: 16 multiplies per 2x2 output tile where the direct sum has 36'
+    return 1.0, 'direct implicit GEMM, fp32 MFMA'
 
 
 def attach_pmc_traffic(roof, workload, batch):
@@ -203,6 +222,55 @@ def attach_pmc_traffic(roof, workload, batch):
             roof['traffic'] = r['hbm_bytes_per_launch']
             roof['traffic_source'] = r.get('source')
             roof['algorithmic_bytes_per_launch'] = r.get('algorithmic_bytes_per_launch')
+
+
+def parity_of_timed_output(img, size, z, world):
+    """Compares the image batch the LAST TIMED step produced with tests/golden/gen_s<size>_full.npz -- the digest of
+    the reference's own CPU forward (oracle/make_golden.py executing /root/reference/utils/stylegan2/models.py:41-141)
+    of the first rows of the same z stream.  Row j of a batch gets row j of RandomState(0).randn(batch, H*W) as noise
+    whatever the batch size (quirk Q1) and standard_z_sample fills row-major, so rows 0..b-1 of a 64-seed batch are
+    exactly the fixture's b seeds.  Fields: linf over the strided sub-sample and the four full-resolution crops,
+    row/column-sum deviation (every pixel of the rows enters one of each), the rows compared."""
+    import numpy
+    path = os.path.join(ROOT, 'tests', 'golden', 'gen_s%d_full.npz' % size)
+    if not os.path.isfile(path):
+        return None
+    g = numpy.load(path)
+    zg = torch.from_numpy(g['z'])
+    rows = [j for j in range(min(zg.shape[0], z.shape[0])) if torch.equal(z[j].cpu(), zg[j])]
+    if not rows:
+        return dict(fixture=os.path.relpath(path, ROOT), rows=[], note='no row of this rank\'s batch is a fixture seed')
+    stride = int(g['image/stride'])
+    got = img[rows].detach()
+    want = torch.from_numpy(g['image/strided'])[rows]
+    linf = (got[:, :, ::stride, ::stride].cpu() - want).abs().max().item()
+    crops = g['image/crops']
+    c = crops.shape[-1]
+    for k, (y, x) in enumerate(g['image/crop_origin']):
+        linf = max(linf, (got[:, :, y:y + c, x:x + c].cpu() - torch.from_numpy(crops[k])[rows]).abs().max().item())
+    rs = (got.double().sum(3).cpu().numpy() - g['image/rowsum'][rows])
+    cs = (got.double().sum(2).cpu().numpy() - g['image/colsum'][rows])
+    return dict(fixture=os.path.relpath(path, ROOT), rows=rows, linf=float('%.3e' % linf),
+                max_abs_image=float('%.3f' % want.abs().max().item()),
+                rowsum_dev=float('%.3e' % max(abs(rs).max(), abs(cs).max())), bar_linf=1e-3,
+                ok=bool(linf < 1e-3 and torch.isfinite(got).all().item()),
+                what='output of the last timed step, batch rows %s, vs the reference CPU forward of the same seeds '
+                     '(reference-generated fixture; north_star bar 1e-3 L-inf)' % rows)
+
+
+def attach_pmc_step(step, workload, batch):
+    """HBM bytes of ONE whole step, summed over every kernel of the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+    (profiles/pmc_traffic.json 'steps'), if a committed summary matches this workload."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    if not os.path.isfile(path):
+        return
+    with open(path) as f:
+        rec = json.load(f)
+    for r in rec.get('steps', []):
+        if r.get('workload') == workload and r.get('batch') == batch:
+            step['hbm_bytes_pmc'] = r['hbm_bytes_per_step']
+            step['hbm_pmc_over_algorithmic'] = round(r['hbm_bytes_per_step'] / step['hbm_bytes_algorithmic'], 3)
+            step['hbm_pmc_source'] = r.get('source')
 
 
 def build_generator(size, device):
@@ -267,7 +335,7 @@ def cpu_baseline_forward(size, images=8):
             dt = time.perf_counter() - t0
     finally:
         torch.set_num_threads(saved)
-    return dict(value=round(n / dt, 4), unit='images/sec', cores=best, kind=kind,
+    return dict(value=round(n / dt, 4), unit='images/sec', cores=best, threads=best, host_cores=ncpu, kind=kind,
                 sample='%d images of the stylegan2-%d forward in batches of %d through %s (torch %s CPU kernels), '
                        '%.1f s at %d threads; probe img/s by (threads, batch): %s; host has %d logical cpus'
                        % (n, size, batch, "the reference's own utils/stylegan2/models.py (oracle/reference_shim.py)"
@@ -275,22 +343,37 @@ def cpu_baseline_forward(size, images=8):
                           best, json.dumps({k: round(v, 3) for k, v in probe.items()}), ncpu))
 
 
+def bench_device(local):
+    """This rank's MI355X.  (tests/bench_cpu_driver.py -- test infrastructure -- substitutes CPU tensors and the
+    kernel stand-ins of tests/hip_emulation.py here to drive the launcher and the rank plumbing without a GPU.)"""
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (the HIP kernels have no CPU path)')
+    torch.cuda.set_device(local)
+    return torch.device('cuda', local)
+
+
+def device_sync():
+    torch.cuda.synchronize()
+
+
 def timed(fn, steps, warmup, world):
+    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks."""
     import torch.distributed as dist
+    from rewriting_amd import parallel
     for _ in range(warmup):
         fn()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    device_sync()
     t0 = time.perf_counter()
     for _ in range(steps):
         fn()
-    torch.cuda.synchronize()
+    device_sync()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+        t = torch.tensor([dt], device=parallel.collective_device(), dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     return dt
@@ -303,9 +386,11 @@ def run_forward(args, rank, world, device, size, batch, name, cpu=True):
     zall = zdataset.standard_z_sample(batch * world, 512, seed=1)
     z = zall[rank::world].contiguous().to(device)
 
+    last = [None]
+
     def step():
         with torch.no_grad():
-            g(z)
+            last[0] = g(z)
     timed(step, 1, args.warmup, world)                      # warm-up incl. weight repack caches
     timer = ConvTimer()
     timer.install()
@@ -322,13 +407,28 @@ def run_forward(args, rank, world, device, size, batch, name, cpu=True):
                            conv_gflop_per_image=round(conv_flops(size) / 1e9, 2)))
     roof = timer.result()
     tot_ms = roof.pop('_tot_ms')
+    issued = roof.pop('_issued_flops')
     roof['all_conv_kernels']['ms_per_step'] = round(tot_ms / args.steps, 3)
-    # whole-forward algorithmic HBM rate (SURVEY.md 8d bytes/img), for the second roof
-    roof['forward_hbm_algorithmic_gbs'] = round(
-        {256: 276.3e6, 1024: 1217.7e6}.get(size, 0) * batch * world * args.steps / dt / 1e9, 1)
     attach_pmc_traffic(roof, 'ffhq%d' % size, batch)
     out['roofline'] = roof
+    # the whole step against both roofs: matrix FLOPs issued by all conv launches / (wall time x fp32 MFMA peak), and
+    # SURVEY 8d's algorithmic bytes (a perfectly block-fused forward) / (wall time x HBM peak); PMC bytes beside them
+    alg_bytes = {256: 276.3e6, 1024: 1217.7e6}.get(size, 0) * batch
+    step = dict(mfma_issue_frac=round(issued / world / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                mfma_issued_tflops=round(issued / world / dt / 1e12, 2),
+                direct_sum_tflops=round(conv_flops(size) * batch * args.steps / dt / 1e12, 2),
+                direct_sum_over_fp32_roof=round(conv_flops(size) * batch * args.steps / dt / 1e12
+                                                / FP32_MFMA_PEAK_TFLOPS, 4),
+                hbm_frac=round(alg_bytes * args.steps / dt / 1e9 / HBM_PEAK_GBS, 4),
+                hbm_algorithmic_gbs=round(alg_bytes * args.steps / dt / 1e9, 1),
+                hbm_bytes_algorithmic=round(alg_bytes), hbm_bytes_pmc=None,
+                note='per GPU and step; north_star\'s ">= 60 % of the HBM roofline" presupposes reduced-precision '
+                     'convolutions: in exact fp32 the step is bound by the matrix pipe (SURVEY.md 8d)')
+    attach_pmc_step(step, 'ffhq%d' % size, batch)
+    out['step'] = step
+    out['parity'] = parity_of_timed_output(last[0], size, z, world)
     del g, z
+    last[0] = None
     if cpu and rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline_forward(size)
     return out
@@ -411,14 +511,14 @@ def run_edit(args, rank, world, device):
                 roofline=dict(e['solve_roofline'], traffic=None))
 
 
-def measure_sweep(device, size, layer, nseeds, steps, warmup, world):
+def measure_sweep(device, size, layer, nseeds, steps, warmup, world, g=None):
     """configs[3]: the key second-moment sweep as the rewriters run it -- launches of k x 10 seeds, every seed
     with the noise row of its reference batch of 10 (noise_batch_period), launches dealt round-robin to the
     ranks, ONE all-reduce of (mom2, count)."""
     from rewriting_amd import parallel
     from rewriting_amd.utils import tally, zdataset, nethook
     from rewriting_amd.utils.stylegan2.models import noise_batch_period
-    g = build_generator(size, device)
+    g = g if g is not None else build_generator(size, device)
     ctx = nethook.subsequence(g, upto_layer='layer%d.sconv.mconv.dconv' % layer, share_weights=True)
     zds = zdataset.z_dataset_for_model(g, size=nseeds)
     flops_ctx, (cin, res) = context_flops(size, layer)
@@ -461,15 +561,19 @@ def run_watermark(args, rank, world, device):
 
 
 def extras(args, rank, world, device):
-    """The rest of BASELINE.json's metric, timed in this process after the headline workload (whose buffers
-    are released first).  Sweep: every rank takes part (it contains the path's one collective); the edit and
-    the 256^2 forward are per-GPU quantities and are measured on one GPU runs only."""
+    """The rest of BASELINE.json's metric and configs, timed in this process after the headline workload (whose
+    buffers are released first).  Sweeps: every rank takes part (they contain the path's one collective); the
+    watermark job deals its five variants to the ranks as replicas; the edit and the 256^2 forward are per-GPU
+    quantities and are measured on one-GPU runs only."""
     out = {}
     torch.cuda.empty_cache()
-    sw = measure_sweep(device, 1024, 8, 10000 if world > 1 else 2000, 2, 1, world)
-    out['sweep_ffhq1024_layer8'] = sw
-    if world == 1:
+    g = build_generator(1024, device)
+    for layer, seeds in ((8, 2000), (10, 1000), (14, 500)):      # configs[3]: the three sweep layers of SURVEY 8d
+        n = 10000 if world > 1 else seeds
+        out['sweep_ffhq1024_layer%d' % layer] = measure_sweep(device, 1024, layer, n, 2, 1, world, g=g)
         torch.cuda.empty_cache()
+    del g
+    if world == 1:
         out['edit_horse256_layer8'] = measure_edit(device, 3, 1)
         torch.cuda.empty_cache()
         saved = (args.steps, args.warmup)
@@ -478,7 +582,16 @@ def extras(args, rank, world, device):
         args.steps, args.warmup = saved
         out['forward_ffhq256_b64'] = dict(images_per_s=f['value'], ms_per_step=f['ms_per_step'],
                                           all_conv_kernels=f['roofline']['all_conv_kernels'],
-                                          forward_hbm_algorithmic_gbs=f['roofline']['forward_hbm_algorithmic_gbs'])
+                                          step=f['step'], parity=f['parity'])
+        torch.cuda.empty_cache()
+    # configs[4]: the five watermark.sh variants (statistics, erase solves, sample sets), one warm-up job
+    saved = (args.steps, args.warmup, args.seeds)
+    args.steps, args.warmup, args.seeds = 1, 1, 1000
+    w = run_watermark(args, rank, world, device)
+    args.steps, args.warmup, args.seeds = saved
+    out['watermark_church256'] = dict(seconds_per_job=w['value'], images_per_s=w['config']['images_per_s'],
+                                      variants=w['config']['variants'], scaling=w['scaling'],
+                                      workload=w['config']['workload'])
     return out
 
 
@@ -491,8 +604,13 @@ def self_launch(argv, gpus):
         sock.bind(('127.0.0.1', 0))
         port = sock.getsockname()[1]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    # RW_BENCH_ENTRY: the script the ranks execute (default: this file).  tests/test_bench_launcher.py points it at
+    # tests/bench_cpu_driver.py, which calls this file's main() on emulated kernels.
+    entry = os.environ.get('RW_BENCH_ENTRY') or os.path.abspath(__file__)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(gpus),
-           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + argv
+           '--master-addr', '127.0.0.1', '--master-port', str(port), entry] + argv
+    # torch.distributed.run exits non-zero as soon as ANY rank does (it then terminates the others): that code is
+    # this process's exit code, so a failure on a rank other than 0 cannot look like success
     return subprocess.call(cmd, env=env)
 
 
@@ -506,6 +624,8 @@ def main():
     ap.add_argument('--size', type=int, default=1024)
     ap.add_argument('--layer', type=int, default=8)
     ap.add_argument('--seeds', type=int, default=1000)
+    ap.add_argument('--niters', type=int, default=2001, help='watermark workload: solver steps per erase (reference: 2001)')
+    ap.add_argument('--wm-size', type=int, default=256, help='watermark workload: generator resolution (reference: 256)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='headline workload only')
     ap.add_argument('--precision', default='f32', choices=['f32', 'bf16x6'],
@@ -526,10 +646,7 @@ def main():
     rank, world, local = parallel.init_from_env()
     if args.gpus != world:
         raise SystemExit('bench.py: --gpus %d but the launcher started %d ranks' % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X (the HIP kernels have no CPU path)')
-    torch.cuda.set_device(local)
-    device = torch.device('cuda', local)
+    device = bench_device(local)
     if args.workload == 'ffhq1024':
         out = run_forward(args, rank, world, device, 1024, args.batch or 64,
                           'stylegan2-1024 generator forward (FFHQ-1024 architecture)')
@@ -546,6 +663,8 @@ def main():
         out = run_watermark(args, rank, world, device)
     if world > 1:
         import torch.distributed as dist
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit('bench.py: process group of %d ranks for --gpus %d' % (dist.get_world_size(), args.gpus))
         out['rccl'] = dict(backend=dist.get_backend(), world_size=dist.get_world_size())
     if rank == 0:
         print(json.dumps(out), flush=True)

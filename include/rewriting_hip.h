@@ -197,8 +197,11 @@ int rw_conv3x3_wino_to_rgb_f32(const float* x, const float* uf, float* y, int ba
 /* The same convolution by Winograd F(4x4, 3x3) in fp32: 36 multiplications per 4x4 output tile and channel pair
  * (4x fewer matrix FLOPs than the direct sum, 1.78x fewer than F(2x2,3x3)).  Its transforms carry the constants
  * 4, 5, 8, 1/24: measured fp32 error 4e-6 .. 9e-6 of the output range per layer against 2e-7 .. 6e-7 for the two
- * kernels above.  OPT-IN for image generation (the image tolerance of the path is 1e-3 L-inf); the statistics
- * sweeps and the solve never use it.  Shapes: out_ch % 32 == 0, in_ch % 8 == 0, w % 64 == 0, h % 8 == 0.
+ * kernels above.  The Python host makes it the DEFAULT inside the un-hooked forward of the whole generator (image
+ * generation: the image tolerance of the path is 1e-3 L-inf, the measured deviation from the reference image 3e-5)
+ * and nowhere else: a hooked or sliced model -- the statistics sweeps, goal maps, the solve's context and its
+ * rendering -- runs F(2x2,3x3), so the same weights run hooked and un-hooked differ by 1e-5 .. 1e-4 on the image.
+ * Shapes: out_ch % 32 == 0, in_ch % 8 == 0, w % 64 == 0, h % 8 == 0.
  *   uf: rw_packed_conv_weight_wino4_elems(out_ch, in_ch) = 36*out_ch*in_ch floats from
  *       rw_pack_conv_weight_wino4_f32: uf[o / 16][i / 4][xi / 4][lane][xi % 4], o = 16 (o/16) + (lane & 15),
  *       i = 4 (i/4) + (lane >> 4), xi = 6 a + b the transform point (row a, column b of G g G^T). */
@@ -242,8 +245,8 @@ int rw_conv_transpose3x3s2_wino_f32(const float* x, const float* uf, float* y, i
  * NoiseInjectionF -> FusedLeakyReLUF  (models.py:315-316,328; 277-281; 539-546; 622-626):
  * x (B,Cin,H,W) -> y (B,Cout,2H,2W).  A stride-2 transposed 3x3 convolution followed by the 4x4 FIR is a stride-2
  * transposed convolution with their 6x6 composition, and each of its four output-parity phases is a 3x3 'same'
- * convolution of x: the phases run as 4*Cout virtual channels of the F(4x4,3x3) kernel above (its error class:
- * opt-in for image generation), the (2H+1)x(2W+1) map is never written, there are no border strips.
+ * convolution of x: the phases run as 4*Cout virtual channels of the F(4x4,3x3) kernel above (its error class; like
+ * it the host uses it inside the un-hooked whole-generator forward only), the (2H+1)x(2W+1) map is never written, there are no border strips.
  * Shapes: out_ch % 8 == 0, 8 <= in_ch <= 512, in_ch % 8 == 0, w % 64 == 0, h % 8 == 0.
  *   uf: rw_packed_conv_transpose_blur_wino4_elems(out_ch, in_ch) = 144*out_ch*in_ch floats from
  *       rw_pack_conv_transpose_blur_weight_wino4_f32(w, k4): w = the (1,out_ch,in_ch,3,3) parameter, k4 = the 4x4
@@ -357,11 +360,13 @@ typedef struct rw_solve_problem {
 
 /* split-K factor for a convolution-output map of h x w positions ((2h+1) x (2w+1) of the key for upsampling) */
 int rw_solve_ksplit(int out_ch, int in_ch, int h, int w);
-/* 0 when rw_solve_step_f32 takes this shape (h, w of the key crop), RW_ERR_UNSUPPORTED otherwise: out_ch % 64,
- * in_ch % 16, <= 64 KB of LDS for the blur staging of an upsampling target (plain == 0) and for the rank-r
- * projection (constrained != 0).  rw_solve_step_f32 runs the same check before its first launch. */
+/* 1 when rw_solve_step_f32 takes this shape (h, w of the key crop), 0 otherwise -- like every other *_supported
+ * entry point: out_ch % 64, in_ch % 16, <= 64 KB of LDS for the blur staging of an upsampling target (plain == 0)
+ * and for the rank-r projection (constrained != 0).  rw_solve_step_f32 runs the same check before its first launch
+ * and returns RW_ERR_UNSUPPORTED / RW_ERR_BAD_ARGUMENT. */
 int rw_solve_supported(int out_ch, int in_ch, int h, int w, int upsample, int plain, int constrained);
-/* sizes[0..4] = element counts of conv, wsq, gd, c2, grad for this shape */
+/* sizes[0..4] = element counts of conv, wsq, gd, c2, grad for this shape; sizes[5] = the split-K factor they were
+ * sized for, i.e. the value rw_solve_problem.ksplit must carry (the caller passes long long sizes[6]) */
 int rw_solve_scratch_elems(int out_ch, int in_ch, int h, int w, int upsample, long long* sizes);
 /* one iteration `it` (loss, gradient, Adam); project != 0 also applies W <- ortho + P(W) */
 int rw_solve_step_f32(const rw_solve_problem* p, int project, rw_stream_t stream);

@@ -262,6 +262,72 @@ def golden_edit_full(ref, name):
     save(name, **arrays)
 
 
+def golden_edit_full_keys(ref, name):
+    """Companion of rw_s256_l8_horsehat_1000: how reproducible the reference's OWN context direction is at
+    configs[2]'s size, so that the bar on `mkey` can be its scatter instead of a guess.  The 'zca' direction
+    (rewrite/ganrewrite.py:339-374) whitens twice with Z = C^-1/2; the reference's C carries float32 accumulation
+    error (2.2e-4), its Z 2.8e-3.  Recorded: the reference at 8 threads and at 1 thread, the reference's
+    arithmetic on the float64-accumulated C, and the same definition in float64 end to end."""
+    g = build_stylegan(ref, 256, 0.5)
+    zds = ref.zdataset.z_dataset_for_model(g, size=1000)
+    with open(os.path.join(MASKS, 'recorded_horse_hat.json')) as f:
+        request = json.load(f)
+    keys = request['key']
+
+    def rewriter(threads):
+        torch.set_num_threads(threads)
+        return ref.ganrewrite.SeqStyleGanRewriter(g, zds, 8, cachedir=None, low_rank_insert=True,
+                                                  key_method='zca', tight_paste=True)
+    runs = {}
+    gw8 = rewriter(8)
+    runs['t8'] = gw8.multi_key_from_selection(keys, rank=1).double()
+    gw1 = rewriter(1)
+    runs['t1'] = gw1.multi_key_from_selection(keys, rank=1).double()
+    torch.set_num_threads(8)
+    n = gw8.c_matrix.shape[0]
+    exact = torch.zeros(n, n, dtype=torch.float64)
+    with torch.no_grad():
+        for b0 in range(0, 1000, 10):
+            zb = torch.stack([zds[i][0] for i in range(b0, b0 + 10)])
+            a = gw8.context_model(zb).fmap.permute(0, 2, 3, 1).reshape(-1, n).double()
+            exact += a.t() @ a
+    exact /= 1000.0 * gw8.k_shape[2] * gw8.k_shape[3]
+    gw8.c_matrix = exact.float()
+    gw8.zca_matrix = ref.ganrewrite.zca_from_cov(gw8.c_matrix)
+    runs['c64'] = gw8.multi_key_from_selection(keys, rank=1).double()
+    # float64 end to end
+    vals, vecs = torch.linalg.eigh(exact)
+    Z = (vecs * (1.0 / vals.sqrt().clamp(1e-20))[None, :]) @ vecs.t()
+    rows = []
+    with torch.no_grad():
+        for imgnum, mask in keys:
+            acts = gw8.context_model(gw8.get_z(imgnum)).fmap
+            w = ref.renormalize.from_url(mask, target='pt', size=gw8.k_shape[2:])[0].reshape(-1)[:, None].double()
+            obs = acts.permute(0, 2, 3, 1).reshape(-1, n).double()
+            rows.append((w * (obs @ Z))[(w > 0).nonzero()[:, 0]])
+    zk = torch.cat(rows)
+    vh = torch.linalg.svd(zk, full_matrices=False)[2]
+    q = torch.linalg.qr((Z @ vh.t()[:, :1]))[0]
+    q = q * (q * zk.sum(0)[:, None]).sum(0).sign()[None, :]
+    truth = q.t()
+    dev = lambda a, b: 1.0 - abs((a * b).sum().item()) / (a.norm() * b.norm()).item()
+    arrays = dict(meta=json.dumps(dict(size=256, layernum=8, mask='recorded_horse_hat.json', nseeds=1000,
+                                       weight_seed=0, truncation=0.5, rank=1, runs=sorted(runs))),
+                  mkey_exact=truth.numpy(), cond=numpy.float64((vals.max() / vals.min()).item()))
+    for k, v in runs.items():
+        arrays['mkey_' + k] = v.numpy()
+    arrays['dev_vs_exact'] = numpy.array([dev(runs[k], truth) for k in sorted(runs)])
+    arrays['maxabs_vs_exact'] = numpy.array([(runs[k] - truth).abs().max().item() for k in sorted(runs)])
+    arrays['between'] = numpy.array([dev(runs['t1'], runs['t8']), dev(runs['t1'], runs['c64']),
+                                     dev(runs['t8'], runs['c64'])])
+    arrays['maxabs_between'] = numpy.array([(runs['t1'] - runs['t8']).abs().max().item(),
+                                            (runs['t1'] - runs['c64']).abs().max().item(),
+                                            (runs['t8'] - runs['c64']).abs().max().item()])
+    print('mkey: reference runs', sorted(runs), '1-cos vs float64', arrays['dev_vs_exact'], 'max abs',
+          arrays['maxabs_vs_exact'], 'between runs', arrays['between'], arrays['maxabs_between'])
+    save(name, **arrays)
+
+
 def golden_sweep_1024(ref, name):
     """BASELINE.json configs[3] (rewrite/ganrewrite.py:83-96 on the 1024 generator): for the sweep layers
     {8, 10, 14} the second moment of the first two reference batches of 10 seeds, and the key maps
@@ -686,6 +752,240 @@ def golden_proggan(ref, name, resolution, layernum, maskfile, nseeds):
     save(name, **arrays)
 
 
+def _c_digest(arrays, prefix, C, exact):
+    """Digest of a (C, C) statistic of the reference next to the float64 accumulation of its own key maps."""
+    arrays[prefix + 'c_matrix'] = C.numpy()[::4, ::4].copy()
+    arrays[prefix + 'c_matrix_norm'] = numpy.float64(C.double().norm().item())
+    arrays[prefix + 'c_matrix_diag'] = C.diag().numpy()
+    arrays[prefix + 'c_exact'] = exact.numpy()[::4, ::4].copy()
+    arrays[prefix + 'c_exact_diag'] = exact.diag().numpy()
+    arrays[prefix + 'c_exact_norm'] = numpy.float64(exact.norm().item())
+    arrays[prefix + 'c_ref_vs_exact'] = numpy.float64(((C.double() - exact).norm() / exact.norm()).item())
+    arrays[prefix + 'c_ref_vs_exact_max'] = numpy.float64((C.double() - exact).abs().max().item())
+    ev = torch.linalg.eigvalsh(exact)
+    arrays[prefix + 'c_eig_minmax'] = numpy.array([ev.min().item(), ev.max().item()])
+    print(prefix, 'reference C vs float64 accumulation of its own key maps: rel %.3e, max abs %.3e (max |C| %.3f), '
+          'eig %.3e..%.3e' % (arrays[prefix + 'c_ref_vs_exact'], arrays[prefix + 'c_ref_vs_exact_max'],
+                              C.abs().max().item(), ev.min().item(), ev.max().item()))
+
+
+def golden_proggan_full(ref, name):
+    """BASELINE.json configs[0] at its own size: ProgressiveGenerator(resolution=256)
+    (utils/proggan.py:65-193), 1000 seeds, layer 6 (k, v (1,512,16,16); W (512,512,3,3)), the request
+    notebooks/masks/proggan/church/spire2tree.json with its REAL seed indices (object 971, paste 18, key = paste),
+    rank 1, piter 10, lr 0.05: statistics, goal tensors, context direction, weights after 1/10/11/100/101 steps
+    (rewrite/ganrewrite.py:148-169,254-298) and the 2001-step result at 8 threads and at 1 thread."""
+    g = ref.proggan.ProgressiveGenerator(resolution=256)
+    synthetic.randomize_(g, seed=0, kind='proggan')
+    g.eval()
+    zds = ref.zdataset.z_dataset_for_model(g, size=1000)
+    with open(os.path.join(MASKS, 'spire2tree.json')) as f:
+        request = json.load(f)
+    import tempfile
+    cachedir = tempfile.mkdtemp()
+
+    def fresh():
+        return ref.ganrewrite.ProgressiveGanRewriter(g, zds, 6, cachedir=cachedir)
+    gw = fresh()
+    arrays = dict(meta=json.dumps(dict(resolution=256, layernum=6, mask='spire2tree.json', nseeds=1000,
+                                       weight_seed=0, rank=1)))
+    with torch.no_grad():
+        zs = torch.stack([zds[i][0] for i in (0, request['paste'][0])])
+        for k, v in image_digest(g(zs), 4).items():
+            arrays['image/' + k] = v
+    C = gw.c_matrix
+    exact = torch.zeros(C.shape[0], C.shape[0], dtype=torch.float64)
+    with torch.no_grad():
+        for b0 in range(0, 1000, 10):
+            zb = torch.stack([zds[i][0] for i in range(b0, b0 + 10)])
+            a = gw.context_acts(gw.context_model(zb)).permute(0, 2, 3, 1).reshape(-1, C.shape[0]).double()
+            exact += a.t() @ a
+    exact /= 1000.0 * gw.k_shape[2] * gw.k_shape[3]
+    _c_digest(arrays, '', C, exact)
+    arrays['zca'] = gw.zca_matrix.numpy()[::4, ::4].copy()
+    arrays['zca_norm'] = numpy.float64(gw.zca_matrix.double().norm().item())
+    vals, vecs = torch.linalg.eigh(exact)
+    zca_exact = (vecs * (1.0 / vals.sqrt().clamp(1e-20))[None, :]) @ vecs.t()
+    arrays['zca_exact'] = zca_exact.float().numpy()[::4, ::4].copy()
+    arrays['zca_ref_vs_exact_max'] = numpy.float64((gw.zca_matrix.double() - zca_exact).abs().max().item())
+    arrays['k_shape'] = numpy.array(gw.k_shape)
+    arrays['v_shape'] = numpy.array(gw.v_shape)
+    o_imgnum, o_mask = request['object']
+    p_imgnum, p_mask = request['paste']
+    key_examples = request.get('key', [(p_imgnum, p_mask)])
+    obj_acts, _, obj_area, bounds = gw.object_from_selection(o_imgnum, o_mask)
+    goal_in, goal_out, _, pbounds = gw.paste_from_selection(p_imgnum, p_mask, obj_acts, obj_area)
+    mkey = gw.multi_key_from_selection(key_examples, rank=1)
+    arrays['mkey'] = mkey.numpy()
+    arrays['n_sel'] = numpy.array(ref.ganrewrite.all_obs.shape[0])
+    arrays['obj_bounds'] = numpy.array(bounds)
+    arrays['paste_bounds'] = numpy.array(pbounds)
+    arrays['obj_area'] = obj_area.detach().numpy()
+    arrays['goal_in'] = goal_in.detach().numpy()
+    arrays['goal_out'] = goal_out.detach().numpy()
+    W0 = gw.target_weights().detach().clone()
+    arrays['W0_sub'], arrays['W0_norm'] = sub(W0, 16384)
+
+    def record(tag, W):
+        dW = W - W0
+        arrays['dW_%s_sub' % tag], arrays['dW_%s_norm' % tag] = sub(dW, 8192)
+        arrays['dW_%s_cos' % tag] = torch.einsum('oiyx,di->odyx', dW, mkey).numpy()
+        return dW
+    for niter in (1, 11, 101):
+        gwn = fresh()
+        pre, losses = {}, []
+
+        def cb(it, loss, pre=pre, gwn=gwn, losses=losses):
+            losses.append(loss.item())
+            if it in (9, 99):
+                pre[it] = gwn.target_weights().detach().clone()
+        gwn.insert(goal_in, goal_out, mkey, niter=niter, piter=10, lr=0.05, update_callback=cb)
+        record('%d' % niter, gwn.target_weights().detach())
+        for it, W in pre.items():
+            record('%d' % (it + 1), W)
+        if niter == 101:
+            arrays['losses'] = numpy.array(losses)
+            with torch.no_grad():
+                for k, v in image_digest(gwn.sample_image_from_latent(zs), 4).items():
+                    arrays['edited_image/' + k] = v
+    full = {}
+    for nthreads in (8, 1):
+        with reference_shim.threads(nthreads):
+            gwn = fresh()
+            losses = []
+            gwn.insert(goal_in, goal_out, mkey, niter=2001, piter=10, lr=0.05,
+                       update_callback=lambda it, loss: losses.append(loss.item()))
+            full[nthreads] = record('2001_t%d' % nthreads, gwn.target_weights().detach())
+            arrays['losses_2001_t%d' % nthreads] = numpy.array(losses)[::50]
+    arrays['self_scatter_2001'] = numpy.float64(((full[8] - full[1]).norm() / full[1].norm()).item())
+    print('reference self-scatter of dW after 2001 steps, 8 threads vs 1:', arrays['self_scatter_2001'])
+    save(name, **arrays)
+
+
+def golden_watermark_full(ref, name):
+    """BASELINE.json configs[4] at its own size, as metrics/make_watermark_images.py:39-84 and watermark.sh:11-24 run
+    it: the 256^2 generator twice (truncation 1.0 for the statistics, truncation 0.5 for the rewriter that loads
+    that cache: quirk Q7), 1000 seeds, layer 6, the request multikey_markandbottom.json (10 keys, paste seed 820),
+    low_rank_insert + low_rank_gradient, tight_paste.  Recorded: the statistics; for drank 60 and 30 the
+    dissected units, unit scales, goal tensors, context direction and weights after 1/10/11/100/101 steps of the
+    first erase; for drank 60 the `ours` variant end to end -- two consecutive 2001-step erases -- at 8 threads
+    and at 1 thread (weights and images of three seeds: the reference's own scatter is the bar there); the
+    gandissect units for drank 30 / 60."""
+    g10 = build_stylegan(ref, 256, 1.0)
+    g05 = build_stylegan(ref, 256, 0.5)
+    zds = ref.zdataset.z_dataset_for_model(g05, size=1000)
+    with open(os.path.join(MASKS, 'multikey_markandbottom.json')) as f:
+        request = json.load(f)
+    import tempfile
+    cachedir = tempfile.mkdtemp()
+
+    def rewriter(model, key_method='zca'):
+        return ref.ganrewrite.SeqStyleGanRewriter(model, zds, 6, cachedir=cachedir, low_rank_insert=True,
+                                                  low_rank_gradient=True, key_method=key_method, tight_paste=True)
+    gwc = rewriter(g10)                   # the statistics come from the truncation-1.0 model ...
+    gwc.collect_2nd_moment()
+    gw = rewriter(g05)                    # ... and the truncation-0.5 rewriter loads them from the cache
+    assert torch.equal(gw.c_matrix, gwc.c_matrix)
+    arrays = dict(meta=json.dumps(dict(size=256, layernum=6, mask='multikey_markandbottom.json', nseeds=1000,
+                                       weight_seed=0, truncation=0.5, stats_truncation=1.0, rank=1,
+                                       dranks=[60, 30], nreps=2)))
+    C = gw.c_matrix
+    exact = torch.zeros(C.shape[0], C.shape[0], dtype=torch.float64)
+    with torch.no_grad():
+        for b0 in range(0, 1000, 10):
+            zb = torch.stack([zds[i][0] for i in range(b0, b0 + 10)])
+            a = gwc.context_model(zb).fmap.permute(0, 2, 3, 1).reshape(-1, C.shape[0]).double()
+            exact += a.t() @ a
+    exact /= 1000.0 * gw.k_shape[2] * gw.k_shape[3]
+    _c_digest(arrays, '', C, exact)
+    arrays['zca'] = gw.zca_matrix.numpy()[::4, ::4].copy()
+    arrays['zca_norm'] = numpy.float64(gw.zca_matrix.double().norm().item())
+    vals, vecs = torch.linalg.eigh(exact)
+    zca_exact = (vecs * (1.0 / vals.sqrt().clamp(1e-20))[None, :]) @ vecs.t()
+    arrays['zca_exact'] = zca_exact.float().numpy()[::4, ::4].copy()
+    arrays['zca_ref_vs_exact_max'] = numpy.float64((gw.zca_matrix.double() - zca_exact).abs().max().item())
+    arrays['k_shape'] = numpy.array(gw.k_shape)
+    arrays['v_shape'] = numpy.array(gw.v_shape)
+    p_imgnum, p_mask = request['paste']
+    key_examples = request['key']
+    W0 = gw.target_weights().detach().clone()
+    arrays['W0_sub'], arrays['W0_norm'] = sub(W0, 16384)
+    with torch.no_grad():
+        arrays['unit_scale'] = gw.square_scales_for_units().numpy()      # statistics of the truncation-0.5 model
+    mkey = gw.multi_key_from_selection(key_examples, rank=1)
+    arrays['mkey'] = mkey.numpy()
+    arrays['n_sel'] = numpy.array(ref.ganrewrite.all_obs.shape[0])
+    arrays['all_obs_norm'] = numpy.float64(ref.ganrewrite.all_obs.double().norm().item())
+
+    def record(tag, W):
+        dW = (W - W0)[0]
+        arrays['dW_%s_sub' % tag], arrays['dW_%s_norm' % tag] = sub(dW, 8192)
+        arrays['dW_%s_cos' % tag] = torch.einsum('oiyx,di->odyx', dW, mkey).numpy()
+        return dW
+    sample_seeds = (p_imgnum, 0, 1)
+    arrays['sample_seeds'] = numpy.array(sample_seeds)
+
+    def fresh_on_copy():
+        """A fresh rewriter: the constructor deep-copies the model it is given (rewrite/ganrewrite.py:47)."""
+        return rewriter(g05)
+    for drank in (60, 30):
+        pre = 'd%d/' % drank
+        with torch.no_grad():
+            goal_in, goal_out = gw.erase_from_selection(p_imgnum, p_mask, key_examples, drank)
+            arrays[pre + 'd_units'] = gw.normdissect_units(key_examples, drank).numpy()
+        for nm, bag in (('goal_in', goal_in), ('goal_out', goal_out)):
+            arrays[pre + nm + '_fmap'] = bag.fmap.detach().numpy()
+            arrays[pre + nm + '_style'] = bag.style.detach().numpy()
+        for niter in ((1, 11, 101) if drank == 60 else (1, 11)):
+            gwn = fresh_on_copy()
+            snaps, losses = {}, []
+
+            def cb(it, loss, snaps=snaps, gwn=gwn, losses=losses):
+                losses.append(loss.item())
+                if it in (9, 99):
+                    snaps[it] = gwn.target_weights().detach().clone()
+            gwn.insert(goal_in, goal_out, mkey, niter=niter, piter=10, lr=0.05, update_callback=cb)
+            record(pre + '%d' % niter, gwn.target_weights().detach())
+            for it, W in snaps.items():
+                record(pre + '%d' % (it + 1), W)
+            if niter == 101:
+                arrays[pre + 'losses'] = numpy.array(losses)
+    # ---- `ours --nreps 2 --drank 60 --rank 1` end to end (make_watermark_images.py:60-68)
+    full, imgs = {}, {}
+    for nthreads in (8, 1):
+        with reference_shim.threads(nthreads):
+            gwn = fresh_on_copy()
+            for rep in range(2):
+                gwn.apply_erase(request, rank=1, drank=60, niter=2001, piter=10, lr=0.05)
+                record('ours60_rep%d_t%d' % (rep + 1, nthreads), gwn.target_weights().detach())
+            full[nthreads] = (gwn.target_weights().detach() - W0)[0]
+            with torch.no_grad():
+                zs = torch.stack([zds[i][0] for i in sample_seeds])
+                imgs[nthreads] = gwn.model(zs)
+            for k, v in image_digest(imgs[nthreads], 4).items():
+                arrays['ours60_image_t%d/' % nthreads + k] = v
+    arrays['ours60_self_scatter'] = numpy.float64(((full[8] - full[1]).norm() / full[1].norm()).item())
+    arrays['ours60_image_self_scatter'] = numpy.float64((imgs[8] - imgs[1]).abs().max().item())
+    with torch.no_grad():
+        zs = torch.stack([zds[i][0] for i in sample_seeds])
+        base = g05(zs)
+        for k, v in image_digest(base, 4).items():
+            arrays['base_image/' + k] = v
+        arrays['ours60_image_change'] = numpy.float64((imgs[8] - base).abs().max().item())
+    print('ours/60: reference self-scatter 8 vs 1 threads: dW %.3e, image max abs %.3e (the edit moves the image by %.3e)'
+          % (arrays['ours60_self_scatter'], arrays['ours60_image_self_scatter'], arrays['ours60_image_change']))
+    # ---- gandissect variants (:69-71): the units; zero() itself is deterministic given them
+    # (own rewriter without a cache directory: the reference's tally_quantile cannot SAVE its sketch under numpy 2 --
+    # savez of the ragged per-level list raises -- which is version drift of the container, not the algorithm)
+    torch.manual_seed(0)
+    gwg = ref.ganrewrite.SeqStyleGanRewriter(g05, zds, 6, cachedir=None, low_rank_insert=True, low_rank_gradient=True,
+                                             key_method='gandissect', tight_paste=True)
+    gwg.c_matrix, gwg.zca_matrix = gw.c_matrix, gw.zca_matrix
+    for drank in (30, 60):
+        arrays['gandissect_units_%d' % drank] = gwg.multi_key_from_selection(key_examples, rank=drank).argmax(1).numpy()
+    save(name, **arrays)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default=None)
@@ -720,7 +1020,10 @@ def main():
         'gen_s256_full': lambda: golden_generator_full(ref, 'gen_s256_full', 256, 4, 4),
         'gen_s1024_full': lambda: golden_generator_full(ref, 'gen_s1024_full', 1024, 2, 8),
         'rw_s256_l8_horsehat_1000': lambda: golden_edit_full(ref, 'rw_s256_l8_horsehat_1000'),
+        'rw_s256_l8_horsehat_1000_keys': lambda: golden_edit_full_keys(ref, 'rw_s256_l8_horsehat_1000_keys'),
         'sweep_s1024': lambda: golden_sweep_1024(ref, 'sweep_s1024'),
+        'pg256_l6_spire2tree_1000': lambda: golden_proggan_full(ref, 'pg256_l6_spire2tree_1000'),
+        'rw_s256_l6_watermark_1000': lambda: golden_watermark_full(ref, 'rw_s256_l6_watermark_1000'),
     }
     for nm, fn in jobs.items():
         if args.only in (None, nm):

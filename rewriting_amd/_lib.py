@@ -14,7 +14,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('RW_HIP_LIB') or os.path.join(_HERE, 'librewriting_hip.so')    # RW_HIP_LIB: tuning builds
 
-ABI_VERSION = 1
+ABI_VERSION = 2        # 2: rw_solve_supported returns 1/0, rw_solve_scratch_elems fills sizes[6] (+ksplit), round-3 exports
 
 
 class ConvEpilogue(Structure):
@@ -133,13 +133,25 @@ def load():
             'g.build()"` or rewriting_amd/csrc/build.sh (hipcc --offload-arch=gfx950). There is no '
             'CPU or PyTorch fallback for the HIP kernels.' % LIB_PATH)
     lib = ctypes.CDLL(LIB_PATH)
+    # version first: a stale .so (it is git-ignored; RW_HIP_LIB may point at an old tuning build) must say
+    # "rebuild" instead of failing on the first symbol it lacks
+    stale = 'rewriting_amd: %s is stale (%s) -- rebuild it with rewriting_amd/csrc/build.sh or ' \
+            '`python -c "import __graft_entry__ as g; g.build()"`'
+    try:
+        lib.rw_abi_version.restype = c_int
+        lib.rw_abi_version.argtypes = []
+        have = lib.rw_abi_version()
+    except AttributeError:
+        raise RuntimeError(stale % (LIB_PATH, 'no rw_abi_version symbol')) from None
+    if have != ABI_VERSION:
+        raise RuntimeError(stale % (LIB_PATH, 'ABI %d, this package binds ABI %d' % (have, ABI_VERSION)))
     for name, (restype, argtypes) in SIGNATURES.items():
-        fn = getattr(lib, name)
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise RuntimeError(stale % (LIB_PATH, 'ABI %d but no symbol %s' % (have, name))) from None
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.rw_abi_version() != ABI_VERSION:
-        raise RuntimeError('rewriting_amd: %s has ABI %d, expected %d (rebuild it)'
-                           % (LIB_PATH, lib.rw_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 

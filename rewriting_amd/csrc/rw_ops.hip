@@ -9,7 +9,7 @@
 #include <stdlib.h>
 #include <stdint.h>
 
-extern "C" int rw_abi_version(void) { return 1; }
+extern "C" int rw_abi_version(void) { return 2; }
 
 extern "C" const char* rw_error_string(int code) {
   if (code == 0) return "success";

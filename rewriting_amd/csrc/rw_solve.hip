@@ -544,7 +544,7 @@ extern "C" int rw_project_weight_f32(const float* w, const float* context, const
 // the host mirrors it in _hip_solvable): 64 out-channels per workgroup in both GEMMs, 16-channel K chunks,
 // the blur / blur-backward staging of an upsampling target in <= 64 KB of LDS, and the two weight rows of the
 // rank-r projection in <= 64 KB.
-extern "C" int rw_solve_supported(int out_ch, int in_ch, int h, int w, int upsample, int plain, int constrained) {
+static int sv_check_shape(int out_ch, int in_ch, int h, int w, int upsample, int plain, int constrained) {
   if (out_ch <= 0 || in_ch <= 0 || h <= 0 || w <= 0) return RW_ERR_BAD_ARGUMENT;
   if (out_ch % SV_BM || in_ch % SV_KC) return RW_ERR_UNSUPPORTED;
   if (upsample && !plain) {
@@ -555,8 +555,14 @@ extern "C" int rw_solve_supported(int out_ch, int in_ch, int h, int w, int upsam
   return 0;
 }
 
+// 1 when rw_solve_step_f32 takes the shape, 0 otherwise -- the convention of every other *_supported export.
+extern "C" int rw_solve_supported(int out_ch, int in_ch, int h, int w, int upsample, int plain, int constrained) {
+  return sv_check_shape(out_ch, in_ch, h, w, upsample, plain, constrained) == 0 ? 1 : 0;
+}
+
 // Element counts of the scratch buffers of rw_solve_problem for this shape: sizes[0..4] =
-// {conv, wsq, gd, c2, grad} (floats).  Rows of conv / gd are padded to ceil64 of the positions of the map the
+// {conv, wsq, gd, c2, grad} (floats), and sizes[5] = the split-K factor they were sized for (= rw_solve_ksplit of the
+// map the convolution writes: the value rw_solve_problem.ksplit has to carry).  Rows of conv / gd are padded to ceil64 of the positions of the map the
 // convolution writes (h*w, or (2h+1)(2w+1) for an upsampling target); c2 carries the per-channel loss behind it.
 extern "C" int rw_solve_scratch_elems(int out_ch, int in_ch, int h, int w, int upsample, long long* sizes) {
   if (!sizes || out_ch <= 0 || in_ch <= 0 || h <= 0 || w <= 0) return RW_ERR_BAD_ARGUMENT;
@@ -568,6 +574,7 @@ extern "C" int rw_solve_scratch_elems(int out_ch, int in_ch, int h, int w, int u
   sizes[2] = (long long)out_ch * pp;
   sizes[3] = 2LL * out_ch;
   sizes[4] = (long long)out_ch * in_ch * 9;
+  sizes[5] = ks;
   return 0;
 }
 
@@ -586,8 +593,8 @@ extern "C" int rw_solve_step_f32(const rw_solve_problem* pr, int project, rw_str
   RW_CHECK_ARG(!p.upsample || !p.bias || p.blur_k);
   // every shape / LDS limit is checked BEFORE the first launch: a step either runs completely or not at all
   {
-    const int rc = rw_solve_supported(p.out_ch, p.in_ch, p.h, p.w, p.upsample, p.bias ? 0 : 1,
-                                      (project || p.low_rank_gradient || p.linear_insert) ? 1 : 0);
+    const int rc = sv_check_shape(p.out_ch, p.in_ch, p.h, p.w, p.upsample, p.bias ? 0 : 1,
+                                  (project || p.low_rank_gradient || p.linear_insert) ? 1 : 0);
     if (rc) return rc;
   }
   hipStream_t s = rw_s(stream);

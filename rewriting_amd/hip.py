@@ -273,8 +273,9 @@ def pack_conv_weight_wino4(weight):
 
 
 def conv3x3_wino4(x, uf, out_ch, w_scale, style=None, demod=None, noise=None, noise_w=None, bias=None, act=False):
-    """Stride-1 3x3 convolution by Winograd F(4x4,3x3) in fp32 (opt-in: ~1e-5 relative error per layer); same
-    arguments and epilogue as conv3x3."""
+    """Stride-1 3x3 convolution by Winograd F(4x4,3x3) in fp32 (~1e-5 relative error per layer: the default of the
+    un-hooked whole-generator forward, never used by a hooked or sliced model -- models.conv_algo); same arguments
+    and epilogue as conv3x3."""
     x = _dev(x, 'fmap')
     uf = _dev(uf, 'packed weight')
     b, i, h, w = x.shape
@@ -582,13 +583,15 @@ def solve_ksplit(out_ch, in_ch, h, w):
 def solve_supported(out_ch, in_ch, h, w, upsample, plain, constrained):
     """True when rw_solve_step_f32 takes this target (h, w: the key crop); never raises."""
     return lib().rw_solve_supported(out_ch, in_ch, h, w, int(bool(upsample)), int(bool(plain)),
-                                    int(bool(constrained))) == 0
+                                    int(bool(constrained))) == 1
 
 
 def solve_scratch_elems(out_ch, in_ch, h, w, upsample):
-    sizes = (ctypes.c_longlong * 5)()
+    """Element counts of the solver's scratch buffers and the split-K factor they are sized for -- both from the
+    library, so that rw_solve_problem.ksplit and the buffers cannot disagree."""
+    sizes = (ctypes.c_longlong * 6)()
     check(lib().rw_solve_scratch_elems(out_ch, in_ch, h, w, int(bool(upsample)), sizes))
-    return dict(zip(('conv', 'wsq', 'gd', 'c2', 'grad'), (int(v) for v in sizes)))
+    return dict(zip(('conv', 'wsq', 'gd', 'c2', 'grad', 'ksplit'), (int(v) for v in sizes)))
 
 
 def solve_step(problem, project):

@@ -61,10 +61,14 @@ def shard():
     return None
 
 
-def _coll_device():
+def collective_device():
+    """Where tensors handed to a collective have to live: this rank's GPU under nccl (= RCCL), the host under gloo."""
     if dist.get_backend() == 'nccl':
         return torch.device('cuda', torch.cuda.current_device())
     return torch.device('cpu')
+
+
+_coll_device = collective_device
 
 
 def all_agree(flag):

@@ -283,8 +283,59 @@ class ProgressiveGanRewriter(object):
 
     def linear_insert(self, key, val, context=None, update_callback=None, niter=2001, lr=0.05,
                       return_timing=False):
-        raise NotImplementedError(
-            'linear_insert (rewrite/ganrewrite.py:201-252) is a "next" row (SURVEY.md section 8f.4)')
+        """weight = W0 + Lambda . context with Adam on Lambda alone (rewrite/ganrewrite.py:201-252), through torch
+        autograd for targets made of torch ops: the module that owns the target weight gets a forward that
+        rebuilds its weight from Lambda on every call and is restored afterwards, the frozen parameters stay
+        frozen (:206), the learned update is written into the original parameter (:246-249).
+
+        The reference sizes Lambda as (ws[0], ws[1], rank, ws[3], ws[4]) and therefore raises IndexError on
+        ProgGAN's 4-d nn.Conv2d weight (use_linear_insert=True never worked on its config 1); here a 4-d weight
+        (O, I, ky, kx) gets Lambda (O, rank, ky, kx), a 5-d one (1, O, I, ky, kx) the reference's shape."""
+        sync = (lambda: torch.cuda.synchronize()) if self.device.type == 'cuda' else (lambda: None)
+        if return_timing:
+            sync()
+            started = time.time()
+        nethook.set_requires_grad(False, self.model)
+        key, val = self.detach(key), self.detach(val)
+        weight = self.target_weights()
+        owner = [m for m in self.target_model.modules() if getattr(m, 'weight', None) is weight][0]
+        five = weight.dim() == 5
+        rule = 'godyx,di->goiyx' if five else 'odyx,di->oiyx'
+        lam = torch.zeros(tuple(weight.shape[:2 if five else 1]) + (context.shape[0],) + tuple(weight.shape[-2:]),
+                          device=weight.device, dtype=weight.dtype, requires_grad=True)
+        hooked_before = owner.__dict__.get('forward')        # an instance-level forward (a nethook edit), if any
+        plain_forward = owner.forward
+        del owner._parameters['weight']
+
+        def forward_with_lambda(*args, **kwargs):
+            owner.weight = weight + torch.einsum(rule, lam, context)
+            return plain_forward(*args, **kwargs)
+        owner.forward = forward_with_lambda
+        try:
+            optimizer = torch.optim.Adam([lam], lr=lr)
+            goal = self.target_acts(val)
+            for it in range(niter):
+                with torch.enable_grad():
+                    loss = torch.nn.functional.l1_loss(goal, self.target_acts(self.target_model(key)))
+                    optimizer.zero_grad()
+                    loss.backward()
+                    optimizer.step()
+                    if update_callback is not None:
+                        update_callback(it, loss)
+        finally:
+            with torch.no_grad():
+                weight[...] = weight + torch.einsum(rule, lam.detach(), context)
+            if 'weight' in owner.__dict__:
+                del owner.weight
+            owner.register_parameter('weight', weight)
+            if hooked_before is not None:
+                owner.forward = hooked_before
+            else:
+                del owner.forward         # the instance attribute; the class's forward is back
+        _weights_changed()
+        if return_timing:
+            sync()
+            return (time.time() - started) * 1000
 
     def all_weights_insert(self, *args, **kwargs):
         raise NotImplementedError('see apply_overfit')

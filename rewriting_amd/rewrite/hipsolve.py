@@ -40,6 +40,13 @@ class Solver:
         _, O, I, kh, kw = w.shape
         assert (kh, kw) == (3, 3)
         _, _, h, wd = key.shape
+        constrained = low_rank_insert or low_rank_gradient or linear
+        # the shape limits first: before any allocation, and before project_weight meets the same LDS limit
+        if not hip.solve_supported(O, I, h, wd, upsample, plain, constrained):
+            raise NotImplementedError(
+                'the fused HIP solver takes out_ch %% 64 == 0, in_ch %% 16 == 0, in_ch <= 910 with a context '
+                'direction, and for an upsampling target a key crop with (2h+1)(2w+1) + 4hw <= 16384 '
+                '(got %d -> %d channels, key crop %d x %d, upsample=%s)' % (I, O, h, wd, bool(upsample)))
         self.niter, self.piter = niter, piter
         self.low_rank_insert, self.low_rank_gradient = low_rank_insert, low_rank_gradient
         f32 = dict(device=dev, dtype=torch.float32)
@@ -54,7 +61,6 @@ class Solver:
         self.blur_k = blur_kernel.detach().contiguous().float() if (upsample and not plain) else None
         self.linear = linear
         self.noise_w = None if plain else noise_w.detach().reshape(1).contiguous().float()
-        constrained = low_rank_insert or low_rank_gradient or linear
         self.context = context.detach().contiguous().float().to(dev) if constrained else None
         self.ortho = None
         self.lam = None
@@ -70,13 +76,9 @@ class Solver:
         self.bc2_sqrt = torch.tensor([math.sqrt(1 - 0.999 ** t) for t in steps], **f32)
         self.counter = torch.full((1,), -1, device=dev, dtype=torch.int32)
         self.losses = torch.zeros(niter, **f32)
-        if not hip.solve_supported(O, I, h, wd, upsample, plain, constrained):
-            raise NotImplementedError(
-                'the fused HIP solver takes out_ch %% 64 == 0, in_ch %% 16 == 0, in_ch <= 910 with a context '
-                'direction, and for an upsampling target a key crop with (2h+1)(2w+1) + 4hw <= 16384 '
-                '(got %d -> %d channels, key crop %d x %d, upsample=%s)' % (I, O, h, wd, bool(upsample)))
-        ks = hip.solve_ksplit(O, I, ch, cw)
-        n = hip.solve_scratch_elems(O, I, h, wd, upsample)      # sizes as the library states them
+        n = hip.solve_scratch_elems(O, I, h, wd, upsample)      # sizes AND split-K factor as the library states them
+        ks = n['ksplit']
+        assert n['wsq'] == ks * O
         self.conv = torch.empty(n['conv'], **f32)
         self.wsq = torch.empty(n['wsq'], **f32)
         self.gd = torch.empty(n['gd'], **f32)

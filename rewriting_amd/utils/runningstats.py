@@ -271,9 +271,10 @@ class RunningQuantile:
 
     # ------------------------------------------------------------------ collecting
     def add(self, incoming):
-        if self._levels is not None:
-            raise NotImplementedError('this RunningQuantile was compressed (or loaded from a cache); a finished '
-                                      'statistic does not take more samples')
+        """More samples.  Into a fresh statistic: kept exactly.  Into one that was compressed or loaded from a
+        cache (the reference's sketch keeps streaming, utils/runningstats.py:340-383): the new samples are kept
+        exactly BESIDE the levels, each with weight 1 like a level-0 sample of the reference's representation;
+        read-outs merge the two, and the next compress_() reduces the weighted union to the budget."""
         if incoming.dim() == 1:
             incoming = incoming[:, None]
         assert incoming.dim() == 2
@@ -282,9 +283,10 @@ class RunningQuantile:
         assert incoming.shape[1] == self.depth
         self._chunks.append(incoming.detach().t().contiguous())        # (units, samples)
         self._sorted = None
+        self._table = None
         self.count += incoming.shape[0]
         self.batchcount += 1
-        if self.count * self.depth * 4 > self.max_bytes:
+        if sum(c.shape[1] for c in self._chunks) * self.depth * 4 > self.max_bytes:
             raise MemoryError('RunningQuantile holds %d x %d samples (> max_bytes); pass a smaller '
                               'sample_size or raise max_bytes' % (self.count, self.depth))
 
@@ -344,14 +346,43 @@ class RunningQuantile:
         assert pos == n
         return [numpy.concatenate(lv) for lv in levels]
 
+    def _representation(self):
+        """(levels, extremes) of the reference's representation for the current state, WITHOUT changing it:
+        exact sorted sample -> retained order statistics (see retained_order_statistics); levels plus samples
+        added since -> the same order statistics of the weighted union, a level-l value standing for 2^l equal
+        samples (so the result depends only on the union, not on when compress_() ran)."""
+        if self.count == 0:
+            return None, None
+        if self._levels is None:
+            s = self._data()
+            return ([s[:, torch.from_numpy(idx).to(s.device)].contiguous()
+                     for idx in self.retained_order_statistics(self.count, self.resolution)],
+                    torch.stack([s[:, 0], s[:, -1]], dim=1))
+        if not self._chunks:
+            return self._levels, self._extremes
+        new = self._data()
+        dev = new.device
+        vals = torch.cat([lv.to(dev, new.dtype) for lv in self._levels] + [new], dim=1)
+        wts = torch.cat([torch.full((lv.shape[1],), 1 << l, dtype=torch.int64, device=dev)
+                         for l, lv in enumerate(self._levels)]
+                        + [torch.ones(new.shape[1], dtype=torch.int64, device=dev)])
+        vals, order = vals.sort(dim=1, stable=True)
+        cum = wts[order].cumsum(dim=1)                           # (units, m): ranks < cum[j] belong to value j
+        total = int(cum[0, -1].item())                           # = the samples represented (self.count)
+        ext = self._extremes.to(dev, new.dtype)
+        ext = torch.stack([torch.minimum(ext[:, 0], new[:, 0]), torch.maximum(ext[:, 1], new[:, -1])], dim=1)
+        levels = []
+        for idx in self.retained_order_statistics(total, self.resolution):
+            ranks = torch.from_numpy(idx).to(dev)[None, :].expand(vals.shape[0], -1).contiguous()
+            pick = torch.searchsorted(cum, ranks, right=True).clamp_(max=vals.shape[1] - 1)
+            levels.append(vals.gather(1, pick).contiguous())
+        return levels, ext
+
     def compress_(self):
-        """Exact sorted sample -> levels of the reference's representation (see retained_order_statistics)."""
-        if self._levels is not None or self.count == 0:
+        """Current state -> levels of the reference's representation; the exact samples are dropped."""
+        if self.count == 0 or (self._levels is not None and not self._chunks):
             return self
-        s = self._data()
-        self._extremes = torch.stack([s[:, 0], s[:, -1]], dim=1)
-        self._levels = [s[:, torch.from_numpy(idx).to(s.device)].contiguous()
-                        for idx in self.retained_order_statistics(self.count, self.resolution)]
+        self._levels, self._extremes = self._representation()
         self._chunks, self._sorted, self._table = [], None, None
         return self
 
@@ -360,12 +391,21 @@ class RunningQuantile:
         """(values, position): per unit the sorted retained samples between the extremes and the cumulative
         weight at the middle of each, normalised to [0, 1] (utils/runningstats.py:530-563)."""
         if self._table is None:
-            vals = torch.cat(self._levels, dim=1)
-            wts = torch.cat([torch.full((lv.shape[1],), 2.0 ** l, dtype=torch.float64, device=vals.device)
-                             for l, lv in enumerate(self._levels)])
+            parts = list(self._levels)
+            weights = [2.0 ** l for l in range(len(parts))]
+            ext = self._extremes
+            if self._chunks:                                     # samples added after the compression: weight 1
+                new = self._data()
+                parts = [p.to(new.device, new.dtype) for p in parts] + [new]
+                weights.append(1.0)
+                ext = ext.to(new.device, new.dtype)
+                ext = torch.stack([torch.minimum(ext[:, 0], new[:, 0]), torch.maximum(ext[:, 1], new[:, -1])], dim=1)
+            vals = torch.cat(parts, dim=1)
+            wts = torch.cat([torch.full((lv.shape[1],), wt, dtype=torch.float64, device=vals.device)
+                             for wt, lv in zip(weights, parts)])
             vals, order = vals.sort(dim=1)
             wts = wts[order]
-            ext = self._extremes.to(vals.device, vals.dtype)
+            ext = ext.to(vals.device, vals.dtype)
             zero = wts.new_zeros(self.depth, 1)
             vals = torch.cat([ext[:, :1], vals, ext[:, 1:]], dim=1)
             wts = torch.cat([zero, wts, zero], dim=1)
@@ -405,7 +445,8 @@ class RunningQuantile:
 
     def minmax(self):
         if self._levels is not None:
-            return self._extremes.clone()
+            vals, _ = self._weighted_table()
+            return torch.stack([vals[:, 0], vals[:, -1]], dim=1)
         s = self._data()
         return torch.stack([s[:, 0], s[:, -1]], dim=1)
 
@@ -416,7 +457,8 @@ class RunningQuantile:
         """sum over the represented samples of fun(sample) (utils/runningstats.py:577-591)."""
         if self._levels is None:
             return fun(self._data()).sum(dim=-1)
-        return sum(fun(lv).sum(dim=-1) * (2.0 ** l) for l, lv in enumerate(self._levels) if lv.shape[1])
+        total = sum(fun(lv).sum(dim=-1) * (2.0 ** l) for l, lv in enumerate(self._levels) if lv.shape[1])
+        return total + fun(self._data()).sum(dim=-1).to(total.device) if self._chunks else total
 
     def mean(self):
         return self.integrate(lambda x: x) / self.count
@@ -470,13 +512,14 @@ class RunningQuantile:
     # ------------------------------------------------------------------ the reference's cache schema
     def state_dict(self):
         """utils/runningstats.py:422-437.  `data` holds one (retained, units) array per level; it is stored as an
-        object array because the levels differ in length."""
-        self.compress_()
-        levels = self._levels if self._levels is not None else []
+        object array because the levels differ in length.  Saving does not change the statistic: the exact
+        samples collected so far stay, and more can be added afterwards."""
+        levels, extremes = self._representation()
+        levels = levels if levels is not None else []
         data = numpy.empty(len(levels), dtype=object)
         for l, lv in enumerate(levels):
             data[l] = lv.t().contiguous().cpu().numpy()
-        extremes = (self._extremes.cpu().numpy() if self._extremes is not None
+        extremes = (extremes.cpu().numpy() if extremes is not None
                     else numpy.zeros((self.depth or 0, 2), dtype=numpy.float32))
         return dict(constructor=self.__module__ + '.' + self.__class__.__name__ + '()',
                     resolution=self.resolution, depth=self.depth, buffersize=self.buffersize, samplerate=1.0,

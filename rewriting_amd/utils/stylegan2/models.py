@@ -169,12 +169,19 @@ def conv_precision():
 
 
 def conv_algo():
-    """Algorithm of the stride-1 3x3 convolutions where both exist: 'winograd' = F(2x2,3x3) in fp32
-    (hip.conv3x3_wino: 2.25x fewer matrix FLOPs, fp32 error class of the direct sum) or 'direct' = the implicit
-    GEMM.  RW_CONV_ALGO selects; shapes the Winograd kernel does not take always run direct.
-    'winograd4' (opt-in, image generation only): F(4x4,3x3) where hip.wino4_supported says so -- 4x fewer matrix
-    FLOPs at ~1e-5 relative error per layer, ~1e-4 on the image (the path's image tolerance is 1e-3); F(2x2,3x3)
-    elsewhere, including the last layer whose ToRGB is fused."""
+    """Algorithm of the stride-1 3x3 convolutions where more than one exists.
+
+    Without RW_CONV_ALGO the answer depends on HOW the modules are being run:
+      * inside the un-hooked forward of the whole generator (SeqStyleGAN2.forward sets a thread-local flag; image
+        generation): 'winograd4' = F(4x4,3x3) where hip.wino4_supported says so -- 4x fewer matrix FLOPs at ~1e-5
+        relative error per layer, 3e-5 measured on the 1024^2 image against the reference (the path's image
+        tolerance is 1e-3) -- and F(2x2,3x3) elsewhere;
+      * every other way -- a hooked model, a nethook.subsequence slice (key statistics, goal maps, the solve's
+        context and its rendering), RW_FUSE=0: 'winograd' = F(2x2,3x3) (hip.conv3x3_wino: 2.25x fewer matrix FLOPs,
+        the fp32 error class of the direct sum).
+    Consequence: model(z) and the same weights run through rewriter.sample_image_from_latent differ by 1e-5 .. 1e-4
+    on the image.  RW_CONV_ALGO=direct|winograd|winograd4 forces one algorithm everywhere; shapes an algorithm
+    does not take always run the next one down ('direct' = the implicit GEMM takes everything)."""
     explicit = os.environ.get('RW_CONV_ALGO')
     if explicit:
         return explicit

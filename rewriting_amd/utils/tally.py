@@ -58,7 +58,12 @@ def load_cached_state(cachefile, args, construct=None, shard=None):
                     break
             if ok:
                 result = construct(dat) if construct is not None else dat
-        except Exception:
+        except FileNotFoundError:
+            result = None                      # no cache yet: the ordinary miss, nothing to report
+        except Exception as e:
+            # a file that does not parse or a schema `construct` cannot rebuild is a miss, not an error -- but a
+            # SILENT miss would turn a bug in set_state_dict into a full re-sweep on every run: say why
+            pbar.print('%s not used as a cache (%s: %s); recomputing' % (cachefile, type(e).__name__, e))
             result = None
     if shard is not None and shard[1] > 1 and not parallel.all_agree(result is not None):
         return None

@@ -136,9 +136,15 @@ def load_request(name='multikey_markandbottom.json'):
         return json.load(f)
 
 
+def fold_request(request, nseeds):
+    """The request with its seed indices folded into [0, nseeds): lets a reduced sample (smoke runs, launcher
+    tests) serve the recorded masks; the identity at the reference's sample size."""
+    return {k: ([[n % nseeds, m] for n, m in v] if k == 'key' else [v[0] % nseeds, v[1]]) for k, v in request.items()}
+
+
 def watermark_job(device, rank=0, world=1, sample_size=1000, niters=2001, size=256, layer=6, variants=None):
     """The five variants, variant i on rank i mod world.  Returns {variant name: (timings, stats)} of this rank."""
-    request = load_request()
+    request = fold_request(load_request(), sample_size)
     variants = WATERMARK_VARIANTS if variants is None else variants
     out = {}
     with parallel.replicas():
@@ -158,7 +164,8 @@ def watermark_bench(args, rank, world, device, timed):
 
     def step():
         results.clear()
-        results.update(watermark_job(device, rank, world, sample_size=args.seeds, niters=2001))
+        results.update(watermark_job(device, rank, world, sample_size=args.seeds,
+                                     niters=getattr(args, 'niters', 2001), size=getattr(args, 'wm_size', 256)))
     dt = timed(step, args.steps, args.warmup, world)
     mine = {name: dict(t, mu_sigma=[a.tolist() for a in stats.mean_cov()]) for name, (t, stats) in results.items()}
     if world > 1:
@@ -181,8 +188,8 @@ def watermark_bench(args, rank, world, device, timed):
                 value=round(dt / n, 4), unit='s', n_gpus=world, steps=n, warmup=args.warmup,
                 ms_per_step=round(dt / n * 1e3, 2), higher_is_better=False, scaling='strong', vs_baseline=None,
                 dtype='f32', data='synthetic',
-                config=dict(workload='church-256 architecture, layer 6, %d-seed statistics, 2001-step erase solves '
+                config=dict(workload='church-%d architecture, layer 6, %d-seed statistics, %d-step erase solves '
                                      '(low_rank_gradient), variants dealt round-robin to ranks as independent replicas'
-                                     % args.seeds,
+                                     % (getattr(args, 'wm_size', 256), args.seeds, getattr(args, 'niters', 2001)),
                             variants=per_variant, images_per_s=round(images / (dt / n), 1),
                             frechet_vs_unedited_pooled_rgb=frechet))

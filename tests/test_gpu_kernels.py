@@ -439,6 +439,7 @@ def test_one_pass_upsampling_conv_matches_conv_then_blur(case):
     wide = hip.conv_transpose3x3s2(x.to(DEV), wp, o, s, style=style.to(DEV), demod=dm,
                                    impl=0 if i % 16 == 0 and o % 32 == 0 else 1)
     uf = hip.pack_conv_transpose_blur_weight_wino4(wt.to(DEV), k4)
+    results = []
     for kw in (dict(noise=noise, noise_w=nw, bias=bias, act=True), dict()):
         want = hip.blur_noise_act(wide, k4, kw.get('noise'), kw.get('noise_w'), kw.get('bias'))
         got = hip.conv_transpose3x3s2_blur_wino4(x.to(DEV), uf, o, s, style=style.to(DEV), demod=dm, **kw)
@@ -446,11 +447,16 @@ def test_one_pass_upsampling_conv_matches_conv_then_blur(case):
         scale = want.abs().max().item()
         assert (got - want).abs().max().item() < 1e-4 * scale, (got - want).abs().max().item() / scale
         assert rel(got, want) < 3e-5, rel(got, want)
-    if b * i * o * h * w <= 2 ** 28:
-        key = style[:, :, None, None] * x
-        pre = R.demod_conv(key, style, wt, upsample=True)
-        ref = R.upfirdn2d(pre, k4.cpu(), pad=(1, 1))
-        assert rel(got, ref) < 3e-5
+        results.append((kw, got.cpu()))
+    # the oracle leg, INCLUDING the bench's own shape (1, 64, 32, 512, 512) = layer 17 of the 1024 model: the host
+    # convolution of one image costs under a second (9.7 GFLOP)
+    assert b * i * o * h * w <= 2 ** 29
+    key = style[:, :, None, None] * x
+    blur = R.upfirdn2d(R.demod_conv(key, style, wt, upsample=True), k4.cpu(), pad=(1, 1))
+    for kw, got in results:
+        ref = R.fused_leaky_relu(blur + nw.cpu() * noise.cpu(), bias.cpu()) if kw else blur
+        assert rel(got, ref) < 3e-5, rel(got, ref)
+        assert (got - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
 
 
 def test_winograd_rejects_shapes_it_does_not_take():

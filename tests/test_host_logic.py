@@ -15,7 +15,7 @@ from rewriting_amd.rewrite import ganrewrite
 from rewriting_amd.utils import nethook, proggan, renormalize, runningstats, tally, zdataset
 from rewriting_amd.utils.stylegan2 import models
 from rewriting_amd import synthetic
-from tests.conftest import golden_meta, load_golden, load_mask_request, ROOT
+from tests.conftest import golden_meta, load_golden, load_mask_request, subsample, ROOT
 
 
 def _nest():
@@ -329,3 +329,177 @@ def test_final_pair_identifies_last_styled_conv_and_its_to_rgb():
     from rewriting_amd import hip
     assert hip.to_rgb_fusable(32, 32, 1024) and hip.to_rgb_fusable(64, 64, 512)
     assert not hip.to_rgb_fusable(128, 128, 256) and not hip.to_rgb_fusable(32, 32, 16)
+
+
+def _check_digest(g, prefix, img, bar=1e-4):
+    """Image batch against a fixture digest (oracle/make_golden.py image_digest): strided sub-sample, the four
+    full-resolution crops, float64 row / column sums (every pixel enters one of each), norm."""
+    stride = int(g[prefix + 'stride'])
+    assert list(img.shape) == list(g[prefix + 'shape'])
+    want = torch.from_numpy(g[prefix + 'strided'])
+    scale = max(1.0, want.abs().max().item())
+    worst = (img[:, :, ::stride, ::stride].cpu() - want).abs().max().item()
+    crops = g[prefix + 'crops']
+    c = crops.shape[-1]
+    for k, (y, x) in enumerate(g[prefix + 'crop_origin']):
+        worst = max(worst, (img[:, :, y:y + c, x:x + c].cpu() - torch.from_numpy(crops[k])).abs().max().item())
+    assert worst < bar * scale, (worst, scale)
+    width = img.shape[-1]
+    assert numpy.abs(img.double().sum(3).cpu().numpy() - g[prefix + 'rowsum']).max() < bar * scale * width ** 0.5 * 4
+    assert numpy.abs(img.double().sum(2).cpu().numpy() - g[prefix + 'colsum']).max() < bar * scale * width ** 0.5 * 4
+    assert abs(img.double().norm().item() / float(g[prefix + 'norm']) - 1) < 1e-5
+    return worst
+
+
+def test_proggan_rewriter_config1_at_its_own_size_matches_reference_golden(tmp_path):
+    """BASELINE.json configs[0] as SURVEY.md 8d states it: ProgressiveGenerator(resolution=256), 1000 seeds, layer 6,
+    notebooks/masks/proggan/church/spire2tree.json with its real seed indices (object 971, paste 18), rank 1 --
+    against pg256_l6_spire2tree_1000.npz, written by the reference's own utils/proggan.py:65-193 and
+    rewrite/ganrewrite.py:24-298 (oracle/make_golden.py golden_proggan_full).  CPU by definition of the config."""
+    g = load_golden('pg256_l6_spire2tree_1000')
+    meta = golden_meta(g)
+    assert meta['resolution'] == 256 and meta['nseeds'] == 1000 and meta['layernum'] == 6
+    model = proggan.ProgressiveGenerator(resolution=256)
+    synthetic.randomize_(model, seed=0, kind='proggan')
+    model.eval()
+    zds = zdataset.z_dataset_for_model(model, size=1000)
+    req = load_mask_request(meta['mask'])
+    assert req['object'][0] == 971 and req['paste'][0] == 18 and 'key' not in req
+    zs = torch.stack([zds[i][0] for i in (0, req['paste'][0])])
+    with torch.no_grad():
+        _check_digest(g, 'image/', model(zs))
+    cachedir = str(tmp_path / 'cache')
+
+    def fresh():
+        return ganrewrite.ProgressiveGanRewriter(model, zds, 6, cachedir=cachedir)
+    gw = fresh()
+    assert list(gw.k_shape) == list(g['k_shape']) == [1, 512, 16, 16] and list(gw.v_shape) == list(g['v_shape'])
+    # statistics: as close to the reference's C as the reference is to the float64 accumulation of its own keys
+    C = gw.c_matrix
+    cmax = C.abs().max().item()
+    ref_abs, ref_rel = float(g['c_ref_vs_exact_max']), float(g['c_ref_vs_exact'])
+    assert (C[::4, ::4].double() - torch.from_numpy(g['c_exact'])).abs().max().item() < 1.2 * ref_abs + 2e-5 * cmax
+    assert (C[::4, ::4] - torch.from_numpy(g['c_matrix'])).abs().max().item() < 1.2 * ref_abs + 2e-5 * cmax
+    assert (C.diag() - torch.from_numpy(g['c_matrix_diag'])).abs().max().item() < 1.2 * ref_abs + 2e-5 * cmax
+    assert abs(C.double().norm().item() / float(g['c_matrix_norm']) - 1) < 1.5 * ref_rel + 1e-5
+    Z = gw.zca_matrix
+    zbar = 1.2 * float(g['zca_ref_vs_exact_max']) + 2e-4 * Z.abs().max().item()
+    assert (Z[::4, ::4] - torch.from_numpy(g['zca'])).abs().max().item() < zbar
+    assert (Z[::4, ::4] - torch.from_numpy(g['zca_exact'])).abs().max().item() < zbar
+    # goals and the context direction
+    obj_acts, _, obj_area, bounds = gw.object_from_selection(*req['object'])
+    goal_in, goal_out, _, pb = gw.paste_from_selection(req['paste'][0], req['paste'][1], obj_acts, obj_area)
+    assert list(bounds) == list(g['obj_bounds']) and list(pb) == list(g['paste_bounds'])
+    assert (obj_area - torch.from_numpy(g['obj_area'])).abs().max() < 1e-6
+    for got, nm in ((goal_in, 'goal_in'), (goal_out, 'goal_out')):
+        want = torch.from_numpy(g[nm])
+        assert (got - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item()), nm
+    mkey = gw.multi_key_from_selection([req['paste']], rank=1)
+    assert ganrewrite.all_obs.shape[0] == int(g['n_sel'])
+    assert (mkey * torch.from_numpy(g['mkey'])).sum().item() > 1 - 1e-5
+    # the solve on the reference's own goal and direction: 1e-4 relative (north_star) at every recorded horizon
+    mkey = torch.from_numpy(g['mkey'])
+    gin, gout = torch.from_numpy(g['goal_in']), torch.from_numpy(g['goal_out'])
+    W0 = gw.target_weights().detach().clone()
+    assert (subsample(W0, 16384) - torch.from_numpy(g['W0_sub'])).abs().max().item() == 0.0
+
+    def rel(W, tag):
+        dW = W - W0
+        r_cos = ((torch.einsum('oiyx,di->odyx', dW, mkey) - torch.from_numpy(g['dW_%s_cos' % tag])).norm()
+                 / float(g['dW_%s_norm' % tag])).item()
+        gsub = torch.from_numpy(g['dW_%s_sub' % tag])
+        return max(r_cos, ((subsample(dW, 8192) - gsub).norm() / gsub.norm()).item())
+    for niter in (1, 11, 101):
+        gwn = fresh()
+        snaps, losses = {}, []
+
+        def cb(it, loss, snaps=snaps, gwn=gwn, losses=losses):
+            losses.append(float(loss))
+            if it in (9, 99):
+                snaps[it + 1] = gwn.target_weights().detach().clone()
+        gwn.insert(gin, gout, mkey, niter=niter, piter=10, lr=0.05, update_callback=cb)
+        snaps[niter] = gwn.target_weights().detach().clone()
+        for n, W in snaps.items():
+            assert rel(W, '%d' % n) < 1e-4, (n, rel(W, '%d' % n))
+        if niter == 101:
+            assert numpy.abs(numpy.array(losses) - g['losses']).max() < 1e-5
+            with torch.no_grad():
+                _check_digest(g, 'edited_image/', gwn.sample_image_from_latent(zs))
+
+
+def test_proggan_linear_insert_learns_lambda_on_a_4d_weight():
+    """ProgressiveGanRewriter.linear_insert (rewrite/ganrewrite.py:201-252).  The reference sizes Lambda from
+    ws[3], ws[4] of a 5-d weight and raises IndexError on ProgGAN's nn.Conv2d weight, so there is no reference
+    output to compare with: the check is the definition -- Adam(lr) on Lambda with weight = W0 + Lambda . d, written
+    independently here with a functional convolution -- plus the rank-r structure and the restored module."""
+    g = load_golden('pg64_l6_spire2tree')
+    meta = golden_meta(g)
+    model = proggan.ProgressiveGenerator(resolution=meta['resolution'])
+    synthetic.randomize_(model, seed=0, kind='proggan')
+    model.eval()
+    zds = zdataset.z_dataset_for_model(model, size=meta['nseeds'])
+    gw = ganrewrite.ProgressiveGanRewriter(model, zds, meta['layernum'], use_linear_insert=True)
+    mkey = torch.from_numpy(g['mkey'])
+    gin, gout = torch.from_numpy(g['goal_in']), torch.from_numpy(g['goal_out'])
+    W0 = gw.target_weights().detach().clone()
+    conv = [m for m in gw.target_model.modules() if getattr(m, 'weight', None) is gw.target_weights()][0]
+    losses = []
+    gw.insert(gin, gout, mkey, niter=5, lr=0.05, update_callback=lambda it, loss: losses.append(float(loss)))
+    W = gw.target_weights()
+    assert isinstance(conv._parameters.get('weight'), torch.nn.Parameter) and 'forward' not in conv.__dict__
+    dW = (W - W0).detach()
+    assert dW.norm() > 0 and ((dW - ganrewrite.projected_conv(dW, mkey)).norm() / dW.norm()).item() < 1e-5
+    # the definition, written independently
+    lam = torch.zeros(W0.shape[0], 1, 3, 3, requires_grad=True)
+    opt = torch.optim.Adam([lam], lr=0.05)
+    want_losses = []
+    for _ in range(5):
+        w = W0 + torch.einsum('odyx,di->oiyx', lam, mkey)
+        loss = torch.nn.functional.l1_loss(gout, torch.nn.functional.conv2d(
+            gin, w, conv.bias, conv.stride, conv.padding))
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        want_losses.append(loss.item())
+    want = torch.einsum('odyx,di->oiyx', lam.detach(), mkey)
+    assert ((dW - want).norm() / want.norm()).item() < 1e-5
+    assert numpy.abs(numpy.array(losses) - numpy.array(want_losses)).max() < 1e-6
+
+
+def test_running_quantile_keeps_streaming_after_a_save_and_after_a_cache_load():
+    """utils/runningstats.py:269-620: the reference's sketch can be saved and extended.  Here: state_dict() does not
+    finalise the statistic, and a statistic rebuilt from a state dict (or compressed) takes more samples -- kept
+    exactly beside the levels, weight 1 each -- with read-outs of the weighted union."""
+    torch.manual_seed(1)
+    x = torch.randn(6000, 3) * torch.tensor([1., 3., .3]) + torch.tensor([0., -2., 5.])
+    qs = [0.0, 0.001, 0.05, 0.5, 0.95, 0.999, 1.0]
+    whole = runningstats.RunningQuantile(r=256)
+    whole.add(x)
+    want = whole.quantiles(qs)
+    # saving in the middle of a stream changes nothing
+    rq = runningstats.RunningQuantile(r=256)
+    rq.add(x[:2500])
+    state = rq.state_dict()
+    rq.add(x[2500:])
+    assert torch.equal(rq.quantiles(qs), want) and rq.size() == 6000
+    # a loaded statistic (2r = 512 retained of 2500) extended by the rest of the stream
+    loaded = runningstats.RunningQuantile(state=state)
+    assert loaded.size() == 2500
+    loaded.add(x[2500:4000])
+    loaded.add(x[4000:])
+    assert loaded.size() == 6000 and loaded.batchcount == 3
+    got = loaded.quantiles(qs)
+    spread = (want[:, -1] - want[:, 0])[:, None]
+    assert ((got - want).abs() / spread).max() < 2e-3            # body: rank error of the compressed part
+    assert torch.equal(got[:, 0], want[:, 0]) and torch.equal(got[:, -1], want[:, -1])      # extremes exact
+    assert torch.allclose(loaded.mean(), x.mean(0), atol=2e-2) and torch.equal(loaded.minmax(), whole.minmax())
+    rank = loaded.normalize(x[:50].t())
+    emp = (x[None, :, :] < x[:50, None, :]).float().mean(1).t()
+    assert (rank - emp).abs().max() < 5e-3
+    # compressing the union, saving and loading it again: the same statistic in the reference's schema
+    again = runningstats.RunningQuantile(state=loaded.state_dict())
+    assert again.size() == 6000 and sum(lv.shape[1] for lv in again._levels) <= 512
+    assert ((again.quantiles(qs) - want).abs() / spread).max() < 4e-3
+    assert abs(sum(lv.shape[1] * 2 ** l for l, lv in enumerate(again._levels)) - 6000) == 0
+    loaded.compress_()
+    assert torch.equal(loaded.quantiles(qs), again.quantiles(qs))
