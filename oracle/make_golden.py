@@ -933,9 +933,14 @@ def golden_watermark_full(ref, name):
         with torch.no_grad():
             goal_in, goal_out = gw.erase_from_selection(p_imgnum, p_mask, key_examples, drank)
             arrays[pre + 'd_units'] = gw.normdissect_units(key_examples, drank).numpy()
-        for nm, bag in (('goal_in', goal_in), ('goal_out', goal_out)):
-            arrays[pre + nm + '_fmap'] = bag.fmap.detach().numpy()
-            arrays[pre + nm + '_style'] = bag.style.detach().numpy()
+        if drank == 60:                 # whole goal tensors (the solver is fed the reference's own goal) ...
+            for nm, bag in (('goal_in', goal_in), ('goal_out', goal_out)):
+                arrays[pre + nm + '_fmap'] = bag.fmap.detach().numpy()
+                arrays[pre + nm + '_style'] = bag.style.detach().numpy()
+        else:                           # ... once: goal_in is the un-erased key map for every drank
+            arrays[pre + 'goal_in_style'] = goal_in.style.detach().numpy()
+            arrays[pre + 'goal_out_style'] = goal_out.style.detach().numpy()
+            arrays[pre + 'goal_out_fmap_sub'], arrays[pre + 'goal_out_fmap_norm'] = sub(goal_out.fmap, 16384)
         for niter in ((1, 11, 101) if drank == 60 else (1, 11)):
             gwn = fresh_on_copy()
             snaps, losses = {}, []
@@ -962,14 +967,14 @@ def golden_watermark_full(ref, name):
             with torch.no_grad():
                 zs = torch.stack([zds[i][0] for i in sample_seeds])
                 imgs[nthreads] = gwn.model(zs)
-            for k, v in image_digest(imgs[nthreads], 4).items():
+            for k, v in image_digest(imgs[nthreads], 4, crop=32).items():
                 arrays['ours60_image_t%d/' % nthreads + k] = v
     arrays['ours60_self_scatter'] = numpy.float64(((full[8] - full[1]).norm() / full[1].norm()).item())
     arrays['ours60_image_self_scatter'] = numpy.float64((imgs[8] - imgs[1]).abs().max().item())
     with torch.no_grad():
         zs = torch.stack([zds[i][0] for i in sample_seeds])
         base = g05(zs)
-        for k, v in image_digest(base, 4).items():
+        for k, v in image_digest(base, 4, crop=32).items():
             arrays['base_image/' + k] = v
         arrays['ours60_image_change'] = numpy.float64((imgs[8] - base).abs().max().item())
     print('ours/60: reference self-scatter 8 vs 1 threads: dW %.3e, image max abs %.3e (the edit moves the image by %.3e)'
