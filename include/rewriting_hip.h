@@ -374,6 +374,23 @@ int rw_solve_step_f32(const rw_solve_problem* p, int project, rw_stream_t stream
 int rw_project_weight_f32(const float* w, const float* context, const float* base, float* out,
                           int out_ch, int in_ch, int taps, int rank, float scale_w, rw_stream_t stream);
 
+/* ---- gradients of the demodulated 3x3 convolution (the autograd path of `insert` on targets the fused solver does
+ * not restate: rewrite/ganrewrite.py:265-283 through utils/stylegan2/models.py:313-329).  Backward-to-input needs
+ * no entry point of its own: it is rw_conv3x3_f32 on the transposed (stride 1: and flipped) weights.
+ *
+ * rw_conv_wgrad_f32: dw[o][i][tap] = scale * sum_{b, p} (g[b][o][p] * gscale[b][o]) * (xcol_b[(i, tap)][p] * xscale[b][i])
+ *   g  (batch, out_ch, CH, CW)  gradient w.r.t. the map the convolution writes: (h, w), or (2h+1, 2w+1) when
+ *                               upsample != 0 (the stride-2 transposed convolution)
+ *   x  (batch, in_ch, h, w)     the convolution's input map;  gscale (batch, out_ch), xscale (batch, in_ch): nullable
+ *   scratch  rw_conv_wgrad_ksplit(...) * out_ch * in_ch * 9 floats (split-K partial sums, reduced in a fixed order)
+ *   dw (out_ch, in_ch, 3, 3) is overwritten. */
+int rw_conv_wgrad_ksplit(int batch, int in_ch, int out_ch, int h, int w, int upsample);
+int rw_conv_wgrad_f32(const float* g, const float* x, const float* gscale, const float* xscale, float* scratch,
+                      float* dw, int batch, int in_ch, int out_ch, int h, int w, int upsample, float scale,
+                      rw_stream_t stream);
+/* out[r] = sum_j a[r][j] * b[r][j] for `rows` rows of length n (per-(image, channel) sums over a feature map) */
+int rw_rowdot_f32(const float* a, const float* b, float* out, long long rows, long long n, rw_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -117,6 +117,9 @@ SIGNATURES = {
     'rw_solve_step_f32': (c_int, [POINTER(SolveProblem), c_int, c_void_p]),
     'rw_project_weight_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                       c_int, c_float, c_void_p]),
+    'rw_conv_wgrad_ksplit': (c_int, [c_int] * 6),
+    'rw_conv_wgrad_f32': (c_int, [c_void_p] * 6 + [c_int] * 6 + [c_float, c_void_p]),
+    'rw_rowdot_f32': (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_longlong, ctypes.c_longlong, c_void_p]),
 }
 
 _lib = None

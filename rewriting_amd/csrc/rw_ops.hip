@@ -834,11 +834,45 @@ __global__ void __launch_bounds__(256) to_rgb_kernel(const float* __restrict__ x
   }
 }
 
+// The same for maps whose pixel count is not a multiple of four (the cropped goal maps of a rewriter whose target
+// spans a ToRGB: rows of 5 x 7, ...): one pixel per thread, same order of additions.
+__global__ void __launch_bounds__(256) to_rgb_scalar_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ style,
+                                                            const float* __restrict__ bias,
+                                                            const float* __restrict__ skip, float* __restrict__ y,
+                                                            int in_ch, int64_t hw, float w_scale) {
+  extern __shared__ float wm[];  // [3][in_ch]
+  const int b = blockIdx.y;
+  for (int t = threadIdx.x; t < 3 * in_ch; t += 256) wm[t] = w_scale * w[t] * style[(int64_t)b * in_ch + t % in_ch];
+  __syncthreads();
+  const float* xb = x + (int64_t)b * in_ch * hw;
+  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < hw; q += (int64_t)gridDim.x * 256) {
+    float a[3] = {0.f, 0.f, 0.f};
+    for (int i = 0; i < in_ch; ++i) {
+      const float v = xb[(int64_t)i * hw + q];
+      a[0] += wm[i] * v; a[1] += wm[in_ch + i] * v; a[2] += wm[2 * in_ch + i] * v;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int64_t off = ((int64_t)b * 3 + c) * hw + q;
+      float o = a[c] + (bias ? bias[c] : 0.f);
+      if (skip) o += skip[off];
+      y[off] = o;
+    }
+  }
+}
+
 extern "C" int rw_to_rgb_f32(const float* x, const float* w, const float* style, const float* bias,
                              const float* skip, float* y, int batch, int in_ch, int64_t hw,
                              float w_scale, rw_stream_t stream) {
   RW_CHECK_ARG(x && w && style && y && batch > 0 && in_ch > 0 && hw > 0);
-  if (hw % 4) return RW_ERR_UNSUPPORTED;
+  if (hw % 4) {
+    int gs = (int)rw_cdiv(hw, 256);
+    if (gs > 2048) gs = 2048;
+    hipLaunchKernelGGL(to_rgb_scalar_kernel, dim3(gs, batch), dim3(256), 3 * in_ch * sizeof(float), rw_s(stream), x, w,
+                       style, bias, skip, y, in_ch, hw, w_scale);
+    return RW_LAUNCH_RESULT();
+  }
   int gx = (int)rw_cdiv(hw / 4, 256);
   const int cap = (256 * 8 + batch - 1) / batch;
   if (gx > cap) gx = cap;

@@ -405,7 +405,9 @@ __device__ __forceinline__ void w4_dma_global_b32(unsigned lds_addr, const void*
 template <int WGN, int UDEPTH, int MODE, bool STYLE>
 __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
   constexpr bool UP = MODE == 1, RGB = MODE == 2;
-  constexpr int NSZ = RGB ? 384 : 256;            // floats of a wave's noise strip (RGB: also the exchange buffer)
+  // floats of a wave's share of the noise strips (RGB: also the exchange buffer; UP: the 8 x 128 output-resolution
+  // strip of a tile row is shared by the two out-channel waves, 512 floats each)
+  constexpr int NSZ = RGB ? 384 : (UP ? 512 : 256);
   constexpr int NST = RGB ? 3 : 16;               // stores of a group's epilogue per wave
   constexpr int WGM = 2;
   constexpr int WAVES = WGM * WGN, THREADS = 64 * WAVES;
@@ -510,6 +512,18 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
   };
   // noise rows y0 + 4 wn .. + 3, columns x0 .. x0 + 63 of this image -> Ns[wave][64 r + c]
   auto nload = [&](int g) __attribute__((always_inline)) {
+    if (UP) {
+      // output rows 2 (y0 + 4 wn) .. + 7, columns 128 (gx0 + g) .. + 127 of this image -> Ns[wn][128 r + c]; wave
+      // (wm, wn) copies rows 4 wm .. 4 wm + 3 as two 16-byte pieces of two rows each
+      const float* sb = p.noise + (int64_t)ib * 4 * hw + (int64_t)(2 * (y0 + 4 * wn) + 4 * wm) * (2 * p.w)
+                        + (gx0 + g) * 128;                              // wave-uniform: a scalar base
+      const int vo = ((lane >> 5) * (2 * p.w) + 4 * (lane & 31)) * 4;   // bytes
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        w4_dma_global_b128_s(ns_base + (unsigned)((wn * 1024 + (4 * wm + 2 * j) * 128) * 4), vo,
+                             sb + (int64_t)(2 * j) * (2 * p.w));
+      return;
+    }
     const float* np = p.noise + (int64_t)ib * hw + (int64_t)(y0 + 4 * wn) * p.w + (gx0 + g) * 64 + lane;
 #pragma unroll
     for (int r = 0; r < 4; ++r) w4_dma_global_b32(ns_base + (unsigned)((wave * NSZ + 64 * r) * 4), np + (int64_t)r * p.w);
@@ -583,7 +597,9 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
     const int64_t hw2 = 4 * hw;
     const int ch = (o0 >> 2) + 4 * wm + lk;
     float* yb = p.y + ((int64_t)ib * (p.out_ch >> 2) + ch) * hw2 + (int64_t)(2 * oy) * W2 + 2 * ox;
-    const float* nb = p.noise ? p.noise + (int64_t)ib * hw2 + (int64_t)(2 * oy) * W2 + 2 * ox : nullptr;
+    // the noise of this tile row's 8 x 128 output pixels sits in LDS (nload, one interval earlier): a plain load here
+    // would queue behind the patch pieces just issued for interval v + 2 and cost the group a memory latency
+    const float* nb = &Ns[wn * 1024 + 8 * lt];
     // leaky ReLU and its gain as max(t, 0.2 t) on values that already carry the gain (act off: slope 1, gain 1)
     const float gain = p.act ? 1.4142135623730951f : 1.f, slope = p.act ? 0.2f : 1.f;
     const float scale = Ct[0][16 * wm + 4 * lk] * gain, bias = Ct[1][16 * wm + 4 * lk] * gain;
@@ -618,8 +634,8 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
         const int64_t off = (int64_t)(2 * r + py) * W2;
         w4_f32x4 n0 = {0.f, 0.f, 0.f, 0.f}, n1 = n0;
         if (p.noise) {
-          n0 = *reinterpret_cast<const w4_f32x4*>(nb + off) * nwg;
-          n1 = *reinterpret_cast<const w4_f32x4*>(nb + off + 4) * nwg;
+          n0 = *reinterpret_cast<const w4_f32x4*>(nb + (2 * r + py) * 128) * nwg;
+          n1 = *reinterpret_cast<const w4_f32x4*>(nb + (2 * r + py) * 128 + 4) * nwg;
         }
         w4_f32x4 q0 = {v[0][r][0], v[1][r][0], v[0][r][1], v[1][r][1]};
         w4_f32x4 q1 = {v[0][r][2], v[1][r][2], v[0][r][3], v[1][r][3]};
@@ -804,7 +820,7 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
   int fg = 2 / NC, fc = 2 % NC;                     // (group, k-quad) of interval v + 2
   for (int v = 0; v < VT; ++v) {
     const int ring2 = ring == 0 ? 2 : ring - 1;     // (v + 2) % 3
-    if (!UP && p.noise && c == NC - 2) nload(g);    // older than this interval's pieces: retired by its wait
+    if (p.noise && c == NC - 2) nload(g);           // older than this interval's pieces: retired by its wait
     static_assert(2 * 9 >= PPW, "two patch pieces per weight quad cover the wave's share");
     if (UDEPTH == 2) {
       if (!(W4_ABL & 4)) uload((v + 1) & 1, c + 1 < NC ? c + 1 : 0);      // weights of interval v + 1

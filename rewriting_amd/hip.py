@@ -598,4 +598,39 @@ def solve_step(problem, project):
     check(lib().rw_solve_step_f32(ctypes.byref(problem), int(bool(project)), _stream()))
 
 
+# ------------------------------------------------------------------ gradients of the styled convolution (autograd path)
+def conv_wgrad(g, x, upsample, scale=1.0, gscale=None, xscale=None):
+    """dW (out_ch, in_ch, 3, 3) of y = conv(x, W) [stride 1, pad 1] or conv_transpose(x, W) [stride 2] given
+    g = dL/dy: scale * sum_{b,p} (g * gscale[b,o]) * (xcol * xscale[b,i]) -- rw_conv_wgrad_f32."""
+    g = _dev(g, 'output gradient')
+    x = _dev(x, 'fmap')
+    b, i, h, w = x.shape
+    o = g.shape[1]
+    want = (b, o, 2 * h + 1, 2 * w + 1) if upsample else (b, o, h, w)
+    if tuple(g.shape) != want:
+        raise ValueError('output gradient %s does not belong to an input map %s' % (tuple(g.shape), tuple(x.shape)))
+    gscale, xscale = _opt(gscale, 'gscale'), _opt(xscale, 'xscale')
+    ks = lib().rw_conv_wgrad_ksplit(b, i, o, h, w, int(bool(upsample)))
+    scratch = torch.empty(ks * o * i * 9, device=x.device, dtype=torch.float32)
+    dw = torch.empty(o, i, 3, 3, device=x.device, dtype=torch.float32)
+    check(lib().rw_conv_wgrad_f32(_p(g), _p(x), _p(gscale), _p(xscale), _p(scratch), _p(dw), b, i, o, h, w,
+                                  int(bool(upsample)), float(scale), _stream()))
+    return dw
+
+
+def rowdot(a, b):
+    """(rows,) sums of a * b over everything but the leading `a.dim() - 2` ... dimensions: a, b (..., H, W) ->
+    (...,) = sum over the last two dimensions (rw_rowdot_f32)."""
+    a = _dev(a, 'a')
+    b = _dev(b, 'b')
+    if a.shape != b.shape or a.dim() < 3:
+        raise ValueError('rowdot takes two maps of the same (..., H, W) shape')
+    lead = tuple(a.shape[:-2])
+    n = a.shape[-1] * a.shape[-2]
+    rows = a.numel() // n
+    out = torch.empty(rows, device=a.device, dtype=torch.float32)
+    check(lib().rw_rowdot_f32(_p(a), _p(b), _p(out), rows, n, _stream()))
+    return out.view(lead)
+
+
 __all__ = [n for n in dir() if not n.startswith('_')] + ['SolveProblem', 'ConvEpilogue']

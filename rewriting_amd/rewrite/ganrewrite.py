@@ -9,10 +9,11 @@ call them unchanged.  Underneath:
   the parameters of a private deep copy of the model, as in the reference (:47-58);
 * the key statistics sweep feeds the NCHW key map straight into the fp32-MFMA second-moment
   kernel, optionally sharded over ranks with one RCCL all-reduce (``parallel``);
-* ``insert`` on a stride-1 SeqStyleGAN2 layer runs the fused HIP solver (four kernels per
-  iteration, ten iterations per HIP graph, no host synchronisation unless the caller's
-  ``update_callback`` asks for one); any other target (ProgGAN's plain ``nn.Conv2d``, CPU
-  tensors) takes the autograd path the reference describes, on torch ops;
+* ``insert`` on the targets the reference's StyleGAN rewriters define runs the fused HIP solver (four kernels
+  per iteration, ten iterations per HIP graph, no host synchronisation unless the caller's
+  ``update_callback`` asks for one); any other target takes the autograd path the reference describes --
+  ProgGAN's plain ``nn.Conv2d`` on torch ops, a SeqStyleGAN2 target of several layers / with a hooked module /
+  with a goal batch > 1 through the adjoints of utils/stylegan2/grad.py on the HIP kernels;
 * the tiny dense factorizations (fp64 ``eigh`` for ZCA, ``svd``/``qr`` of the ~100 x 512 key
   matrix) run in LAPACK on the host, as in the reference's CPU configuration.
 """
@@ -692,11 +693,12 @@ class SeqStyleGanRewriter(ProgressiveGanRewriter):
     def _run_insert(self, key, val, context, update_callback, niter, piter, lr, linear=False):
         parts = self._hip_solvable(key) if isinstance(key, dict) else None
         if parts is None:
-            if self._kernels():
-                raise NotImplementedError(
-                    'the fused HIP solver covers the targets [adain] dconv [blur] noise activate and dconv '
-                    'alone of a SeqStyleGAN2 layer with a batch-1 goal; the kernels have no autograd path '
-                    'for other targets')
+            # any other target -- several layers, a hooked module, a goal batch > 1: the reference's own loop
+            # (loss.backward() through the module chain + torch.optim.Adam), every module's forward and adjoint on
+            # the HIP kernels (utils/stylegan2/grad.py)
+            if linear:
+                return ProgressiveGanRewriter.linear_insert(self, key, val, context, update_callback=update_callback,
+                                                            niter=niter, lr=lr)
             return super()._run_insert(key, val, context, update_callback, niter, piter, lr)
         from . import hipsolve
         adain, dconv, blur, noise, act = parts

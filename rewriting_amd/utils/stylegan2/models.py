@@ -22,7 +22,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from . import op
+from . import grad, op
 from ... import hip
 
 # ------------------------------------------------------------------------------------------
@@ -141,6 +141,8 @@ class _RgbBranch(threading.local):      # per thread: two threads may run genera
         self.final = None        # (last StyledConvSeq, its ToRGBF, latent index of the ToRGB) of the running forward
         self.image_path = False  # inside the un-hooked forward of a whole generator (see conv_algo)
         self.successor = {}      # id(upsampling StyledConvSeq) -> (the StyledConvSeq that reads its result, latent index)
+        self.pre = {}            # id(StyledConvSeq) -> (style, demod factors), id(ToRGBF) -> style: computed up front
+        self.pre_join = None     # the stream they were computed on, until the trunk has waited for it
 
 
 _rgb_branch = _RgbBranch()
@@ -149,6 +151,17 @@ _rgb_side_streams = {}          # one per device, module-level: models are deep-
 
 def _rgb_stream():
     return _rgb_branch.stream
+
+
+def _prefetched(module):
+    """(style, demod) of a StyledConvSeq / the style of a ToRGBF computed at the start of the un-hooked forward
+    (SeqStyleGAN2._prefetch_modulations), or None.  The first reader makes the trunk wait for the stream they
+    were computed on."""
+    entry = _rgb_branch.pre.get(id(module))
+    if entry is not None and _rgb_branch.pre_join is not None:
+        torch.cuda.current_stream().wait_stream(_rgb_branch.pre_join)
+        _rgb_branch.pre_join = None
+    return entry
 
 
 _CONV_IMPLS = {'auto': 0, 'mfma': 0, 'direct': 1, 'generic': 2, 'halo': 3, 'nosplitk': 5}
@@ -364,7 +377,7 @@ class ApplyStyle(nn.Module):
     """fmap * style -- its output is the rewriter's key (rewrite/ganrewrite.py:662-665)."""
 
     def forward(self, d):
-        return DataBag(d, fmap=hip.style_mul(d.fmap, d.style))
+        return DataBag(d, fmap=grad.StyleMul.apply(d.fmap, d.style))
 
 
 class DemodulatedConv2dF(nn.Module):
@@ -437,8 +450,9 @@ class DemodulatedConv2dF(nn.Module):
     def demod_factors(self, style):
         return hip.demod(self.squared_sums(), style) if self.demodulate else None
 
-    def run(self, fmap, style, style_on_load, **epilogue):
-        demod = self.demod_factors(style)
+    def run(self, fmap, style, style_on_load, demod=None, **epilogue):
+        if demod is None:
+            demod = self.demod_factors(style)
         load_style = style if style_on_load else None
         if self.upsample:
             aux = _rgb_branch.aux
@@ -491,7 +505,9 @@ class DemodulatedConv2dF(nn.Module):
                            style=load_style, demod=demod, impl=conv_impl(), **epilogue)
 
     def forward(self, d):
-        return DataBag(d, fmap=self.run(d.fmap, d.style, style_on_load=False))
+        # through torch.autograd (grad.DemodConv: backward to the input map, the weight -- both terms, quirk Q3 --
+        # and the style); without a graph this is run() and nothing else
+        return DataBag(d, fmap=grad.DemodConv.apply(d.fmap, self.weight, d.style, self))
 
 
 class Blur(nn.Module):
@@ -558,8 +574,7 @@ class NoiseInjectionF(nn.Module):
 
     def forward(self, d):
         b, _, h, w = d.fmap.shape
-        return DataBag(d, fmap=hip.noise_add(d.fmap, self.noise_for(d, b, h, w, d.fmap.device),
-                                             self.weight))
+        return DataBag(d, fmap=grad.NoiseAdd.apply(d.fmap, self.noise_for(d, b, h, w, d.fmap.device), self.weight))
 
 
 class FusedLeakyReLUF(op.FusedLeakyReLU):
@@ -658,9 +673,10 @@ class ToRGBF(nn.Module):
             out = hip.to_rgb(d.fmap, conv.weight.view(3, conv.in_channel), style, self.bias.view(3), skip,
                              conv.scale)
             return DataBag(d, output=out)
+        ahead = _prefetched(self)
         side.wait_stream(torch.cuda.current_stream())      # the feature map and the latent come from the trunk
         with torch.cuda.stream(side):
-            style = conv.modulation(d.style)
+            style = ahead if ahead is not None else conv.modulation(d.style)
             out = hip.to_rgb(d.fmap, conv.weight.view(3, conv.in_channel), style, self.bias.view(3), skip,
                              conv.scale)
         # The branch reads trunk tensors from another stream: they stay referenced until the join
@@ -717,6 +733,11 @@ class StyledConvSeq(nn.Sequential):
     def _fusable(self):
         if not fusion_enabled() or set(self._modules) != {'mconv', 'noise', 'activate'}:
             return False
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.mconv.dconv.parameters()):
+            # somebody may differentiate through this layer (an `insert` whose target spans it, rewrite/ganrewrite.py:
+            # 265-283): module by module, where every step carries its adjoint (grad.py).  Image generation and
+            # the statistics sweeps run under no_grad and never come here.
+            return False
         mconv = self.mconv
         if not isinstance(mconv, ModulatedConv2dSeq):
             return False
@@ -744,7 +765,10 @@ class StyledConvSeq(nn.Sequential):
             return super().forward(d)
         mconv, act = self.mconv, self.activate
         # `pre`: the layer in front already multiplied this layer's style into fmap (and computed it)
-        style = pre if pre is not None else mconv.modulation(DataBag(style=d.style)).style
+        ahead = _prefetched(self)
+        style = pre if pre is not None else ahead[0] if ahead is not None else \
+            mconv.modulation(DataBag(style=d.style)).style
+        demod = ahead[1] if ahead is not None else None        # else: computed where it is used
         on_load = pre is None
         fmap = d.fmap
         b = fmap.shape[0]
@@ -766,16 +790,18 @@ class StyledConvSeq(nn.Sequential):
             # the MFMAs -- its style multiply (18 packed multiplies per 6x6 item) moves into this layer's epilogue
             nxt = _rgb_branch.successor.get(id(self)) if _rgb_branch.image_path and pre is None else None
             if nxt is not None and nxt[0]._hands_over_prescaled(2 * fmap.shape[2], 2 * fmap.shape[3]):
-                post = nxt[0].mconv.modulation(DataBag(style=d.latent[:, nxt[1]])).style
+                nxt_ahead = _prefetched(nxt[0])
+                post = nxt_ahead[0] if nxt_ahead is not None else \
+                    nxt[0].mconv.modulation(DataBag(style=d.latent[:, nxt[1]])).style
             h, w = 2 * fmap.shape[2], 2 * fmap.shape[3]
             noise = self.noise.noise_for(d, b, h, w, fmap.device)
             if dconv.one_pass_upsample(fmap, mconv.blur):
                 out = hip.conv_transpose3x3s2_blur_wino4(
                     fmap, dconv.up_blur_wino4_weight(mconv.blur.kernel), dconv.out_channel, dconv.scale, style=style,
-                    demod=dconv.demod_factors(style), noise=noise, noise_w=self.noise.weight, bias=act.bias, act=True,
-                    post_scale=post)
+                    demod=demod if demod is not None else dconv.demod_factors(style), noise=noise,
+                    noise_w=self.noise.weight, bias=act.bias, act=True, post_scale=post)
             else:
-                wide = dconv.run(fmap, style, style_on_load=True)
+                wide = dconv.run(fmap, style, style_on_load=True, demod=demod)
                 out = hip.blur_noise_act(wide, mconv.blur.kernel, noise, self.noise.weight, act.bias, post_scale=post)
         else:
             h, w = fmap.shape[2:]
@@ -792,7 +818,8 @@ class StyledConvSeq(nn.Sequential):
                 main = torch.cuda.current_stream()
                 if _rgb_branch.stream is not None:
                     main.wait_stream(_rgb_branch.stream)           # the running image comes from the RGB stream
-                rgb_style = torgb.conv.modulation(d.latent[:, idx])
+                rgb_ahead = _prefetched(torgb)
+                rgb_style = rgb_ahead if rgb_ahead is not None else torgb.conv.modulation(d.latent[:, idx])
                 wino = (conv_algo() in ('winograd', 'winograd4') and dconv.out_channel == 32
                         and hip.wino_supported(dconv.out_channel, dconv.in_channel, h, w))
                 wino4 = (conv_algo() == 'winograd4' and os.environ.get('RW_RGB_F4', '1') != '0'
@@ -803,10 +830,11 @@ class StyledConvSeq(nn.Sequential):
                     fmap, dconv.wino4_weight() if wino4 else dconv.wino_weight() if wino else dconv.packed_weight(),
                     dconv.out_channel, dconv.scale,
                     torgb.conv.weight.view(3, torgb.conv.in_channel), rgb_style, torgb.bias.view(3), skip,
-                    torgb.conv.scale, style=style if on_load else None, demod=dconv.demod_factors(style), noise=noise,
+                    torgb.conv.scale, style=style if on_load else None,
+                    demod=demod if demod is not None else dconv.demod_factors(style), noise=noise,
                     noise_w=self.noise.weight, bias=act.bias, act=True)
                 return DataBag(d, style=style, fmap=None, fused_rgb=rgb)
-            out = dconv.run(fmap, style, style_on_load=on_load, noise=noise,
+            out = dconv.run(fmap, style, style_on_load=on_load, demod=demod, noise=noise,
                             noise_w=self.noise.weight, bias=act.bias, act=True)
         if post is not None:        # only inside the un-hooked forward: bags that callers see never carry the key
             return DataBag(d, style=style, fmap=out, prescaled=post)
@@ -910,11 +938,17 @@ class SeqStyleGAN2(nn.Sequential):
         _rgb_branch.aux = aux
         _rgb_branch.final = self._final_pair()
         try:
-            out = super().forward(input)
+            out = input
+            for name, module in self._modules.items():
+                out = module(out)
+                if name == 'latents' and _rgb_branch.image_path and os.environ.get('RW_PREFETCH_STYLES', '1') != '0':
+                    self._prefetch_modulations(out, aux)
         finally:
             _rgb_branch.stream = None
             _rgb_branch.aux = None
             _rgb_branch.final = None
+            _rgb_branch.pre = {}
+            _rgb_branch.pre_join = None
             main.wait_stream(side)                          # join: the image is complete on the caller's stream
             del _rgb_branch.keep[:]                      # freed to the trunk's pool AFTER the join is queued
         if torch.is_tensor(out):
@@ -951,6 +985,42 @@ class SeqStyleGAN2(nn.Sequential):
         finally:
             _rgb_branch.final = None
         return out
+
+    def _prefetch_modulations(self, d, aux):
+        """Every styled convolution's style (EqualLinearS of its latent row) and demodulation factors, and every
+        ToRGB's style, depend on the latents and the weights only: inside the un-hooked forward they are all computed
+        HERE, right after the mapping network, on the auxiliary stream beside the 4x4 / 8x8 layers -- instead of as
+        ~60 launches of a few microseconds each BETWEEN the large convolutions, where each one is a kernel boundary on
+        the trunk and two of them (in front of layers 15 / 17) sat 0.3 - 0.6 ms behind the grid-stride workgroups of
+        the RGB branch waiting for a wave slot (rocprofv3 trace of round 2).  The first layer's are computed inline
+        (it needs them at once); the trunk waits for the rest at its first use (_prefetched).  Values are those of
+        the per-layer path: same kernels, same inputs."""
+        pre = {}
+        todo = []
+        for name, mod in self._modules.items():
+            if not isinstance(mod, nn.Sequential) or isinstance(mod, StyledConvSeq):
+                continue
+            kids = list(mod.children())
+            if len(kids) != 2 or not isinstance(kids[0], PickLatent):
+                continue
+            if isinstance(kids[1], StyledConvSeq) and kids[1]._fusable() and isinstance(kids[1].mconv, ModulatedConv2dSeq):
+                todo.append((kids[0].index, kids[1]))
+            elif isinstance(kids[1], ToRGBF):
+                todo.append((kids[0].index, kids[1]))
+        if len(todo) < 3:
+            return
+        main = torch.cuda.current_stream()
+        aux.wait_stream(main)                       # the latents come from the trunk
+        with torch.cuda.stream(aux):
+            for index, mod in todo[2:]:
+                lat = d.latent[:, index]
+                if isinstance(mod, ToRGBF):
+                    pre[id(mod)] = mod.conv.modulation(lat)
+                else:
+                    style = mod.mconv.modulation(DataBag(style=lat)).style
+                    pre[id(mod)] = (style, mod.mconv.dconv.demod_factors(style))
+        _rgb_branch.pre = pre
+        _rgb_branch.pre_join = aux
 
     def _successors(self):
         """{id(upsampling StyledConvSeq): (next StyledConvSeq, its latent index)} for the layer pairs

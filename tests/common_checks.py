@@ -255,3 +255,80 @@ def check_fast_mconv_equals_seq(device):
     assert sum(n.endswith('mconv.modulation') for n in checked) >= 7, checked
     return dict(image_linf=(img.cpu() - want).abs().max().item(), stages=len(checked),
                 reference_seq_vs_fast=float(g['seq_vs_fast_max']))
+
+
+def two_layer_rewriter_class():
+    """The reference's SeqStyleGanRewriter with a target that spans TWO styled convolutions: the edited
+    layerN.sconv.mconv.dconv (+ noise, activation) and the whole upsampling layer N+1 behind it."""
+    from rewriting_amd.rewrite import ganrewrite
+
+    class TwoLayer(ganrewrite.SeqStyleGanRewriter):
+        def maplayers(self, n):
+            return 'layer%d.sconv.mconv.dconv' % n, 'layer%d.sconv.activate' % (n + 1)
+    return TwoLayer
+
+
+def check_two_layer_target(device, hook=False):
+    """`insert` on a target the fused solver does not restate (rewrite/ganrewrite.py:254-298 is plain autograd over
+    any target_model): gradient through activation, noise, a second modulated (transposed) convolution, its blur,
+    noise and activation back to the edited weight -- utils/stylegan2/grad.py on the kernels -- against the
+    reference's own run of the same target (fixture rw_s64_l8l9_twolayer).  hook=True: additionally an identity
+    edit hooked into the target (nethook-style instance-level forward), which must change nothing."""
+    from rewriting_amd.utils import zdataset
+    from rewriting_amd.utils.stylegan2.models import DataBag
+    g = load_golden('rw_s64_l8l9_twolayer')
+    meta = golden_meta(g)
+    model = build_stylegan(meta['size'], meta['truncation'], device=device)
+    zds = zdataset.z_dataset_for_model(model, size=meta['nseeds'])
+    cls = two_layer_rewriter_class()
+
+    def fresh():
+        return cls(model, zds, meta['layernum'], cachedir=None, low_rank_insert=True, key_method='zca',
+                   tight_paste=True)
+    gw = fresh()
+    assert list(gw.k_shape) == list(g['k_shape']) and list(gw.v_shape) == list(g['v_shape'])
+    assert gw.v_shape[2] == 2 * gw.k_shape[2]
+    assert abs(gw.c_matrix.double().norm().item() / float(g['c_matrix_norm']) - 1) < 1e-5
+    assert gw._hip_solvable(DataBag(fmap=torch.zeros(1, 1, 1, 1))) is None      # not one of the solver's targets
+    req = load_mask_request(meta['mask'], meta['nseeds'])
+    obj_acts, _, obj_area, bounds = gw.object_from_selection(*req['object'])
+    goal_in, goal_out, _, pb = gw.paste_from_selection(req['paste'][0], req['paste'][1], obj_acts, obj_area)
+    assert list(bounds) == list(g['obj_bounds']) and list(pb) == list(g['paste_bounds'])
+    for nm, bag in (('goal_in', goal_in), ('goal_out', goal_out)):
+        want = torch.from_numpy(g[nm + '_fmap'])
+        assert (bag.fmap.cpu() - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item()), nm
+    mkey = gw.multi_key_from_selection(req['key'], rank=1)
+    assert (mkey.cpu() * torch.from_numpy(g['mkey'])).sum().item() > 1 - 1e-4
+    mkey = _dev(g['mkey'], device)
+    gin = DataBag(goal_in, fmap=_dev(g['goal_in_fmap'], device), style=_dev(g['goal_in_style'], device),
+                  latent=_dev(g['goal_in_latent'], device))
+    gout = DataBag(goal_out, fmap=_dev(g['goal_out_fmap'], device))
+    W0 = gw.target_weights().detach().clone()
+    out = {}
+    for niter in (1, 11):
+        gwn = fresh()
+        if hook:
+            act = [m for n, m in gwn.target_model.named_modules() if n.endswith('activate')][0]
+            plain = act.forward
+            act.forward = lambda d, plain=plain: plain(d)          # an instance-level forward = a hooked module
+        losses = []
+        gwn.insert(gin, gout, mkey, niter=niter, piter=10, lr=0.05,
+                   update_callback=lambda it, loss: losses.append(float(loss)))
+        dW = (gwn.target_weights().detach() - W0)[0]
+        out[niter] = _cos_rel(dW, mkey, g, 'dW_%d' % niter)
+        gsub = torch.from_numpy(g['dW_%d_sub' % niter])
+        out['sub%d' % niter] = ((subsample(dW, 8192) - gsub).norm() / gsub.norm()).item()
+        # One step: north_star's 1e-4.  Eleven steps: the L1 loss puts a sign() into the gradient and this target has
+        # 82 000 outputs; an output within rounding of its goal flips a whole gradient contribution -- a discrete event.
+        # The fixture records what that does to the REFERENCE itself: its own 11-step update moves by 2.6e-4 .. 6.3e-3
+        # (six runs, a few repeating states) when its convolutions are perturbed at 1e-6, the level at which two
+        # correct float32 convolutions differ.  The kernels land in one of those states (2.69e-3 on the MI355X); what
+        # is exact -- loss and gradient from the SAME weights, every iteration -- is test_two_layer_target_gradients_...
+        bar = 1e-4 if niter == 1 else max(1e-4, 1.5 * float(g['perturbed_reference_dev_11'].max()))
+        assert out[niter] < bar and out['sub%d' % niter] < bar, (out, bar)
+        dl = numpy.abs(numpy.array(losses) - g['losses_%d' % niter])
+        assert dl[:2].max() < 2e-5 and (dl / g['losses_%d' % niter]).max() < 5e-3
+        # the update stays in the rank-1 subspace of the context direction
+        from rewriting_amd.rewrite import ganrewrite
+        assert ((dW - ganrewrite.projected_conv(dW[None], mkey)[0]).norm() / dW.norm()).item() < 1e-4
+    return out

@@ -382,6 +382,26 @@ def conv_transpose3x3s2_blur_wino4(x, uf, out_ch, w_scale, style=None, demod=Non
     return y
 
 
+def conv_wgrad(g, x, upsample, scale=1.0, gscale=None, xscale=None):
+    """d W of conv2d(x, W, pad 1) / conv_transpose2d(x, W^T, stride 2) given g = d L / d y, through torch's own
+    autograd of the same op (rw_conv_wgrad_f32's definition)."""
+    g, x = g.detach(), x.detach()
+    if gscale is not None:
+        g = g * gscale.detach()[:, :, None, None]
+    if xscale is not None:
+        x = x * xscale.detach()[:, :, None, None]
+    o, i = g.shape[1], x.shape[1]
+    w = torch.zeros(o, i, 3, 3, requires_grad=True)
+    with torch.enable_grad():
+        y = F.conv_transpose2d(x, w.transpose(0, 1), stride=2) if upsample else F.conv2d(x, w, padding=1)
+        (y * g).sum().backward()
+    return w.grad.detach() * scale
+
+
+def rowdot(a, b):
+    return (a.detach() * b.detach()).sum((-2, -1))
+
+
 def install(monkeypatch):
     """Replaces the kernel wrappers of rewriting_amd.hip and makes host code take the
     'tensors live on the device' branches."""
@@ -393,7 +413,7 @@ def install(monkeypatch):
              'conv3x3_bf16x6', 'pack_conv_weight_wino', 'conv3x3_wino', 'pack_conv_weight_wino4', 'conv3x3_wino4', 'pack_conv_transpose_weight_wino', 'conv_transpose3x3s2_wino',
              'pack_conv_transpose_blur_weight_wino4', 'conv_transpose3x3s2_blur_wino4',
              'second_moment_accumulate', 'channel_sums', 'project_weight', 'solve_ksplit',
-             'solve_step']
+             'solve_step', 'conv_wgrad', 'rowdot']
     for n in names:
         monkeypatch.setattr(hip, n, globals()[n])
     monkeypatch.setattr(hip, 'on_device', lambda t: True)

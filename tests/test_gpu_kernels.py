@@ -608,6 +608,13 @@ def test_fused_epilogues_and_streaming_blocks():
     want = torch.einsum('bci,bihw->bchw', wm, x) + brgb.view(1, 3, 1, 1) + skip
     got = hip.to_rgb(x.to(DEV), wrgb.to(DEV), style.to(DEV), brgb.to(DEV), skip.to(DEV), 1 / math.sqrt(i))
     assert rel(got, want) < 1e-6
+    # maps whose pixel count is not a multiple of four (cropped goal maps: 5 x 7): the one-pixel-per-thread kernel
+    xo, so = x[:, :, :5, :7].contiguous(), skip[:, :, :5, :7].contiguous()
+    want = torch.einsum('bci,bihw->bchw', wm, xo) + brgb.view(1, 3, 1, 1) + so
+    got = hip.to_rgb(xo.to(DEV), wrgb.to(DEV), style.to(DEV), brgb.to(DEV), so.to(DEV), 1 / math.sqrt(i))
+    assert rel(got, want) < 1e-6
+    got = hip.to_rgb(xo.to(DEV), wrgb.to(DEV), style.to(DEV), None, None, 1 / math.sqrt(i))
+    assert rel(got, want - brgb.view(1, 3, 1, 1) - so) < 1e-6
 
 
 @pytest.mark.parametrize('channels,batch,h,w', [(512, 10, 32, 32), (512, 3, 4, 4), (128, 2, 64, 64),
@@ -648,3 +655,57 @@ def test_projection_kernel():
         wd = w.to(DEV).clone()
         hip.project_weight(wd, d.to(DEV), base=base.to(DEV), out=wd)       # in place
         assert rel(wd, base + want) < 1e-5
+
+
+GRAD_CASES = [  # batch, in_ch, out_ch, h, w  (forward kernels: in_ch % 16 == 0, out_ch % 32 == 0)
+    (1, 16, 32, 8, 8), (3, 48, 96, 5, 9), (2, 64, 64, 16, 16), (1, 512, 512, 6, 7), (2, 128, 64, 32, 32),
+    (1, 32, 160, 4, 4),
+]
+
+
+@pytest.mark.parametrize('upsample', [False, True])
+@pytest.mark.parametrize('case', GRAD_CASES)
+def test_conv_weight_and_input_gradients_match_autograd_of_the_oracle(case, upsample):
+    """rw_conv_wgrad_f32 (split-K MFMA GEMM over batch x positions, gather of the stride-1 / stride-2-transposed
+    columns, per-(image, channel) factors on both operands), rw_rowdot_f32, and the backward-to-input formed from
+    the forward kernels on transposed weights -- i.e. grad.DemodConv end to end -- against torch.autograd of
+    oracle/restatement.py's demod_conv on the host, for the map, the weight (both terms) and the style."""
+    from rewriting_amd import hip
+    from rewriting_amd.utils.stylegan2 import models
+    from oracle import restatement as R
+    b, i, o, h, w = case
+    rs = numpy.random.RandomState(7 + b + i)
+    x = torch.from_numpy(rs.randn(b, i, h, w).astype('float32'))
+    wt = torch.from_numpy(rs.randn(1, o, i, 3, 3).astype('float32'))
+    st = torch.from_numpy((1 + 0.3 * rs.randn(b, i)).astype('float32'))
+    m = models.DemodulatedConv2dF(i, o, 3, upsample=upsample).to(DEV)
+    with torch.no_grad():
+        m.weight.copy_(wt.to(DEV))
+    xd, sd_ = x.to(DEV).requires_grad_(True), st.to(DEV).requires_grad_(True)
+    y = m(models.DataBag(fmap=xd, style=sd_)).fmap
+    x2, st2, w2 = (t.clone().requires_grad_(True) for t in (x, st, wt))
+    y2 = R.demod_conv(x2, st2, w2, upsample=upsample)
+    g = torch.from_numpy(rs.randn(*y2.shape).astype('float32'))
+    assert rel(y, y2) < 1e-5
+    (y * g.to(DEV)).sum().backward()
+    (y2 * g).sum().backward()
+    for name, got, want in (('d fmap', xd.grad, x2.grad), ('d weight', m.weight.grad, w2.grad), ('d style', sd_.grad, st2.grad)):
+        assert rel(got, want) < 2e-5, (name, rel(got, want))
+        assert (got.cpu() - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item()), name
+    # the raw kernel with both per-channel factors, against the same gradient taken on pre-scaled operands
+    gs = torch.from_numpy((1 + 0.2 * rs.randn(b, o)).astype('float32')).to(DEV)
+    xs = torch.from_numpy((1 + 0.2 * rs.randn(b, i)).astype('float32')).to(DEV)
+    # ... and on channel counts no other kernel of the library takes
+    if case == GRAD_CASES[0]:
+        gg = torch.from_numpy(rs.randn(2, 5, 7 if not upsample else 15, 9 if not upsample else 19).astype('float32'))
+        xx = torch.from_numpy(rs.randn(2, 7, 7, 9).astype('float32'))
+        wz = torch.zeros(5, 7, 3, 3, requires_grad=True)
+        yy = torch.nn.functional.conv_transpose2d(xx, wz.transpose(0, 1), stride=2) if upsample else \
+            torch.nn.functional.conv2d(xx, wz, padding=1)
+        (yy * gg).sum().backward()
+        assert rel(hip.conv_wgrad(gg.to(DEV), xx.to(DEV), upsample), wz.grad) < 1e-5
+    a = hip.conv_wgrad(g.to(DEV), x.to(DEV), upsample, scale=0.37, gscale=gs, xscale=xs)
+    c = hip.conv_wgrad(g.to(DEV) * gs[:, :, None, None], x.to(DEV) * xs[:, :, None, None], upsample, scale=0.37)
+    assert rel(a, c) < 1e-6
+    r = hip.rowdot(y.detach(), g.to(DEV))
+    assert rel(r, (y2.detach() * g).sum((2, 3))) < 1e-5

@@ -439,3 +439,107 @@ def test_premultiplied_style_and_one_pass_layers_on_the_image_path(monkeypatch):
         exact = model(z)
     assert (got - base).abs().max().item() < 5e-5
     assert (got - exact).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize('hook', [False, True])
+def test_insert_on_a_two_layer_target_matches_reference_golden(hook):
+    """The autograd path on the kernels: a target of two styled convolutions (and the same with a hooked module),
+    weights after 1 and 11 steps and every loss against the reference's own run (rw_s64_l8l9_twolayer)."""
+    from tests.common_checks import check_two_layer_target
+    report = check_two_layer_target(DEV, hook=hook)
+    os.makedirs('gpurun_out', exist_ok=True)
+    json.dump(report, open('gpurun_out/solve_parity_two_layer_hook%d.json' % int(hook), 'w'))
+
+
+def test_goal_batch_of_two_takes_the_autograd_path_and_matches_the_oracle():
+    """A goal of two key/value pairs (the fused solver is batch-1): loss and d W of the first step against
+    torch.autograd of oracle/restatement.py's styled convolution on the host."""
+    from rewriting_amd.rewrite import ganrewrite
+    from rewriting_amd.utils import zdataset
+    from rewriting_amd.utils.stylegan2.models import DataBag
+    from oracle import restatement as R
+    model = build_stylegan(32, 0.5, device=DEV)
+    zds = zdataset.z_dataset_for_model(model, size=20)
+    gw = ganrewrite.SeqStyleGanRewriter(model, zds, 6, cachedir=None)
+    with torch.no_grad():
+        k = gw.context_model(torch.cat([gw.get_z(3), gw.get_z(5)]))
+        v = gw.target_model(k)
+    goal_out = DataBag(v, fmap=v.fmap * 1.1 + 0.05)
+    mkey = torch.linalg.qr(torch.randn(512, 1, generator=torch.Generator().manual_seed(0)))[0].t().contiguous().to(DEV)
+    assert gw._hip_solvable(k) is None
+    W0 = gw.target_weights().detach().clone()
+    losses = []
+    gw.insert(k, goal_out, mkey, niter=1, piter=10, lr=0.05, update_callback=lambda it, l: losses.append(float(l)))
+    # host: the same step by autograd over the restatement (Adam's first step moves every entry by lr * sign(grad),
+    # then the projection: compare the projected update)
+    sd = {n: p.detach().cpu() for n, p in gw.target_model.state_dict().items()}
+    w = W0.cpu().clone().requires_grad_(True)
+    key, style = k.fmap.cpu(), k.style.cpu()
+    y = R.demod_conv(key, style, w, upsample=False)
+    b, _, h, wd = y.shape
+    y = y + sd['layer6.sconv.noise.weight'] * R.noise_rows(b, h * wd).view(b, 1, h, wd)
+    y = R.fused_leaky_relu(y, sd['layer6.sconv.activate.bias'])
+    loss = torch.nn.functional.l1_loss(goal_out.fmap.cpu(), y)
+    loss.backward()
+    assert abs(losses[0] - loss.item()) < 1e-5 * max(1.0, abs(loss.item()))
+    step = -0.05 * w.grad / (w.grad.abs() + 1e-8)               # Adam, t = 1: m / (sqrt(v) + eps) = g / (|g| + eps)
+    want = R.projected_conv((W0.cpu() + step) - W0.cpu(), mkey.cpu())
+    got = (gw.target_weights().detach() - W0).cpu()
+    assert ((got - want).norm() / want.norm()).item() < 1e-3, ((got - want).norm() / want.norm()).item()
+
+
+def test_two_layer_target_gradients_match_the_oracle_at_every_iteration():
+    """What IS well defined on the two-layer target whatever the rounding: the loss and d W of the kernels' autograd
+    path against torch.autograd over oracle/restatement.py on the host, FROM THE SAME WEIGHTS, at each of the eleven
+    iterations of the reference's loop (projection at 0 and 10).  An output within rounding of its goal may flip one
+    sign between the two evaluations (an L1 tie: 3e-4 of the gradient when it happens); everything else agrees to 1e-6."""
+    from tests.common_checks import two_layer_rewriter_class
+    from rewriting_amd.rewrite import ganrewrite
+    from rewriting_amd.utils import zdataset
+    from rewriting_amd.utils.stylegan2.models import DataBag
+    from oracle import restatement as R
+    g = load_golden('rw_s64_l8l9_twolayer')
+    meta = golden_meta(g)
+    model = build_stylegan(64, 0.5, device=DEV)
+    zds = zdataset.z_dataset_for_model(model, size=meta['nseeds'])
+    gw = two_layer_rewriter_class()(model, zds, 8, cachedir=None)
+    sd = {k: v.detach().cpu().clone() for k, v in gw.model.state_dict().items()}
+    with torch.no_grad():
+        bag = gw.context_model(gw.get_z(0))
+    dev = lambda a: torch.from_numpy(g[a]).to(DEV)
+    gin = DataBag(bag, fmap=dev('goal_in_fmap'), style=dev('goal_in_style'), latent=dev('goal_in_latent'))
+    gin.output = bag.output[:, :, :gin.fmap.shape[2], :gin.fmap.shape[3]].contiguous()
+    val, mkey = dev('goal_out_fmap'), dev('mkey')
+    weight = gw.target_weights()
+    opt = torch.optim.Adam([weight], lr=0.05)
+    with torch.no_grad():
+        ortho = weight - ganrewrite.projected_conv(weight, mkey)
+    key_c, style_c, lat_c, val_c = gin.fmap.cpu(), gin.style.cpu(), gin.latent.cpu(), val.cpu()
+    lat_idx = list(gw.model.layer9.children())[0].index
+    grad_rel, report = [], []
+    for it in range(11):
+        with torch.enable_grad():
+            out = gw.target_model(gin).fmap
+            loss = torch.nn.functional.l1_loss(val, out)
+            opt.zero_grad()
+            loss.backward()
+        Wc = weight.detach().cpu().clone().requires_grad_(True)
+        y = R.demod_conv(key_c, style_c, Wc, upsample=False)
+        b, _, h, w = y.shape
+        y = y + sd['layer8.sconv.noise.weight'] * R.noise_rows(b, h * w).view(b, 1, h, w)
+        y = R.fused_leaky_relu(y, sd['layer8.sconv.activate.bias'])
+        y9, _ = R.styled_conv(sd, 'layer9.sconv', y, lat_c[:, lat_idx], upsample=True)
+        lc = torch.nn.functional.l1_loss(val_c, y9)
+        lc.backward()
+        assert abs(loss.item() - lc.item()) < 2e-6 * max(1.0, abs(lc.item())), (it, loss.item(), lc.item())
+        assert rel(out.detach(), y9.detach()) < 5e-6, it
+        grad_rel.append(rel(weight.grad.detach(), Wc.grad))
+        report.append(dict(it=it, loss=loss.item(), loss_host=lc.item(), grad_rel=grad_rel[-1]))
+        opt.step()
+        if it % 10 == 0:
+            with torch.no_grad():
+                weight[...] = ortho + ganrewrite.projected_conv(weight, mkey)
+    assert sorted(grad_rel)[len(grad_rel) // 2] < 5e-6 and max(grad_rel) < 5e-3, grad_rel
+    assert sum(r > 1e-5 for r in grad_rel) <= 3, grad_rel               # ties are rare events, not the rule
+    os.makedirs('gpurun_out', exist_ok=True)
+    json.dump(report, open('gpurun_out/two_layer_gradients.json', 'w'), indent=1)
