@@ -1096,6 +1096,48 @@ def golden_watermark_scatter(ref, name):
                                          low_rank_gradient=True, snapshots=snaps, dtype=dt)
             for n, W in ss.items():
                 runs[(tag, n)] = (W - W0.to(dt))[0]
+    # drank 30: its goal is not stored whole in the main fixture -- rebuilt here with the reference's own rewriter
+    zds = ref.zdataset.z_dataset_for_model(g05, size=1000)
+    with open(os.path.join(MASKS, 'multikey_markandbottom.json')) as f:
+        request = json.load(f)
+    gw = ref.ganrewrite.SeqStyleGanRewriter(g05, zds, 6, cachedir=None, low_rank_insert=True, low_rank_gradient=True,
+                                            key_method='zca', tight_paste=True)
+    with torch.no_grad():
+        gi, go = gw.erase_from_selection(request['paste'][0], request['paste'][1], request['key'], 30)
+    assert numpy.abs(gi.style.numpy() - g['d30/goal_in_style']).max() == 0
+    for tag, dt in (('exact30', torch.float64), ('f3230', torch.float32)):
+        for niter in (1, 11):
+            _, _, ss = R.insert_explicit(W0, gi.fmap.detach(), gi.style.detach(), go.fmap.detach(), bias, nw, mkey,
+                                         niter=niter, piter=10, low_rank_gradient=True, snapshots=(niter,), dtype=dt)
+            runs[(tag, niter)] = (ss[niter] - W0.to(dt))[0]
+    for n in (1, 11):
+        ex = runs[('exact30', n)]
+        cos_ex = torch.einsum('oiyx,di->odyx', ex, mkey.double())
+        arrays['d30/exact_dW_%d_cos' % n] = cos_ex.float().numpy()
+        arrays['d30/exact_dW_%d_norm' % n] = numpy.float64(ex.norm().item())
+        ref_cos = torch.from_numpy(g['dW_d30/%d_cos' % n]).double()
+        arrays['d30/reference_vs_exact_%d' % n] = numpy.float64(((ref_cos - cos_ex).norm() / ex.norm()).item())
+        arrays['d30/restatement_f32_vs_exact_%d' % n] = numpy.float64(
+            ((runs[('f3230', n)].double() - ex).norm() / ex.norm()).item())
+        print('drank 30, steps %3d: reference vs exact %.3e   float32 restatement vs exact %.3e' % (
+            n, arrays['d30/reference_vs_exact_%d' % n], arrays['d30/restatement_f32_vs_exact_%d' % n]))
+    # ... and the float32 restatement with its convolution perturbed at 1e-6 of the mean magnitude (the level at which
+    # two correct float32 convolutions with K = 4608 differ -- the MI355X kernels against torch's CPU kernels: 1e-6),
+    # five draws each: the spread of the trajectory at THAT noise level, per horizon
+    for tag, (k_, s_, v_) in (('d60', (key, style, val)), ('d30', (gi.fmap.detach(), gi.style.detach(), go.fmap.detach()))):
+        devs = {n: [] for n in ((10, 11, 100, 101) if tag == 'd60' else (11,))}
+        for seed in range(5):
+            for niter in ((11, 101) if tag == 'd60' else (11,)):
+                gen = torch.Generator().manual_seed(100 * seed + niter)
+                snaps = (niter - 1, niter) if tag == 'd60' else (niter,)
+                _, _, ss = R.insert_explicit(W0, k_, s_, v_, bias, nw, mkey, niter=niter, piter=10, low_rank_gradient=True,
+                                             snapshots=snaps, conv_noise=(1e-6, gen))
+                for n, W in ss.items():
+                    ex = runs[('exact' if tag == 'd60' else 'exact30', n)]
+                    devs[n].append((((W - W0)[0].double() - ex).norm() / ex.norm()).item())
+        for n, v in devs.items():
+            arrays['%s/perturbed_f32_vs_exact_%d' % (tag, n)] = numpy.array(v)
+            print(tag, 'steps', n, 'float32 restatement with 1e-6 convolution noise vs exact:', ['%.2e' % x for x in v])
     for n in (1, 10, 11, 100, 101):
         ex = runs[('exact', n)]
         cos_ex = torch.einsum('oiyx,di->odyx', ex, mkey.double())

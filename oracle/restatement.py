@@ -397,9 +397,12 @@ def projected_conv(weight, direction):
 
 def insert_explicit(W0, key, style, val, bias, noise_w, context, niter, piter=10, lr=0.05,
                     low_rank_insert=True, low_rank_gradient=False, snapshots=(),
-                    dtype=torch.float32):
+                    dtype=torch.float32, conv_noise=None):
     """Stride-1 layer solve.  W0 (1,O,I,3,3); key (1,I,h,w) = adain output crop; style (1,I);
-    val (1,O,h,w); context (r,I) orthonormal.  Returns (W, losses, {it+1: W snapshot})."""
+    val (1,O,h,w); context (r,I) orthonormal.  Returns (W, losses, {it+1: W snapshot}).
+    conv_noise = (amplitude, torch.Generator): every convolution result is perturbed by amplitude x its mean
+    magnitude -- a sensitivity probe (how far the trajectory moves when the convolution is rounded differently),
+    used by oracle/make_golden.py to record scatter; None for the restatement itself."""
     W = W0.clone().to(dtype)
     key, style, val, bias, context = [t.to(dtype) for t in (key, style, val, bias, context)]
     noise_w = float(noise_w)
@@ -416,6 +419,8 @@ def insert_explicit(W0, key, style, val, bias, noise_w, context, niter, piter=10
     for it in range(niter):
         Wm = W[0]
         conv = (s * Wm.reshape(O, -1)) @ xcol                     # (O, P)
+        if conv_noise is not None:
+            conv = conv + conv_noise[0] * conv.abs().mean() * torch.randn(conv.shape, generator=conv_noise[1]).to(dtype)
         demod = torch.rsqrt(((s * Wm) ** 2 * sig2).sum([1, 2, 3]) + 1e-8)
         pre = conv * demod[:, None] + noise_w * n.view(1, -1) + bias[:, None]
         out = SQRT2 * torch.where(pre > 0, pre, 0.2 * pre)

@@ -455,7 +455,15 @@ class DemodulatedConv2dF(nn.Module):
             demod = self.demod_factors(style)
         load_style = style if style_on_load else None
         if self.upsample:
+            # the border strips go to an auxiliary stream beside the tiles: the one of the running whole-generator
+            # forward, else (a sliced or hooked model: the statistics sweeps, the rewriter's sub-models) the
+            # device's own -- in a 250-seed sweep launch the three strip kernels were 17 % of the time, in line
             aux = _rgb_branch.aux
+            if (aux is None and fmap.is_cuda and os.environ.get('RW_STRIP_STREAM', '1') != '0'
+                    and not torch.cuda.is_current_stream_capturing()):
+                aux = _rgb_side_streams.get((fmap.device, 'aux'))
+                if aux is None:
+                    aux = _rgb_side_streams[(fmap.device, 'aux')] = torch.cuda.Stream(device=fmap.device)
             b, _, h, w = fmap.shape
             f22 = (up_conv_algo() == 'winograd' and conv_impl() == 0
                    and hip.up_halo_applicable(self.out_channel, self.in_channel, w)
