@@ -40,6 +40,11 @@ def main(dirs):
             rec['hbm_bytes_per_launch_raw'] = (rec['FETCH_SIZE_KiB_per_launch'] + rec['WRITE_SIZE_KiB_per_launch']) * 1024
             rec['hbm_bytes_per_launch_fetch_x2'] = (2 * rec['FETCH_SIZE_KiB_per_launch'] + rec['WRITE_SIZE_KiB_per_launch']) * 1024
         out[k] = rec
+    # the whole step: every kernel's raw FETCH + WRITE bytes, per forward pass (one pixel_norm launch per forward)
+    forwards = out.get('pixel_norm_kernel', {}).get('FETCH_SIZE_launches', 0)
+    if forwards:
+        total = sum(r.get('hbm_bytes_per_launch_raw', 0.0) * r.get('FETCH_SIZE_launches', 0) for r in out.values())
+        out['__step__'] = dict(forwards=forwards, hbm_bytes_per_step_raw=total / forwards)
     json.dump(out, sys.stdout, indent=1, sort_keys=True)
 
 
