@@ -6,6 +6,9 @@
 // matter are coalesced 16-byte accesses along W (NCHW => W is the fast axis), one pass over
 // each feature map, and >> 256 workgroups.  Nothing here is reshaped into a GEMM.
 #include "rw_common.h"
+#ifndef OPS_NTS
+#define OPS_NTS 0         // A/B builds: non-temporal stores of upfirdn2d_plane (1) / to_rgb (2)
+#endif
 #include <stdlib.h>
 #include <stdint.h>
 
@@ -205,7 +208,11 @@ __global__ void __launch_bounds__(256) upfirdn2d_plane_kernel(const float* __res
     }
     float* yo = ym + (int64_t)oy * p.out_w + ox;
     if (vec) {
+#if OPS_NTS & 1
+      __builtin_nontemporal_store(rw_f32x4{acc[0], acc[1], acc[2], acc[3]}, reinterpret_cast<rw_f32x4*>(yo));
+#else
       *reinterpret_cast<float4*>(yo) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+#endif
     } else {
 #pragma unroll
       for (int e = 0; e < 4; ++e) if (ox + e < p.out_w) yo[e] = acc[e];
@@ -665,6 +672,10 @@ extern "C" int rw_pack_conv_weight_f32(const float* w, float* wp, int out_ch, in
 #endif
 #define BL_TW 64
 #define BL_PITCH (BL_TW + 4)
+#ifndef BL_NT
+#define BL_NT 2           // bit 0: non-temporal loads of the (2H+1)^2 map (measured -8 %: its halo rows ARE re-read),
+                          // bit 1: non-temporal stores of the result (+9 % on the kernel: 3.77 -> 4.15 TB/s at 64 x 512^2 x 64)
+#endif
 __global__ void __launch_bounds__(256) blur_noise_act_kernel(
     const float* __restrict__ x, const float* __restrict__ k4, const float* __restrict__ noise,
     const float* __restrict__ nw_ptr, const float* __restrict__ bias, float* __restrict__ y,
@@ -701,7 +712,11 @@ __global__ void __launch_bounds__(256) blur_noise_act_kernel(
       const bool rok = rr < RPP && r < BL_TH + 3 && iy >= 0 && iy < in_h;
       const float* src = xp + (int64_t)iy * in_w + ix;
       if (rok && ix >= 0 && ix + 3 < in_w) {
+#if BL_NT & 1
+        v[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_u*>(src));
+#else
         v[q] = *reinterpret_cast<const f32x4_u*>(src);
+#endif
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[q][e] = (rok && ix + e >= 0 && ix + e < in_w) ? src[e] : 0.f;
@@ -760,7 +775,11 @@ __global__ void __launch_bounds__(256) blur_noise_act_kernel(
     }
     float* yo = y + (bc * out_h + oy) * (int64_t)out_w + ox;
     if (full) {
+#if BL_NT & 2
+      __builtin_nontemporal_store(rw_f32x4{res[0], res[1], res[2], res[3]}, reinterpret_cast<rw_f32x4*>(yo));
+#else
       *reinterpret_cast<float4*>(yo) = make_float4(res[0], res[1], res[2], res[3]);
+#endif
     } else {
 #pragma unroll
       for (int q = 0; q < 4; ++q) if (ox + q < out_w) yo[q] = res[q];
@@ -829,7 +848,11 @@ __global__ void __launch_bounds__(256) to_rgb_kernel(const float* __restrict__ x
         const float4 s = reinterpret_cast<const float4*>(skip)[off];
         o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w;
       }
+#if OPS_NTS & 2
+      __builtin_nontemporal_store(rw_f32x4{o.x, o.y, o.z, o.w}, reinterpret_cast<rw_f32x4*>(y) + off);
+#else
       reinterpret_cast<float4*>(y)[off] = o;
+#endif
     }
   }
 }

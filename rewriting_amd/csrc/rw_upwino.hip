@@ -43,6 +43,9 @@ struct UpWinoProblem {
   float w_scale;
 };
 
+#ifndef UW_NTS
+#define UW_NTS 0          // non-temporal stores of the (2H+1)^2 map (A/B builds)
+#endif
 #define UW_PITCH 36             // row pitch of a patch channel in LDS: 33 columns + 3
 #define UW_PIECES 3             // 5 rows x 36 = 180 floats -> three 64-float pieces
 
@@ -226,7 +229,11 @@ __global__ void __launch_bounds__(256, 2) conv_up_wino_kernel(const UpWinoProble
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         f32x4_u v = {px[r][0] * sc, px[r][1] * sc, px[r][2] * sc, px[r][3] * sc};
+#if UW_NTS
+        __builtin_nontemporal_store(v, reinterpret_cast<f32x4_u*>(yb + (int64_t)j * ohw + (int64_t)r * ow));
+#else
         *reinterpret_cast<f32x4_u*>(yb + (int64_t)j * ohw + (int64_t)r * ow) = v;
+#endif
       }
     }
 #pragma unroll

@@ -355,6 +355,14 @@ __global__ void __launch_bounds__(256, 2) conv_wino36_kernel(const Wino4Problem 
 // weights of an interval serve four waves, the patch halo is 2 rows in 18.
 // ---------------------------------------------------------------------------------------
 #define W4B_PITCH 68
+#ifndef W4_NTS
+#define W4_NTS 0          // non-temporal stores of the output map (A/B builds)
+#endif
+#if W4_NTS
+#define W4_STORE(ptr, val) __builtin_nontemporal_store((val), reinterpret_cast<w4_f32x4*>(ptr))
+#else
+#define W4_STORE(ptr, val) (*reinterpret_cast<w4_f32x4*>(ptr) = (val))
+#endif
 #ifndef W4C_PREFETCH
 #define W4C_PREFETCH 0        // raw window of the next interval read during the MFMAs (36 more live registers)
 #endif
@@ -644,8 +652,8 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
           const float u0 = q0[k] * scale + n0[k] + bias, u1 = q1[k] * scale + n1[k] + bias;
           q0[k] = fmaxf(u0, u0 * slope) * post; q1[k] = fmaxf(u1, u1 * slope) * post;
         }
-        *reinterpret_cast<w4_f32x4*>(yb + off) = q0;
-        *reinterpret_cast<w4_f32x4*>(yb + off + 4) = q1;
+        W4_STORE(yb + off, q0);
+        W4_STORE(yb + off + 4, q1);
       }
     }
 #pragma unroll
@@ -777,7 +785,7 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
           const float u = v[k] * scale + nz[r][k] + bias;
           v[k] = fmaxf(u, u * slope);
         }
-        *reinterpret_cast<w4_f32x4*>(yb + (int64_t)j * hw + (int64_t)r * p.w) = v;
+        W4_STORE(yb + (int64_t)j * hw + (int64_t)r * p.w, v);
       }
     }
 #pragma unroll
