@@ -178,7 +178,7 @@ int rw_conv3x3_bf16x6_f32(const float* x, const void* wb, float* y, int batch, i
  * F(2x2, 3x3) in fp32: 16 instead of 36 multiplications per 2x2 output tile and channel pair, i.e. 2.25x fewer
  * matrix FLOPs for a result that is identical in exact arithmetic and of the direct kernel's error class in
  * fp32 (transform coefficients 0, +-1, +-1/2; fp32 MFMA accumulation).  rw_conv3x3_wino_supported() says which
- * shapes it takes (out_ch % 32 == 0, in_ch % 8 == 0, w % 32 == 0, h % 8 == 0); elsewhere, and whenever the
+ * shapes it takes (out_ch % 32 == 0, in_ch % 8 == 0, and w % 32 == 0 with h % 8 == 0 or w == 16 with h % 16 == 0); elsewhere, and whenever the
  * caller prefers the direct sum, rw_conv3x3_f32 is the kernel.
  *   uf: rw_packed_conv_weight_wino_elems(out_ch, in_ch) = 16*out_ch*in_ch floats from rw_pack_conv_weight_wino_f32:
  *       U = G g G^T of every (o, i) filter in the A-fragment order of v_mfma_f32_16x16x4_f32
@@ -229,7 +229,7 @@ int rw_conv_transpose3x3s2_f32(const float* x, const float* wp, float* y, int ba
 /* The quads y < H, x < W of the same transposed convolution (everything but output row 2H and column 2W, which
  * rw_conv_transpose3x3s2_f32 impl 8 writes) by the minimal-filtering algorithm F(2,2) in fp32: 25 instead of 36
  * multiplications per 2x2 block of quads and channel pair; coefficients 0, +-1 (the direct sum's error class).
- * Shapes: out_ch % 32 == 0, 16 <= in_ch <= 512, in_ch % 8 == 0, w % 32 == 0, h % 4 == 0.
+ * Shapes: out_ch % 32 == 0, 16 <= in_ch <= 512, in_ch % 8 == 0, and w % 32 == 0 with h % 4 == 0 or w == 16 with h % 8 == 0.
  *   uf: rw_packed_conv_transpose_wino_elems(out_ch, in_ch) = 28*out_ch*in_ch floats from
  *       rw_pack_conv_transpose_wino_f32 (w = the (1,out_ch,in_ch,3,3) parameter as rw_pack_conv_weight_f32 takes it):
  *       uf[o / 16][i / 4][q][lane][xi % 4], xi = 4 q + e < 25 the point (rw_upwino.hip lists them), 25..27 zero.

@@ -64,7 +64,14 @@ __device__ __forceinline__ void uw_dma_global_b128_s(unsigned lds_addr, int voff
                : "memory");
 }
 
-__global__ void __launch_bounds__(256, 2) conv_up_wino_kernel(const UpWinoProblem p) {
+// NRW = input maps 16 pixels wide (layer 7 of the generators: 16^2 -> 33^2, a fifth of a key-statistics sweep at layer
+// 8): a wave's 16 blocks are then TWO block rows of 8 -- block lt sits at block row 2 wn + (lt >> 3), column lt & 7 --,
+// the patch of a channel is 9 rows x 17 columns at pitch 20 (the same 180 floats = three pieces as 5 x 33 at pitch 36),
+// a workgroup covers 8 quad rows and the map's whole width (groups_x = gpw = 1).  Everything else is unchanged.
+template <bool NRW>
+__device__ __forceinline__ void conv_up_wino_body(const UpWinoProblem& p) {
+  constexpr int PITCH = NRW ? 20 : UW_PITCH;      // row pitch of a patch channel
+  constexpr int PROWS = NRW ? 9 : 5, PCOLS = NRW ? 17 : 33;
   constexpr int IC = 8;                           // channels per interval: two k-quads
   constexpr int PSZ = IC * UW_PIECES * 64;        // floats per patch ring slot
   constexpr int USZ = 2 * 2 * 7 * 256;            // floats per weight ring slot: [16-channel half][k-quad][7][256]
@@ -87,7 +94,9 @@ __global__ void __launch_bounds__(256, 2) conv_up_wino_kernel(const UpWinoProble
   const int gy = pg % p.groups_y;
   const int ib = pg / p.groups_y;
   const int o0 = ot * 32;
-  const int q0y = 4 * gy, gx0 = run * p.gpw;      // first quad row; groups of 32 quad columns
+  const int q0y = (NRW ? 8 : 4) * gy, gx0 = run * p.gpw;      // first quad row; groups of 32 quad columns
+  const int b_row = NRW ? 2 * wn + (lt >> 3) : wn;            // this lane's block: block row within the workgroup,
+  const int b_col = NRW ? (lt & 7) : lt;                       // block column within the group
   const int64_t hw = (int64_t)p.h * p.w;
   const float* xb = p.x + (int64_t)ib * p.in_ch * hw;
   const int NC = p.in_ch / IC;
@@ -110,9 +119,9 @@ __global__ void __launch_bounds__(256, 2) conv_up_wino_kernel(const UpWinoProble
 #pragma unroll
     for (int s = 0; s < UW_PIECES; ++s) {
       const int f = 64 * s + lane;
-      const int r = f / UW_PITCH, c = f - r * UW_PITCH;
+      const int r = f / PITCH, c = f - r * PITCH;
       const int iy = q0y - 1 + r, ix = x0 - 1 + c;
-      const bool ok = r < 5 && c < 33 && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
+      const bool ok = r < PROWS && c < PCOLS && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
       xoff[s] = ok ? (iy * p.w + ix) * 4 : 0x7fffffff;
     }
   };
@@ -143,7 +152,7 @@ __global__ void __launch_bounds__(256, 2) conv_up_wino_kernel(const UpWinoProble
   for (int xi = 0; xi < 25; ++xi) acc[xi] = uw_f32x4{0.f, 0.f, 0.f, 0.f};
 
   // this lane's window: patch rows 2 wn .. 2 wn + 2, columns 2 lt .. 2 lt + 2 of channel lk (+ 4 per k-quad)
-  const int item_off = lk * (UW_PIECES * 64) + (2 * wn) * UW_PITCH + 2 * lt;
+  const int item_off = lk * (UW_PIECES * 64) + (2 * b_row) * PITCH + 2 * b_col;
   auto compute = [&](int ring, int uslot, int c, bool spread) __attribute__((always_inline)) {
 #pragma unroll
     for (int kql = 0; kql < 2; ++kql) {
@@ -152,8 +161,8 @@ __global__ void __launch_bounds__(256, 2) conv_up_wino_kernel(const UpWinoProble
       float d[3][3];
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
-        const uw_f32x2 lo = *reinterpret_cast<const uw_f32x2*>(src + r * UW_PITCH);
-        d[r][0] = lo[0] * sv; d[r][1] = lo[1] * sv; d[r][2] = src[r * UW_PITCH + 2] * sv;
+        const uw_f32x2 lo = *reinterpret_cast<const uw_f32x2*>(src + r * PITCH);
+        d[r][0] = lo[0] * sv; d[r][1] = lo[1] * sv; d[r][2] = src[r * PITCH + 2] * sv;
       }
       // T[v][h]: v, h in (d0-d1, d1, d2-d1, d2)
       float t[4][3];
@@ -195,7 +204,7 @@ __global__ void __launch_bounds__(256, 2) conv_up_wino_kernel(const UpWinoProble
   const int oh = 2 * p.h + 1, ow = 2 * p.w + 1;
   const int64_t ohw = (int64_t)oh * ow;
   auto group_epilogue = [&](int g) __attribute__((always_inline)) {
-    const int Y0 = 2 * (q0y + 2 * wn), X0 = 2 * (32 * (gx0 + g) + 2 * lt);
+    const int Y0 = 2 * (q0y + 2 * b_row), X0 = 2 * (32 * (gx0 + g) + 2 * b_col);
     float* yb = p.y + ((int64_t)ib * p.out_ch + o0 + 16 * wm + 4 * lk) * ohw + (int64_t)Y0 * ow + X0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -279,6 +288,9 @@ __global__ void __launch_bounds__(256, 2) conv_up_wino_kernel(const UpWinoProble
 #undef UW_WAIT
 }
 
+__global__ void __launch_bounds__(256, 2) conv_up_wino_kernel(const UpWinoProblem p) { conv_up_wino_body<false>(p); }
+__global__ void __launch_bounds__(256, 2) conv_up_wino_narrow_kernel(const UpWinoProblem p) { conv_up_wino_body<true>(p); }
+
 // One thread: the 25 (+3 zero) values of one (o, i).  W[o][i][ky][kx] as rw_conv_transpose3x3s2_f32 sees it.
 __global__ void __launch_bounds__(256) pack_up_wino_kernel(const float* __restrict__ w, float* __restrict__ uf,
                                                            int out_ch, int in_ch) {
@@ -318,8 +330,11 @@ __global__ void __launch_bounds__(256) pack_up_wino_kernel(const float* __restri
   }
 }
 
+static bool up_wino_narrow(int h, int w) { return w == 16 && h % 8 == 0; }
+
 static bool up_wino_shape_ok(int out_ch, int in_ch, int h, int w) {
-  return out_ch > 0 && in_ch >= 16 && in_ch <= 512 && out_ch % 32 == 0 && in_ch % 8 == 0 && w % 32 == 0 && h % 4 == 0;
+  if (!(out_ch > 0 && in_ch >= 16 && in_ch <= 512 && out_ch % 32 == 0 && in_ch % 8 == 0)) return false;
+  return (w % 32 == 0 && h % 4 == 0) || up_wino_narrow(h, w);
 }
 
 extern "C" int rw_conv_transpose3x3s2_wino_supported(int out_ch, int in_ch, int h, int w) {
@@ -351,8 +366,9 @@ extern "C" int rw_conv_transpose3x3s2_wino_f32(const float* x, const float* uf, 
   UpWinoProblem p;
   p.x = x; p.uf = uf; p.y = y; p.style = style; p.demod = demod;
   p.batch = batch; p.in_ch = in_ch; p.out_ch = out_ch; p.h = h; p.w = w; p.w_scale = w_scale;
-  p.groups_x = w / 32;
-  p.groups_y = h / 4;
+  const bool narrow = up_wino_narrow(h, w);
+  p.groups_x = narrow ? 1 : w / 32;
+  p.groups_y = narrow ? h / 8 : h / 4;
   const int o_tiles = out_ch / 32;
   const char* e = getenv("RW_UPWINO_GPW");
   int gpw = e ? atoi(e) : 4;
@@ -366,6 +382,7 @@ extern "C" int rw_conv_transpose3x3s2_wino_f32(const float* x, const float* uf, 
   p.gpw = gpw;
   const int64_t work = (int64_t)batch * p.groups_y * (p.groups_x / gpw) * o_tiles;
   if (work <= 0 || work > 0x7fffffff) return RW_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(conv_up_wino_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
+  if (narrow) hipLaunchKernelGGL(conv_up_wino_narrow_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
+  else hipLaunchKernelGGL(conv_up_wino_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
   return RW_LAUNCH_RESULT();
 }

@@ -74,15 +74,23 @@ template <int N> struct wn_int { static constexpr int value = N; };
 // ---------------------------------------------------------------------------------------
 typedef float wn_f32x4 __attribute__((ext_vector_type(4)));
 
-template <int WGM, int WGN, int IC, bool RGB>
+// NRW = maps 16 pixels wide (the 16^2 layers: most of a key-statistics sweep at layer 8): a wave's "tile row" of 16
+// tiles is then TWO map tile rows of 8 tiles -- tile lt sits at map tile row 2 wn + (lt >> 3), column lt & 7 -- the
+// raw patch is (4 WGN + 2) rows x 18 columns, one group spans the map's width (groups_x = gpw = 1); everything else
+// (chunk pipeline, operand streams, slot schedule: NRAW and NIT are those of the wide shapes) is unchanged.
+template <int WGM, int WGN, int IC, bool RGB, bool NRW = false>
 __global__ void __launch_bounds__(256, 2) conv_wino16_kernel(const WinoProblem p) {
   static_assert(WGM * WGN == 4, "4 waves per workgroup");
+  static_assert(!(RGB && NRW), "the ToRGB epilogue is for the last (widest) layer");
   constexpr int KQ = IC / 4;                       // k-quads per chunk
   constexpr int NT = 16 * WGN;                     // tiles per workgroup: WGN tile rows x 16 tile columns
   constexpr int VP = NT == 16 ? 48 : NT + 16;      // padded channel-row pitch of V (see the bank notes above)
-  constexpr int RS = NT == 16 ? 40 : 48;           // row pitch of the raw patch
-  constexpr int PR = 2 * WGN + 2;                  // patch rows
-  constexpr int NPOS = PR * WN_PC;
+  // row pitch of the raw patch (NRW: 24 -- the two 8-lane halves of a transform read sit two rows apart, 48 floats =
+  // 16 banks)
+  constexpr int RS = NRW ? 24 : (NT == 16 ? 40 : 48);
+  constexpr int PC = NRW ? 18 : WN_PC;             // patch columns
+  constexpr int PR = NRW ? 4 * WGN + 2 : 2 * WGN + 2;   // patch rows
+  constexpr int NPOS = PR * PC;
   constexpr int PSLOT = (NPOS + 255) / 256;
   constexpr int NRAW = PSLOT * IC;
   // transform items (tile, channel) per thread and chunk; with fewer items than threads (<4,1>: 16 tiles x 8
@@ -117,12 +125,16 @@ __global__ void __launch_bounds__(256, 2) conv_wino16_kernel(const WinoProblem p
   const int gy = pg % p.groups_y;
   const int ib = pg / p.groups_y;
   const int o0 = ot * 32 * WGM;
-  const int y0 = gy * 2 * WGN, gx0 = run * p.gpw;
+  const int y0 = gy * (NRW ? 4 : 2) * WGN, gx0 = run * p.gpw;
   const int64_t hw = (int64_t)p.h * p.w;
   const float* xb = p.x + (int64_t)ib * p.in_ch * hw;
   const float* st = p.style ? p.style + (int64_t)ib * p.in_ch : nullptr;
   const int NC = p.in_ch / IC;
   const int VT = p.gpw * NC;
+  // map position of this lane's tile (tile row wn of the workgroup, tile lt): first pixel row relative to y0 / column
+  // relative to the group's first column
+  const int t_row = NRW ? 2 * (2 * wn + (lt >> 3)) : 2 * wn;
+  const int t_col = NRW ? 2 * (lt & 7) : 2 * lt;
 
   // The epilogue runs once per tile group, in the middle of the load stream: a global load there queues behind the
   // patch fetch just issued (vmcnt retires in order) and costs a full memory latency per group.  Everything it needs
@@ -149,7 +161,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino16_kernel(const WinoProblem p
 #pragma unroll
   for (int sl = 0; sl < PSLOT; ++sl) {
     const int pos = tid + 256 * sl;
-    const int r = pos / WN_PC, c = pos - r * WN_PC;
+    const int r = pos / PC, c = pos - r * PC;
     xlds[sl] = pos < NPOS ? r * RS + c : RS - 1;
   }
   auto set_group = [&](int g) __attribute__((always_inline)) {
@@ -157,7 +169,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino16_kernel(const WinoProblem p
 #pragma unroll
     for (int sl = 0; sl < PSLOT; ++sl) {
       const int pos = tid + 256 * sl;
-      const int r = pos / WN_PC, c = pos - r * WN_PC;
+      const int r = pos / PC, c = pos - r * PC;
       const int iy = y0 - 1 + r, ix = x0 - 1 + c;
       const bool ok = pos < NPOS && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
       xoff[sl] = ok ? (iy * p.w + ix) * 4 : 0x7fffffff;          // bytes; out of range -> 0
@@ -192,7 +204,8 @@ __global__ void __launch_bounds__(256, 2) conv_wino16_kernel(const WinoProblem p
 
   // ---- transform items: tile tl of the workgroup (tile row tl >> 4, column tl & 15), channel tch + CH_STEP * item
   const int tl = tid % NT, tch = tid / NT;
-  const float* rsrc = &Rs[0][tch][2 * (tl >> 4)][2 * (tl & 15)];
+  const float* rsrc = NRW ? &Rs[0][tch][2 * (2 * (tl >> 4) + ((tl & 15) >> 3))][2 * (tl & 7)]
+                          : &Rs[0][tch][2 * (tl >> 4)][2 * (tl & 15)];
   float* vdst = &Vs[0][0][tch][tl];
   float2 drow[NIT][4][2];
   float e[4][4];
@@ -284,7 +297,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino16_kernel(const WinoProblem p
               rgb_b2 = RGB && p.rgb_bias ? p.rgb_bias[2] : 0.f;
   const float noise_w = p.noise ? p.noise_w[0] : 0.f;
   auto epilogue_prefetch = [&](int g) __attribute__((always_inline)) {
-    const int64_t pix = (int64_t)(y0 + 2 * wn) * p.w + (gx0 + g) * 32 + 2 * lt;
+    const int64_t pix = (int64_t)(y0 + t_row) * p.w + (gx0 + g) * 32 + t_col;
     if (p.noise) {
       const float* np = p.noise + (int64_t)ib * hw + pix;
       pre_nz[0] = *reinterpret_cast<const float2*>(np);
@@ -301,7 +314,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino16_kernel(const WinoProblem p
   };
   auto group_epilogue = [&](int g) __attribute__((always_inline)) {
     const int x0 = (gx0 + g) * 32;
-    const int oy = y0 + 2 * wn, ox = x0 + 2 * lt;
+    const int oy = y0 + t_row, ox = x0 + t_col;
     const int o_first = o0 + 32 * wm + 4 * lk;            // + 16 half + j
     float nz[4] = {0.f, 0.f, 0.f, 0.f};
     if (p.noise) {
@@ -483,9 +496,11 @@ __global__ void __launch_bounds__(256) pack_wino16_kernel(const float* __restric
   }
 }
 
+static bool wino_narrow(int h, int w) { return w == 16 && h % 16 == 0; }      // the NRW shapes (see conv_wino16_kernel)
+
 static bool wino_shape_ok(int out_ch, int in_ch, int h, int w) {
-  return out_ch > 0 && in_ch > 0 && out_ch % 32 == 0 && in_ch % 8 == 0 && w % 32 == 0 && w >= 32 && h >= 8 &&
-         h % 8 == 0;
+  if (!(out_ch > 0 && in_ch > 0 && out_ch % 32 == 0 && in_ch % 8 == 0 && h >= 8)) return false;
+  return (w % 32 == 0 && w >= 32 && h % 8 == 0) || wino_narrow(h, w);
 }
 
 extern "C" int rw_conv3x3_wino_supported(int out_ch, int in_ch, int h, int w) {
@@ -517,10 +532,12 @@ static int launch_wino(WinoProblem& p, bool rgb, hipStream_t s) {
   int bm = p.out_ch % 64 == 0 ? 64 : 32;
   const int force = wn_env("RW_WINO_TILE", 0);
   if (force && p.out_ch % force == 0 && (force == 32 || force == 64 || force == 128)) bm = force;
+  const bool narrow = wino_narrow(p.h, p.w);
+  if (narrow && bm == 128) bm = 64;               // NRW exists for the <2,2> and <1,4> shapes
   const int wgn = 128 / bm;                       // tile rows per workgroup: 1, 2, 4
-  if (p.h % (2 * wgn)) return RW_ERR_UNSUPPORTED;
-  p.groups_x = p.w / 32;
-  p.groups_y = p.h / (2 * wgn);
+  if (p.h % ((narrow ? 4 : 2) * wgn) || (narrow && rgb)) return RW_ERR_UNSUPPORTED;
+  p.groups_x = narrow ? 1 : p.w / 32;
+  p.groups_y = p.h / ((narrow ? 4 : 2) * wgn);
   const int o_tiles = p.out_ch / bm;
   int gpw = wn_env("RW_WINO_GPW", 8);
   if (gpw < 1) gpw = 1;
@@ -536,7 +553,9 @@ static int launch_wino(WinoProblem& p, bool rgb, hipStream_t s) {
   if (work <= 0 || work > 0x7fffffff) return RW_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)work), block(256);
   if (rgb && bm != 32) return RW_ERR_UNSUPPORTED;
-  if (bm == 128) hipLaunchKernelGGL((conv_wino16_kernel<4, 1, 8, false>), grid, block, 0, s, p);
+  if (narrow && bm == 64) hipLaunchKernelGGL((conv_wino16_kernel<2, 2, 8, false, true>), grid, block, 0, s, p);
+  else if (narrow) hipLaunchKernelGGL((conv_wino16_kernel<1, 4, 4, false, true>), grid, block, 0, s, p);
+  else if (bm == 128) hipLaunchKernelGGL((conv_wino16_kernel<4, 1, 8, false>), grid, block, 0, s, p);
   else if (bm == 64) hipLaunchKernelGGL((conv_wino16_kernel<2, 2, 8, false>), grid, block, 0, s, p);
   else if (rgb) hipLaunchKernelGGL((conv_wino16_kernel<1, 4, 4, true>), grid, block, 0, s, p);
   else hipLaunchKernelGGL((conv_wino16_kernel<1, 4, 4, false>), grid, block, 0, s, p);

@@ -253,7 +253,10 @@ def test_bench_shape_transposed_convs_and_blur_match_oracle(case):
 # ---- Winograd F(2x2,3x3) stride-1 convolution (rw_wino.hip)
 WINO_CASES = [(1, 16, 32, 8, 32), (2, 64, 64, 16, 32), (1, 128, 128, 32, 64), (2, 32, 32, 16, 64), (1, 512, 512, 32, 32),
               (3, 48, 96, 24, 96), (2, 24, 160, 8, 64), (1, 32, 32, 1024, 1024), (1, 64, 64, 512, 512),
-              (1, 128, 128, 256, 256), (1, 256, 256, 128, 128), (1, 512, 512, 64, 64)]
+              (1, 128, 128, 256, 256), (1, 256, 256, 128, 128), (1, 512, 512, 64, 64),
+              # maps 16 wide (the NRW shapes: a wave's 16 tiles = two map tile rows of 8): the 16^2 layers, both
+              # workgroup shapes, several workgroups per image
+              (3, 512, 512, 16, 16), (2, 64, 96, 16, 16), (2, 32, 64, 32, 16), (1, 16, 32, 48, 16)]
 
 
 @pytest.mark.parametrize('case', WINO_CASES)
@@ -298,7 +301,7 @@ def test_winograd_conv_matches_oracle_and_direct_kernel(case):
         assert e_w < 4 * e_d + 2e-7 and e_w < 3e-6, (e_w, e_d)
     same = hip.conv3x3(x.to(DEV), wp, o, s, impl=0 if i % 16 == 0 else 1, **args)
     assert (got - same).abs().max().item() < 2e-5 * max(1.0, same.abs().max().item())
-    if o == 32:                                             # ToRGB in the epilogue, feature map stored or not
+    if o == 32 and w >= 32:                                 # ToRGB in the epilogue (the widest layer: not the 16-wide shapes)
         wrgb = torch.from_numpy(rs.randn(3, o).astype('float32')).to(DEV)
         srgb = torch.from_numpy((1 + 0.3 * rs.randn(b, o)).astype('float32')).to(DEV)
         brgb = torch.from_numpy(rs.randn(3).astype('float32')).to(DEV)
@@ -371,7 +374,9 @@ def test_winograd_f4_conv_matches_oracle_within_its_error_class(case):
 
 
 UP_WINO_CASES = [(2, 16, 32, 4, 32), (1, 64, 64, 8, 32), (1, 128, 64, 16, 64), (3, 32, 32, 12, 96), (1, 512, 512, 32, 32),
-                 (1, 24, 96, 8, 64), (1, 64, 32, 512, 512), (1, 128, 64, 256, 256), (1, 512, 256, 64, 64)]
+                 (1, 24, 96, 8, 64), (1, 64, 32, 512, 512), (1, 128, 64, 256, 256), (1, 512, 256, 64, 64),
+                 # input maps 16 wide (a wave's 16 blocks = two block rows of 8): layer 7 of the generators
+                 (2, 512, 512, 16, 16), (1, 64, 32, 8, 16), (3, 32, 64, 24, 16)]
 
 
 @pytest.mark.parametrize('case', UP_WINO_CASES)
@@ -461,9 +466,10 @@ def test_one_pass_upsampling_conv_matches_conv_then_blur(case):
 
 def test_winograd_rejects_shapes_it_does_not_take():
     from rewriting_amd import hip
-    assert not hip.wino_supported(32, 32, 16, 16) and not hip.wino_supported(48, 32, 32, 32)
+    assert not hip.wino_supported(32, 32, 8, 8) and not hip.wino_supported(48, 32, 32, 32)
     assert not hip.wino_supported(32, 12, 32, 32) and not hip.wino_supported(32, 32, 36, 32)
-    x, wt, _ = _conv_inputs(1, 32, 32, 16, 16)
+    assert hip.wino_supported(32, 32, 16, 16) and not hip.wino_supported(32, 32, 24, 16)     # 16 wide: h % 16 == 0
+    x, wt, _ = _conv_inputs(1, 32, 32, 8, 8)
     with pytest.raises(RuntimeError):
         hip.conv3x3_wino(x.to(DEV), hip.pack_conv_weight_wino(wt.to(DEV)), 32, 0.1)
 
