@@ -441,10 +441,13 @@ class ProgressiveGanRewriter(object):
 
     def paste_from_selection(self, imgnum, mask, obj_acts, obj_area):
         area = renormalize.from_url(mask, target='pt', size=self.v_shape[2:])[0]
-        source_outputs = self.context_model(self.get_z(imgnum))
-        source_acts = self.context_acts(source_outputs)
-        unchanged_outputs = self.target_model(source_outputs)
-        unchanged_acts = self.target_acts(unchanged_outputs)
+        # goal construction is not differentiated (insert detaches key and value, :265): no graph, and the sub-models
+        # keep their fused kernels (under grad mode a styled convolution runs module by module, utils/stylegan2/grad.py)
+        with torch.no_grad():
+            source_outputs = self.context_model(self.get_z(imgnum))
+            source_acts = self.context_acts(source_outputs)
+            unchanged_outputs = self.target_model(source_outputs)
+            unchanged_acts = self.target_acts(unchanged_outputs)
         target_acts, bounds = paste_clip_at_center(
             unchanged_acts, obj_acts, centered_location(area), obj_area if self.alpha_area else None)
         full_target_acts = target_acts
@@ -470,13 +473,14 @@ class ProgressiveGanRewriter(object):
     def erase_from_selection(self, imgnum, mask, context_mask_pairs, rank):
         k_area = renormalize.from_url(mask, target='pt', size=self.k_shape[2:])[0]
         area = renormalize.from_url(mask, target='pt', size=self.v_shape[2:])[0]
-        source_outputs = self.context_model(self.get_z(imgnum))
-        source_acts = self.context_acts(source_outputs)
-        unchanged_outputs = self.target_model(source_outputs)
-        without = source_acts.clone()
-        without[:, self.normdissect_units(context_mask_pairs, rank)] = 0.0
-        erased_out = self.target_model(self.merge_target_output(source_outputs, without, None))
-        target_acts = self.target_acts(erased_out)
+        with torch.no_grad():               # see paste_from_selection
+            source_outputs = self.context_model(self.get_z(imgnum))
+            source_acts = self.context_acts(source_outputs)
+            unchanged_outputs = self.target_model(source_outputs)
+            without = source_acts.clone()
+            without[:, self.normdissect_units(context_mask_pairs, rank)] = 0.0
+            erased_out = self.target_model(self.merge_target_output(source_outputs, without, None))
+            target_acts = self.target_acts(erased_out)
         source_bounds = target_bounds = None
         if self.tight_paste:
             source_bounds = positive_bounding_box(k_area)
