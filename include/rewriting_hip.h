@@ -370,6 +370,17 @@ int rw_solve_supported(int out_ch, int in_ch, int h, int w, int upsample, int pl
 int rw_solve_scratch_elems(int out_ch, int in_ch, int h, int w, int upsample, long long* sizes);
 /* one iteration `it` (loss, gradient, Adam); project != 0 also applies W <- ortho + P(W) */
 int rw_solve_step_f32(const rw_solve_problem* p, int project, rw_stream_t stream);
+/* The same solve as ONE launch for iterations [it_begin, it_end) of niter (rewrite/ganrewrite.py:271-294 incl. the
+ * projection rule `it % piter == 0 or it == niter - 1` when low_rank_insert != 0): every workgroup owns two out-channels
+ * for the whole run, weight and Adam moments stay in registers, the key crop in LDS; no scratch of rw_solve_problem but
+ * lpart (niter * out_ch floats) is used, the step counter is not touched, losses[it] is written for the iterations
+ * run, state is read from / written back to weight, exp_avg, exp_avg_sq (consecutive calls continue each other).
+ * rw_solve_run_supported: 1 for stride-1 targets (with or without bias), in_ch % 64 == 0, in_ch <= 512,
+ * out_ch % 2 == 0, rank <= 8, no linear_insert, in_ch * ((h*w + 1) | 1) floats + scratch within 160 KB of LDS; else 0 and
+ * rw_solve_step_f32 is the way. */
+int rw_solve_run_supported(int out_ch, int in_ch, int h, int w, int rank, int upsample, int linear_insert);
+int rw_solve_run_f32(const rw_solve_problem* p, int it_begin, int it_end, int niter, int piter, int low_rank_insert,
+                     float* lpart, rw_stream_t stream);
 /* W <- W - P(W) + amount*P(1)  (zero(), ganrewrite.py:190-195) and ortho = W - P(W) helpers */
 int rw_project_weight_f32(const float* w, const float* context, const float* base, float* out,
                           int out_ch, int in_ch, int taps, int rank, float scale_w, rw_stream_t stream);

@@ -540,6 +540,357 @@ extern "C" int rw_project_weight_f32(const float* w, const float* context, const
   return RW_LAUNCH_RESULT();
 }
 
+// ---------------------------------------------------------------------------------------
+// The whole solve in ONE launch, with the weight never leaving the compute unit (round 3).
+//
+// `insert` decomposes over OUT channels: the convolution, the demodulation norm, the loss terms, both parts of the
+// gradient, Adam and the rank-r projection of out-channel o read and write W[o, :, :] only --
+// the loss VALUE is the one quantity that sums over o, and nothing in the update depends on it.  So a workgroup owns
+// two out-channels for all niter iterations; thread i of it owns input channel i: the 2 x 9 weights W[o][i][:], their
+// Adam moments and the ortho part sit in its registers (72), the key crop sits in LDS, and per iteration
+//   A  partial conv of my channel at every position, summed over the wave by a transposed DPP tree and over the
+//      waves through LDS -- likewise the demodulation norm;
+//   B  one wave per out-channel: demod, noise, bias, leaky ReLU, L1 loss, dL/dpre, sum g*conv, gd -> LDS;
+//   C  dW of my 18 weights (the same LDS reads), the demodulation term, [projection of the gradient], Adam,
+//      [projection of the weight];
+// three workgroup barriers, NO global-memory traffic besides one loss value per out-channel, NO kernel boundary, no
+// inter-workgroup synchronisation at all (so no residency requirement and nothing to deadlock).  The kernel is bound
+// by the INSTRUCTIONS a wave issues (one per ~4 cycles), not by FLOPs, so the layout is chosen for instruction count:
+//   * a channel's crop is stored zero-padded with row pitch w+1 -- one zero row above and below, one zero column that
+//     serves as the right border of row y and the left border of row y+1 -- so the nine taps of position n are at the
+//     FIXED offsets ky*(w+1) + kx from n, no bounds logic at all; positions are visited linearly over the padded rows,
+//     two at a time (the values computed at pad columns are never read, gd there is 0);
+//   * the two positions of a pair share their key reads: per kernel row four adjacent floats (two ds_read2_b32)
+//     feed six packed FMAs (v_pk_fma_f32: both out-channels in one instruction);
+//   * the four sums of a pair (2 positions x 2 out-channels) are reduced over the 64 lanes TOGETHER: two exchange
+//     steps leave lane l with value (l & 3) summed over its quad, row rotations by 4 and 8 and the gfx950 row / half
+//     swaps (v_permlane16_swap, v_permlane32_swap) finish it in 15 instructions instead of 4 x 6.
+// The channel row pitch is odd, so consecutive channels fall on different LDS banks.
+// Limits: stride-1 target (with or without the noise / bias / activation stage), in_ch % 64 == 0, in_ch <= 512,
+// out_ch % 2 == 0, rank <= 8, in_ch * ((h+2)(w+1) + 3 | 1) floats + ~6 KB within the 160 KB of LDS (512 channels: 5 x 8,
+// 6 x 8, 4 x 11 crops; 256 channels: up to 10 x 12).  Everything else (upsampling targets, linear_insert, larger crops)
+// takes rw_solve_step_f32.
+// ---------------------------------------------------------------------------------------
+#define SVP_RMAX 8
+typedef float svp_f2 __attribute__((ext_vector_type(2)));
+typedef float svp_f4 __attribute__((ext_vector_type(4)));
+typedef unsigned svp_u2 __attribute__((ext_vector_type(2)));
+
+template <int CTRL>
+__device__ __forceinline__ float svp_dpp(float v) {        // the DPP-selected lane's v (controls that read valid lanes)
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float svp_dpp_add(float v) {
+  // v + (the DPP-selected lane's v, 0 where the row is masked or the source invalid)
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+// sum over the 64 lanes of a wave; the total is in lane 63 (rocPRIM's DPP sequence for gfx9)
+__device__ __forceinline__ float svp_wave_sum63(float v) {
+  v = svp_dpp_add<0xB1, 0xf>(v);      // quad_perm [1,0,3,2]
+  v = svp_dpp_add<0x4E, 0xf>(v);      // quad_perm [2,3,0,1]
+  v = svp_dpp_add<0x141, 0xf>(v);     // row_half_mirror
+  v = svp_dpp_add<0x140, 0xf>(v);     // row_mirror: every lane of a row of 16 holds the row's sum
+  v = svp_dpp_add<0x142, 0xa>(v);     // row_bcast:15 into rows 1 and 3
+  v = svp_dpp_add<0x143, 0xc>(v);     // row_bcast:31 into rows 2 and 3
+  return v;
+}
+// v[l] + v[l ^ 16] and then + [l ^ 32]: the rows of 16 and the halves of the wave exchanged by the gfx950 swaps
+__device__ __forceinline__ float svp_rows_sum(float v) {
+  svp_u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// Four values per lane (a: position n, b: position n+1; [0], [1]: the two out-channels) summed over the wave; every
+// lane l returns the total of value (l & 3), numbered 2 * position + channel.
+__device__ __forceinline__ float svp_wave_sum4(svp_f2 a, svp_f2 b, bool odd, bool hi) {
+  const float k01 = odd ? a[1] : a[0], s01 = odd ? a[0] : a[1];
+  const float k23 = odd ? b[1] : b[0], s23 = odd ? b[0] : b[1];
+  const float v01 = k01 + svp_dpp<0xB1>(s01);              // quad_perm [1,0,3,2]: even lanes hold channel 0, odd 1
+  const float v23 = k23 + svp_dpp<0xB1>(s23);
+  const float kk = hi ? v23 : v01, ss = hi ? v01 : v23;
+  float v = kk + svp_dpp<0x4E>(ss);                        // quad_perm [2,3,0,1]: lanes 2, 3 of a quad hold n+1
+  v += svp_dpp<0x124>(v);                                  // row_ror:4
+  v += svp_dpp<0x128>(v);                                  // row_ror:8  -> the row's sum of value (l & 3)
+  return svp_rows_sum(v);
+}
+
+__host__ __device__ static inline int svp_row_pitch(int h, int w) { return ((h + 2) * (w + 1) + 3) | 1; }
+__host__ __device__ static inline int svp_positions(int h, int w) { return (h * (w + 1) + 1) & ~1; }
+__host__ __device__ static inline int svp_pair_row(int h, int w) { return (2 * svp_positions(h, w) + 3) & ~3; }
+__host__ __device__ static inline int svp_part_floats(int nw, int h, int w) {
+  const int a = nw * svp_pair_row(h, w), b = nw * 18 * SVP_RMAX;     // wave partials; aliased by the projection's
+  return a > b ? a : b;
+}
+
+__global__ void __launch_bounds__(512) solve_persistent_kernel(const rw_solve_problem p, int it0, int it1, int niter,
+                                                                int piter, int low_rank_insert, float* lpart_all) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nth = blockDim.x, NW = nth >> 6;
+  const int P = p.h * p.w, WP = p.w + 1;
+  const int PS = svp_row_pitch(p.h, p.w);           // floats per channel row
+  const int NP = svp_positions(p.h, p.w);           // positions visited: h padded rows, rounded up to a pair
+  const int PA = svp_pair_row(p.h, p.w);            // floats per (position, channel)-interleaved row
+  float* Ks = lds;                                  // [in_ch][PS]   zero-padded key crops
+  float* part = Ks + (size_t)p.in_ch * PS;          // [NW][PA]      per-wave conv sums (n, o); the projection's scratch
+  float* gds = part + svp_part_floats(NW, p.h, p.w);   // [PA]       g_pre * demod at (n, o); 0 at pad positions
+  float* vals = gds + PA;                           // [PA]          the target values at (n, o)
+  float* nz = vals + PA;                            // [PA]          noise_w * noise at n
+  float* wq = nz + PA;                              // [NW][2]       demodulation partials
+  float* chn = wq + 16;                             // [2][4]        c2 per out-channel
+  int* nmap = reinterpret_cast<int*>(chn + 8);      // [P]           position index n of crop element q
+  float* red = part;
+  const int o0 = 2 * blockIdx.x;
+  const int i = tid;                                // my input channel
+  const int K = 9 * p.in_ch;
+  const bool plain = p.bias == nullptr;
+  const bool constrained = p.context != nullptr && p.rank > 0;
+  const bool odd = lane & 1, hi = lane & 2;
+
+  for (int e = tid; e < p.in_ch * PS; e += nth) Ks[e] = 0.f;
+  for (int e = tid; e < 3 * PA; e += nth) gds[e] = 0.f;       // gds, vals, nz
+  __syncthreads();
+  for (int e = tid; e < p.in_ch * P; e += nth) {
+    const int c = e / P, q = e - c * P, y = q / p.w, x = q - y * p.w;
+    Ks[c * PS + (y + 1) * WP + x + 1] = p.key[e];
+  }
+  for (int q = tid; q < P; q += nth) {
+    const int y = q / p.w, n = y * WP + (q - y * p.w);
+    nmap[q] = n;
+    vals[2 * n] = p.val[(int64_t)o0 * P + q];
+    vals[2 * n + 1] = p.val[(int64_t)(o0 + 1) * P + q];
+    if (!plain) nz[n] = p.noise_w[0] * p.noise[q];
+  }
+  svp_f2 W[9], M[9], V[9], Or[9];                   // [tap]{out-channel o0, o0 + 1}
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+      const int64_t idx = (int64_t)(o0 + o) * K + i * 9 + t;
+      W[t][o] = p.weight[idx]; M[t][o] = p.exp_avg[idx]; V[t][o] = p.exp_avg_sq[idx];
+      Or[t][o] = (low_rank_insert && p.ortho) ? p.ortho[idx] : 0.f;
+    }
+  float dctx[SVP_RMAX];
+#pragma unroll
+  for (int r = 0; r < SVP_RMAX; ++r) dctx[r] = (constrained && r < p.rank) ? p.context[(int64_t)r * p.in_ch + i] : 0.f;
+  const float sg = p.style[i], sig2 = sg * sg, s = p.w_scale;
+  const float inv_numel = 1.0f / ((float)p.out_ch * (float)P);
+  const float* kb = Ks + i * PS;
+  const float bias0 = plain ? 0.f : p.bias[o0], bias1 = plain ? 0.f : p.bias[o0 + 1];
+  __syncthreads();
+
+  // x[t][o] <- sum_r (sum_i x[t][o][i] d[r][i]) d[r][i] over the workgroup's channels; two barriers
+  auto project_rows = [&](svp_f2 (&x)[9]) __attribute__((always_inline)) {
+    for (int r = 0; r < p.rank; ++r) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+          const float sum = svp_wave_sum63(x[t][o] * dctx[r]);
+          if (lane == 63) red[(wave * SVP_RMAX + r) * 18 + 2 * t + o] = sum;
+        }
+    }
+    __syncthreads();
+    svp_f2 out[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) out[t] = svp_f2{0.f, 0.f};
+    for (int r = 0; r < p.rank; ++r) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        svp_f2 c = {0.f, 0.f};
+        for (int w2 = 0; w2 < NW; ++w2) c += *reinterpret_cast<const svp_f2*>(red + (w2 * SVP_RMAX + r) * 18 + 2 * t);
+        out[t] += c * dctx[r];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) x[t] = out[t];
+    __syncthreads();
+  };
+
+  float ss_next = p.step_size[it0 < it1 ? it0 : 0], bc_next = p.bc2_sqrt[it0 < it1 ? it0 : 0];
+  for (int it = it0; it < it1; ++it) {
+    // Adam's step tables one iteration ahead of their use: the load's latency is never waited for
+    const float step_size = ss_next, bc2s = bc_next;
+    if (it + 1 < it1) { ss_next = p.step_size[it + 1]; bc_next = p.bc2_sqrt[it + 1]; }
+    // ---- A: partial convolution of my channel, the demodulation partial
+    {
+      svp_f2 wq2 = {0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const svp_f2 a = (s * W[t]) * sg;
+        wq2 += a * a;
+      }
+      const float wq0 = svp_wave_sum63(wq2[0]), wq1 = svp_wave_sum63(wq2[1]);
+      if (lane == 63) { wq[wave * 2] = wq0; wq[wave * 2 + 1] = wq1; }
+      for (int n = 0; n < NP; n += 2) {
+        svp_f2 a = {0.f, 0.f}, b = {0.f, 0.f};
+        float kk[3][4];                                       // all twelve reads in flight before the first FMA
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const float* r = kb + n + ky * WP;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) kk[ky][c] = r[c];
+        }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const float k0 = kk[ky][0], k1 = kk[ky][1], k2 = kk[ky][2], k3 = kk[ky][3];
+          a = __builtin_elementwise_fma(W[3 * ky], svp_f2{k0, k0}, a);
+          b = __builtin_elementwise_fma(W[3 * ky], svp_f2{k1, k1}, b);
+          a = __builtin_elementwise_fma(W[3 * ky + 1], svp_f2{k1, k1}, a);
+          b = __builtin_elementwise_fma(W[3 * ky + 1], svp_f2{k2, k2}, b);
+          a = __builtin_elementwise_fma(W[3 * ky + 2], svp_f2{k2, k2}, a);
+          b = __builtin_elementwise_fma(W[3 * ky + 2], svp_f2{k3, k3}, b);
+        }
+        const float v = svp_wave_sum4(a, b, odd, hi);
+        if (lane < 4) part[wave * PA + 2 * n + lane] = v;
+      }
+    }
+    __syncthreads();
+    // ---- B: wave o finishes out-channel o0 + o
+    for (int o = wave; o < 2; o += NW) {            // (a 64-channel layer has one wave: it takes both)
+      float wsq = 0.f;
+      for (int w2 = 0; w2 < NW; ++w2) wsq += wq[w2 * 2 + o];
+      const float demod = rsqrtf(wsq + 1e-8f);
+      const float bv = o ? bias1 : bias0;
+      float lsum = 0.f, tsum = 0.f;
+      for (int q = lane; q < P; q += 64) {
+        const int n2 = 2 * nmap[q] + o;
+        float conv = 0.f;
+        for (int w2 = 0; w2 < NW; ++w2) conv += part[w2 * PA + n2];
+        conv *= s;
+        float out, pre;
+        if (plain) { pre = conv * demod; out = pre; }
+        else {
+          pre = conv * demod + nz[n2 >> 1] + bv;
+          out = 1.4142135623730951f * ((pre > 0.f) ? pre : 0.2f * pre);
+        }
+        const float diff = out - vals[n2];
+        lsum += fabsf(diff);
+        const float sgn = (diff > 0.f) ? 1.f : ((diff < 0.f) ? -1.f : 0.f);
+        const float g_out = sgn * inv_numel;
+        const float g_pre = plain ? g_out : ((pre > 0.f) ? g_out : g_out * 0.2f) * 1.4142135623730951f;
+        gds[n2] = g_pre * demod;
+        tsum += g_pre * conv;
+      }
+      lsum = svp_wave_sum63(lsum);
+      tsum = svp_wave_sum63(tsum);
+      if (lane == 63) {
+        chn[o * 4] = s * s * demod * demod * demod * tsum;
+        lpart_all[(int64_t)it * p.out_ch + o0 + o] = lsum * inv_numel;
+      }
+    }
+    __syncthreads();
+    // ---- C: gradient of my 18 weights, Adam, projections
+    {
+      svp_f2 G[9];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) G[t] = svp_f2{0.f, 0.f};
+      for (int n = 0; n < NP; n += 2) {
+        const svp_f4 gq = *reinterpret_cast<const svp_f4*>(gds + 2 * n);      // (n, o0) (n, o1) (n+1, o0) (n+1, o1)
+        const svp_f2 ga = {gq[0], gq[1]}, gb = {gq[2], gq[3]};
+        float kk[3][4];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const float* r = kb + n + ky * WP;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) kk[ky][c] = r[c];
+        }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const float k0 = kk[ky][0], k1 = kk[ky][1], k2 = kk[ky][2], k3 = kk[ky][3];
+          G[3 * ky] = __builtin_elementwise_fma(ga, svp_f2{k0, k0}, G[3 * ky]);
+          G[3 * ky] = __builtin_elementwise_fma(gb, svp_f2{k1, k1}, G[3 * ky]);
+          G[3 * ky + 1] = __builtin_elementwise_fma(ga, svp_f2{k1, k1}, G[3 * ky + 1]);
+          G[3 * ky + 1] = __builtin_elementwise_fma(gb, svp_f2{k2, k2}, G[3 * ky + 1]);
+          G[3 * ky + 2] = __builtin_elementwise_fma(ga, svp_f2{k2, k2}, G[3 * ky + 2]);
+          G[3 * ky + 2] = __builtin_elementwise_fma(gb, svp_f2{k3, k3}, G[3 * ky + 2]);
+        }
+      }
+      const svp_f2 c2 = {chn[0], chn[4]};
+#pragma unroll
+      for (int t = 0; t < 9; ++t) G[t] = s * G[t] - c2 * W[t] * sig2;
+      if (p.low_rank_gradient) project_rows(G);
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+          float wv = W[t][o], mv = M[t][o], vv = V[t][o];
+          adam_update(G[t][o], wv, mv, vv, p.one_minus_beta1, p.beta2, p.one_minus_beta2, p.eps, step_size, bc2s);
+          W[t][o] = wv; M[t][o] = mv; V[t][o] = vv;
+        }
+      if (low_rank_insert && (it % piter == 0 || it == niter - 1)) {
+        svp_f2 pw[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) pw[t] = W[t];
+        project_rows(pw);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) W[t] = Or[t] + pw[t];
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+      const int64_t idx = (int64_t)(o0 + o) * K + i * 9 + t;
+      p.weight[idx] = W[t][o]; p.exp_avg[idx] = M[t][o]; p.exp_avg_sq[idx] = V[t][o];
+    }
+}
+
+// losses[it] = sum over out-channels of the per-channel parts, in channel order (deterministic)
+__global__ void __launch_bounds__(64) solve_loss_sum_kernel(const float* __restrict__ lpart_all, float* __restrict__ losses,
+                                                            int out_ch, int it0, int it1) {
+  const int it = it0 + blockIdx.x;
+  if (it >= it1) return;
+  float l = 0.f;
+  for (int o = threadIdx.x; o < out_ch; o += 64) l += lpart_all[(int64_t)it * out_ch + o];
+  l = rw_wave_sum(l);
+  if (threadIdx.x == 0) losses[it] = l;
+}
+
+static size_t svp_lds_bytes(int in_ch, int h, int w) {
+  const int NW = in_ch / 64;
+  return ((size_t)in_ch * svp_row_pitch(h, w) + svp_part_floats(NW, h, w) + 3 * (size_t)svp_pair_row(h, w) + 16 + 8 +
+          (size_t)h * w) * sizeof(float);
+}
+
+// 1 when rw_solve_run_f32 takes the target, 0 otherwise (then rw_solve_step_f32 is the way)
+extern "C" int rw_solve_run_supported(int out_ch, int in_ch, int h, int w, int rank, int upsample, int linear_insert) {
+  if (out_ch <= 0 || in_ch <= 0 || h <= 0 || w <= 0 || upsample || linear_insert) return 0;
+  if (out_ch % 2 || in_ch % 64 || in_ch > 512 || rank > SVP_RMAX) return 0;
+  return svp_lds_bytes(in_ch, h, w) <= 160 * 1024 ? 1 : 0;
+}
+
+// Iterations [it_begin, it_end) of the niter-iteration solve in one launch (state is read from and written back to
+// weight / exp_avg / exp_avg_sq, so consecutive calls continue each other); project on the iterations the reference
+// projects on (it % piter == 0 or it == niter - 1) when low_rank_insert != 0.  lpart: (niter, out_ch) floats of
+// scratch; losses[it] is written for the iterations run.  Uses no other scratch of rw_solve_problem and not its
+// step counter.
+extern "C" int rw_solve_run_f32(const rw_solve_problem* pr, int it_begin, int it_end, int niter, int piter,
+                                int low_rank_insert, float* lpart, rw_stream_t stream) {
+  RW_CHECK_ARG(pr && lpart);
+  const rw_solve_problem& p = *pr;
+  RW_CHECK_ARG(p.key && p.style && p.val && p.weight && p.exp_avg && p.exp_avg_sq && p.step_size && p.bc2_sqrt &&
+               p.losses);
+  RW_CHECK_ARG(!p.bias || (p.noise && p.noise_w));
+  RW_CHECK_ARG(0 <= it_begin && it_begin <= it_end && it_end <= niter && piter > 0);
+  RW_CHECK_ARG(!(low_rank_insert || p.low_rank_gradient) || (p.context && p.rank > 0));
+  RW_CHECK_ARG(!low_rank_insert || p.ortho);
+  if (!rw_solve_run_supported(p.out_ch, p.in_ch, p.h, p.w, p.rank, p.upsample, p.linear_insert)) return RW_ERR_UNSUPPORTED;
+  if (it_begin == it_end) return 0;
+  const size_t ldsb = svp_lds_bytes(p.in_ch, p.h, p.w);
+  hipStream_t s = rw_s(stream);
+  hipError_t e = hipFuncSetAttribute((const void*)solve_persistent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)ldsb);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(solve_persistent_kernel, dim3(p.out_ch / 2), dim3(p.in_ch), ldsb, s, p, it_begin, it_end, niter, piter,
+                     low_rank_insert, lpart);
+  hipLaunchKernelGGL(solve_loss_sum_kernel, dim3(it_end - it_begin), dim3(64), 0, s, (const float*)lpart, p.losses,
+                     p.out_ch, it_begin, it_end);
+  return RW_LAUNCH_RESULT();
+}
+
 // Shape limits of the solver kernels, in one place (rw_solve_step_f32 calls it before its first launch and
 // the host mirrors it in _hip_solvable): 64 out-channels per workgroup in both GEMMs, 16-channel K chunks,
 // the blur / blur-backward staging of an upsampling target in <= 64 KB of LDS, and the two weight rows of the

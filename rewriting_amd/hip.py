@@ -594,6 +594,16 @@ def solve_scratch_elems(out_ch, in_ch, h, w, upsample):
     return dict(zip(('conv', 'wsq', 'gd', 'c2', 'grad', 'ksplit'), (int(v) for v in sizes)))
 
 
+def solve_run_supported(out_ch, in_ch, h, w, rank, upsample, linear):
+    """True when the one-launch solver (rw_solve_run_f32) takes this target."""
+    return lib().rw_solve_run_supported(out_ch, in_ch, h, w, int(rank), int(bool(upsample)), int(bool(linear))) == 1
+
+
+def solve_run(problem, it_begin, it_end, niter, piter, low_rank_insert, lpart):
+    check(lib().rw_solve_run_f32(ctypes.byref(problem), int(it_begin), int(it_end), int(niter), int(piter),
+                                 int(bool(low_rank_insert)), _p(lpart), _stream()))
+
+
 def solve_step(problem, project):
     check(lib().rw_solve_step_f32(ctypes.byref(problem), int(bool(project)), _stream()))
 

@@ -1,12 +1,17 @@
-"""Driver of the fused HIP solver (``rw_solve_step_f32``) behind ``SeqStyleGanRewriter.insert``.
+"""Driver of the fused HIP solver (``rw_solve_run_f32`` / ``rw_solve_step_f32``) behind
+``SeqStyleGanRewriter.insert``.
 
 Reference loop: rewrite/ganrewrite.py:271-294 -- 2001 iterations of {L1 loss through
 dconv+demod, noise, bias+lrelu; backward to W; Adam; optional callback; projection when
-``it % piter == 0 or it == niter-1``}.  Here an iteration is three kernels (+ one projection
-kernel), the Adam bias corrections come from per-step tables computed on the host in double
-precision exactly as torch.optim.Adam computes them, and blocks of ``piter`` iterations are
-captured once in a HIP graph and replayed, so the host never synchronises unless the caller's
-``update_callback`` reads a loss.
+``it % piter == 0 or it == niter-1``}.  The Adam bias corrections come from per-step tables
+computed on the host in double precision exactly as torch.optim.Adam computes them.  A stride-1
+target whose key crop fits the LDS (``hip.solve_run_supported``: every edit the reference's
+notebooks and metrics make at layers 5-14) is solved in ONE launch -- a workgroup per pair of
+out-channels keeps its weights and Adam moments in registers for all iterations; with an
+``update_callback`` the same kernel is launched per iteration.  Any other target (upsampling
+layers, ``linear_insert``, crops beyond the LDS) takes the step path: three kernels (+ one
+projection kernel) per iteration, blocks of ``piter`` iterations captured once in a HIP graph
+and replayed.  The host never synchronises unless the caller's ``update_callback`` reads a loss.
 """
 import ctypes
 import math
@@ -106,12 +111,20 @@ class Solver:
         p.lambda_ = _ptr(self.lam)
         self.problem = p
         self._w = w
+        # the one-launch path: decided once per solve, so the step counter and the tables stay consistent
+        self.one_launch = (os.environ.get('RW_SOLVE_ONE_LAUNCH', '1') != '0'
+                           and hip.solve_run_supported(O, I, h, wd, p.rank, upsample, linear))
+        self.lpart = torch.empty(niter * O, **f32) if self.one_launch else None
 
     def projects(self, it):
         return self.low_rank_insert and (it % self.piter == 0 or it == self.niter - 1)
 
     def step(self, it, project=None):
         hip.solve_step(self.problem, self.projects(it) if project is None else project)
+
+    def run_range(self, it0, it1, project=True):
+        """Iterations [it0, it1) in one launch (one_launch targets only)."""
+        hip.solve_run(self.problem, it0, it1, self.niter, self.piter, self.low_rank_insert and project, self.lpart)
 
     def project_now(self):
         hip.project_weight(self._w, self.context, base=self.ortho, out=self._w)
@@ -129,10 +142,16 @@ class Solver:
 
     def _run(self, update_callback):
         niter, piter = self.niter, self.piter
+        if self.one_launch and update_callback is None:
+            self.run_range(0, niter)
+            return
         if update_callback is not None:
             # reference order: step, callback (sees the stepped, not yet projected weight), projection
             for it in range(niter):
-                self.step(it, project=False)
+                if self.one_launch:
+                    self.run_range(it, it + 1, project=False)
+                else:
+                    self.step(it, project=False)
                 bump_weight_epoch()
                 update_callback(it, self.losses[it])
                 if self.projects(it):

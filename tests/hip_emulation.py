@@ -238,6 +238,18 @@ def solve_step(problem, project):
     s = _solvers[ctypes.addressof(problem)]
     it = int(s.counter.item()) + 1
     s.counter.fill_(it)
+    _solve_iteration(s, problem, it, project)
+
+
+def solve_run(problem, it_begin, it_end, niter, piter, low_rank_insert, lpart):
+    """rw_solve_run_f32: iterations [it_begin, it_end), projecting where the reference does."""
+    import ctypes
+    s = _solvers[ctypes.addressof(problem)]
+    for it in range(it_begin, it_end):
+        _solve_iteration(s, problem, it, bool(low_rank_insert) and (it % piter == 0 or it == niter - 1))
+
+
+def _solve_iteration(s, problem, it, project):
     W = s._w
     O, I = W.shape[1:3]
     up = bool(problem.upsample)
@@ -413,7 +425,7 @@ def install(monkeypatch):
              'conv3x3_bf16x6', 'pack_conv_weight_wino', 'conv3x3_wino', 'pack_conv_weight_wino4', 'conv3x3_wino4', 'pack_conv_transpose_weight_wino', 'conv_transpose3x3s2_wino',
              'pack_conv_transpose_blur_weight_wino4', 'conv_transpose3x3s2_blur_wino4',
              'second_moment_accumulate', 'channel_sums', 'project_weight', 'solve_ksplit',
-             'solve_step', 'conv_wgrad', 'rowdot']
+             'solve_step', 'solve_run', 'conv_wgrad', 'rowdot']
     for n in names:
         monkeypatch.setattr(hip, n, globals()[n])
     monkeypatch.setattr(hip, 'on_device', lambda t: True)

@@ -257,23 +257,76 @@ def test_solver_against_oracle_explicit_arithmetic():
     nw = torch.tensor([0.1])
     ctx = torch.linalg.qr(torch.from_numpy(rs.randn(I, 2).astype('float32')))[0].t().contiguous()
     for lrg in (False, True):
-        _, losses, snaps = R.insert_explicit(W0, key, style, val, bias, nw, ctx, niter=41, piter=10,
-                                             low_rank_gradient=lrg, snapshots=(1, 10, 11, 30, 41))
-        for graph in ('1', '0'):
-            os.environ['RW_SOLVE_GRAPH'] = graph
+        for mode in ('one_launch', 'graph', 'eager'):
+            os.environ['RW_SOLVE_ONE_LAUNCH'] = '1' if mode == 'one_launch' else '0'
+            os.environ['RW_SOLVE_GRAPH'] = '0' if mode == 'eager' else '1'
             for n in (1, 10, 11, 30, 41):
                 Wd = W0.to(DEV).clone()
                 s = hipsolve.run(Wd, key.to(DEV), style.to(DEV), val.to(DEV), bias.to(DEV), nw.to(DEV),
                                  ctx.to(DEV), niter=n, piter=10, lr=0.05, low_rank_insert=True,
                                  low_rank_gradient=lrg)
+                assert s.one_launch == (mode == 'one_launch')
                 # a run of n iterations projects at its last iteration; compare with the oracle run
                 # of the same length
                 _, l2, s2 = R.insert_explicit(W0, key, style, val, bias, nw, ctx, niter=n, piter=10,
                                               low_rank_gradient=lrg, snapshots=(n,))
                 r = rel(Wd - W0.to(DEV), s2[n] - W0)
-                assert r < 1e-4, (lrg, graph, n, r)
+                assert r < 1e-4, (lrg, mode, n, r)
                 assert numpy.abs(s.losses.cpu().numpy() - numpy.array(l2)).max() < 1e-5
     os.environ.pop('RW_SOLVE_GRAPH', None)
+    os.environ.pop('RW_SOLVE_ONE_LAUNCH', None)
+
+
+@pytest.mark.parametrize('O,I,h,w,rank,plain', [(512, 512, 5, 8, 1, False), (256, 512, 6, 8, 3, False),
+                                                 (64, 64, 1, 1, 1, False), (128, 256, 4, 4, 8, True),
+                                                 (64, 192, 3, 17, 2, False), (128, 256, 8, 12, 1, False),
+                                                 (64, 128, 7, 1, 2, False)])
+def test_one_launch_solver_equals_step_solver(O, I, h, w, rank, plain):
+    """rw_solve_run_f32 (one workgroup per pair of out-channels, the whole solve in one launch) against the step
+    kernels on the same problem: the same update in another summation order, so 11 iterations agree to rounding;
+    a per-iteration callback drives the same kernel one iteration per launch (state round-trips through HBM) with the
+    projection done by the stand-alone kernel after the callback, as the reference orders them."""
+    from rewriting_amd import hip
+    from rewriting_amd.rewrite import hipsolve
+    rs = numpy.random.RandomState(O + I + h)
+    W0 = torch.from_numpy(rs.randn(1, O, I, 3, 3).astype('float32')).to(DEV)
+    key = torch.from_numpy(rs.randn(1, I, h, w).astype('float32')).to(DEV)
+    style = torch.from_numpy((1 + 0.3 * rs.randn(1, I)).astype('float32')).to(DEV)
+    val = torch.from_numpy(rs.randn(1, O, h, w).astype('float32')).to(DEV)
+    bias = None if plain else torch.from_numpy((0.1 * rs.randn(O)).astype('float32')).to(DEV)
+    nw = None if plain else torch.tensor([0.1], device=DEV)
+    ctx = torch.linalg.qr(torch.from_numpy(rs.randn(I, rank).astype('float32')))[0].t().contiguous().to(DEV)
+    assert hip.solve_run_supported(O, I, h, w, rank, False, False)
+    res = {}
+    for mode in ('one_launch', 'step', 'callback'):
+        os.environ['RW_SOLVE_ONE_LAUNCH'] = '0' if mode == 'step' else '1'
+        Wd = W0.clone()
+        seen = []
+        cb = (lambda it, loss: seen.append(float(loss))) if mode == 'callback' else None
+        s = hipsolve.run(Wd, key, style, val, bias, nw, ctx, niter=11, piter=10, lr=0.05, low_rank_insert=True,
+                         upsample=False, update_callback=cb)
+        res[mode] = (Wd, s.losses.clone())
+        if mode == 'callback':
+            assert numpy.array_equal(numpy.array(seen, dtype='float32'), s.losses.cpu().numpy())
+    os.environ.pop('RW_SOLVE_ONE_LAUNCH', None)
+    assert rel(res['one_launch'][0] - W0, res['callback'][0] - W0) < 1e-5
+    assert (res['one_launch'][1] - res['callback'][1]).abs().max().item() < 1e-6
+    r = rel(res['one_launch'][0] - W0, res['step'][0] - W0)
+    assert r < 1e-4, r
+    assert (res['one_launch'][1] - res['step'][1]).abs().max().item() < 1e-5
+
+
+def test_one_launch_solver_limits():
+    from rewriting_amd import hip
+    assert hip.solve_run_supported(512, 512, 6, 8, 1, False, False)          # 8 x 9 padded rows: within the LDS
+    assert hip.solve_run_supported(256, 256, 8, 12, 1, False, False)
+    assert not hip.solve_run_supported(512, 512, 8, 9, 1, False, False)      # not at 512 channels
+    assert not hip.solve_run_supported(512, 512, 16, 16, 1, False, False)
+    assert not hip.solve_run_supported(512, 512, 4, 4, 1, True, False)       # upsampling targets: step path
+    assert not hip.solve_run_supported(512, 512, 4, 4, 1, False, True)       # linear_insert: step path
+    assert not hip.solve_run_supported(512, 1024, 2, 2, 1, False, False)
+    assert not hip.solve_run_supported(512, 96, 2, 2, 1, False, False)
+    assert not hip.solve_run_supported(512, 128, 2, 2, 9, False, False)
 
 
 def test_odd_layer_edit_matches_reference_golden():
