@@ -490,15 +490,31 @@ def measure_edit(device, reps, warmup):
             times['solve'].append((solve_ms or 0.0) / 1e3)
             times['total'].append(t2 - t0)
     med = lambda v: sorted(v)[len(v) // 2]
-    solve_bytes = 7 * 512 * 512 * 9 * 4 * 2001
     solve_s = med(times['solve']) or med(times['edit'])
+    from rewriting_amd.rewrite import hipsolve
+    last = dict(hipsolve.LAST)
+    if last.get('one_launch'):
+        # rw_solve_run_f32: the weight stays in registers, the key crop in LDS; no HBM traffic to price.  Its work is
+        # the two 3x3 correlations of an iteration (forward and weight gradient), 2 x 2 x O x I x 9 x h x w FLOPs, on
+        # the packed fp32 VALU (v_pk_fma_f32: the same 157.3 TFLOP/s as the fp32 MFMA pipe); the kernel is bound by
+        # instruction issue (reductions over channels, Adam's IEEE sqrt and divisions).
+        flops = 4.0 * last['out_ch'] * last['in_ch'] * 9 * last['h'] * last['w'] * last['niter']
+        roof = dict(bound='valu', achieved=round(flops / solve_s / 1e12, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
+                    frac=round(flops / solve_s / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                    note='one-launch solver, %d x %d channels on a %d x %d key crop: 4 x O x I x 9 x h x w FLOPs per '
+                         'iteration (forward + weight gradient); %.1f us per iteration'
+                         % (last['out_ch'], last['in_ch'], last['h'], last['w'], solve_s * 1e6 / last['niter']))
+    else:
+        solve_bytes = 7 * 512 * 512 * 9 * 4 * 2001
+        roof = dict(bound='hbm', achieved=round(solve_bytes / solve_s / 1e9, 1), peak=HBM_PEAK_GBS,
+                    unit='GB/s', frac=round(solve_bytes / solve_s / 1e9 / HBM_PEAK_GBS, 4),
+                    note='7 x |W| x 4 B per step algorithmic (SURVEY.md 8d); latency-bound')
     return dict(seconds_per_edit=round(med(times['total']), 4), key_collect_s=round(med(times['stats']), 4),
                 apply_edit_s=round(med(times['edit']), 4), solve_s=round(solve_s, 4), reps=reps,
                 workload='stylegan2-256 layer 8, recorded_horse_hat.json: 1000-seed key statistics + ZCA, goal, '
                          'context direction, 2001-step rank-1 solve',
-                solve_roofline=dict(bound='hbm', achieved=round(solve_bytes / solve_s / 1e9, 1), peak=HBM_PEAK_GBS,
-                                    unit='GB/s', frac=round(solve_bytes / solve_s / 1e9 / HBM_PEAK_GBS, 4),
-                                    note='7 x |W| x 4 B per step algorithmic (SURVEY.md 8d); latency-bound'))
+                solve_path='rw_solve_run_f32' if last.get('one_launch') else 'rw_solve_step_f32',
+                solve_roofline=roof)
 
 
 def run_edit(args, rank, world, device):
@@ -508,7 +524,7 @@ def run_edit(args, rank, world, device):
                 ms_per_step=round(e['seconds_per_edit'] * 1e3, 2), higher_is_better=False, scaling='weak',
                 vs_baseline=None, dtype='f32', data='synthetic',
                 config=dict(workload=e['workload'], key_collect_s=e['key_collect_s'], edit_s=e['apply_edit_s'],
-                            solve_s=e['solve_s'], replicas=world),
+                            solve_s=e['solve_s'], solve_path=e['solve_path'], replicas=world),
                 roofline=dict(e['solve_roofline'], traffic=None))
 
 

@@ -23,6 +23,9 @@ from .. import hip
 from ..utils.stylegan2.models import bump_weight_epoch, reference_noise
 
 
+LAST = {}      # shape and path of the most recent solve (read by bench.py and the tests; diagnostics only)
+
+
 def _ptr(t):
     return t.data_ptr() if t is not None else 0
 
@@ -115,6 +118,9 @@ class Solver:
         self.one_launch = (os.environ.get('RW_SOLVE_ONE_LAUNCH', '1') != '0'
                            and hip.solve_run_supported(O, I, h, wd, p.rank, upsample, linear))
         self.lpart = torch.empty(niter * O, **f32) if self.one_launch else None
+        LAST.clear()
+        LAST.update(one_launch=bool(self.one_launch), out_ch=O, in_ch=I, h=h, w=wd, niter=niter,
+                    upsample=bool(upsample), linear=bool(linear))
 
     def projects(self, it):
         return self.low_rank_insert and (it % self.piter == 0 or it == self.niter - 1)
