@@ -220,6 +220,69 @@ __global__ void __launch_bounds__(256) upfirdn2d_plane_kernel(const float* __res
   }
 }
 
+// The generator's own upsampling (UpsampleO on the running RGB image: up 2, a 4 x 4 kernel, minor 1; the polyphase
+// walk above spends ~40 integer instructions per tap on it).  Here everything that does not depend on the row is
+// computed once per thread -- per output column its two input columns, their validity and kernel columns -- and a row
+// costs two row pointers, sixteen loads and sixteen FMAs per four outputs.  Same taps in the same order as
+// upfirdn2d_kernel (a ascending, then c ascending; out-of-map taps skipped, not added as zeros) -> bit-identical.
+__global__ void __launch_bounds__(256) upfirdn2d_up2k4_kernel(const float* __restrict__ x, const float* __restrict__ k,
+                                                              float* __restrict__ y, UpfirdnParams p, int tiles_x,
+                                                              int tiles_y) {
+  __shared__ float sk[16];
+  if (threadIdx.x < 16) {
+    const int ky = threadIdx.x >> 2, kx = threadIdx.x & 3;
+    sk[threadIdx.x] = k[(3 - ky) * 4 + (3 - kx)];
+  }
+  __syncthreads();
+  int blk = blockIdx.x;
+  const int tx = blk % tiles_x; blk /= tiles_x;
+  const int ty = blk % tiles_y;
+  const int ma = blk / tiles_y;
+  const int ox = tx * UF_TW + (threadIdx.x & 63) * 4;
+  if (ox >= p.out_w) return;
+  const float* xm = x + (int64_t)ma * p.in_h * p.in_w;
+  float* ym = y + (int64_t)ma * p.out_h * p.out_w;
+  int ix[4][2], kc[4][2];
+  bool okc[4][2];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c0 = (p.px0 - (ox + e)) & 1;                      // kernel columns c0, c0 + 2 land on samples
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = c0 + 2 * j, vx = ox + e + c - p.px0;
+      kc[e][j] = c;
+      ix[e][j] = vx >> 1;
+      okc[e][j] = vx >= 0 && (vx >> 1) < p.in_w;
+      if (!okc[e][j]) ix[e][j] = 0;
+    }
+  }
+  const bool vec = (p.out_w % 4 == 0);
+  const int oy1 = min((ty + 1) * UF_TH, p.out_h);
+  for (int oy = ty * UF_TH + (threadIdx.x >> 6); oy < oy1; oy += 4) {
+    const int a0 = (p.py0 - oy) & 1;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j2 = 0; j2 < 2; ++j2) {
+      const int a = a0 + 2 * j2, vy = oy + a - p.py0, iy = vy >> 1;
+      if (vy < 0 || iy >= p.in_h) continue;
+      const float* xr = xm + (int64_t)iy * p.in_w;
+      const float* kr = sk + 4 * a;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          if (okc[e][j]) acc[e] += xr[ix[e][j]] * kr[kc[e][j]];
+    }
+    float* yo = ym + (int64_t)oy * p.out_w + ox;
+    if (vec) {
+      *reinterpret_cast<float4*>(yo) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (ox + e < p.out_w) yo[e] = acc[e];
+    }
+  }
+}
+
 extern "C" int rw_upfirdn2d_f32(const float* x, const float* k, float* y, int major, int in_h,
                                 int in_w, int minor, int kh, int kw, int up_x, int up_y,
                                 int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0,
@@ -239,7 +302,9 @@ extern "C" int rw_upfirdn2d_f32(const float* x, const float* k, float* y, int ma
       blocks <= 0x7fffffff) {
     const dim3 grid((unsigned)blocks), block(256);
     hipStream_t st = rw_s(stream);
-    if (up_x == 1 && down_x == 1)
+    if (up_x == 2 && down_x == 1 && kh == 4 && kw == 4)
+      hipLaunchKernelGGL(upfirdn2d_up2k4_kernel, grid, block, 0, st, x, k, y, p, tiles_x, tiles_y);
+    else if (up_x == 1 && down_x == 1)
       hipLaunchKernelGGL((upfirdn2d_plane_kernel<1, 1>), grid, block, 0, st, x, k, y, p, tiles_x, tiles_y);
     else if (up_x == 2 && down_x == 1)
       hipLaunchKernelGGL((upfirdn2d_plane_kernel<2, 1>), grid, block, 0, st, x, k, y, p, tiles_x, tiles_y);
@@ -830,7 +895,8 @@ __global__ void __launch_bounds__(256) to_rgb_kernel(const float* __restrict__ x
   const float* xb = x + (int64_t)b * in_ch * hw;
   for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < hw4; q += (int64_t)gridDim.x * 256) {
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
-    for (int i = 0; i < in_ch; ++i) {
+#pragma unroll 8
+    for (int i = 0; i < in_ch; ++i) {             // (eight 16-byte loads in flight per thread)
       const float4 v = reinterpret_cast<const float4*>(xb + (int64_t)i * hw)[q];
       const float w0 = wm[i], w1 = wm[in_ch + i], w2 = wm[2 * in_ch + i];
       a0.x += w0 * v.x; a0.y += w0 * v.y; a0.z += w0 * v.z; a0.w += w0 * v.w;

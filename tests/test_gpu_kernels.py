@@ -91,6 +91,26 @@ def test_upfirdn2d_random_configs_against_c_oracle_and_autograd():
     assert (x.grad.cpu() - want).abs().max().item() < 1e-5
 
 
+def test_upsampling_kernel_of_the_rgb_skip_is_the_generic_walk():
+    """up 2 with a 4 x 4 kernel and minor 1 has its own kernel (upfirdn2d_up2k4_kernel): against the C oracle over
+    pads, ragged widths (scalar stores) and maps wider than one 256-column tile, and BIT FOR BIT against the generic
+    kernel (which the same call takes with minor 2: two interleaved copies of the planes)."""
+    from rewriting_amd import hip
+    from oracle import native
+    rs = numpy.random.RandomState(5)
+    for (major, h, w, pads) in [(3, 8, 8, (2, 1, 2, 1)), (2, 5, 7, (2, 1, 2, 1)), (1, 130, 150, (2, 1, 2, 1)),
+                                (2, 9, 6, (1, 2, 0, 3)), (1, 4, 4, (3, 3, -1, 2)), (6, 32, 32, (2, 1, 2, 1))]:
+        x = rs.randn(major, h, w, 1).astype('float32')
+        k = rs.randn(4, 4).astype('float32')
+        want = native.upfirdn2d(x, k, 2, 2, 1, 1, *pads)
+        got = hip.upfirdn2d_major(cuda(x), cuda(k), 2, 2, 1, 1, *pads).cpu().numpy()
+        assert got.shape == want.shape
+        assert numpy.abs(got - want).max() < 1e-5, (major, h, w, pads)
+        two = numpy.concatenate([x, x], axis=3)
+        generic = hip.upfirdn2d_major(cuda(two), cuda(k), 2, 2, 1, 1, *pads).cpu().numpy()
+        assert numpy.array_equal(generic[..., :1], got), (major, h, w, pads)
+
+
 def test_mapping_network_pieces():
     from rewriting_amd import hip
     from oracle import restatement as R
