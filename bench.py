@@ -107,7 +107,8 @@ class ConvTimer:
                 e.record()
                 b, i, h, w = x.shape
                 if wino == 'up':
-                    name = 'conv_up_wino_narrow_kernel' if w == 16 else 'conv_up_wino_kernel'
+                    name = {16: 'conv_up_wino_narrow_kernel', 8: 'conv_up_wino_8x8_kernel',
+                            4: 'conv_up_wino_4x4_kernel'}.get(w, 'conv_up_wino_kernel')
                 elif wino in ('up4', 'f4rgb', 'f4'):
                     # rw_wino4.hip picks the no-style variants when the input map already carries the style
                     ns = k.get('style') is None
@@ -120,8 +121,9 @@ class ConvTimer:
                     else:
                         name = 'conv_wino36b_ns_kernel' if ns else 'conv_wino36b_kernel<2, 2>'
                 elif wino is not None:
+                    # last template argument: 16 / 8 / 4 = the shapes for maps that narrow (rw_wino.hip)
                     name = 'conv_wino16_kernel<%s, %s%s>' % ('2, 2, 8' if out_ch % 64 == 0 else '1, 4, 4', wino,
-                                                             ', true' if w == 16 else '')      # true: the 16-wide shape
+                                                             ', %d' % w if w <= 16 else '')
                 else:
                     name = ('conv_halo_bf16x6_kernel<2, 2, %s>' % ('2, 2' if out_ch % 128 == 0 else '1, 4') if split
                             else conv_kernel_name(out_ch, i, w, upsample))

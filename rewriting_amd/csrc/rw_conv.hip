@@ -1325,7 +1325,11 @@ extern "C" int rw_conv_transpose3x3s2_f32(const float* x, const float* wp, float
     p.ntaps = ntaps[phase];
     for (int t = 0; t < p.ntaps; ++t) set_tap(p, t, tdy[phase][t], tdx[phase][t]);
   }
-  if ((impl == 3 || impl == 4 || impl == 7 || impl == 8) && !halo_applicable(ps, 4)) return RW_ERR_UNSUPPORTED;
+  // impl 8 = the border strips alone (output row 2H, column 2W): a batched im2col launch that needs the channel
+  // multiples of the halo kernels but no tile shape, so it also serves maps the tiles do not (4 wide, rw_upwino.hip)
+  const bool strips_ok = in_ch % 16 == 0 && in_ch <= 1024 && out_ch % 32 == 0;
+  if (impl == 8 && !strips_ok) return RW_ERR_UNSUPPORTED;
+  if ((impl == 3 || impl == 4 || impl == 7) && !halo_applicable(ps, 4)) return RW_ERR_UNSUPPORTED;
   if (impl == 7 || impl == 8) return launch_up_halo(ps, wp, impl - 6, rw_s(stream));
   if (impl == 4) return launch_halo(ps, 4, nullptr, rw_s(stream));        // per-phase halo tiles (kept for A/B)
   if (impl == 3 || (impl == 0 && halo_applicable(ps, 4))) return launch_up_halo(ps, wp, 0, rw_s(stream));

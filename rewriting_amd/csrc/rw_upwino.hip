@@ -47,7 +47,6 @@ struct UpWinoProblem {
 #define UW_NTS 0          // non-temporal stores of the (2H+1)^2 map (A/B builds)
 #endif
 #define UW_PITCH 36             // row pitch of a patch channel in LDS: 33 columns + 3
-#define UW_PIECES 3             // 5 rows x 36 = 180 floats -> three 64-float pieces
 
 __device__ __forceinline__ int uw_xcd_remap(int id, int total) {
   const int q = total >> 3, r = total & 7;
@@ -64,21 +63,32 @@ __device__ __forceinline__ void uw_dma_global_b128_s(unsigned lds_addr, int voff
                : "memory");
 }
 
-// NRW = input maps 16 pixels wide (layer 7 of the generators: 16^2 -> 33^2, a fifth of a key-statistics sweep at layer
-// 8): a wave's 16 blocks are then TWO block rows of 8 -- block lt sits at block row 2 wn + (lt >> 3), column lt & 7 --,
-// the patch of a channel is 9 rows x 17 columns at pitch 20 (the same 180 floats = three pieces as 5 x 33 at pitch 36),
-// a workgroup covers 8 quad rows and the map's whole width (groups_x = gpw = 1).  Everything else is unchanged.
-template <bool NRW>
+// NRW = 16: input maps 16 pixels wide (layer 7 of the generators: 16^2 -> 33^2, a fifth of a key-statistics sweep at
+// layer 8): a wave's 16 blocks are then TWO block rows of 8 -- block lt sits at block row 2 wn + (lt >> 3), column
+// lt & 7 --, the patch of a channel is 9 rows x 17 columns at pitch 20 (the same 180 floats = three pieces as 5 x 33 at
+// pitch 36), a workgroup covers 8 quad rows and the map's whole width (groups_x = gpw = 1).
+// NRW = 8, 4: the 8^2 and 4^2 maps (layers 5 and 3: a quarter of that sweep on kernels built for big maps).  A wave's
+// 16 blocks are then ONE whole 8 x 8 image (4 x 4 blocks) or FOUR 4 x 4 images (2 x 2 blocks each), a workgroup covers
+// 2 / 8 consecutive images of the batch: the patch of a channel is 2 x (9 rows x 9 columns at pitch 10) = 180 floats
+// resp. 8 x (5 rows x 5 columns at pitch 6, 32 floats apart) = 256 floats = four pieces; the demodulation factors
+// are per lane (registers) instead of per workgroup, and the input arrives ALREADY multiplied by its style (the host
+// side does that on these tiny maps: a per-image style table for 8 images would not fit beside the rings).
+// Everything else is unchanged.
+template <int NRW>
 __device__ __forceinline__ void conv_up_wino_body(const UpWinoProblem& p) {
-  constexpr int PITCH = NRW ? 20 : UW_PITCH;      // row pitch of a patch channel
-  constexpr int PROWS = NRW ? 9 : 5, PCOLS = NRW ? 17 : 33;
+  constexpr int PITCH = NRW == 16 ? 20 : (NRW == 8 ? 10 : (NRW == 4 ? 6 : UW_PITCH));      // row pitch of a patch channel
+  constexpr int PROWS = NRW == 16 ? 9 : (NRW == 8 ? 9 : 5);
+  constexpr int PCOLS = NRW == 16 ? 17 : (NRW == 8 ? 9 : (NRW == 4 ? 5 : 33));
+  constexpr int IPW = NRW == 8 ? 2 : (NRW == 4 ? 8 : 1);        // images per workgroup
+  constexpr int ISTRIDE = NRW == 8 ? 90 : (NRW == 4 ? 32 : 256); // floats between the images of a channel's patch
+  constexpr int UW_PIECES = NRW == 4 ? 4 : 3;     // 64-float pieces per channel
   constexpr int IC = 8;                           // channels per interval: two k-quads
   constexpr int PSZ = IC * UW_PIECES * 64;        // floats per patch ring slot
   constexpr int USZ = 2 * 2 * 7 * 256;            // floats per weight ring slot: [16-channel half][k-quad][7][256]
   __shared__ __attribute__((aligned(16))) float Ps[3 * PSZ];
   __shared__ __attribute__((aligned(16))) float Us[2 * USZ];
-  __shared__ float St[512];
-  __shared__ float Sc[32];
+  __shared__ float St[IPW == 1 ? 512 : 1];        // IPW > 1: the input carries its style already
+  __shared__ float Sc[IPW == 1 ? 32 : 1];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -94,21 +104,33 @@ __device__ __forceinline__ void conv_up_wino_body(const UpWinoProblem& p) {
   const int gy = pg % p.groups_y;
   const int ib = pg / p.groups_y;
   const int o0 = ot * 32;
-  const int q0y = (NRW ? 8 : 4) * gy, gx0 = run * p.gpw;      // first quad row; groups of 32 quad columns
-  const int b_row = NRW ? 2 * wn + (lt >> 3) : wn;            // this lane's block: block row within the workgroup,
-  const int b_col = NRW ? (lt & 7) : lt;                       // block column within the group
+  const int q0y = (NRW == 16 ? 8 : 4) * gy, gx0 = run * p.gpw;  // first quad row; groups of 32 quad columns
+  // this lane's block: image within the workgroup, block row within the workgroup (image), block column within the group
+  const int img_l = NRW == 8 ? wn : (NRW == 4 ? 4 * wn + (lt >> 2) : 0);
+  const int b_row = NRW == 16 ? 2 * wn + (lt >> 3) : (NRW == 8 ? lt >> 2 : (NRW == 4 ? (lt >> 1) & 1 : wn));
+  const int b_col = NRW == 16 ? (lt & 7) : (NRW == 8 ? lt & 3 : (NRW == 4 ? lt & 1 : lt));
   const int64_t hw = (int64_t)p.h * p.w;
-  const float* xb = p.x + (int64_t)ib * p.in_ch * hw;
+  const int img0 = ib * IPW;                       // first image of this workgroup
+  const int nimg = min(IPW, p.batch - img0);
+  const float* xb = p.x + (int64_t)img0 * p.in_ch * hw;
   const int NC = p.in_ch / IC;
   const int VT = p.gpw * NC;
 
-  for (int i = tid; i < p.in_ch; i += 256) St[i] = p.style ? p.style[(int64_t)ib * p.in_ch + i] : 1.0f;
-  if (tid < 32) Sc[tid] = p.demod ? p.demod[(int64_t)ib * p.out_ch + o0 + tid] * p.w_scale : p.w_scale;
+  if (IPW == 1) {
+    for (int i = tid; i < p.in_ch; i += 256) St[i] = p.style ? p.style[(int64_t)ib * p.in_ch + i] : 1.0f;
+    if (tid < 32) Sc[tid] = p.demod ? p.demod[(int64_t)ib * p.out_ch + o0 + tid] * p.w_scale : p.w_scale;
+  }
+  const bool img_ok = img_l < nimg;
+  float scl[4] = {p.w_scale, p.w_scale, p.w_scale, p.w_scale};        // IPW > 1: this lane's demodulation factors
+  if (IPW > 1 && p.demod && img_ok) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) scl[j] = p.demod[(int64_t)(img0 + img_l) * p.out_ch + o0 + 16 * wm + 4 * lk + j] * p.w_scale;
+  }
 
   typedef __attribute__((address_space(3))) float* lds_f;
   const unsigned ps_base = (unsigned)(size_t)(lds_f)Ps, us_base = (unsigned)(size_t)(lds_f)Us;
   const unsigned long long xaddr = (unsigned long long)xb;
-  const uw_i32x4 xsrc = {(int)(unsigned)xaddr, (int)(unsigned)(xaddr >> 32), (int)((int64_t)p.in_ch * hw * 4),
+  const uw_i32x4 xsrc = {(int)(unsigned)xaddr, (int)(unsigned)(xaddr >> 32), (int)((int64_t)nimg * p.in_ch * hw * 4),
                          0x00020000};
   const int hw4 = (int)hw * 4;
   // patch pieces of this wave: channels 2 wave, 2 wave + 1 of the interval, three pieces each.  Patch row r = input
@@ -119,10 +141,11 @@ __device__ __forceinline__ void conv_up_wino_body(const UpWinoProblem& p) {
 #pragma unroll
     for (int s = 0; s < UW_PIECES; ++s) {
       const int f = 64 * s + lane;
-      const int r = f / PITCH, c = f - r * PITCH;
+      const int m = IPW > 1 ? f / ISTRIDE : 0, fm = f - m * ISTRIDE;
+      const int r = fm / PITCH, c = fm - r * PITCH;
       const int iy = q0y - 1 + r, ix = x0 - 1 + c;
-      const bool ok = r < PROWS && c < PCOLS && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
-      xoff[s] = ok ? (iy * p.w + ix) * 4 : 0x7fffffff;
+      const bool ok = m < nimg && r < PROWS && c < PCOLS && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
+      xoff[s] = ok ? (m * p.in_ch * (int)hw + iy * p.w + ix) * 4 : 0x7fffffff;
     }
   };
   int p_soff = 0;
@@ -132,7 +155,7 @@ __device__ __forceinline__ void conv_up_wino_body(const UpWinoProblem& p) {
     p_soff = (IC * fc + 2 * wave) * hw4;
     p_dst = ps_base + (unsigned)((ring * PSZ + 2 * wave * (UW_PIECES * 64)) * 4);
   };
-  // piece s = 0..5: channel 2 wave + s / 3, piece s % 3
+  // piece s = 0 .. 2 UW_PIECES - 1: channel 2 wave + s / UW_PIECES, piece s % UW_PIECES
   auto pload_piece = [&](int s) __attribute__((always_inline)) {
     uw_dma_buffer_b32(p_dst + 256 * s, xoff[s % UW_PIECES], xsrc, p_soff + (s / UW_PIECES) * hw4);
   };
@@ -152,12 +175,12 @@ __device__ __forceinline__ void conv_up_wino_body(const UpWinoProblem& p) {
   for (int xi = 0; xi < 25; ++xi) acc[xi] = uw_f32x4{0.f, 0.f, 0.f, 0.f};
 
   // this lane's window: patch rows 2 wn .. 2 wn + 2, columns 2 lt .. 2 lt + 2 of channel lk (+ 4 per k-quad)
-  const int item_off = lk * (UW_PIECES * 64) + (2 * b_row) * PITCH + 2 * b_col;
+  const int item_off = lk * (UW_PIECES * 64) + (IPW > 1 ? img_l * ISTRIDE : 0) + (2 * b_row) * PITCH + 2 * b_col;
   auto compute = [&](int ring, int uslot, int c, bool spread) __attribute__((always_inline)) {
 #pragma unroll
     for (int kql = 0; kql < 2; ++kql) {
       const float* src = &Ps[ring * PSZ + kql * 4 * (UW_PIECES * 64) + item_off];
-      const float sv = St[IC * c + 4 * kql + lk];
+      const float sv = IPW == 1 ? St[IC * c + 4 * kql + lk] : 1.0f;
       float d[3][3];
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
@@ -182,7 +205,7 @@ __device__ __forceinline__ void conv_up_wino_body(const UpWinoProblem& p) {
 #pragma unroll
       for (int q = 0; q < 7; ++q) {
         if (q + 2 < 7) a4[(q + 2) % 3] = *reinterpret_cast<const uw_f32x4*>(ub + (q + 2) * 256);
-        if (spread && q < 3) pload_piece(3 * kql + q);
+        if (spread && q < UW_PIECES) pload_piece(UW_PIECES * kql + q);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -205,10 +228,10 @@ __device__ __forceinline__ void conv_up_wino_body(const UpWinoProblem& p) {
   const int64_t ohw = (int64_t)oh * ow;
   auto group_epilogue = [&](int g) __attribute__((always_inline)) {
     const int Y0 = 2 * (q0y + 2 * b_row), X0 = 2 * (32 * (gx0 + g) + 2 * b_col);
-    float* yb = p.y + ((int64_t)ib * p.out_ch + o0 + 16 * wm + 4 * lk) * ohw + (int64_t)Y0 * ow + X0;
+    float* yb = p.y + ((int64_t)(img0 + img_l) * p.out_ch + o0 + 16 * wm + 4 * lk) * ohw + (int64_t)Y0 * ow + X0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float sc = Sc[16 * wm + 4 * lk + j];
+      const float sc = IPW > 1 ? scl[j] : Sc[IPW == 1 ? 16 * wm + 4 * lk + j : 0];
       float px[4][4];                              // [2 a + py][2 b + px]
       // phase (0,0): 3 x 3 -> 2 x 2
       {
@@ -235,6 +258,7 @@ __device__ __forceinline__ void conv_up_wino_body(const UpWinoProblem& p) {
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) px[2 * a + 1][2 * b + 1] = acc[21 + 2 * a + b][j];
+      if (IPW > 1 && !img_ok) continue;              // past the batch: nothing to write
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         f32x4_u v = {px[r][0] * sc, px[r][1] * sc, px[r][2] * sc, px[r][3] * sc};
@@ -250,10 +274,11 @@ __device__ __forceinline__ void conv_up_wino_body(const UpWinoProblem& p) {
   };
 
 #define UW_WAIT(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (((n) >> 4) << 14) | 0x70)
-  // in flight across the barrier of an interval: the 6 patch pieces issued in it (the weights of v + 1 go first
-  // and have landed); + 16 stores after a group's epilogue
+  // in flight across the barrier of an interval: the 2 UW_PIECES patch pieces issued in it (the weights of v + 1 go
+  // first and have landed); + 16 stores after a group's epilogue (a lane past the batch issues none: it then waits for
+  // older pieces than it needs to, which is harmless)
   auto sync_interval = [&](bool stores) __attribute__((always_inline)) {
-    if (stores) UW_WAIT(6 + 16); else UW_WAIT(6);
+    if (stores) UW_WAIT(2 * UW_PIECES + 16); else UW_WAIT(2 * UW_PIECES);
     __builtin_amdgcn_s_barrier();
   };
 
@@ -264,11 +289,11 @@ __device__ __forceinline__ void conv_up_wino_body(const UpWinoProblem& p) {
   uload(0, 0);
   pload_begin(0, fg, fc);
 #pragma unroll
-  for (int s = 0; s < 6; ++s) pload_piece(s);
+  for (int s = 0; s < 2 * UW_PIECES; ++s) pload_piece(s);
   advance();
   pload_begin(1, fg, fc);
 #pragma unroll
-  for (int s = 0; s < 6; ++s) pload_piece(s);
+  for (int s = 0; s < 2 * UW_PIECES; ++s) pload_piece(s);
   advance();
   sync_interval(false);                             // U(0), patch 0 landed; patch 1 may be in flight
 
@@ -288,8 +313,10 @@ __device__ __forceinline__ void conv_up_wino_body(const UpWinoProblem& p) {
 #undef UW_WAIT
 }
 
-__global__ void __launch_bounds__(256, 2) conv_up_wino_kernel(const UpWinoProblem p) { conv_up_wino_body<false>(p); }
-__global__ void __launch_bounds__(256, 2) conv_up_wino_narrow_kernel(const UpWinoProblem p) { conv_up_wino_body<true>(p); }
+__global__ void __launch_bounds__(256, 2) conv_up_wino_kernel(const UpWinoProblem p) { conv_up_wino_body<0>(p); }
+__global__ void __launch_bounds__(256, 2) conv_up_wino_narrow_kernel(const UpWinoProblem p) { conv_up_wino_body<16>(p); }
+__global__ void __launch_bounds__(256, 2) conv_up_wino_8x8_kernel(const UpWinoProblem p) { conv_up_wino_body<8>(p); }
+__global__ void __launch_bounds__(256, 2) conv_up_wino_4x4_kernel(const UpWinoProblem p) { conv_up_wino_body<4>(p); }
 
 // One thread: the 25 (+3 zero) values of one (o, i).  W[o][i][ky][kx] as rw_conv_transpose3x3s2_f32 sees it.
 __global__ void __launch_bounds__(256) pack_up_wino_kernel(const float* __restrict__ w, float* __restrict__ uf,
@@ -331,10 +358,11 @@ __global__ void __launch_bounds__(256) pack_up_wino_kernel(const float* __restri
 }
 
 static bool up_wino_narrow(int h, int w) { return w == 16 && h % 8 == 0; }
+static bool up_wino_whole(int h, int w) { return (w == 8 && h == 8) || (w == 4 && h == 4); }    // whole images per wave
 
 static bool up_wino_shape_ok(int out_ch, int in_ch, int h, int w) {
   if (!(out_ch > 0 && in_ch >= 16 && in_ch <= 512 && out_ch % 32 == 0 && in_ch % 8 == 0)) return false;
-  return (w % 32 == 0 && h % 4 == 0) || up_wino_narrow(h, w);
+  return (w % 32 == 0 && h % 4 == 0) || up_wino_narrow(h, w) || up_wino_whole(h, w);
 }
 
 extern "C" int rw_conv_transpose3x3s2_wino_supported(int out_ch, int in_ch, int h, int w) {
@@ -363,26 +391,32 @@ extern "C" int rw_conv_transpose3x3s2_wino_f32(const float* x, const float* uf, 
                                                const float* demod, rw_stream_t stream) {
   RW_CHECK_ARG(x && uf && y && batch > 0 && in_ch > 0 && out_ch > 0 && h > 0 && w > 0);
   if (!up_wino_shape_ok(out_ch, in_ch, h, w)) return RW_ERR_UNSUPPORTED;
+  const bool whole = up_wino_whole(h, w);
+  if (whole && style) return RW_ERR_UNSUPPORTED;       // 8^2 and 4^2 maps arrive already multiplied by their style
   UpWinoProblem p;
   p.x = x; p.uf = uf; p.y = y; p.style = style; p.demod = demod;
   p.batch = batch; p.in_ch = in_ch; p.out_ch = out_ch; p.h = h; p.w = w; p.w_scale = w_scale;
   const bool narrow = up_wino_narrow(h, w);
-  p.groups_x = narrow ? 1 : w / 32;
-  p.groups_y = narrow ? h / 8 : h / 4;
+  p.groups_x = (narrow || whole) ? 1 : w / 32;
+  p.groups_y = whole ? 1 : (narrow ? h / 8 : h / 4);
+  const int ipw = whole ? (w == 8 ? 2 : 8) : 1;        // images per workgroup
+  const int wg_batch = (batch + ipw - 1) / ipw;
   const int o_tiles = out_ch / 32;
   const char* e = getenv("RW_UPWINO_GPW");
   int gpw = e ? atoi(e) : 4;
   if (gpw < 1) gpw = 1;
   if (gpw > p.groups_x) gpw = p.groups_x;
   while (p.groups_x % gpw) --gpw;
-  while (gpw > 1 && (int64_t)batch * p.groups_y * (p.groups_x / gpw) * o_tiles < 1024) {
+  while (gpw > 1 && (int64_t)wg_batch * p.groups_y * (p.groups_x / gpw) * o_tiles < 1024) {
     --gpw;
     while (p.groups_x % gpw) --gpw;
   }
   p.gpw = gpw;
-  const int64_t work = (int64_t)batch * p.groups_y * (p.groups_x / gpw) * o_tiles;
+  const int64_t work = (int64_t)wg_batch * p.groups_y * (p.groups_x / gpw) * o_tiles;
   if (work <= 0 || work > 0x7fffffff) return RW_ERR_UNSUPPORTED;
-  if (narrow) hipLaunchKernelGGL(conv_up_wino_narrow_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
+  if (whole && w == 8) hipLaunchKernelGGL(conv_up_wino_8x8_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
+  else if (whole) hipLaunchKernelGGL(conv_up_wino_4x4_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
+  else if (narrow) hipLaunchKernelGGL(conv_up_wino_narrow_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
   else hipLaunchKernelGGL(conv_up_wino_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
   return RW_LAUNCH_RESULT();
 }

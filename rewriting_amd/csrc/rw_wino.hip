@@ -74,11 +74,15 @@ template <int N> struct wn_int { static constexpr int value = N; };
 // ---------------------------------------------------------------------------------------
 typedef float wn_f32x4 __attribute__((ext_vector_type(4)));
 
-// NRW = maps 16 pixels wide (the 16^2 layers: most of a key-statistics sweep at layer 8): a wave's "tile row" of 16
+// NRW = 16: maps 16 pixels wide (the 16^2 layers: most of a key-statistics sweep at layer 8): a wave's "tile row" of 16
 // tiles is then TWO map tile rows of 8 tiles -- tile lt sits at map tile row 2 wn + (lt >> 3), column lt & 7 -- the
 // raw patch is (4 WGN + 2) rows x 18 columns, one group spans the map's width (groups_x = gpw = 1); everything else
 // (chunk pipeline, operand streams, slot schedule: NRAW and NIT are those of the wide shapes) is unchanged.
-template <int WGM, int WGN, int IC, bool RGB, bool NRW = false>
+// NRW = 8, 4: the 8^2 and 4^2 maps.  A wave's 16 tiles are ONE whole 8 x 8 image (4 x 4 tiles) or FOUR 4 x 4 images (2 x 2
+// tiles each); a workgroup covers WGN resp. 4 WGN consecutive images of the batch, whose zero-bordered windows
+// ((H + 2) x (W + 2) each) are stacked in the raw patch.  The demodulation factors are then per lane (registers) and
+// the input arrives ALREADY multiplied by its style (the host side does that on these tiny maps).
+template <int WGM, int WGN, int IC, bool RGB, int NRW = 0>
 __global__ void __launch_bounds__(256, 2) conv_wino16_kernel(const WinoProblem p) {
   static_assert(WGM * WGN == 4, "4 waves per workgroup");
   static_assert(!(RGB && NRW), "the ToRGB epilogue is for the last (widest) layer");
@@ -87,9 +91,12 @@ __global__ void __launch_bounds__(256, 2) conv_wino16_kernel(const WinoProblem p
   constexpr int VP = NT == 16 ? 48 : NT + 16;      // padded channel-row pitch of V (see the bank notes above)
   // row pitch of the raw patch (NRW: 24 -- the two 8-lane halves of a transform read sit two rows apart, 48 floats =
   // 16 banks)
-  constexpr int RS = NRW ? 24 : (NT == 16 ? 40 : 48);
-  constexpr int PC = NRW ? 18 : WN_PC;             // patch columns
-  constexpr int PR = NRW ? 4 * WGN + 2 : 2 * WGN + 2;   // patch rows
+  constexpr bool WHOLE = NRW == 8 || NRW == 4;     // whole images per wave
+  constexpr int IPW = NRW == 8 ? WGN : (NRW == 4 ? 4 * WGN : 1);       // images per workgroup
+  constexpr int IROWS = NRW + 2;                   // WHOLE: window rows of one image
+  constexpr int RS = NRW == 16 ? 24 : (NRW == 8 ? 12 : (NRW == 4 ? 8 : (NT == 16 ? 40 : 48)));
+  constexpr int PC = NRW == 16 ? 18 : (WHOLE ? NRW + 2 : WN_PC);       // patch columns
+  constexpr int PR = NRW == 16 ? 4 * WGN + 2 : (WHOLE ? IPW * IROWS : 2 * WGN + 2);   // patch rows
   constexpr int NPOS = PR * PC;
   constexpr int PSLOT = (NPOS + 255) / 256;
   constexpr int NRAW = PSLOT * IC;
@@ -125,24 +132,36 @@ __global__ void __launch_bounds__(256, 2) conv_wino16_kernel(const WinoProblem p
   const int gy = pg % p.groups_y;
   const int ib = pg / p.groups_y;
   const int o0 = ot * 32 * WGM;
-  const int y0 = gy * (NRW ? 4 : 2) * WGN, gx0 = run * p.gpw;
+  const int y0 = WHOLE ? 0 : gy * (NRW == 16 ? 4 : 2) * WGN, gx0 = run * p.gpw;
   const int64_t hw = (int64_t)p.h * p.w;
-  const float* xb = p.x + (int64_t)ib * p.in_ch * hw;
-  const float* st = p.style ? p.style + (int64_t)ib * p.in_ch : nullptr;
+  const int img0 = ib * IPW;                       // first image of this workgroup
+  const int nimg = min(IPW, p.batch - img0);
+  const float* xb = p.x + (int64_t)img0 * p.in_ch * hw;
+  const float* st = (p.style && !WHOLE) ? p.style + (int64_t)ib * p.in_ch : nullptr;
   const int NC = p.in_ch / IC;
   const int VT = p.gpw * NC;
   // map position of this lane's tile (tile row wn of the workgroup, tile lt): first pixel row relative to y0 / column
   // relative to the group's first column
-  const int t_row = NRW ? 2 * (2 * wn + (lt >> 3)) : 2 * wn;
-  const int t_col = NRW ? 2 * (lt & 7) : 2 * lt;
+  const int t_row = NRW == 16 ? 2 * (2 * wn + (lt >> 3)) : (NRW == 8 ? 2 * (lt >> 2) : (NRW == 4 ? 2 * ((lt >> 1) & 1) : 2 * wn));
+  const int t_col = NRW == 16 ? 2 * (lt & 7) : (NRW == 8 ? 2 * (lt & 3) : (NRW == 4 ? 2 * (lt & 1) : 2 * lt));
+  const int img_l = NRW == 8 ? wn : (NRW == 4 ? 4 * wn + (lt >> 2) : 0);       // this lane's image within the workgroup
+  const bool img_ok = img_l < nimg;
+  const int img = img0 + img_l;
 
   // The epilogue runs once per tile group, in the middle of the load stream: a global load there queues behind the
   // patch fetch just issued (vmcnt retires in order) and costs a full memory latency per group.  Everything it needs
   // per out-channel is therefore put into LDS once per workgroup (visible after the prologue's first barrier); the
   // per-pixel noise / running image are fetched at the start of a group's last chunk, ahead of that chunk's fetch.
+  float scl[8];                                     // WHOLE: this lane's w_scale * demod, [half 2][j 4]
+  if (WHOLE) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      scl[q] = (p.demod && img_ok) ? p.demod[(int64_t)img * p.out_ch + o0 + 32 * wm + 16 * (q >> 2) + 4 * lk + (q & 3)] * p.w_scale
+                                   : p.w_scale;
+  }
   if (tid < 32 * WGM) {
     const int o = o0 + tid;
-    Ct[0][tid] = p.demod ? p.demod[(int64_t)ib * p.out_ch + o] * p.w_scale : p.w_scale;
+    Ct[0][tid] = (p.demod && !WHOLE) ? p.demod[(int64_t)ib * p.out_ch + o] * p.w_scale : p.w_scale;
     Ct[1][tid] = p.act ? p.bias[o] : 0.f;
     if (RGB) {
       const float sr = p.rgb_scale * p.rgb_style[(int64_t)ib * p.out_ch + o];
@@ -156,7 +175,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino16_kernel(const WinoProblem p
   // image get an out-of-range offset and the hardware returns 0 -- the zero padding costs no instruction, and
   // there is no 64-bit address arithmetic.  Lane offsets are recomputed when the fetch cursor enters a new group.
   const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(xb), 0, (int)((int64_t)p.in_ch * hw * 4), 0x00020000);
+      const_cast<float*>(xb), 0, (int)((int64_t)nimg * p.in_ch * hw * 4), 0x00020000);
   int xoff[PSLOT], xlds[PSLOT];
 #pragma unroll
   for (int sl = 0; sl < PSLOT; ++sl) {
@@ -170,9 +189,10 @@ __global__ void __launch_bounds__(256, 2) conv_wino16_kernel(const WinoProblem p
     for (int sl = 0; sl < PSLOT; ++sl) {
       const int pos = tid + 256 * sl;
       const int r = pos / PC, c = pos - r * PC;
-      const int iy = y0 - 1 + r, ix = x0 - 1 + c;
-      const bool ok = pos < NPOS && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
-      xoff[sl] = ok ? (iy * p.w + ix) * 4 : 0x7fffffff;          // bytes; out of range -> 0
+      const int m = WHOLE ? r / IROWS : 0;                        // image of this window row
+      const int iy = y0 - 1 + (WHOLE ? r - m * IROWS : r), ix = x0 - 1 + c;
+      const bool ok = pos < NPOS && m < nimg && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
+      xoff[sl] = ok ? (m * p.in_ch * (int)hw + iy * p.w + ix) * 4 : 0x7fffffff;          // bytes; out of range -> 0
     }
   };
   float xreg[PSLOT][IC];
@@ -204,8 +224,10 @@ __global__ void __launch_bounds__(256, 2) conv_wino16_kernel(const WinoProblem p
 
   // ---- transform items: tile tl of the workgroup (tile row tl >> 4, column tl & 15), channel tch + CH_STEP * item
   const int tl = tid % NT, tch = tid / NT;
-  const float* rsrc = NRW ? &Rs[0][tch][2 * (2 * (tl >> 4) + ((tl & 15) >> 3))][2 * (tl & 7)]
-                          : &Rs[0][tch][2 * (tl >> 4)][2 * (tl & 15)];
+  const float* rsrc = NRW == 16 ? &Rs[0][tch][2 * (2 * (tl >> 4) + ((tl & 15) >> 3))][2 * (tl & 7)]
+                      : NRW == 8 ? &Rs[0][tch][(tl >> 4) * IROWS + 2 * ((tl & 15) >> 2)][2 * (tl & 3)]
+                      : NRW == 4 ? &Rs[0][tch][(4 * (tl >> 4) + ((tl & 15) >> 2)) * IROWS + 2 * ((tl >> 1) & 1)][2 * (tl & 1)]
+                                 : &Rs[0][tch][2 * (tl >> 4)][2 * (tl & 15)];
   float* vdst = &Vs[0][0][tch][tl];
   float2 drow[NIT][4][2];
   float e[4][4];
@@ -298,8 +320,8 @@ __global__ void __launch_bounds__(256, 2) conv_wino16_kernel(const WinoProblem p
   const float noise_w = p.noise ? p.noise_w[0] : 0.f;
   auto epilogue_prefetch = [&](int g) __attribute__((always_inline)) {
     const int64_t pix = (int64_t)(y0 + t_row) * p.w + (gx0 + g) * 32 + t_col;
-    if (p.noise) {
-      const float* np = p.noise + (int64_t)ib * hw + pix;
+    if (p.noise && (!WHOLE || img_ok)) {
+      const float* np = p.noise + (int64_t)(WHOLE ? img : ib) * hw + pix;
       pre_nz[0] = *reinterpret_cast<const float2*>(np);
       pre_nz[1] = *reinterpret_cast<const float2*>(np + p.w);
     }
@@ -328,13 +350,15 @@ __global__ void __launch_bounds__(256, 2) conv_wino16_kernel(const WinoProblem p
     // neighbouring lanes (tile columns 2m, 2m+1) exchange halves: the even lane stores four consecutive pixels of
     // output row oy, the odd lane four of row oy + 1 -- one aligned 16-byte store per lane and channel
     const bool odd = lt & 1;
-    float* yb = p.y ? p.y + ((int64_t)ib * p.out_ch + o_first) * hw + (int64_t)(oy + (odd ? 1 : 0)) * p.w + (ox & ~3)
+    // (WHOLE: a lane whose image lies past the batch writes nothing; its exchange partner shares the image)
+    float* yb = (p.y && (!WHOLE || img_ok))
+                    ? p.y + ((int64_t)(WHOLE ? img : ib) * p.out_ch + o_first) * hw + (int64_t)(oy + (odd ? 1 : 0)) * p.w + (ox & ~3)
                     : nullptr;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int half = q >> 2, j = q & 3;
       const int oc = 16 * half + j;
-      const float scale = ct[oc];
+      const float scale = WHOLE ? scl[q] : ct[oc];
       const float bias = ct[32 * WGM + oc];
       float wr[3] = {0.f, 0.f, 0.f};
       if (RGB) {
@@ -497,10 +521,11 @@ __global__ void __launch_bounds__(256) pack_wino16_kernel(const float* __restric
 }
 
 static bool wino_narrow(int h, int w) { return w == 16 && h % 16 == 0; }      // the NRW shapes (see conv_wino16_kernel)
+static bool wino_whole(int h, int w) { return (w == 8 && h == 8) || (w == 4 && h == 4); }   // whole images per wave
 
 static bool wino_shape_ok(int out_ch, int in_ch, int h, int w) {
-  if (!(out_ch > 0 && in_ch > 0 && out_ch % 32 == 0 && in_ch % 8 == 0 && h >= 8)) return false;
-  return (w % 32 == 0 && w >= 32 && h % 8 == 0) || wino_narrow(h, w);
+  if (!(out_ch > 0 && in_ch > 0 && out_ch % 32 == 0 && in_ch % 8 == 0)) return false;
+  return (w % 32 == 0 && w >= 32 && h % 8 == 0 && h >= 8) || wino_narrow(h, w) || wino_whole(h, w);
 }
 
 extern "C" int rw_conv3x3_wino_supported(int out_ch, int in_ch, int h, int w) {
@@ -532,29 +557,36 @@ static int launch_wino(WinoProblem& p, bool rgb, hipStream_t s) {
   int bm = p.out_ch % 64 == 0 ? 64 : 32;
   const int force = wn_env("RW_WINO_TILE", 0);
   if (force && p.out_ch % force == 0 && (force == 32 || force == 64 || force == 128)) bm = force;
-  const bool narrow = wino_narrow(p.h, p.w);
-  if (narrow && bm == 128) bm = 64;               // NRW exists for the <2,2> and <1,4> shapes
+  const bool narrow = wino_narrow(p.h, p.w), whole = wino_whole(p.h, p.w);
+  if ((narrow || whole) && bm == 128) bm = 64;    // NRW exists for the <2,2> and <1,4> shapes
   const int wgn = 128 / bm;                       // tile rows per workgroup: 1, 2, 4
-  if (p.h % ((narrow ? 4 : 2) * wgn) || (narrow && rgb)) return RW_ERR_UNSUPPORTED;
-  p.groups_x = narrow ? 1 : p.w / 32;
-  p.groups_y = p.h / ((narrow ? 4 : 2) * wgn);
+  if (whole && (rgb || p.style)) return RW_ERR_UNSUPPORTED;      // 8^2 / 4^2 maps arrive multiplied by their style
+  if (!whole && (p.h % ((narrow ? 4 : 2) * wgn) || (narrow && rgb))) return RW_ERR_UNSUPPORTED;
+  p.groups_x = (narrow || whole) ? 1 : p.w / 32;
+  p.groups_y = whole ? 1 : p.h / ((narrow ? 4 : 2) * wgn);
+  const int ipw = whole ? (p.w == 8 ? wgn : 4 * wgn) : 1;        // images per workgroup
+  const int wg_batch = (p.batch + ipw - 1) / ipw;
   const int o_tiles = p.out_ch / bm;
   int gpw = wn_env("RW_WINO_GPW", 8);
   if (gpw < 1) gpw = 1;
   if (gpw > p.groups_x) gpw = p.groups_x;
   while (p.groups_x % gpw) --gpw;
   // short launches: keep at least ~4 workgroups per CU
-  while (gpw > 1 && (int64_t)p.batch * p.groups_y * (p.groups_x / gpw) * o_tiles < 1024) {
+  while (gpw > 1 && (int64_t)wg_batch * p.groups_y * (p.groups_x / gpw) * o_tiles < 1024) {
     --gpw;
     while (p.groups_x % gpw) --gpw;
   }
   p.gpw = gpw;
-  const int64_t work = (int64_t)p.batch * p.groups_y * (p.groups_x / gpw) * o_tiles;
+  const int64_t work = (int64_t)wg_batch * p.groups_y * (p.groups_x / gpw) * o_tiles;
   if (work <= 0 || work > 0x7fffffff) return RW_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)work), block(256);
   if (rgb && bm != 32) return RW_ERR_UNSUPPORTED;
-  if (narrow && bm == 64) hipLaunchKernelGGL((conv_wino16_kernel<2, 2, 8, false, true>), grid, block, 0, s, p);
-  else if (narrow) hipLaunchKernelGGL((conv_wino16_kernel<1, 4, 4, false, true>), grid, block, 0, s, p);
+  if (whole && p.w == 8 && bm == 64) hipLaunchKernelGGL((conv_wino16_kernel<2, 2, 8, false, 8>), grid, block, 0, s, p);
+  else if (whole && p.w == 8) hipLaunchKernelGGL((conv_wino16_kernel<1, 4, 4, false, 8>), grid, block, 0, s, p);
+  else if (whole && bm == 64) hipLaunchKernelGGL((conv_wino16_kernel<2, 2, 8, false, 4>), grid, block, 0, s, p);
+  else if (whole) hipLaunchKernelGGL((conv_wino16_kernel<1, 4, 4, false, 4>), grid, block, 0, s, p);
+  else if (narrow && bm == 64) hipLaunchKernelGGL((conv_wino16_kernel<2, 2, 8, false, 16>), grid, block, 0, s, p);
+  else if (narrow) hipLaunchKernelGGL((conv_wino16_kernel<1, 4, 4, false, 16>), grid, block, 0, s, p);
   else if (bm == 128) hipLaunchKernelGGL((conv_wino16_kernel<4, 1, 8, false>), grid, block, 0, s, p);
   else if (bm == 64) hipLaunchKernelGGL((conv_wino16_kernel<2, 2, 8, false>), grid, block, 0, s, p);
   else if (rgb) hipLaunchKernelGGL((conv_wino16_kernel<1, 4, 4, true>), grid, block, 0, s, p);

@@ -250,6 +250,10 @@ def conv3x3_wino(x, uf, out_ch, w_scale, style=None, demod=None, noise=None, noi
     if uf.numel() != lib().rw_packed_conv_weight_wino_elems(out_ch, i):
         raise ValueError('packed weight does not come from pack_conv_weight_wino(%d x %d)' % (out_ch, i))
     y = torch.empty(b, out_ch, h, w, device=x.device, dtype=x.dtype)
+    if style is not None and w <= 8:
+        # whole 8^2 / 4^2 images per wave (several images per workgroup): the kernel takes these maps already
+        # multiplied by their style -- the same product, rounded the same way, one tiny launch earlier
+        x, style = style_mul(x, _dev(style, 'style')), None
     ep, keep = _epilogue(style, demod, noise, noise_w, bias, act)
     check(lib().rw_conv3x3_wino_f32(_p(x), _p(uf), _p(y), b, i, out_ch, h, w, float(w_scale), ctypes.byref(ep),
                                     _stream()))
@@ -385,6 +389,11 @@ def up_halo_applicable(out_ch, in_ch, width):
             and (width >= 24 or 9 <= width <= 16 or (5 <= width <= 8 and out_ch % 128 == 0)))
 
 
+def up_strips_applicable(out_ch, in_ch):
+    """Channel counts conv_transpose3x3s2(impl=8) -- the border row and column of the (2H+1) x (2W+1) map alone -- takes."""
+    return in_ch % 16 == 0 and in_ch <= 1024 and out_ch % 32 == 0
+
+
 def conv_transpose3x3s2(x, wp, out_ch, w_scale, style=None, demod=None, impl=0, out=None):
     x = _dev(x, 'fmap')
     wp = _dev(wp, 'packed weight')
@@ -428,6 +437,10 @@ def conv_transpose3x3s2_wino(x, uf, out_ch, w_scale, style=None, demod=None, out
         raise ValueError('out has the wrong shape')
     style = _opt(style, 'style')
     demod = _opt(demod, 'demod')
+    if style is not None and w <= 8:
+        # whole 8^2 / 4^2 images per wave (several images per workgroup): the kernel takes these maps already
+        # multiplied by their style -- the same product, rounded the same way, one tiny launch earlier
+        x, style = style_mul(x, style), None
     check(lib().rw_conv_transpose3x3s2_wino_f32(_p(x), _p(uf), _p(y), b, i, out_ch, h, w, float(w_scale), _p(style),
                                                 _p(demod), _stream()))
     return y

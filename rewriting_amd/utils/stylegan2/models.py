@@ -466,10 +466,10 @@ class DemodulatedConv2dF(nn.Module):
                     aux = _rgb_side_streams[(fmap.device, 'aux')] = torch.cuda.Stream(device=fmap.device)
             b, _, h, w = fmap.shape
             f22 = (up_conv_algo() == 'winograd' and conv_impl() == 0
-                   and hip.up_halo_applicable(self.out_channel, self.in_channel, w)
+                   and hip.up_strips_applicable(self.out_channel, self.in_channel)
                    and hip.conv_transpose_wino_supported(self.out_channel, self.in_channel, h, w))
-            if conv_impl() == 0 and hip.up_halo_applicable(self.out_channel, self.in_channel, w) and (
-                    aux is not None or f22):
+            if conv_impl() == 0 and (f22 or (aux is not None and hip.up_halo_applicable(
+                    self.out_channel, self.in_channel, w))):
                 # quad tiles (F(2,2) where it applies, else the direct kernel) and the border row / column strips
                 # write disjoint elements of the same map; in the un-hooked full forward the strips
                 # (latency-bound, 2 % of the step) go to a third stream beside the tiles

@@ -223,7 +223,7 @@ def test_generator_with_winograd_convolutions_holds_the_golden_bars(emulated_hip
     monkeypatch.setenv('RW_CONV_ALGO', 'winograd')
     with torch.no_grad():
         fused = model(z)
-    assert sorted(s[-1] for s in calls) == [16, 32, 64]            # layers 6, 8 and 10 (maps >= 16 wide)
+    assert sorted(s[-1] for s in calls) == [4, 8, 16, 32, 64]     # layers 2, 4, 6, 8 and 10 (every stride-1 layer)
     assert (fused - torch.from_numpy(g['image'])).abs().max() < 1e-4
     monkeypatch.setenv('RW_FUSE', '0')
     img, store = _stage_outputs(model, z)

@@ -276,7 +276,11 @@ WINO_CASES = [(1, 16, 32, 8, 32), (2, 64, 64, 16, 32), (1, 128, 128, 32, 64), (2
               (1, 128, 128, 256, 256), (1, 256, 256, 128, 128), (1, 512, 512, 64, 64),
               # maps 16 wide (the NRW shapes: a wave's 16 tiles = two map tile rows of 8): the 16^2 layers, both
               # workgroup shapes, several workgroups per image
-              (3, 512, 512, 16, 16), (2, 64, 96, 16, 16), (2, 32, 64, 32, 16), (1, 16, 32, 48, 16)]
+              (3, 512, 512, 16, 16), (2, 64, 96, 16, 16), (2, 32, 64, 32, 16), (1, 16, 32, 48, 16),
+              # whole 8 x 8 / 4 x 4 images per wave (layers 4 and 2), both workgroup shapes, batches that fill the last
+              # workgroup and batches that do not
+              (4, 512, 512, 8, 8), (3, 64, 64, 8, 8), (5, 32, 96, 8, 8), (1, 16, 32, 8, 8), (16, 512, 512, 4, 4),
+              (11, 64, 64, 4, 4), (37, 32, 32, 4, 4), (1, 24, 96, 4, 4), (250, 64, 128, 4, 4)]
 
 
 @pytest.mark.parametrize('case', WINO_CASES)
@@ -396,7 +400,11 @@ def test_winograd_f4_conv_matches_oracle_within_its_error_class(case):
 UP_WINO_CASES = [(2, 16, 32, 4, 32), (1, 64, 64, 8, 32), (1, 128, 64, 16, 64), (3, 32, 32, 12, 96), (1, 512, 512, 32, 32),
                  (1, 24, 96, 8, 64), (1, 64, 32, 512, 512), (1, 128, 64, 256, 256), (1, 512, 256, 64, 64),
                  # input maps 16 wide (a wave's 16 blocks = two block rows of 8): layer 7 of the generators
-                 (2, 512, 512, 16, 16), (1, 64, 32, 8, 16), (3, 32, 64, 24, 16)]
+                 (2, 512, 512, 16, 16), (1, 64, 32, 8, 16), (3, 32, 64, 24, 16),
+                 # whole 8 x 8 / 4 x 4 images per wave, two / eight images per workgroup (layers 5 and 3): batches that
+                 # fill the last workgroup and batches that do not
+                 (4, 512, 512, 8, 8), (3, 32, 64, 8, 8), (1, 64, 32, 8, 8), (16, 512, 512, 4, 4), (11, 32, 32, 4, 4),
+                 (1, 48, 96, 4, 4), (250, 64, 64, 4, 4)]
 
 
 @pytest.mark.parametrize('case', UP_WINO_CASES)
