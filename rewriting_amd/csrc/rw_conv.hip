@@ -18,6 +18,7 @@
 // and writes its output once.
 #include "rw_common.h"
 #include <stdlib.h>
+#include <string.h>
 
 __host__ __device__ __forceinline__ int rw_tap_off(unsigned bits, int t) {
   return (int)((bits >> (2 * t)) & 3u) - 1;
@@ -1043,6 +1044,146 @@ static int launch_batch(const ConvProblem* ps, int n, int impl, hipStream_t s);
 
 // part: 0 = everything, 1 = the quad tiles only, 2 = output row 2H / column 2W only (the two parts write
 // disjoint elements, so a caller may issue them on two streams)
+// ---------------------------------------------------------------------------------------
+// The border strips of a stride-2 transposed convolution: output row 2H and output column 2W of the (2H+1) x (2W+1)
+// map, which the quad-tile kernels (here and in rw_upwino.hip) leave out.  Both are 1-D transposed convolutions of
+// the LAST input row / column with one row / column of the 3 x 3 kernel,
+//   even output 2m    = W_a x[m] + W_b x[m-1]      row strip: W[2][0], W[2][2]   column strip: W[0][2], W[2][2]
+//   odd  output 2m+1  = W_c x[m]                               W[2][1]                         W[1][2]
+// i.e. three (out_ch x in_ch) GEMMs over the strip's samples of ALL images: M = 32 out-channels per workgroup, N = 64
+// strip positions (image, m) -- m = 0..W for the row strip (x[W] = 0 closes it with the corner pixel), 0..H-1 for the
+// column strip --, K = in_ch in chunks of 16 on v_mfma_f32_16x16x4_f32; a wave owns 16 positions, its even-output tile
+// accumulates both taps (x[m-1] is the neighbouring column of the same LDS tile).  The batched im2col launch this
+// replaces walked 9 x in_ch gathered columns per position in 64-position tiles that do not span images: 0.96 ms for
+// the 65 border pixels of the 16 -> 33 layer at 250 images, beside 2.7 ms for the other 1024.
+// Weights: the [slab][in_ch][out_ch] part of rw_pack_conv_weight_f32 mode 1 (slab -> tap: rw_up_tap_order).
+// ---------------------------------------------------------------------------------------
+struct StripProblem {
+  const float* x; const float* wp; float* y; const float* style; const float* demod;
+  int batch, in_ch, out_ch, h, w;
+  float w_scale;
+  int n_row_tiles;                  // workgroups along x that belong to the row strip; the rest: column strip
+};
+#define ST_KC 16
+__global__ void __launch_bounds__(256) up_strip_kernel(const StripProblem p) {
+  __shared__ float As[3][ST_KC][32];
+  __shared__ float Bs[ST_KC][64 + 4];            // column 0 = the position before the tile's first
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool col = (int)blockIdx.x >= p.n_row_tiles;
+  const int n0 = 64 * (col ? blockIdx.x - p.n_row_tiles : blockIdx.x);
+  const int o0 = 32 * blockIdx.y;
+  const int L = col ? p.h : p.w;                 // samples of the last row / column
+  const int P = col ? p.h : p.w + 1;             // positions per image
+  const int ntot = p.batch * P;
+  const int slab_a = col ? 1 : 2, slab_b = 3, slab_c = col ? 7 : 5;
+  const int64_t hw = (int64_t)p.h * p.w, slab = (int64_t)p.in_ch * p.out_ch;
+  // B staging: thread -> (channel tid / 16 of the chunk, positions n0 - 1 + (tid % 16) + 16 j, j = 0..4)
+  const int bk = tid >> 4, bc = tid & 15;
+  int64_t boff[5]; int bimg[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int cidx = bc + 16 * j;                // column of Bs: position n0 - 1 + cidx
+    const int n = n0 - 1 + cidx;
+    boff[j] = -1; bimg[j] = 0;
+    if (cidx < 65 && n >= 0 && n < ntot) {
+      const int img = n / P, m = n - img * P;
+      if (m < L) {
+        bimg[j] = img;
+        boff[j] = (int64_t)img * p.in_ch * hw + (col ? (int64_t)m * p.w + (p.w - 1) : (int64_t)(p.h - 1) * p.w + m);
+      }
+    }
+  }
+  // A staging: thread -> slab tid / 85.. : 3 x 16 x 32 floats = 1536 = 6 per thread as (row = e / 32, o = e % 32)
+  float areg[6], breg[5];
+  auto fetch = [&](int c) __attribute__((always_inline)) {
+    const int i0 = c * ST_KC;
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+      const int f = tid + 256 * e;               // 0 .. 1535
+      const int t = f / (ST_KC * 32), r = f - t * (ST_KC * 32), k = r >> 5, o = r & 31;
+      const int sl = t == 0 ? slab_a : (t == 1 ? slab_b : slab_c);
+      areg[e] = p.wp[sl * slab + (int64_t)(i0 + k) * p.out_ch + o0 + o];
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      float v = 0.f;
+      if (boff[j] >= 0) {
+        v = p.x[boff[j] + (int64_t)(i0 + bk) * hw];
+        if (p.style) v *= p.style[(int64_t)bimg[j] * p.in_ch + i0 + bk];
+      }
+      breg[j] = v;
+    }
+  };
+  auto stash = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+      const int f = tid + 256 * e;
+      const int t = f / (ST_KC * 32), r = f - t * (ST_KC * 32);
+      (&As[0][0][0])[t * (ST_KC * 32) + r] = areg[e];
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+      if (bc + 16 * j < 65) Bs[bk][bc + 16 * j] = breg[j];
+  };
+  rw_f32x4 accE[2], accO[2];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb) { accE[mb] = rw_f32x4{0.f, 0.f, 0.f, 0.f}; accO[mb] = accE[mb]; }
+  const int lk = lane >> 4, ln = lane & 15;
+  // this lane's position and whether x[m-1] exists for it (m >= 1: the previous position is the same image's)
+  const int n = n0 + 16 * wave + ln;
+  const bool n_ok = n < ntot;
+  const int img = n_ok ? n / P : 0, m = n_ok ? n - img * P : 0;
+  const float prev_mask = (n_ok && m >= 1) ? 1.f : 0.f;
+  const int chunks = p.in_ch / ST_KC;
+  fetch(0);
+  for (int c = 0; c < chunks; ++c) {
+    __syncthreads();                             // the previous chunk's reads are done
+    stash();
+    __syncthreads();
+    if (c + 1 < chunks) fetch(c + 1);
+#pragma unroll
+    for (int ks = 0; ks < ST_KC / 4; ++ks) {
+      const int k = 4 * ks + lk;
+      const float bcur = Bs[k][16 * wave + ln + 1];
+      const float bprev = Bs[k][16 * wave + ln] * prev_mask;
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        const float a0 = As[0][k][16 * mb + ln], a1 = As[1][k][16 * mb + ln], a2 = As[2][k][16 * mb + ln];
+        accE[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bcur, accE[mb], 0, 0, 0);
+        accE[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bprev, accE[mb], 0, 0, 0);
+        accO[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, bcur, accO[mb], 0, 0, 0);
+      }
+    }
+  }
+  if (!n_ok) return;
+  const int oh = 2 * p.h + 1, ow = 2 * p.w + 1;
+  const int64_t ohw = (int64_t)oh * ow;
+  // even output 2m, odd output 2m + 1 (none behind the last sample: m == L only exists on the row strip, as the corner)
+  const int64_t pos_e = col ? (int64_t)(2 * m) * ow + 2 * p.w : (int64_t)(2 * p.h) * ow + 2 * m;
+  const int64_t step_o = col ? ow : 1;
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int o = o0 + 16 * mb + 4 * lk + r;
+      const float sc = p.demod ? p.demod[(int64_t)img * p.out_ch + o] * p.w_scale : p.w_scale;
+      float* yo = p.y + ((int64_t)img * p.out_ch + o) * ohw + pos_e;
+      yo[0] = accE[mb][r] * sc;
+      if (m < L) yo[step_o] = accO[mb][r] * sc;
+    }
+}
+
+static int launch_up_strips(const ConvProblem& c, const float* wp_all, hipStream_t s) {
+  StripProblem p;
+  p.x = c.x; p.wp = wp_all; p.y = c.y; p.style = c.style; p.demod = c.demod;
+  p.batch = c.batch; p.in_ch = c.in_ch; p.out_ch = c.out_ch; p.h = c.h; p.w = c.w; p.w_scale = c.w_scale;
+  const int64_t nrow = rw_cdiv((int64_t)c.batch * (c.w + 1), 64), ncol = rw_cdiv((int64_t)c.batch * c.h, 64);
+  if (nrow + ncol > 0x7fffffff) return RW_ERR_UNSUPPORTED;
+  p.n_row_tiles = (int)nrow;
+  hipLaunchKernelGGL(up_strip_kernel, dim3((unsigned)(nrow + ncol), (unsigned)(c.out_ch / 32)), dim3(256), 0, s, p);
+  return RW_LAUNCH_RESULT();
+}
+
 static int launch_up_halo(const ConvProblem* ps, const float* wp_all, int part, hipStream_t s) {
   const ConvProblem& c = ps[0];
   UpProblem u;
@@ -1068,8 +1209,10 @@ static int launch_up_halo(const ConvProblem* ps, const float* wp_all, int part, 
     else hipLaunchKernelGGL((conv_up_halo_kernel<1, 4, 16, 32>), dim3(work), dim3(256), 0, s, u);
   }
   if (part == 1) return RW_LAUNCH_RESULT();
-  // Output row 2H and column 2W: quads y' = H (phases (0,0),(0,1)) and x' = W, y' < H (phases
-  // (0,0),(1,0)) as four strip problems of ONE batched im2col launch.
+  // Output row 2H and column 2W: quads y' = H (phases (0,0),(0,1)) and x' = W, y' < H (phases (0,0),(1,0)): the strip
+  // kernel above; RW_UP_STRIPS=im2col keeps the four strip problems of one batched im2col launch (A/B, cross-check)
+  static const bool strips_gemm = !(getenv("RW_UP_STRIPS") && !strcmp(getenv("RW_UP_STRIPS"), "im2col"));
+  if (strips_gemm && c.in_ch % ST_KC == 0 && c.out_ch % 32 == 0) return launch_up_strips(c, wp_all, s);
   ConvProblem e[4] = {ps[0], ps[1], ps[0], ps[2]};
   e[0].ph = 1; e[0].pw = c.w + 1; e[0].yoff = c.h;
   e[1].ph = 1; e[1].pw = c.w;     e[1].yoff = c.h;

@@ -494,10 +494,12 @@ def test_one_pass_upsampling_conv_matches_conv_then_blur(case):
 
 def test_winograd_rejects_shapes_it_does_not_take():
     from rewriting_amd import hip
-    assert not hip.wino_supported(32, 32, 8, 8) and not hip.wino_supported(48, 32, 32, 32)
+    assert not hip.wino_supported(32, 32, 8, 4) and not hip.wino_supported(48, 32, 32, 32)
     assert not hip.wino_supported(32, 12, 32, 32) and not hip.wino_supported(32, 32, 36, 32)
     assert hip.wino_supported(32, 32, 16, 16) and not hip.wino_supported(32, 32, 24, 16)     # 16 wide: h % 16 == 0
-    x, wt, _ = _conv_inputs(1, 32, 32, 8, 8)
+    assert hip.wino_supported(32, 32, 8, 8) and hip.wino_supported(32, 32, 4, 4)             # whole images per wave
+    assert not hip.wino_supported(32, 32, 16, 8) and not hip.wino_supported(32, 32, 12, 12)
+    x, wt, _ = _conv_inputs(1, 32, 32, 16, 8)
     with pytest.raises(RuntimeError):
         hip.conv3x3_wino(x.to(DEV), hip.pack_conv_weight_wino(wt.to(DEV)), 32, 0.1)
 
