@@ -139,8 +139,9 @@ typedef struct rw_conv_epilogue {
  * the im2col MFMA kernel, 3 = force the halo-tile MFMA kernel (RW_ERR_UNSUPPORTED if not applicable),
  * 4 = (transposed conv only) per-phase halo tiles, 5 = im2col MFMA kernel without split-K,
  * 6 = im2col MFMA kernel with split-K forced; transposed conv only: 7 = the quad tiles of the halo
- * kernel without output row 2H / column 2W, 8 = that row and column only (disjoint writes: the two may be
- * issued on different streams; RW_ERR_UNSUPPORTED where the halo kernel does not apply). */
+ * kernel without output row 2H / column 2W (RW_ERR_UNSUPPORTED where the halo kernel does not apply), 8 = that row
+ * and column only (disjoint writes: the two may be issued on different streams) -- three GEMMs over the last input row /
+ * column of all images, any map size, in_ch % 16 == 0 and out_ch % 32 == 0. */
 int rw_conv3x3_f32(const float* x, const float* wp, float* y, int batch, int in_ch, int out_ch,
                    int h, int w, float w_scale, const rw_conv_epilogue* ep, int impl,
                    rw_stream_t stream);
@@ -178,8 +179,10 @@ int rw_conv3x3_bf16x6_f32(const float* x, const void* wb, float* y, int batch, i
  * F(2x2, 3x3) in fp32: 16 instead of 36 multiplications per 2x2 output tile and channel pair, i.e. 2.25x fewer
  * matrix FLOPs for a result that is identical in exact arithmetic and of the direct kernel's error class in
  * fp32 (transform coefficients 0, +-1, +-1/2; fp32 MFMA accumulation).  rw_conv3x3_wino_supported() says which
- * shapes it takes (out_ch % 32 == 0, in_ch % 8 == 0, and w % 32 == 0 with h % 8 == 0 or w == 16 with h % 16 == 0); elsewhere, and whenever the
- * caller prefers the direct sum, rw_conv3x3_f32 is the kernel.
+ * shapes it takes (out_ch % 32 == 0, in_ch % 8 == 0, and w % 32 == 0 with h % 8 == 0, w == 16 with h % 16 == 0, or the
+ * whole 8 x 8 / 4 x 4 maps -- several images per workgroup; these take ep->style == NULL, i.e. an input that already
+ * carries its style, RW_ERR_UNSUPPORTED otherwise); elsewhere, and whenever the caller prefers the direct sum,
+ * rw_conv3x3_f32 is the kernel.
  *   uf: rw_packed_conv_weight_wino_elems(out_ch, in_ch) = 16*out_ch*in_ch floats from rw_pack_conv_weight_wino_f32:
  *       U = G g G^T of every (o, i) filter in the A-fragment order of v_mfma_f32_16x16x4_f32
  *       uf[o / 32][i / 4][xi / 4][(o % 32) / 16][lane][xi % 4],  o = 32 (o/32) + 16 ((o%32)/16) + (lane & 15),
@@ -229,7 +232,9 @@ int rw_conv_transpose3x3s2_f32(const float* x, const float* wp, float* y, int ba
 /* The quads y < H, x < W of the same transposed convolution (everything but output row 2H and column 2W, which
  * rw_conv_transpose3x3s2_f32 impl 8 writes) by the minimal-filtering algorithm F(2,2) in fp32: 25 instead of 36
  * multiplications per 2x2 block of quads and channel pair; coefficients 0, +-1 (the direct sum's error class).
- * Shapes: out_ch % 32 == 0, 16 <= in_ch <= 512, in_ch % 8 == 0, and w % 32 == 0 with h % 4 == 0 or w == 16 with h % 8 == 0.
+ * Shapes: out_ch % 32 == 0, 16 <= in_ch <= 512, in_ch % 8 == 0, and w % 32 == 0 with h % 4 == 0, w == 16 with h % 8 == 0,
+ * or the whole 8 x 8 / 4 x 4 maps (two / eight images per workgroup; these take style == NULL, i.e. an input that
+ * already carries its style, RW_ERR_UNSUPPORTED otherwise).
  *   uf: rw_packed_conv_transpose_wino_elems(out_ch, in_ch) = 28*out_ch*in_ch floats from
  *       rw_pack_conv_transpose_wino_f32 (w = the (1,out_ch,in_ch,3,3) parameter as rw_pack_conv_weight_f32 takes it):
  *       uf[o / 16][i / 4][q][lane][xi % 4], xi = 4 q + e < 25 the point (rw_upwino.hip lists them), 25..27 zero.
