@@ -42,6 +42,14 @@
 typedef float w4_f32x4 __attribute__((ext_vector_type(4)));
 template <int N> struct w4_int { static constexpr int value = N; };
 
+// Order of the 36 transform points in the packed weights (position -> natural index xi = 6 row + column): rows 0, 1, 2
+// first, then the second half in the order the point-split kernels want it -- positions 20..35 = rows 5, 3, 4 as far as
+// sixteen floats go, positions 18, 19 = the last two columns of row 4 -- so that BOTH halves read four whole quads
+// (at quad 5 WM) and one half quad (quad 4, components 2 WM, 2 WM + 1) and their local points 6 a + b mean (row, column)
+// = ((0, 1, 2)[a], b) resp. ((5, 3, 4)[a], b): one instruction stream for both waves.  Everything that reads or writes
+// the packed buffer goes through this function.
+__host__ __device__ constexpr int w4_nat(int pos) { return pos < 18 ? pos : (pos < 26 ? pos + 10 : pos - 8); }
+
 struct Wino4Problem {
   const float* x; const float* uf; float* y;
   const float* style; const float* demod; const float* noise; const float* noise_w; const float* bias;
@@ -239,7 +247,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino36_kernel(const Wino4Problem 
       const w4_f32x4 a = *reinterpret_cast<const w4_f32x4*>(base + q * 256);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int xi = 4 * q + e;
+        const int xi = w4_nat(4 * q + e);
         acc[xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], d[xi / 6][xi % 6], acc[xi], 0, 0, 0);
       }
     }
@@ -410,8 +418,35 @@ __device__ __forceinline__ void w4_dma_global_b32(unsigned lds_addr, const void*
 // never written.
 // STYLE = false: the input map already carries this layer's style (its producer multiplied it in: `post` of the
 // UP epilogue, rw_blur_noise_act_scaled_f32) -- 18 packed multiplies per item less in the loop.
-template <int WGN, int UDEPTH, int MODE, bool STYLE>
+// PS = the two out-channel waves of a tile row split the 36 POINTS instead of the 32 out-channels: wave wm computes rows
+// 3 wm .. 3 wm + 2 of B^T d B -- half of the column pass (6 / 7 instead of 13 packed instructions per column pair), three
+// of the six row passes: 36-39 instead of 75 packed instructions per k-quad, the input transform no longer done twice per
+// workgroup -- and multiplies them with the weights of BOTH 16-channel blocks (the same 36 MFMAs and 144 accumulators).
+// The output transform is linear in the points, so each wave transforms its 18 points of a block to a partial 4 x 4
+// tile; per group and accumulator component j the waves swap the partial of the partner's block through the weight
+// slot that has just been consumed (16 floats per lane, 16 KB per workgroup and round, two raw barriers per round)
+// and add: wave wm ends, as before, with the tiles of block wm.
+// The column pass of the three rows a wave of the point split computes, written ONCE for both waves (two copies of the
+// loop behind a branch on the wave id cost the register allocator 90 spilled registers): e0, e2, e4 = patch rows WM,
+// WM + 2, WM + 4 (the single row: 0 or 5), d1..d4 = patch rows 1..4 (the pair rows: 1, 2 or 3, 4) with the wave-uniform
+// coefficients (cA, cB, cC) = (4, 1, 4) or (1, 2, 2): the same values as w4_bt2 computes (scaling by 2 commutes with
+// rounding).  Local row order: (0, 1, 2) resp. (5, 3, 4) -- see w4_nat.
+__device__ __forceinline__ void w4_bt2_rows(const w4_f32x2 e0, const w4_f32x2 e2, const w4_f32x2 e4, const w4_f32x2 d1,
+                                            const w4_f32x2 d2, const w4_f32x2 d3, const w4_f32x2 d4, float cA, float cB,
+                                            float cC, w4_f32x2& o0, w4_f32x2& o1, w4_f32x2& o2) {
+  o0 = 4.f * e0 - 5.f * e2 + e4;
+  const w4_f32x2 p = d4 - cA * d2, q = cB * d3 - cC * d1;
+  o1 = p + q; o2 = p - q;
+}
+// one row of (A^T M) A: six values -> four
+__device__ __forceinline__ void w4_at_row(const float (&t)[6], float (&v)[4]) {
+  const float s1 = t[1] + t[2], s2 = t[1] - t[2], s3 = t[3] + t[4], s4 = t[3] - t[4];
+  v[0] = t[0] + s1 + s3; v[1] = s2 + 2.f * s4; v[2] = s1 + 4.f * s3; v[3] = s2 + 8.f * s4 + t[5];
+}
+
+template <int WGN, int UDEPTH, int MODE, bool STYLE, bool PS = false>
 __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
+  static_assert(!PS || (WGN == 2 && UDEPTH == 2), "the point split is written for the <2, 2> shape");
   constexpr bool UP = MODE == 1, RGB = MODE == 2;
   // floats of a wave's share of the noise strips (RGB: also the exchange buffer; UP: the 8 x 128 output-resolution
   // strip of a tile row is shared by the two out-channel waves, 512 floats each)
@@ -591,15 +626,150 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int xi = 4 * q + e;
+        const int xi = w4_nat(4 * q + e);
         acc[xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], d[xi / 6][xi % 6], acc[xi], 0, 0, 0);
       }
     }
   };
 
+  // PS: this wave's 18 points against both 16-channel blocks: acc[18 ob + le], le = 6 a + b local (rows (0, 1, 2)[a] of
+  // wave 0, (5, 3, 4)[a] of wave 1).  One instruction stream for both waves: everything that depends on wm is a scalar.
+  const float ps_cA = wm ? 1.f : 4.f, ps_cB = wm ? 2.f : 1.f, ps_cC = wm ? 2.f : 4.f;
+  const int ps_row = wm * W4B_PITCH;               // patch rows wm, wm + 2, wm + 4 feed the single row
+  const int ps_quad = wm * (5 * 256), ps_half = 4 * 256 + 2 * wm;       // weight quads 5 wm .. + 3; half quad
+  auto compute_ps = [&](int ring, int uring, int kq, auto spread_tag) __attribute__((always_inline)) {
+    constexpr bool SPREAD = decltype(spread_tag)::value != 0;
+    const float* base = &Us[uring * USZ + a_lane];                        // block 1: + 9 * 256
+    const float* src = &Ps[ring * PSZ + item_off];
+    const float sv = St[4 * kq + lk];
+    w4_f32x4 a4[2][2];
+    a4[0][0] = *reinterpret_cast<const w4_f32x4*>(base + ps_quad);
+    a4[0][1] = *reinterpret_cast<const w4_f32x4*>(base + 9 * 256 + ps_quad);
+    // rows: [0..2] = patch rows wm, wm + 2, wm + 4; [3..6] = patch rows 1..4
+    w4_f32x2 c2[7][3];
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+      const float* rp = r < 3 ? src + ps_row + 2 * r * W4B_PITCH : src + (r - 2) * W4B_PITCH;
+      const w4_f32x4 lo = *reinterpret_cast<const w4_f32x4*>(rp);
+      if (STYLE) {
+        c2[r][0] = w4_f32x2{lo[0], lo[1]} * sv;
+        c2[r][1] = w4_f32x2{lo[2], lo[3]} * sv;
+        c2[r][2] = *reinterpret_cast<const w4_f32x2*>(rp + 4) * sv;
+      } else {
+        c2[r][0] = w4_f32x2{lo[0], lo[1]};
+        c2[r][1] = w4_f32x2{lo[2], lo[3]};
+        c2[r][2] = *reinterpret_cast<const w4_f32x2*>(rp + 4);
+      }
+    }
+    w4_f32x2 hrow[3][3];
+#pragma unroll
+    for (int cp = 0; cp < 3; ++cp)
+      w4_bt2_rows(c2[0][cp], c2[1][cp], c2[2][cp], c2[3][cp], c2[4][cp], c2[5][cp], c2[6][cp], ps_cA, ps_cB, ps_cC,
+                  hrow[0][cp], hrow[1][cp], hrow[2][cp]);
+    float d[3][6];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) w4_bt_row(hrow[a][0], hrow[a][1], hrow[a][2], d[a]);
+    // four whole quads (local points 0..15), then the half quad (16, 17); weights one quad ahead
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      const w4_f32x4 a0 = a4[q & 1][0], a1 = a4[q & 1][1];
+      if (q + 1 < 4) {
+        a4[(q + 1) & 1][0] = *reinterpret_cast<const w4_f32x4*>(base + ps_quad + (q + 1) * 256);
+        a4[(q + 1) & 1][1] = *reinterpret_cast<const w4_f32x4*>(base + 9 * 256 + ps_quad + (q + 1) * 256);
+      } else if (q + 1 == 4) {
+        const w4_f32x2 h0 = *reinterpret_cast<const w4_f32x2*>(base + ps_half);
+        const w4_f32x2 h1 = *reinterpret_cast<const w4_f32x2*>(base + 9 * 256 + ps_half);
+        a4[0][0] = w4_f32x4{h0[0], h0[1], 0.f, 0.f};
+        a4[0][1] = w4_f32x4{h1[0], h1[1], 0.f, 0.f};
+      }
+      if (SPREAD && !(W4_ABL & 2)) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+          if (3 * q + t < PPW) pload_piece(3 * q + t);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 0; e < (q < 4 ? 4 : 2); ++e) {
+        const int le = 4 * q + e;
+        acc[le] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], d[le / 6][le % 6], acc[le], 0, 0, 0);
+        acc[18 + le] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], d[le / 6][le % 6], acc[18 + le], 0, 0, 0);
+      }
+    }
+  };
+
+  // ---- the output transform of one accumulator component j: Y[r][k] = (A^T M A)[r][k] of this wave's out-channel block
+  // (16 wm + 4 lk + j) on its tile.  PS: see the note above the body; `xs` = the weight slot just consumed.
+  auto lds_barrier = [&]() __attribute__((always_inline)) {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);             // lgkmcnt(0): LDS-direct loads stay in flight
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  // partial tile of block ob from the three rows this wave holds: L0, L1, L2 = rows (0, 1, 2) resp. (5, 3, 4).  With
+  // S = L1 + L2, D = L1 - L2 and R(.) the row pass:  wave 0: Y = (R(L0) + R(S), R(D), R(S), R(D));
+  // wave 1: Y = (R(S), 2 R(D), 4 R(S), 8 R(D) + R(L0)) -- one stream, scalar coefficients (1 and 0 are exact).
+  const float ps_k0 = wm ? 0.f : 1.f, ps_k1 = wm ? 2.f : 1.f, ps_k2 = wm ? 4.f : 1.f, ps_k3 = wm ? 8.f : 1.f,
+              ps_k4 = wm ? 1.f : 0.f;
+  auto partial_rows = [&](int j, int ob18, float (&Y)[4][4]) __attribute__((always_inline)) {
+    float t0[6], ts[6], td[6];
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+      const float l0 = acc[ob18 + b][j], l1 = acc[ob18 + 6 + b][j], l2 = acc[ob18 + 12 + b][j];
+      t0[b] = l0; ts[b] = l1 + l2; td[b] = l1 - l2;
+    }
+    float r0[4], rs[4], rd[4];
+    w4_at_row(t0, r0); w4_at_row(ts, rs); w4_at_row(td, rd);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      Y[0][k] = rs[k] + ps_k0 * r0[k];
+      Y[1][k] = ps_k1 * rd[k];
+      Y[2][k] = ps_k2 * rs[k];
+      Y[3][k] = ps_k3 * rd[k] + ps_k4 * r0[k];
+    }
+  };
+  auto tile = [&](int j, int xs, float (&Y)[4][4]) __attribute__((always_inline)) {
+    if (!PS) {
+      float t[4][6];
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        const float m0 = acc[b][j], m1 = acc[6 + b][j], m2 = acc[12 + b][j], m3 = acc[18 + b][j], m4 = acc[24 + b][j],
+                    m5 = acc[30 + b][j];
+        const float s1 = m1 + m2, s2 = m1 - m2, s3 = m3 + m4, s4 = m3 - m4;
+        t[0][b] = m0 + s1 + s3;
+        t[1][b] = s2 + 2.f * s4;
+        t[2][b] = s1 + 4.f * s3;
+        t[3][b] = s2 + 8.f * s4 + m5;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w4_at_row(t[r], Y[r]);
+      return;
+    }
+    // both blocks' partials: block 0 and block 1; mine = block wm, the partner's = block 1 - wm
+    float y0[4][4], y1[4][4];
+    partial_rows(j, 0, y0);
+    partial_rows(j, 18, y1);
+    float* xw = &Us[xs * USZ + wave * 1024 + lane * 4];
+    const float* xr = &Us[xs * USZ + (wave ^ WGN) * 1024 + lane * 4];
+    lds_barrier();                                  // nobody reads what the slot held (weights / the previous round)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      w4_f32x4 o4;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { o4[k] = wm ? y0[r][k] : y1[r][k]; Y[r][k] = wm ? y1[r][k] : y0[r][k]; }
+      *reinterpret_cast<w4_f32x4*>(xw + r * 256) = o4;
+    }
+    lds_barrier();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const w4_f32x4 o4 = *reinterpret_cast<const w4_f32x4*>(xr + r * 256);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) Y[r][k] += o4[k];
+    }
+  };
+
   // UP: lane (lk, lt) of wave (wm, wn) holds the four phases j = 2 py + px of channel o0 / 4 + 4 wm + lk on the tile
   // rows oy .. oy + 3, columns ox .. ox + 3 of the INPUT grid = output rows 2 oy .. + 7, columns 2 ox .. + 7.
-  auto up_epilogue = [&](int g) __attribute__((always_inline)) {
+  auto up_epilogue = [&](int g, int xs) __attribute__((always_inline)) {
     const int oy = y0 + 4 * wn, ox = (gx0 + g) * 64 + 4 * lt;
     const int W2 = 2 * p.w;
     const int64_t hw2 = 4 * hw;
@@ -617,26 +787,7 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
     for (int py = 0; py < 2; ++py) {
       float v[2][4][4];
 #pragma unroll
-      for (int px = 0; px < 2; ++px) {
-        const int j = 2 * py + px;
-        float t[4][6];
-#pragma unroll
-        for (int b = 0; b < 6; ++b) {
-          const float m0 = acc[b][j], m1 = acc[6 + b][j], m2 = acc[12 + b][j], m3 = acc[18 + b][j], m4 = acc[24 + b][j],
-                      m5 = acc[30 + b][j];
-          const float s1 = m1 + m2, s2 = m1 - m2, s3 = m3 + m4, s4 = m3 - m4;
-          t[0][b] = m0 + s1 + s3;
-          t[1][b] = s2 + 2.f * s4;
-          t[2][b] = s1 + 4.f * s3;
-          t[3][b] = s2 + 8.f * s4 + m5;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float s1 = t[r][1] + t[r][2], s2 = t[r][1] - t[r][2], s3 = t[r][3] + t[r][4], s4 = t[r][3] - t[r][4];
-          v[px][r][0] = t[r][0] + s1 + s3; v[px][r][1] = s2 + 2.f * s4; v[px][r][2] = s1 + 4.f * s3;
-          v[px][r][3] = s2 + 8.f * s4 + t[r][5];
-        }
-      }
+      for (int px = 0; px < 2; ++px) tile(2 * py + px, xs, v[px]);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int64_t off = (int64_t)(2 * r + py) * W2;
@@ -660,7 +811,7 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
     for (int xi = 0; xi < 36; ++xi) acc[xi] = w4_f32x4{0.f, 0.f, 0.f, 0.f};
   };
 
-  auto rgb_epilogue = [&](int g) __attribute__((always_inline)) {
+  auto rgb_epilogue = [&](int g, int xs) __attribute__((always_inline)) {
     const int oy = y0 + 4 * wn, ox = (gx0 + g) * 64 + 4 * lt;
     const float gain = p.act ? 1.4142135623730951f : 1.f, slope = p.act ? 0.2f : 1.f;
     w4_f32x4 nz[4];
@@ -678,21 +829,11 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
       const int oc = 16 * wm + 4 * lk + j;
       const float scale = Ct[0][oc] * gain, bias = Ct[1][oc] * gain;
       const float cr[3] = {Cr[0][oc], Cr[1][oc], Cr[2][oc]};
-      float t[4][6];
-#pragma unroll
-      for (int b = 0; b < 6; ++b) {
-        const float m0 = acc[b][j], m1 = acc[6 + b][j], m2 = acc[12 + b][j], m3 = acc[18 + b][j], m4 = acc[24 + b][j],
-                    m5 = acc[30 + b][j];
-        const float s1 = m1 + m2, s2 = m1 - m2, s3 = m3 + m4, s4 = m3 - m4;
-        t[0][b] = m0 + s1 + s3;
-        t[1][b] = s2 + 2.f * s4;
-        t[2][b] = s1 + 4.f * s3;
-        t[3][b] = s2 + 8.f * s4 + m5;
-      }
+      float Y[4][4];
+      tile(j, xs, Y);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float s1 = t[r][1] + t[r][2], s2 = t[r][1] - t[r][2], s3 = t[r][3] + t[r][4], s4 = t[r][3] - t[r][4];
-        const float v[4] = {t[r][0] + s1 + s3, s2 + 2.f * s4, s1 + 4.f * s3, s2 + 8.f * s4 + t[r][5]};
+        const float (&v)[4] = Y[r];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           float u = v[k] * scale + nz[r][k] + bias;
@@ -750,9 +891,9 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
     }
   };
 
-  auto group_epilogue = [&](int g) __attribute__((always_inline)) {
-    if (UP) { up_epilogue(g); return; }
-    if (RGB) { rgb_epilogue(g); return; }
+  auto group_epilogue = [&](int g, int xs) __attribute__((always_inline)) {
+    if (UP) { up_epilogue(g, xs); return; }
+    if (RGB) { rgb_epilogue(g, xs); return; }
     const int oy = y0 + 4 * wn, ox = (gx0 + g) * 64 + 4 * lt;
     const float gain = p.act ? 1.4142135623730951f : 1.f, slope = p.act ? 0.2f : 1.f;
     w4_f32x4 nz[4];
@@ -765,21 +906,11 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float scale = ct[j] * gain, bias = ct[16 * WGM + j] * gain;
-      float t[4][6];
-#pragma unroll
-      for (int b = 0; b < 6; ++b) {
-        const float m0 = acc[b][j], m1 = acc[6 + b][j], m2 = acc[12 + b][j], m3 = acc[18 + b][j], m4 = acc[24 + b][j],
-                    m5 = acc[30 + b][j];
-        const float s1 = m1 + m2, s2 = m1 - m2, s3 = m3 + m4, s4 = m3 - m4;
-        t[0][b] = m0 + s1 + s3;
-        t[1][b] = s2 + 2.f * s4;
-        t[2][b] = s1 + 4.f * s3;
-        t[3][b] = s2 + 8.f * s4 + m5;
-      }
+      float Y[4][4];
+      tile(j, xs, Y);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float s1 = t[r][1] + t[r][2], s2 = t[r][1] - t[r][2], s3 = t[r][3] + t[r][4], s4 = t[r][3] - t[r][4];
-        w4_f32x4 v = {t[r][0] + s1 + s3, s2 + 2.f * s4, s1 + 4.f * s3, s2 + 8.f * s4 + t[r][5]};
+        w4_f32x4 v = {Y[r][0], Y[r][1], Y[r][2], Y[r][3]};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const float u = v[k] * scale + nz[r][k] + bias;
@@ -833,7 +964,8 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
     if (UDEPTH == 2) {
       if (!(W4_ABL & 4)) uload((v + 1) & 1, c + 1 < NC ? c + 1 : 0);      // weights of interval v + 1
       pload_begin(ring2, fg, fc);                   // past the run: legal addresses, never read
-      compute(ring, v & 1, c, w4_int<1>());         // ... issues the patch pieces of v + 2 between its MFMAs
+      if (!PS) compute(ring, v & 1, c, w4_int<1>());        // ... issues the patch pieces of v + 2 between its MFMAs
+      else compute_ps(ring, v & 1, c, w4_int<1>());
     } else {
       if (!(W4_ABL & 2)) pload(ring2, fg, fc);
       if (!(W4_ABL & 4)) uload(ring2, fc);
@@ -841,7 +973,7 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
     }
     const bool last = c == NC - 1;
     if (last) {
-      if (!(W4_ABL & 8) || acc[0][0] == 12345.f) group_epilogue(g);
+      if (!(W4_ABL & 8) || acc[0][0] == 12345.f) group_epilogue(g, v & 1);
       c = 0; ++g;
     } else { ++c; }
     if (++fc == NC) { fc = 0; ++fg; }
@@ -874,6 +1006,27 @@ __global__ void __launch_bounds__(256, 2) conv_up_wino36_ns_kernel(const Wino4Pr
 __global__ void __launch_bounds__(256, 2) conv_wino36_rgb_ns_kernel(const Wino4Problem p) {
   conv_wino36b_body<2, 2, 2, false>(p);
 }
+// The same six with the 36 points split between the two out-channel waves (PS above).  MEASURED FLAT (same box, batch
+// 64, ms per 10 steps, split off / on: layers 10-16 173.3 / 172.8, layer 17 107.0 / 109.9, layer 18 + ToRGB 56.8 / 57.9;
+// profiles/r03_w4_point_split.log): halving the transform's vector instructions buys nothing because the loop is held by
+// the LDS -- 144 B of weights and 144 B of patch per lane and k-quad read by every wave, on top of the LDS-direct
+// writes: ~90 of the CU's 128 B/clk -- and the split reads a seventh patch row.  Built only with -DW4_PSPLIT=1
+// (RW_W4_PSPLIT=1 then selects it at run time); the kernel tests pass in both modes.
+#ifndef W4_PSPLIT
+#define W4_PSPLIT 0
+#endif
+#if W4_PSPLIT
+__global__ void __launch_bounds__(256, 2) conv_wino36b_ps_kernel(const Wino4Problem p) { conv_wino36b_body<2, 2, 0, true, true>(p); }
+__global__ void __launch_bounds__(256, 2) conv_wino36b_ns_ps_kernel(const Wino4Problem p) { conv_wino36b_body<2, 2, 0, false, true>(p); }
+__global__ void __launch_bounds__(256, 2) conv_up_wino36_ps_kernel(const Wino4Problem p) { conv_wino36b_body<2, 2, 1, true, true>(p); }
+__global__ void __launch_bounds__(256, 2) conv_up_wino36_ns_ps_kernel(const Wino4Problem p) { conv_wino36b_body<2, 2, 1, false, true>(p); }
+__global__ void __launch_bounds__(256, 2) conv_wino36_rgb_ps_kernel(const Wino4Problem p) { conv_wino36b_body<2, 2, 2, true, true>(p); }
+__global__ void __launch_bounds__(256, 2) conv_wino36_rgb_ns_ps_kernel(const Wino4Problem p) { conv_wino36b_body<2, 2, 2, false, true>(p); }
+static bool w4_point_split() {
+  static const bool on = [] { const char* e = getenv("RW_W4_PSPLIT"); return e && e[0] == '1'; }();
+  return on;
+}
+#endif
 
 // G g G^T of one 3x3 kernel g[3 ky + kx] -> the 36 values of lane `dst` (stride 256 floats per point quad)
 __device__ __forceinline__ void w4_pack_store(const float* g, float* dst) {
@@ -903,7 +1056,8 @@ __device__ __forceinline__ void w4_pack_store(const float* g, float* dst) {
     }
 #pragma unroll
     for (int q = 0; q < 9; ++q)
-      *reinterpret_cast<w4_f32x4*>(dst + q * 256) = w4_f32x4{u[4 * q], u[4 * q + 1], u[4 * q + 2], u[4 * q + 3]};
+      *reinterpret_cast<w4_f32x4*>(dst + q * 256) =
+          w4_f32x4{u[w4_nat(4 * q)], u[w4_nat(4 * q + 1)], u[w4_nat(4 * q + 2)], u[w4_nat(4 * q + 3)]};
 }
 
 // One thread: the 36 values of one (o, i).  uf[o / 16][i / 4][xi / 4][16 (i % 4) + o % 16][xi % 4]
@@ -1029,6 +1183,12 @@ extern "C" int rw_conv3x3_wino4_f32(const float* x, const float* uf, float* y, i
     return RW_LAUNCH_RESULT();
   }
   if (version == 3 && in_ch <= 512) {
+#if W4_PSPLIT
+    if (w4_point_split()) {
+      if (p.style) hipLaunchKernelGGL(conv_wino36b_ps_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
+      else hipLaunchKernelGGL(conv_wino36b_ns_ps_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
+    } else
+#endif
     if (p.style) hipLaunchKernelGGL((conv_wino36b_kernel<2, 2>), dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
     else hipLaunchKernelGGL(conv_wino36b_ns_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
     return RW_LAUNCH_RESULT();
@@ -1093,6 +1253,12 @@ extern "C" int rw_conv_transpose3x3s2_blur_wino4_f32(const float* x, const float
   p.gpw = gpw;
   const int64_t work = (int64_t)batch * p.groups_y * (p.groups_x / gpw) * o_tiles;
   if (work <= 0 || work > 0x7fffffff) return RW_ERR_UNSUPPORTED;
+#if W4_PSPLIT
+  if (w4_point_split()) {
+    if (p.style) hipLaunchKernelGGL(conv_up_wino36_ps_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
+    else hipLaunchKernelGGL(conv_up_wino36_ns_ps_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
+  } else
+#endif
   if (p.style) hipLaunchKernelGGL(conv_up_wino36_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
   else hipLaunchKernelGGL(conv_up_wino36_ns_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
   return RW_LAUNCH_RESULT();
@@ -1133,6 +1299,12 @@ extern "C" int rw_conv3x3_wino4_to_rgb_f32(const float* x, const float* uf, int 
   p.gpw = gpw;
   const int64_t work = (int64_t)batch * p.groups_y * (p.groups_x / gpw);
   if (work <= 0 || work > 0x7fffffff) return RW_ERR_UNSUPPORTED;
+#if W4_PSPLIT
+  if (w4_point_split()) {
+    if (p.style) hipLaunchKernelGGL(conv_wino36_rgb_ps_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
+    else hipLaunchKernelGGL(conv_wino36_rgb_ns_ps_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
+  } else
+#endif
   if (p.style) hipLaunchKernelGGL(conv_wino36_rgb_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
   else hipLaunchKernelGGL(conv_wino36_rgb_ns_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
   return RW_LAUNCH_RESULT();
