@@ -1008,9 +1008,11 @@ __global__ void __launch_bounds__(256, 2) conv_wino36_rgb_ns_kernel(const Wino4P
 }
 // The same six with the 36 points split between the two out-channel waves (PS above).  MEASURED FLAT (same box, batch
 // 64, ms per 10 steps, split off / on: layers 10-16 173.3 / 172.8, layer 17 107.0 / 109.9, layer 18 + ToRGB 56.8 / 57.9;
-// profiles/r03_w4_point_split.log): halving the transform's vector instructions buys nothing because the loop is held by
-// the LDS -- 144 B of weights and 144 B of patch per lane and k-quad read by every wave, on top of the LDS-direct
-// writes: ~90 of the CU's 128 B/clk -- and the split reads a seventh patch row.  Built only with -DW4_PSPLIT=1
+// profiles/r03_w4_point_split.log): the ~220 vector cycles it saves per k-quad and wave are given back by what it adds -- a
+// seventh patch row read, weights only one quad ahead (16 registers are gone), per group eight raw barriers and the swap
+// -- and by what does not shrink: the LDS counters (profiles/r03_pmc_lds_summary_b64.json) show the LDS itself at 25 % of
+// its bandwidth (32 B/clk per CU), so the interval is paced by its dependent chain (landed pieces -> barrier -> LDS reads
+// -> transform -> MFMAs), not by a throughput that fewer instructions would relieve.  Built only with -DW4_PSPLIT=1
 // (RW_W4_PSPLIT=1 then selects it at run time); the kernel tests pass in both modes.
 #ifndef W4_PSPLIT
 #define W4_PSPLIT 0
