@@ -603,6 +603,8 @@ def extras(args, rank, world, device):
                                           all_conv_kernels=f['roofline']['all_conv_kernels'],
                                           step=f['step'], parity=f['parity'])
         torch.cuda.empty_cache()
+    if world == 1:
+        out['rccl_one_rank'] = rccl_selfcheck()
     # configs[4]: the five watermark.sh variants (statistics, erase solves, sample sets), one warm-up job
     saved = (args.steps, args.warmup, args.seeds)
     args.steps, args.warmup, args.seeds = 1, 1, 1000
@@ -612,6 +614,21 @@ def extras(args, rank, world, device):
                                       variants=w['config']['variants'], scaling=w['scaling'],
                                       workload=w['config']['workload'])
     return out
+
+
+def rccl_selfcheck():
+    """scripts/rccl_selfcheck.py in a child process (its own process group, bounded by a timeout): RCCL initialises a
+    one-rank communicator on this box's GPU and runs the sweep's all-reduce.  A failure is reported, never raised."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'rccl_selfcheck.py')], capture_output=True,
+                           text=True, timeout=180)
+        for line in reversed(r.stdout.strip().splitlines()):
+            if line.startswith('{'):
+                return json.loads(line)
+        return dict(ok=False, error=('rc %d: ' % r.returncode) + (r.stderr or r.stdout)[-300:])
+    except Exception as e:                                  # timeout, missing interpreter, unparsable output
+        return dict(ok=False, error='%s: %s' % (type(e).__name__, e))
 
 
 def self_launch(argv, gpus):
