@@ -6,7 +6,7 @@ naturally is (section 8e):
 * the key-statistics sweep -- whole batches of 10 consecutive seeds are dealt round-robin to
   ranks (every seed keeps its reference noise row), each rank accumulates its own C x C sums,
   and ONE sum all-reduce of (mom2, count) makes every rank hold the same ``C``.  The message
-  is 1 MiB at C=512: latency-bound on xGMI, so a plain ``all_reduce`` is the right collective.
+  is 2 MiB at C=512 (float64): latency-bound on xGMI, so a plain ``all_reduce`` is the right collective.
   The reduction is done in float64 so the result does not depend on the ring order;
 * per-seed generator passes (sample sets): seed i -> rank i mod world, no collective;
 * the solve does not shard (2001 sequential steps on 9.4 MB of state): replicas only.
