@@ -38,6 +38,9 @@
 #ifndef W4_ABL
 #define W4_ABL 0
 #endif
+#ifndef W4_SETPRIO
+#define W4_SETPRIO 0      // A/B builds: wave priority (1..3) while the 36 MFMAs of a k-quad are issued
+#endif
 
 typedef float w4_f32x4 __attribute__((ext_vector_type(4)));
 template <int N> struct w4_int { static constexpr int value = N; };
@@ -615,6 +618,9 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
     }
     // weights two quads ahead (an LDS read issued right in front of its MFMAs costs the wave its latency nine times
     // per interval; two waves per SIMD do not hide that)
+#if W4_SETPRIO
+    __builtin_amdgcn_s_setprio(W4_SETPRIO);
+#endif
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
       const w4_f32x4 a = a4[q % 3];
@@ -630,6 +636,9 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
         acc[xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], d[xi / 6][xi % 6], acc[xi], 0, 0, 0);
       }
     }
+#if W4_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
   };
 
   // PS: this wave's 18 points against both 16-channel blocks: acc[18 ob + le], le = 6 a + b local (rows (0, 1, 2)[a] of
