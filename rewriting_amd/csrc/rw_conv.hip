@@ -1211,7 +1211,8 @@ static int launch_up_halo(const ConvProblem* ps, const float* wp_all, int part, 
   if (part == 1) return RW_LAUNCH_RESULT();
   // Output row 2H and column 2W: quads y' = H (phases (0,0),(0,1)) and x' = W, y' < H (phases (0,0),(1,0)): the strip
   // kernel above; RW_UP_STRIPS=im2col keeps the four strip problems of one batched im2col launch (A/B, cross-check)
-  static const bool strips_gemm = !(getenv("RW_UP_STRIPS") && !strcmp(getenv("RW_UP_STRIPS"), "im2col"));
+  const char* strips_env = getenv("RW_UP_STRIPS");                      // read per call: the tests flip it
+  const bool strips_gemm = !(strips_env && !strcmp(strips_env, "im2col"));
   if (strips_gemm && c.in_ch % ST_KC == 0 && c.out_ch % 32 == 0) return launch_up_strips(c, wp_all, s);
   ConvProblem e[4] = {ps[0], ps[1], ps[0], ps[2]};
   e[0].ph = 1; e[0].pw = c.w + 1; e[0].yoff = c.h;

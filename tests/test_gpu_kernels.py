@@ -444,6 +444,40 @@ def test_transposed_conv_f22_matches_direct_kernel_and_oracle(case):
         assert (out.cpu() - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())
 
 
+@pytest.mark.parametrize('case', [(3, 32, 64, 5, 7), (2, 64, 32, 16, 16), (1, 512, 512, 4, 4), (67, 16, 32, 8, 8),
+                                  (1, 48, 96, 3, 40), (2, 128, 64, 64, 32), (5, 32, 32, 1, 1), (1, 64, 32, 512, 512)])
+def test_border_strips_as_gemms_equal_the_im2col_strips(case, monkeypatch):
+    """rw_conv_transpose3x3s2_f32 impl 8 (output row 2H and column 2W alone): the GEMM strip kernel against the batched
+    im2col launch it replaced (RW_UP_STRIPS=im2col) and against the oracle's transposed convolution, on maps of any
+    shape -- ragged position counts, one-pixel maps, batches that do not fill a tile; nothing else of the map is
+    touched."""
+    from rewriting_amd import hip
+    from oracle import restatement as R
+    b, i, o, h, w = case
+    x, wt, style = _conv_inputs(*case, seed=77)
+    s = 1 / math.sqrt(i * 9)
+    dm = hip.demod(hip.weight_sqsum(wt.to(DEV), s), style.to(DEV))
+    wp = hip.pack_conv_weight(wt.to(DEV), 1)
+    outs = {}
+    for mode in ('gemm', 'im2col'):
+        monkeypatch.setenv('RW_UP_STRIPS', mode)
+        out = torch.full((b, o, 2 * h + 1, 2 * w + 1), float('nan'), device=DEV)
+        hip.conv_transpose3x3s2(x.to(DEV), wp, o, s, style=style.to(DEV), demod=dm, impl=8, out=out)
+        assert torch.isnan(out[:, :, :-1, :-1]).all()
+        assert torch.isfinite(out[:, :, -1, :]).all() and torch.isfinite(out[:, :, :, -1]).all()
+        outs[mode] = out
+    monkeypatch.delenv('RW_UP_STRIPS')
+    row = (outs['gemm'][:, :, -1, :], outs['im2col'][:, :, -1, :])
+    colm = (outs['gemm'][:, :, :, -1], outs['im2col'][:, :, :, -1])
+    scale = max(row[1].abs().max().item(), colm[1].abs().max().item())
+    assert (row[0] - row[1]).abs().max().item() < 2e-6 * scale and (colm[0] - colm[1]).abs().max().item() < 2e-6 * scale
+    if b * i * o * h * w <= 2 ** 29:
+        want = R.demod_conv(style[:, :, None, None] * x, style, wt, upsample=True)
+        got = outs['gemm'].cpu()
+        assert (got[:, :, -1, :] - want[:, :, -1, :]).abs().max().item() < 1e-5 * max(1.0, want.abs().max().item())
+        assert (got[:, :, :, -1] - want[:, :, :, -1]).abs().max().item() < 1e-5 * max(1.0, want.abs().max().item())
+
+
 UP_BLUR_CASES = [(2, 16, 8, 8, 64), (1, 64, 32, 16, 64), (1, 128, 64, 8, 128), (3, 32, 16, 24, 64), (1, 512, 64, 8, 64),
                  (1, 24, 40, 8, 64), (1, 64, 32, 512, 512)]
 
