@@ -856,7 +856,10 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
     for (int xi = 0; xi < 36; ++xi) acc[xi] = w4_f32x4{0.f, 0.f, 0.f, 0.f};
     // sum over the wave's 16 channels = over its four 16-lane groups, as a reduce-scatter: lane (lk, lt) ends with
     // row lk of the tile
-    const bool hi = (lk & 2) != 0, odd = (lk & 1) != 0;
+    // (gfx950's v_permlane32_swap / v_permlane16_swap exchange the halves / the odd and even rows of TWO registers in
+    // one instruction: A' + B' is then "what I keep" + "what my partner sent" for both sides at once -- 36 swaps and adds
+    // where ds_bpermute needed 36 LDS round trips and 72 selects)
+    typedef unsigned w4_u32x2 __attribute__((ext_vector_type(2)));
     float q[2][4][3];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -864,16 +867,20 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
       for (int k = 0; k < 4; ++k)
 #pragma unroll
         for (int cc = 0; cc < 3; ++cc) {
-          const float send = hi ? rp[a][k][cc] : rp[a + 2][k][cc];
-          q[a][k][cc] = (hi ? rp[a + 2][k][cc] : rp[a][k][cc]) + __shfl_xor(send, 32, 64);
+          // lanes 0..31 (lk 0, 1) keep row a, lanes 32..63 keep row a + 2
+          const w4_u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(rp[a][k][cc]),
+                                                              __float_as_uint(rp[a + 2][k][cc]), false, false);
+          q[a][k][cc] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
         }
     w4_f32x4 sum[3];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
 #pragma unroll
       for (int cc = 0; cc < 3; ++cc) {
-        const float send = odd ? q[0][k][cc] : q[1][k][cc];
-        sum[cc][k] = (odd ? q[1][k][cc] : q[0][k][cc]) + __shfl_xor(send, 16, 64);
+        // even 16-lane rows (lk 0, 2) keep q[0], odd rows keep q[1]
+        const w4_u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(q[0][k][cc]), __float_as_uint(q[1][k][cc]),
+                                                            false, false);
+        sum[cc][k] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
       }
     // the other 16 channels of the same pixels are in wave (1 - wm, wn): wave wm finishes rows 2 wm, 2 wm + 1 and
     // hands the other two over
