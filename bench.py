@@ -552,9 +552,30 @@ def measure_sweep(device, size, layer, nseeds, steps, warmup, world, g=None):
     dt = timed(step, steps, warmup, world)
     flops = (flops_ctx + 2.0 * res * res * cin * cin) * nseeds * steps
     achieved = flops / dt / 1e12 / world
+    layers = None
+    if world == 1 and torch.device(device).type == 'cuda':
+        # one more context forward of one launch with HIP events around every convolution: the roofline of each layer's
+        # kernel (matrix FLOPs issued / fp32 MFMA peak), as the headline line gives it for the generator's
+        timer = ConvTimer()
+        timer.install()
+        try:
+            with torch.no_grad(), noise_batch_period(10):
+                zb = torch.stack([zds[j][0] for j in range(launch)]).to(device)
+                ctx(zb)
+                torch.cuda.synchronize()
+        finally:
+            timer.remove()
+        r = timer.result()
+        if r is not None:
+            layers = dict(seeds=launch, conv_ms=round(r['_tot_ms'], 3),
+                          conv_issued_frac=r['all_conv_kernels']['issued_frac'], per_kernel=r['per_kernel'],
+                          note='HIP events around each convolution of ONE %d-seed context forward (border strips '
+                               'and streaming kernels not included); kernel -> layer: conv_wino16<.., 4 / 8 / 16> = '
+                               'layers 2 / 4 / 6, conv_up_wino_4x4 / _8x8 / _narrow = layers 3 / 5 / 7, the un-suffixed '
+                               'kernels = the layers from 32 x 32 up' % launch)
     return dict(seeds_per_s=round(nseeds * steps / dt, 1), ms_per_sweep=round(dt / steps * 1e3, 2), size=size,
                 layer=layer, seeds=nseeds, launch=launch, key_map='%d x %d x %d' % (cin, res, res),
-                gflop_per_seed=round((flops_ctx + 2.0 * res * res * cin * cin) / 1e9, 3),
+                gflop_per_seed=round((flops_ctx + 2.0 * res * res * cin * cin) / 1e9, 3), context_layers=layers,
                 roofline=dict(bound='mfma', achieved=round(achieved, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
                               frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
                               note='per GPU: context-forward conv FLOPs of layers 2..%d + 2 H W C^2 of a^T a per seed '
@@ -570,7 +591,8 @@ def run_sweep(args, rank, world, device):
                 scaling='strong', vs_baseline=None, dtype='f32', data='synthetic',
                 config=dict(workload='%d-seed second-moment sweep, launches of %d seeds (reference batches of 10 '
                                      'inside) dealt round-robin, one all-reduce' % (args.seeds, m['launch']),
-                            key_map=m['key_map'], gflop_per_seed=m['gflop_per_seed']),
+                            key_map=m['key_map'], gflop_per_seed=m['gflop_per_seed'],
+                            context_layers=m['context_layers']),
                 roofline=m['roofline'])
 
 
