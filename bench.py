@@ -541,9 +541,10 @@ def measure_sweep(device, size, layer, nseeds, steps, warmup, world, g=None):
     ctx = nethook.subsequence(g, upto_layer='layer%d.sconv.mconv.dconv' % layer, share_weights=True)
     zds = zdataset.z_dataset_for_model(g, size=nseeds)
     flops_ctx, (cin, res) = context_flops(size, layer)
-    # launch size: as many reference batches as fit in ~2 GB of key map, at most 250 seeds, >= one launch per rank
+    # launch size: as many reference batches as fit in ~2 GB of key map, at most 500 seeds, >= one launch per rank
     per_seed_bytes = cin * res * res * 4
-    launch = max(10, min(250, (2 << 30) // per_seed_bytes // 10 * 10, (nseeds // world) // 10 * 10))
+    cap = int(os.environ.get('RW_SWEEP_LAUNCH', '500'))      # the rewriters' sweep_batch
+    launch = max(10, min(cap, (2 << 30) // per_seed_bytes // 10 * 10, (nseeds // world) // 10 * 10))
 
     def step():
         with torch.no_grad(), noise_batch_period(10):

@@ -311,11 +311,19 @@ def test_sweep_batch_never_starves_a_rank(monkeypatch):
     class Fake(ganrewrite.ProgressiveGanRewriter):
         def __init__(self, n):
             self.zds = list(range(n))
-    for world, n, want in ((1, 1000, 250), (8, 1000, 120), (4, 10000, 250), (8, 100, 10), (2, 35, 10)):
+    for world, n, want in ((1, 1000, 500), (8, 1000, 120), (4, 10000, 500), (8, 100, 10), (2, 35, 10), (1, 300, 300)):
         monkeypatch.setattr(parallel, 'shard', lambda world=world: (0, world) if world > 1 else None)
         b = Fake(n)._sweep_batch()
         assert b == want and b % 10 == 0
         assert (n + b - 1) // b >= min(world, n // 10)             # at least one batch per rank
+    # the key map of a launch stays within sweep_bytes: 128 x 256 x 256 floats per seed (layer 14 of the 1024 model)
+    monkeypatch.setattr(parallel, 'shard', lambda: None)
+    big = Fake(1000)
+    big.k_shape = (1, 128, 256, 256)
+    assert big._sweep_batch() == 60
+    small = Fake(1000)
+    small.k_shape = (1, 512, 32, 32)
+    assert small._sweep_batch() == 500
 
 
 def test_final_pair_identifies_last_styled_conv_and_its_to_rgb():
