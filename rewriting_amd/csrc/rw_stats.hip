@@ -17,10 +17,14 @@ static int stats_ksplit(int channels, int64_t rows) {
   const int nt = (int)rw_cdiv(channels, ts);
   const int tri = nt * (nt + 1) / 2;
   const int64_t chunks = rw_cdiv(rows, ST_KC);
-  int64_t ks = rw_cdiv(512, tri);
+  // tri * ks workgroups, two per CU and NOT ONE MORE: the kernel is bound by the matrix pipe, so a CU that receives
+  // a third workgroup finishes 1.5x later than the rest and the launch with it (512 channels: 10 tile pairs x 52
+  // slices = 520 workgroups ran as long as 768 would have; 51 slices: -30 %).  Few tile pairs (128 channels: one) get
+  // as many row slices as it takes to fill the chip -- the reduction reads ks x C^2 floats, microseconds.
+  int64_t ks = 512 / tri;
   const int64_t max_by_work = chunks / 8 > 0 ? chunks / 8 : 1;
   if (ks > max_by_work) ks = max_by_work;
-  if (ks > 64) ks = 64;
+  if (ks > 512) ks = 512;
   if (ks < 1) ks = 1;
   return (int)ks;
 }
