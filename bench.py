@@ -541,9 +541,9 @@ def measure_sweep(device, size, layer, nseeds, steps, warmup, world, g=None):
     ctx = nethook.subsequence(g, upto_layer='layer%d.sconv.mconv.dconv' % layer, share_weights=True)
     zds = zdataset.z_dataset_for_model(g, size=nseeds)
     flops_ctx, (cin, res) = context_flops(size, layer)
-    # launch size: as many reference batches as fit in ~2 GB of key map, at most 500 seeds, >= one launch per rank
+    # launch size: as many reference batches as fit in ~2 GB of key map, at most 510 seeds, >= one launch per rank
     per_seed_bytes = cin * res * res * 4
-    cap = int(os.environ.get('RW_SWEEP_LAUNCH', '500'))      # the rewriters' sweep_batch
+    cap = int(os.environ.get('RW_SWEEP_LAUNCH', '510'))      # the rewriters' sweep_batch (whole rounds of 512 workgroups)
     launch = max(10, min(cap, (2 << 30) // per_seed_bytes // 10 * 10, (nseeds // world) // 10 * 10))
 
     def step():

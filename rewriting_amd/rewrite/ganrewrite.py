@@ -142,7 +142,11 @@ class ProgressiveGanRewriter(object):
                                                 shard=parallel.shard(), nchw=on_gpu)
             return r2m.moment()
 
-    sweep_batch = 500         # seeds per launch of the statistics sweeps on the GPU (multiple of 10), at most
+    # seeds per launch of the statistics sweeps on the GPU (a multiple of the reference's batch of 10), at most.  510 and
+    # not 500: the kernels of the context forward launch 16 / 8 / 4 / 2 / 1 workgroups per image or pair of images, and
+    # the chip runs 512 at a time -- 510 seeds make whole rounds of it (15.94 of 16) where 500 leave the last round 60 %
+    # full (layer-8 sweep of the 1024 model: +2.7 %, same box)
+    sweep_batch = 510
     sweep_bytes = 2 << 30     # ... and at most this many bytes of key map per launch
 
     def _sweep_batch(self):

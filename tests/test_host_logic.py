@@ -311,7 +311,7 @@ def test_sweep_batch_never_starves_a_rank(monkeypatch):
     class Fake(ganrewrite.ProgressiveGanRewriter):
         def __init__(self, n):
             self.zds = list(range(n))
-    for world, n, want in ((1, 1000, 500), (8, 1000, 120), (4, 10000, 500), (8, 100, 10), (2, 35, 10), (1, 300, 300)):
+    for world, n, want in ((1, 1000, 510), (8, 1000, 120), (4, 10000, 510), (8, 100, 10), (2, 35, 10), (1, 300, 300)):
         monkeypatch.setattr(parallel, 'shard', lambda world=world: (0, world) if world > 1 else None)
         b = Fake(n)._sweep_batch()
         assert b == want and b % 10 == 0
@@ -323,7 +323,7 @@ def test_sweep_batch_never_starves_a_rank(monkeypatch):
     assert big._sweep_batch() == 60
     small = Fake(1000)
     small.k_shape = (1, 512, 32, 32)
-    assert small._sweep_batch() == 500
+    assert small._sweep_batch() == 510
 
 
 def test_final_pair_identifies_last_styled_conv_and_its_to_rgb():
