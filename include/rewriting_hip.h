@@ -32,6 +32,8 @@ typedef void* rw_stream_t; /* hipStream_t */
 #define RW_ERR_BAD_ARGUMENT 10001
 #define RW_ERR_UNSUPPORTED  10002
 
+/* 3 since round 3: rw_solve_run_*, the whole-image 8x8 / 4x4 shapes, a new point order inside the packed F(4x4,3x3)
+ * weights (buffers packed by an older library do not fit this one: repack, as the Python side does per weight version). */
 int rw_abi_version(void);
 const char* rw_error_string(int code);
 

@@ -14,7 +14,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('RW_HIP_LIB') or os.path.join(_HERE, 'librewriting_hip.so')    # RW_HIP_LIB: tuning builds
 
-ABI_VERSION = 2        # 2: rw_solve_supported returns 1/0, rw_solve_scratch_elems fills sizes[6] (+ksplit), round-3 exports
+ABI_VERSION = 3        # 3: rw_solve_run_*, the 8x8 / 4x4 shapes (style == NULL), packed F(4x4,3x3) point order w4_nat; 2: rw_solve_supported 1/0, sizes[6]
 
 
 class ConvEpilogue(Structure):
