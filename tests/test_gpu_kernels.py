@@ -687,6 +687,41 @@ def test_fused_epilogues_and_streaming_blocks():
     assert rel(got, want - brgb.view(1, 3, 1, 1) - so) < 1e-6
 
 
+@pytest.mark.parametrize('ow', [8, 16, 32])
+@pytest.mark.parametrize('planes', [(1, 3), (5, 13), (3, 64), (250, 8)])
+def test_blur_noise_act_on_small_maps_packs_planes(ow, planes):
+    """Outputs of 8^2 / 16^2 / 32^2 (layers 3, 5, 7) take blur_noise_act_small_kernel: 64 / 16 / 4 planes per workgroup.
+    Against the oracle's upfirdn2d + noise + FusedLeakyReLU, with and without noise / bias / the post factor, plane counts
+    that do not fill the last workgroup; and BIT FOR BIT against the tile kernel, which the same data takes when it is
+    presented as a (2 OW) x OW map whose lower half is never looked at (no: the tile kernel needs the real rows) --
+    so against the tile kernel on the map zero-extended to 2 OW x OW outputs, whose first OW rows see the same taps."""
+    from rewriting_amd import hip
+    from oracle import restatement as R
+    b, c = planes
+    rs = numpy.random.RandomState(ow + b)
+    k4 = R.make_kernel([1, 3, 3, 1]) * 4
+    k4[1, 2] += 0.05                                                    # asymmetric: a flipped kernel cannot pass
+    wide = torch.from_numpy(rs.randn(b, c, ow + 1, ow + 1).astype('float32'))
+    bias = torch.from_numpy(rs.randn(c).astype('float32'))
+    nw = torch.tensor([0.41])
+    noise = R.noise_rows(b, ow * ow)
+    post = torch.from_numpy((1 + 0.3 * rs.randn(b, c)).astype('float32'))
+    want = R.fused_leaky_relu(R.upfirdn2d(wide, k4, pad=(1, 1)) + nw * noise.view(b, 1, ow, ow), bias)
+    got = hip.blur_noise_act(wide.to(DEV), k4.to(DEV), noise.to(DEV), nw.to(DEV), bias.to(DEV))
+    assert rel(got, want) < 1e-6
+    plain = hip.blur_noise_act(wide.to(DEV), k4.to(DEV), None, None, None)
+    assert rel(plain, R.upfirdn2d(wide, k4, pad=(1, 1))) < 1e-6
+    scaled = hip.blur_noise_act(wide.to(DEV), k4.to(DEV), noise.to(DEV), nw.to(DEV), bias.to(DEV), post_scale=post.to(DEV))
+    assert torch.equal(scaled, got * post.to(DEV)[:, :, None, None])
+    # the tile kernel on the same planes extended downwards by zeros: its first OW - 2 output rows read the same inputs
+    tall = torch.zeros(b, c, 2 * ow + 1, ow + 1)
+    tall[:, :, :ow + 1] = wide
+    ntall = torch.zeros(b, 2 * ow * ow)
+    ntall[:, :ow * ow] = noise
+    ref = hip.blur_noise_act(tall.to(DEV), k4.to(DEV), ntall.to(DEV), nw.to(DEV), bias.to(DEV))
+    assert torch.equal(ref[:, :, :ow - 2], got[:, :, :ow - 2])
+
+
 @pytest.mark.parametrize('channels,batch,h,w', [(512, 10, 32, 32), (512, 3, 4, 4), (128, 2, 64, 64),
                                                 (64, 4, 16, 16), (32, 2, 32, 32), (96, 2, 8, 8)])
 def test_second_moment_and_channel_sums(channels, batch, h, w):
