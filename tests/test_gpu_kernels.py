@@ -401,6 +401,8 @@ UP_WINO_CASES = [(2, 16, 32, 4, 32), (1, 64, 64, 8, 32), (1, 128, 64, 16, 64), (
                  (1, 24, 96, 8, 64), (1, 64, 32, 512, 512), (1, 128, 64, 256, 256), (1, 512, 256, 64, 64),
                  # input maps 16 wide (a wave's 16 blocks = two block rows of 8): layer 7 of the generators
                  (2, 512, 512, 16, 16), (1, 64, 32, 8, 16), (3, 32, 64, 24, 16),
+                 # ... and launches large enough for RUNS along y (both 8-row groups of an image in one workgroup)
+                 (128, 32, 256, 16, 16), (64, 512, 512, 16, 16), (171, 16, 64, 24, 16),
                  # whole 8 x 8 / 4 x 4 images per wave, two / eight images per workgroup (layers 5 and 3): batches that
                  # fill the last workgroup and batches that do not
                  (4, 512, 512, 8, 8), (3, 32, 64, 8, 8), (1, 64, 32, 8, 8), (16, 512, 512, 4, 4), (11, 32, 32, 4, 4),
