@@ -16,7 +16,8 @@ their HIP-event time, against the 157.3 TFLOP/s fp32-MFMA peak; the direct-sum f
 `cpu_baseline` (the reference's own files when /root/reference is present, else the oracle restatement, timed
 on the host cores on a bounded sample at the best of several thread counts; N=1 only) and `extra`: the other
 half of BASELINE.json's metric (seconds per rank-1 edit = 1000-seed key statistics + 2001-step solve), the
-256^2 forward (configs[1]), the key-statistics sweeps at layers 8/10/14 (configs[3]) and the five-variant
+256^2 forward (configs[1]), the key-statistics sweeps at layers 8/10/14 (configs[3]; each with `context_layers`, the
+roofline of every layer's convolution kernel), a one-rank RCCL self-check (`rccl_one_rank`) and the five-variant
 watermark job (configs[4]), each timed in this process; `step` (the whole step against the MFMA-issue and HBM
 roofs) and `parity` (the output of the last timed step against the reference-generated fixture).
 
