@@ -545,7 +545,7 @@ def measure_sweep(device, size, layer, nseeds, steps, warmup, world, g=None):
     # launch size: as many reference batches as fit in ~2 GB of key map, at most 510 seeds, >= one launch per rank
     per_seed_bytes = cin * res * res * 4
     cap = int(os.environ.get('RW_SWEEP_LAUNCH', '510'))      # the rewriters' sweep_batch (whole rounds of 512 workgroups)
-    launch = max(10, min(cap, (2 << 30) // per_seed_bytes // 10 * 10, (nseeds // world) // 10 * 10))
+    launch = parallel.balanced_batch(nseeds, min(cap, max(10, (2 << 30) // per_seed_bytes // 10 * 10)), world)
 
     def step():
         with torch.no_grad(), noise_batch_period(10):

@@ -87,6 +87,24 @@ def barrier():
         dist.barrier()
 
 
+def balanced_batch(n, cap, world):
+    """Seeds per launch of a sweep over n seeds that is dealt round-robin to `world` ranks: a multiple of 10 (the
+    reference's batch: every seed keeps its noise row), at most `cap`, and such that the number of launches is a
+    multiple of the number of ranks wherever n allows it -- 10 000 seeds at 510 per launch are 20 launches, i.e. three
+    for four of eight ranks and two for the others; 24 launches of 420 are three each -- and never fewer launches than
+    ranks."""
+    cap = max(10, cap // 10 * 10)
+    if world <= 1:
+        return max(10, min(cap, n // 10 * 10))       # one rank: the cap itself (it is chosen for whole rounds of the chip)
+    launches = -(-n // cap)
+    launches = -(-launches // world) * world
+    b = min(cap, max(10, -(-n // launches) + 9) // 10 * 10)
+    b = max(10, b)
+    while b > 10 and -(-n // b) < min(world, max(1, n // 10)):
+        b -= 10
+    return b
+
+
 def batches_for_rank(n_batches, rank, world):
     return list(range(rank, n_batches, world))
 

@@ -152,11 +152,10 @@ class ProgressiveGanRewriter(object):
     def _sweep_batch(self):
         """Seeds per launch: large launches amortise the host side and the tails of ~50 kernel launches per batch
         (layer 8 of the 1024 model: 31.0 k seeds/s at 500 per launch against 29.9 k at 250), but the key map of a launch
-        stays within sweep_bytes, and every rank of a sharded sweep must still receive at least one batch (batches are
-        dealt round-robin)."""
+        stays within sweep_bytes, and a sharded sweep is cut into a multiple of `world` launches (they are dealt
+        round-robin: parallel.balanced_batch), never fewer than there are ranks."""
         sh = parallel.shard()
         world = sh[1] if sh else 1
-        per_rank = max(1, len(self.zds) // world)
         cap = self.sweep_batch
         k_shape = getattr(self, 'k_shape', None)
         if k_shape is not None:
@@ -164,7 +163,7 @@ class ProgressiveGanRewriter(object):
             for n in tuple(k_shape)[1:]:
                 per_seed *= int(n)
             cap = min(cap, max(10, self.sweep_bytes // per_seed // 10 * 10))
-        return max(10, min(cap, per_rank // 10 * 10))
+        return parallel.balanced_batch(len(self.zds), cap, world)
 
     def _noise_periodic(self):
         """Large sweep launches are only equivalent to the reference's batches of 10 if the dataset

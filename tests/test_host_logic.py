@@ -311,11 +311,15 @@ def test_sweep_batch_never_starves_a_rank(monkeypatch):
     class Fake(ganrewrite.ProgressiveGanRewriter):
         def __init__(self, n):
             self.zds = list(range(n))
-    for world, n, want in ((1, 1000, 510), (8, 1000, 120), (4, 10000, 510), (8, 100, 10), (2, 35, 10), (1, 300, 300)):
+    for world, n, want in ((1, 1000, 510), (8, 1000, 130), (4, 10000, 500), (8, 10000, 420), (8, 100, 10), (2, 35, 20),
+                           (1, 300, 300), (1, 2040, 510), (2, 1000, 500)):
         monkeypatch.setattr(parallel, 'shard', lambda world=world: (0, world) if world > 1 else None)
         b = Fake(n)._sweep_batch()
-        assert b == want and b % 10 == 0
-        assert (n + b - 1) // b >= min(world, n // 10)             # at least one batch per rank
+        assert b == want and b % 10 == 0, (world, n, b)
+        launches = (n + b - 1) // b
+        assert launches >= min(world, n // 10)                     # at least one batch per rank
+        if n >= 100 * world:
+            assert launches % world == 0                           # ... and the same number for every rank
     # the key map of a launch stays within sweep_bytes: 128 x 256 x 256 floats per seed (layer 14 of the 1024 model)
     monkeypatch.setattr(parallel, 'shard', lambda: None)
     big = Fake(1000)
