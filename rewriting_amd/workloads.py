@@ -18,6 +18,7 @@ of its position in its batch of 10, quirk Q1), reduced on the fly to float64 fea
 The reference's feature extractor (a TensorFlow Inception graph downloaded at run time, metrics/fid.py:16) is
 out of scope and pluggable; the default here is a fixed 8x8 average-pooled RGB descriptor (192 features).
 """
+import copy
 import json
 import os
 import shutil
@@ -54,19 +55,28 @@ def pooled_rgb_features(images):
 _synthetic_states = {}
 
 
+_templates = {}
+
+
 def build_model(size, truncation, device, seed=0):
     """The "checkpoint" of this offline build: seeded synthetic weights.  The state dict is generated once per
-    (size, seed) and kept on the host -- every variant then loads it like a driver loads its checkpoint file."""
-    g = models.SeqStyleGAN2(size, 512, 8, truncation=truncation, mconv='seq')
+    (size, seed) and kept on the host -- every variant then loads it like a driver loads its checkpoint file.  The
+    module tree is built once per size and copied: constructing a generator draws 30 M random initial weights on the
+    host that the load overwrites (cProfile of a watermark variant, scripts/probe/wm_host_profile.py: 0.17 of its 1.42 s
+    in the two constructors, 0.03 s in a copy)."""
     key = (size, seed)
     if key not in _synthetic_states:
+        g = models.SeqStyleGAN2(size, 512, 8, truncation=truncation, mconv='seq')
         synthetic.randomize_(g, seed=seed)
         _synthetic_states[key] = ({k: v.detach().clone() for k, v in g.state_dict().items()},
                                   g.latents.latent_avg.detach().clone())
-    else:
-        sd, avg = _synthetic_states[key]
-        g.latents.latent_avg = avg.clone()
-        g.load_state_dict(sd)
+        _templates[size] = copy.deepcopy(g)
+        return g.eval().to(device)
+    g = copy.deepcopy(_templates[size])
+    g.latents.truncation = truncation
+    sd, avg = _synthetic_states[key]
+    g.latents.latent_avg = avg.clone()
+    g.load_state_dict(sd)
     return g.eval().to(device)
 
 
