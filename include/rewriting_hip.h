@@ -270,6 +270,38 @@ int rw_conv_transpose3x3s2_blur_wino4_f32(const float* x, const float* uf, float
                                           int out_ch, int h, int w, float w_scale, const rw_conv_epilogue* ep,
                                           const float* post_scale, rw_stream_t stream);
 
+/* The three F(4x4,3x3) operations above with their 36 GEMMs on the 16-bit matrix pipe, fp32-equivalent by an EXACT
+ * operand split ("H16", rw_wino4.hip): every transformed input V and weight U is written as the sum of two f16 numbers
+ * (round to nearest twice: representation error <= 2^-22 relative), all four piece products are accumulated in fp32 by
+ * v_mfma_f32_16x16x16_f16.  Per-product error <= 2^-21 of the product (fp32 multiply: 2^-24); accumulation, transforms
+ * and epilogue are the fp32 kernels' -- same shapes, same results within the F(4x4,3x3) error class (tested at the same
+ * bars), 36 MFMAs of ~17 cycles per k-quad instead of 32-cycle fp32 MFMAs that block the vector lanes.
+ * Powers of two keep the pieces inside f16's normal range:
+ *   uf: rw_packed_*_wino4h_elems floats from rw_pack_*_wino4h_f32: the wino4 layout with every float replaced by the
+ *       32-bit word Uh | Ul << 16 of U 2^eU, + 4 trailing floats [2^-eU, 0, max |U|, 0];
+ *   x_amax (device scalar, required): a bound max |x| <= x_amax[0] on the input map (without the on-load style; the
+ *       kernel multiplies by the style's largest factor itself) -- what the producer of x left in its y_amax, or
+ *       rw_absmax_f32(x).  A bound that is too small overflows f16 (inf/NaN in the result); a bound that is 2^k too
+ *       large costs k low bits of the smallest values only;
+ *   y_amax (device scalar, nullable): receives max |y| of the result (zeroed, then atomic max).
+ * Everything else as in the fp32 entry points. */
+int rw_absmax_f32(const float* x, long long n, float* out, rw_stream_t stream);
+long long rw_packed_conv_weight_wino4h_elems(int out_ch, int in_ch);
+int rw_pack_conv_weight_wino4h_f32(const float* w, float* uf, int out_ch, int in_ch, rw_stream_t stream);
+int rw_conv3x3_wino4h_f32(const float* x, const float* uf, float* y, int batch, int in_ch, int out_ch, int h,
+                          int w, float w_scale, const rw_conv_epilogue* ep, const float* x_amax, float* y_amax,
+                          rw_stream_t stream);
+int rw_conv3x3_wino4h_to_rgb_f32(const float* x, const float* uf, int batch, int in_ch, int out_ch, int h, int w,
+                                 float w_scale, const rw_conv_epilogue* ep, const rw_rgb_epilogue* rgb,
+                                 const float* x_amax, rw_stream_t stream);
+long long rw_packed_conv_transpose_blur_wino4h_elems(int out_ch, int in_ch);
+int rw_pack_conv_transpose_blur_weight_wino4h_f32(const float* w, const float* k4, float* uf, int out_ch, int in_ch,
+                                                  rw_stream_t stream);
+int rw_conv_transpose3x3s2_blur_wino4h_f32(const float* x, const float* uf, float* y, int batch, int in_ch,
+                                           int out_ch, int h, int w, float w_scale, const rw_conv_epilogue* ep,
+                                           const float* post_scale, const float* x_amax, float* y_amax,
+                                           rw_stream_t stream);
+
 /* NoiseInjectionF (models.py:535-546): y[b][c][p] = x[b][c][p] + noise_w[0] * noise[b][p] */
 int rw_noise_add_f32(const float* x, const float* noise, const float* noise_w, float* y,
                      int batch, int channels, int64_t hw, rw_stream_t stream);

@@ -31,10 +31,12 @@
 // per interval.  Weights: uf[o / 16][i / 4][xi / 4][lane = 16 (i % 4) + o % 16][xi % 4], copied to LDS one interval
 // ahead by global_load_lds and read from there (one ds_read_b128 per four points).
 #include "rw_common.h"
+#include <stdlib.h>
 
 // Timing ablations (build a second library with -DW4_ABL=<bits>; results are WRONG when a bit is set): 1 = no input
 // transform arithmetic, 2 = no patch fetch / staging, 4 = no weight copies, 8 = no output transform / stores,
-// 16 = no barriers in the loop.
+// 16 = no barriers in the loop; H16 kernels: 32 = no operand split (the three conversions per value), 64 = no MFMAs,
+// 128 = no duplication of the weight words.
 #ifndef W4_ABL
 #define W4_ABL 0
 #endif
@@ -64,6 +66,9 @@ struct Wino4Problem {
   const float* rgb_weight; const float* rgb_style; const float* rgb_bias; const float* rgb_skip; float* rgb_out;
   float rgb_scale;
   const float* post;            // UP: (batch x real out_ch) factor on the result (the next layer's style), nullable
+  // H16 kernels (operands split into f16 pairs, see conv_wino36b_body): device scalar >= max |x| of the input map;
+  // nullable device scalar that receives (atomic max) max |result| -- the next layer's x_amax
+  const float* x_amax; float* y_amax;
 };
 
 #define W4_PC 66                // patch columns: 64 + 2
@@ -88,6 +93,10 @@ __device__ __forceinline__ void w4_bt(float& d0, float& d1, float& d2, float& d3
 // the same on two columns at once (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32: adjacent columns of a patch row come out
 // of the LDS reads as adjacent registers)
 typedef float w4_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned w4_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned w4_u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 w4_f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 w4_f16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void w4_bt2(w4_f32x2& d0, w4_f32x2& d1, w4_f32x2& d2, w4_f32x2& d3, w4_f32x2& d4,
                                        w4_f32x2& d5) {
   const w4_f32x2 t0 = 4.f * d0 - 5.f * d2 + d4;
@@ -447,7 +456,55 @@ __device__ __forceinline__ void w4_at_row(const float (&t)[6], float (&v)[4]) {
   v[0] = t[0] + s1 + s3; v[1] = s2 + 2.f * s4; v[2] = s1 + 4.f * s3; v[3] = s2 + 8.f * s4 + t[5];
 }
 
-template <int WGN, int UDEPTH, int MODE, bool STYLE, bool PS = false>
+// ---------------------------------------------------------------------------------------
+// H16 (round 4): the 36 GEMMs on the 16-bit matrix pipe, fp32-equivalent by an exact operand split.
+//
+// fp32 MFMA on gfx950 runs at the vector rate (1/16 of the f16 rate) and shares the vector lanes
+// (scripts/probe/mfma_valu_probe.hip), so the fp32 kernel above spends half its time in the matrix instructions and
+// cannot hide the input transform behind them.  Here every transformed operand is written as a sum of two f16 numbers,
+//     V 2^eV = Vh + Vl,   U 2^eU = Uh + Ul      (round to nearest twice: |V 2^eV - Vh - Vl| <= 2^-22 |V 2^eV|),
+// and v_mfma_f32_16x16x16_f16 accumulates all FOUR products in fp32: its k index within a lane group holds
+// A = [Uh, Ul, Uh, Ul], B = [Vh, Vh, Vl, Vl] of ONE input channel -- the lane <-> (channel, tile) / (channel, out-channel)
+// assignment of v_mfma_f32_16x16x4_f32 carries over unchanged, so does everything around the loop (rings, pieces,
+// waits, epilogues).  The powers of two keep the operands inside f16's normal range: eU from max |U| at pack time (stored
+// behind the packed weights), eV from a device scalar x_amax >= max |x| that the producer of the map left behind (or
+// rw_absmax_f32), the style's largest factor and the transform's gain (<= 100): |V 2^eV| < 25600.  Both leave the result
+// through the epilogue's per-channel factor (exact).  Values more than 2^17 below the map's maximum lose low bits of Vl
+// (f16 denormals: absolute error <= 2^-25 2^-eV) -- no worse than what fp32 accumulation does to them beside the large terms.
+// Per-product error <= 2^-21.x of the product against 2^-24 for an fp32 multiply; measured against float64 the kernel's
+// total error is that of the fp32 F(4x4,3x3) kernel (the transforms' constants dominate both).
+// Packed weights: the layout of rw_pack_conv_weight_wino4_f32 with every float replaced by the 32-bit word
+// Uh | Ul << 16 (same size, same pieces) + 4 trailing floats: [2^-eU, 0, max |U| bits, 0].
+// What it costs: 3 VALU per transformed value (v_cvt_pk_f16_f32, v_fma_mix_f32, v_cvt_pk_f16_f32) + 1 per weight word
+// (v_mov: the pair (w, w)); what it buys: 36 MFMAs of ~17 cycles instead of 32, with vector instructions issuing
+// beside them (profiles/r04a_mfma16_valu_probe.jsonl).  The legacy K = 16 instruction takes as long as the K = 32 one;
+// the K = 32 form needs 8-channel intervals whose rings do not fit two workgroups' LDS.
+// ---------------------------------------------------------------------------------------
+// (h, h) and (l, l) of v: h = f16(v), l = f16(v - h)
+__device__ __forceinline__ void w4_split16(float v, w4_f16x2& hh, w4_f16x2& ll) {
+  if (W4_ABL & 32) { hh = __builtin_bit_cast(w4_f16x2, v); ll = hh; return; }
+  hh = __builtin_convertvector(w4_f32x2{v, v}, w4_f16x2);
+  float r;
+  asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hh), "v"(v));     // v - (float)h, exact
+  ll = __builtin_convertvector(w4_f32x2{r, r}, w4_f16x2);
+}
+__device__ __forceinline__ w4_f32x4 w4_mfma16(unsigned w, w4_f16x2 hh, w4_f16x2 ll, w4_f32x4 acc, unsigned w_abl = 0) {
+  const w4_f16x4 a = __builtin_bit_cast(w4_f16x4, (W4_ABL & 128) ? w4_u32x2{w, w_abl} : w4_u32x2{w, w});
+  const w4_f16x4 b = {hh[0], hh[1], ll[0], ll[1]};
+  if (W4_ABL & 64) {
+    asm volatile("" :: "v"(a), "v"(b));
+    return acc;
+  }
+  return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, acc, 0, 0, 0);
+}
+// the word Uh | Ul << 16 of u (already scaled)
+__device__ __forceinline__ unsigned w4_pack16(float u) {
+  const _Float16 h = (_Float16)u;
+  const _Float16 l = (_Float16)(u - (float)h);
+  return (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+}
+
+template <int WGN, int UDEPTH, int MODE, bool STYLE, bool PS = false, bool H16 = false>
 __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
   static_assert(!PS || (WGN == 2 && UDEPTH == 2), "the point split is written for the <2, 2> shape");
   constexpr bool UP = MODE == 1, RGB = MODE == 2;
@@ -470,6 +527,7 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
   __shared__ float St[512];
   __shared__ float Ct[2][16 * WGM];
   __shared__ float Cr[3][16 * WGM];
+  __shared__ float Red[WAVES];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -491,11 +549,30 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
   const int NC = p.in_ch >> 2;
   const int VT = p.gpw * NC;
 
-  for (int i = tid; i < p.in_ch; i += THREADS) St[i] = p.style ? p.style[(int64_t)ib * p.in_ch + i] : 1.0f;
+  // H16: 2^eV rides in the style table (the transform multiplies by it), 2^-(eU + eV) in the per-channel factor
+  float in_scale = 1.f, out_scale = 1.f;
+  if (H16) {
+    float smax = p.style ? 0.f : 1.f;
+    if (p.style)
+      for (int i = tid; i < p.in_ch; i += THREADS) smax = fmaxf(smax, fabsf(p.style[(int64_t)ib * p.in_ch + i]));
+#pragma unroll
+    for (int off = 32; off; off >>= 1) smax = fmaxf(smax, __shfl_xor(smax, off));
+    if (lane == 0) Red[wave] = smax;
+    __syncthreads();
+    smax = Red[0];
+#pragma unroll
+    for (int wv = 1; wv < WAVES; ++wv) smax = fmaxf(smax, Red[wv]);
+    const float am = p.x_amax[0] * smax;                          // >= max |x style|; |B^T d B| <= 100 am < 2^(e + 7)
+    int e = (int)((__float_as_uint(am) >> 23) & 0xff) - 126;      // am < 2^e
+    e = e < -100 ? -100 : (e > 100 ? 100 : e);
+    in_scale = __uint_as_float((unsigned)(127 + 8 - e) << 23);
+    out_scale = __uint_as_float((unsigned)(127 + e - 8) << 23) * p.uf[(int64_t)36 * p.out_ch * p.in_ch];
+  }
+  for (int i = tid; i < p.in_ch; i += THREADS) St[i] = (p.style ? p.style[(int64_t)ib * p.in_ch + i] : 1.0f) * in_scale;
   if (tid < 16 * WGM) {
     const int o = UP ? (o0 + tid) >> 2 : o0 + tid;          // UP: four phases per real channel
     const int real_ch = UP ? p.out_ch >> 2 : p.out_ch;
-    Ct[0][tid] = p.demod ? p.demod[(int64_t)ib * real_ch + o] * p.w_scale : p.w_scale;
+    Ct[0][tid] = (p.demod ? p.demod[(int64_t)ib * real_ch + o] * p.w_scale : p.w_scale) * out_scale;
     Ct[1][tid] = p.act ? p.bias[o] : 0.f;
     if (RGB) {
       const float sr = p.rgb_scale * p.rgb_style[(int64_t)ib * p.out_ch + o];
@@ -578,6 +655,7 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
   w4_f32x4 acc[36];
 #pragma unroll
   for (int xi = 0; xi < 36; ++xi) acc[xi] = w4_f32x4{0.f, 0.f, 0.f, 0.f};
+  float ymax = 0.f;                 // H16: max |result| of this lane -> p.y_amax
 
   const int item_off = lk * (PIECES * 64) + (4 * wn) * W4B_PITCH + 4 * lt;
   auto compute = [&](int ring, int uring, int kq, auto spread_tag) __attribute__((always_inline)) {
@@ -641,6 +719,58 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
 #endif
   };
 
+  // H16: the same interval on v_mfma_f32_16x16x16_f16 (see the note above the body).  Points in the packed order
+  // (w4_nat): a row of B^T d B is finished right before its first point, every value is split where it is used.
+  auto compute16 = [&](int ring, int uring, int kq, auto spread_tag) __attribute__((always_inline)) {
+    constexpr bool SPREAD = decltype(spread_tag)::value != 0;
+    const unsigned* base = reinterpret_cast<const unsigned*>(&Us[uring * USZ + wm * (9 * 256) + a_lane]);
+    const float* src = &Ps[ring * PSZ + item_off];
+    const float sv = St[4 * kq + lk];
+    w4_u32x4 a4[3];
+    a4[0] = *reinterpret_cast<const w4_u32x4*>(base);
+    a4[1] = *reinterpret_cast<const w4_u32x4*>(base + 256);
+    a4[2] = *reinterpret_cast<const w4_u32x4*>(base + 512);
+    w4_f32x2 c2[6][3];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const w4_f32x4 lo = *reinterpret_cast<const w4_f32x4*>(src + r * W4B_PITCH);
+      c2[r][0] = w4_f32x2{lo[0], lo[1]} * sv;
+      c2[r][1] = w4_f32x2{lo[2], lo[3]} * sv;
+      c2[r][2] = *reinterpret_cast<const w4_f32x2*>(src + r * W4B_PITCH + 4) * sv;
+    }
+#pragma unroll
+    for (int cp = 0; cp < 3; ++cp)
+      if (!(W4_ABL & 1)) w4_bt2(c2[0][cp], c2[1][cp], c2[2][cp], c2[3][cp], c2[4][cp], c2[5][cp]);
+    float d[6][6];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      const w4_u32x4 a = a4[q % 3];
+      if (q + 3 < 9) a4[q % 3] = *reinterpret_cast<const w4_u32x4*>(base + (q + 3) * 256);
+      if (SPREAD && !(W4_ABL & 2)) {
+        if (2 * q < PPW) pload_piece(2 * q);
+        if (2 * q + 1 < PPW) pload_piece(2 * q + 1);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int pos = 4 * q + e;
+        const int xi = w4_nat(pos);
+        const int ra = xi / 6;
+        // first point of a row in the packed order: positions 0, 6, 12 (rows 0, 1, 2), 18 (row 4), 20 (row 5), 26 (row 3)
+        if (pos == 0 || pos == 6 || pos == 12 || pos == 18 || pos == 20 || pos == 26) {
+          if (!(W4_ABL & 1)) {
+            w4_bt_row(c2[ra][0], c2[ra][1], c2[ra][2], d[ra]);
+          } else {
+            d[ra][0] = c2[ra][0][0]; d[ra][1] = c2[ra][0][1]; d[ra][2] = c2[ra][1][0]; d[ra][3] = c2[ra][1][1];
+            d[ra][4] = c2[ra][2][0]; d[ra][5] = c2[ra][2][1];
+          }
+        }
+        w4_f16x2 hh, ll;
+        w4_split16(d[ra][xi % 6], hh, ll);
+        acc[xi] = w4_mfma16(a[e], hh, ll, acc[xi], a[e ^ 1]);
+      }
+    }
+  };
+
   // PS: this wave's 18 points against both 16-channel blocks: acc[18 ob + le], le = 6 a + b local (rows (0, 1, 2)[a] of
   // wave 0, (5, 3, 4)[a] of wave 1).  One instruction stream for both waves: everything that depends on wm is a scalar.
   const float ps_cA = wm ? 1.f : 4.f, ps_cB = wm ? 2.f : 1.f, ps_cC = wm ? 2.f : 4.f;
@@ -702,6 +832,59 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
         const int le = 4 * q + e;
         acc[le] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], d[le / 6][le % 6], acc[le], 0, 0, 0);
         acc[18 + le] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], d[le / 6][le % 6], acc[18 + le], 0, 0, 0);
+      }
+    }
+  };
+
+  // H16 + PS: as compute_ps; every value is split once and meets the weight words of both blocks
+  auto compute16_ps = [&](int ring, int uring, int kq, auto spread_tag) __attribute__((always_inline)) {
+    constexpr bool SPREAD = decltype(spread_tag)::value != 0;
+    const unsigned* base = reinterpret_cast<const unsigned*>(&Us[uring * USZ + a_lane]);      // block 1: + 9 * 256
+    const float* src = &Ps[ring * PSZ + item_off];
+    const float sv = St[4 * kq + lk];
+    w4_u32x4 a4[2][2];
+    a4[0][0] = *reinterpret_cast<const w4_u32x4*>(base + ps_quad);
+    a4[0][1] = *reinterpret_cast<const w4_u32x4*>(base + 9 * 256 + ps_quad);
+    w4_f32x2 c2[7][3];
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+      const float* rp = r < 3 ? src + ps_row + 2 * r * W4B_PITCH : src + (r - 2) * W4B_PITCH;
+      const w4_f32x4 lo = *reinterpret_cast<const w4_f32x4*>(rp);
+      c2[r][0] = w4_f32x2{lo[0], lo[1]} * sv;
+      c2[r][1] = w4_f32x2{lo[2], lo[3]} * sv;
+      c2[r][2] = *reinterpret_cast<const w4_f32x2*>(rp + 4) * sv;
+    }
+    w4_f32x2 hrow[3][3];
+#pragma unroll
+    for (int cp = 0; cp < 3; ++cp)
+      w4_bt2_rows(c2[0][cp], c2[1][cp], c2[2][cp], c2[3][cp], c2[4][cp], c2[5][cp], c2[6][cp], ps_cA, ps_cB, ps_cC,
+                  hrow[0][cp], hrow[1][cp], hrow[2][cp]);
+    float d[3][6];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      const w4_u32x4 a0 = a4[q & 1][0], a1 = a4[q & 1][1];
+      if (q + 1 < 4) {
+        a4[(q + 1) & 1][0] = *reinterpret_cast<const w4_u32x4*>(base + ps_quad + (q + 1) * 256);
+        a4[(q + 1) & 1][1] = *reinterpret_cast<const w4_u32x4*>(base + 9 * 256 + ps_quad + (q + 1) * 256);
+      } else if (q + 1 == 4) {
+        const w4_u32x2 h0 = *reinterpret_cast<const w4_u32x2*>(base + ps_half);
+        const w4_u32x2 h1 = *reinterpret_cast<const w4_u32x2*>(base + 9 * 256 + ps_half);
+        a4[0][0] = w4_u32x4{h0[0], h0[1], 0u, 0u};
+        a4[0][1] = w4_u32x4{h1[0], h1[1], 0u, 0u};
+      }
+      if (SPREAD && !(W4_ABL & 2)) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+          if (3 * q + t < PPW) pload_piece(3 * q + t);
+      }
+#pragma unroll
+      for (int e = 0; e < (q < 4 ? 4 : 2); ++e) {
+        const int le = 4 * q + e;
+        if (le % 6 == 0) w4_bt_row(hrow[le / 6][0], hrow[le / 6][1], hrow[le / 6][2], d[le / 6]);
+        w4_f16x2 hh, ll;
+        w4_split16(d[le / 6][le % 6], hh, ll);
+        acc[le] = w4_mfma16(a0[e], hh, ll, acc[le], a0[e ^ 1]);
+        acc[18 + le] = w4_mfma16(a1[e], hh, ll, acc[18 + le], a1[e ^ 1]);
       }
     }
   };
@@ -811,6 +994,7 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
         for (int k = 0; k < 4; ++k) {
           const float u0 = q0[k] * scale + n0[k] + bias, u1 = q1[k] * scale + n1[k] + bias;
           q0[k] = fmaxf(u0, u0 * slope) * post; q1[k] = fmaxf(u1, u1 * slope) * post;
+          if (H16) ymax = fmaxf(ymax, fmaxf(fabsf(q0[k]), fabsf(q1[k])));
         }
         W4_STORE(yb + off, q0);
         W4_STORE(yb + off + 4, q1);
@@ -932,6 +1116,7 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
           const float u = v[k] * scale + nz[r][k] + bias;
           v[k] = fmaxf(u, u * slope);
         }
+        if (H16) ymax = fmaxf(fmaxf(ymax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
         W4_STORE(yb + (int64_t)j * hw + (int64_t)r * p.w, v);
       }
     }
@@ -980,12 +1165,16 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
     if (UDEPTH == 2) {
       if (!(W4_ABL & 4)) uload((v + 1) & 1, c + 1 < NC ? c + 1 : 0);      // weights of interval v + 1
       pload_begin(ring2, fg, fc);                   // past the run: legal addresses, never read
-      if (!PS) compute(ring, v & 1, c, w4_int<1>());        // ... issues the patch pieces of v + 2 between its MFMAs
+      // ... issues the patch pieces of v + 2 between its MFMAs
+      if (H16 && PS) compute16_ps(ring, v & 1, c, w4_int<1>());
+      else if (H16) compute16(ring, v & 1, c, w4_int<1>());
+      else if (!PS) compute(ring, v & 1, c, w4_int<1>());
       else compute_ps(ring, v & 1, c, w4_int<1>());
     } else {
       if (!(W4_ABL & 2)) pload(ring2, fg, fc);
       if (!(W4_ABL & 4)) uload(ring2, fc);
-      compute(ring, ring, c, w4_int<0>());
+      if (H16) compute16(ring, ring, c, w4_int<0>());
+      else compute(ring, ring, c, w4_int<0>());
     }
     const bool last = c == NC - 1;
     if (last) {
@@ -998,6 +1187,11 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
   }
   __builtin_amdgcn_s_waitcnt(0x0070);               // nothing in flight into LDS when the workgroup retires
 #undef W4_WAIT
+  if (H16 && !RGB && p.y_amax) {
+#pragma unroll
+    for (int off = 32; off; off >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, off));
+    if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(p.y_amax), __float_as_uint(ymax));     // ymax >= 0
+  }
 }
 
 template <int WGN, int UDEPTH>
@@ -1022,6 +1216,22 @@ __global__ void __launch_bounds__(256, 2) conv_up_wino36_ns_kernel(const Wino4Pr
 __global__ void __launch_bounds__(256, 2) conv_wino36_rgb_ns_kernel(const Wino4Problem p) {
   conv_wino36b_body<2, 2, 2, false>(p);
 }
+// H16: the six on the 16-bit matrix pipe (see the note above the body), and the point split for the stride-1 convolution
+// and the upsampling layer (its vector work per interval halves; what it adds -- the partial tiles' swap per group --
+// pays where a group has many intervals: in_ch >= W4H_PS_MIN_IN)
+__global__ void __launch_bounds__(256, 2) conv_wino36h_kernel(const Wino4Problem p) { conv_wino36b_body<2, 2, 0, true, false, true>(p); }
+__global__ void __launch_bounds__(256, 2) conv_up_wino36h_kernel(const Wino4Problem p) { conv_wino36b_body<2, 2, 1, true, false, true>(p); }
+__global__ void __launch_bounds__(256, 2) conv_wino36h_rgb_kernel(const Wino4Problem p) { conv_wino36b_body<2, 2, 2, true, false, true>(p); }
+__global__ void __launch_bounds__(256, 2) conv_wino36h_ps_kernel(const Wino4Problem p) { conv_wino36b_body<2, 2, 0, true, true, true>(p); }
+__global__ void __launch_bounds__(256, 2) conv_up_wino36h_ps_kernel(const Wino4Problem p) { conv_wino36b_body<2, 2, 1, true, true, true>(p); }
+__global__ void __launch_bounds__(256, 2) conv_wino36h_rgb_ps_kernel(const Wino4Problem p) { conv_wino36b_body<2, 2, 2, true, true, true>(p); }
+// point split: 0 = never, 1 = always, default = where in_ch >= 128 (RW_W4H_PS overrides)
+static bool w4h_point_split(int in_ch) {
+  const char* e = getenv("RW_W4H_PS");
+  const int mode = e ? atoi(e) : -1;
+  return mode < 0 ? in_ch >= 128 : mode != 0;
+}
+
 // The same six with the 36 points split between the two out-channel waves (PS above).  MEASURED FLAT (same box, batch
 // 64, ms per 10 steps, split off / on: layers 10-16 173.3 / 172.8, layer 17 107.0 / 109.9, layer 18 + ToRGB 56.8 / 57.9;
 // profiles/r03_w4_point_split.log): the ~220 vector cycles it saves per k-quad and wave are given back by what it adds -- a
@@ -1046,8 +1256,8 @@ static bool w4_point_split() {
 }
 #endif
 
-// G g G^T of one 3x3 kernel g[3 ky + kx] -> the 36 values of lane `dst` (stride 256 floats per point quad)
-__device__ __forceinline__ void w4_pack_store(const float* g, float* dst) {
+// G g G^T of one 3x3 kernel g[3 ky + kx]: the 36 values u[6 a + b]
+__device__ __forceinline__ void w4_weight_points(const float* g, float (&u)[36]) {
     // G = [[1/4,0,0],[-1/6,-1/6,-1/6],[-1/6,1/6,-1/6],[1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]]
     float gg[6][3];                                   // G g
 
@@ -1061,7 +1271,6 @@ __device__ __forceinline__ void w4_pack_store(const float* g, float* dst) {
       gg[4][kx] = (1.f / 24.f) * g0 - (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
       gg[5][kx] = g2;
     }
-    float u[36];
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
       const float g0 = gg[a][0], g1 = gg[a][1], g2 = gg[a][2];
@@ -1072,17 +1281,57 @@ __device__ __forceinline__ void w4_pack_store(const float* g, float* dst) {
       u[6 * a + 4] = (1.f / 24.f) * g0 - (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
       u[6 * a + 5] = g2;
     }
+}
+// PASS 0: the 36 fp32 values of lane `dst` (stride 256 floats per point quad); PASS 1: nothing is stored, the
+// return value is max |u|; PASS 2: the f16 pair words of u * su in the same places (H16 kernels)
+template <int PASS>
+__device__ __forceinline__ float w4_pack_store(const float* g, float* dst, float su) {
+    float u[36];
+    w4_weight_points(g, u);
+    float m = 0.f;
+    if (PASS == 1) {
 #pragma unroll
-    for (int q = 0; q < 9; ++q)
-      *reinterpret_cast<w4_f32x4*>(dst + q * 256) =
-          w4_f32x4{u[w4_nat(4 * q)], u[w4_nat(4 * q + 1)], u[w4_nat(4 * q + 2)], u[w4_nat(4 * q + 3)]};
+      for (int i = 0; i < 36; ++i) m = fmaxf(m, fabsf(u[i]));
+      return m;
+    }
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      if (PASS == 0) {
+        *reinterpret_cast<w4_f32x4*>(dst + q * 256) =
+            w4_f32x4{u[w4_nat(4 * q)], u[w4_nat(4 * q + 1)], u[w4_nat(4 * q + 2)], u[w4_nat(4 * q + 3)]};
+      } else {
+        *reinterpret_cast<w4_u32x4*>(dst + q * 256) =
+            w4_u32x4{w4_pack16(u[w4_nat(4 * q)] * su), w4_pack16(u[w4_nat(4 * q + 1)] * su),
+                     w4_pack16(u[w4_nat(4 * q + 2)] * su), w4_pack16(u[w4_nat(4 * q + 3)] * su)};
+      }
+    }
+    return m;
+}
+// H16 packing runs twice: PASS 1 leaves max |U| (as bits, atomic max) in trailer[2]; PASS 2 derives the power of two
+// from it -- max |U| < 2^eu, su = 2^(15 - eu) -- and the first thread writes 2^(eu - 15) to trailer[0].
+__device__ __forceinline__ float w4_weight_scale(const float* trailer, float* inv) {
+  const unsigned bits = __float_as_uint(trailer[2]);
+  int eu = (int)((bits >> 23) & 0xff) - 126;
+  if (bits == 0u) eu = 15;
+  eu = eu < -100 ? -100 : (eu > 100 ? 100 : eu);
+  *inv = __uint_as_float((unsigned)(127 + eu - 15) << 23);
+  return __uint_as_float((unsigned)(127 + 15 - eu) << 23);
+}
+__device__ __forceinline__ void w4_report_absmax(float m, float* trailer) {
+#pragma unroll
+  for (int off = 32; off; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(trailer + 2), __float_as_uint(m));
 }
 
 // One thread: the 36 values of one (o, i).  uf[o / 16][i / 4][xi / 4][16 (i % 4) + o % 16][xi % 4]
+template <int PASS>
 __global__ void __launch_bounds__(256) pack_wino36_kernel(const float* __restrict__ w, float* __restrict__ uf,
                                                           int out_ch, int in_ch) {
   const int64_t total = (int64_t)out_ch * in_ch;
   const int kqn = in_ch >> 2;
+  float* trailer = uf + 36 * total;
+  float su = 1.f, inv = 1.f, m = 0.f;
+  if (PASS == 2) su = w4_weight_scale(trailer, &inv);
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
     const int lane = (int)(idx & 63);
@@ -1090,18 +1339,24 @@ __global__ void __launch_bounds__(256) pack_wino36_kernel(const float* __restric
     const int kq = (int)(rest % kqn);
     const int ob = (int)(rest / kqn);
     const int o = 16 * ob + (lane & 15), i = 4 * kq + (lane >> 4);
-    w4_pack_store(w + ((int64_t)o * in_ch + i) * 9, uf + ((int64_t)ob * kqn + kq) * (9 * 256) + lane * 4);
+    m = fmaxf(m, w4_pack_store<PASS>(w + ((int64_t)o * in_ch + i) * 9, uf + ((int64_t)ob * kqn + kq) * (9 * 256) + lane * 4, su));
   }
+  if (PASS == 1) w4_report_absmax(m, trailer);
+  if (PASS == 2 && blockIdx.x == 0 && threadIdx.x == 0) trailer[0] = inv;
 }
 
 // The same for the transposed convolution + blur problem: virtual channel v = 4 o + 2 py + px carries the phase
 // kernel h[a][b] = g6[2 - 2a + py][2 - 2b + px], g6[ty][tx] = sum_{c,d} k'[c][d] w[ty - 1 + c][tx - 1 + d] (t = -2..3),
 // k' = the blur kernel as upfirdn2d applies it (flipped).  w[o][i][ky][kx] as rw_conv_transpose3x3s2_f32 sees it.
+template <int PASS>
 __global__ void __launch_bounds__(256) pack_up_wino36_kernel(const float* __restrict__ w, const float* __restrict__ k4,
                                                              float* __restrict__ uf, int out_ch, int in_ch) {
   const int vch = 4 * out_ch;
   const int64_t total = (int64_t)vch * in_ch;
   const int kqn = in_ch >> 2;
+  float* trailer = uf + 36 * total;
+  float su = 1.f, inv = 1.f, m = 0.f;
+  if (PASS == 2) su = w4_weight_scale(trailer, &inv);
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
     const int lane = (int)(idx & 63);
@@ -1127,8 +1382,36 @@ __global__ void __launch_bounds__(256) pack_up_wino36_kernel(const float* __rest
           }
         h[3 * a + b] = sum;
       }
-    w4_pack_store(h, uf + ((int64_t)ob * kqn + kq) * (9 * 256) + lane * 4);
+    m = fmaxf(m, w4_pack_store<PASS>(h, uf + ((int64_t)ob * kqn + kq) * (9 * 256) + lane * 4, su));
   }
+  if (PASS == 1) w4_report_absmax(m, trailer);
+  if (PASS == 2 && blockIdx.x == 0 && threadIdx.x == 0) trailer[0] = inv;
+}
+
+// max |x| over n floats -> out[0] (zeroed first): the x_amax of the H16 kernels where no producer left one behind
+__global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+  float m = 0.f;
+  const int64_t n4 = n >> 2;
+  const w4_f32x4* x4 = reinterpret_cast<const w4_f32x4*>(x);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const w4_f32x4 v = x4[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(x[(n4 << 2) + threadIdx.x]));
+#pragma unroll
+  for (int off = 32; off; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(m));
+}
+
+extern "C" int rw_absmax_f32(const float* x, long long n, float* out, rw_stream_t stream) {
+  RW_CHECK_ARG(x && out && n > 0);
+  if (((size_t)x & 15) != 0) return RW_ERR_UNSUPPORTED;
+  { const hipError_t me = hipMemsetAsync(out, 0, sizeof(float), rw_s(stream)); if (me != hipSuccess) return (int)me; }
+  int grid = (int)((n / 4 + 255) / 256);
+  if (grid > 2048) grid = 2048;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, rw_s(stream), x, (int64_t)n, out);
+  return RW_LAUNCH_RESULT();
 }
 
 static bool wino4_shape_ok(int out_ch, int in_ch, int h, int w) {
@@ -1148,26 +1431,12 @@ extern "C" int rw_pack_conv_weight_wino4_f32(const float* w, float* uf, int out_
   RW_CHECK_ARG(w && uf && out_ch > 0 && in_ch > 0);
   if (out_ch % 16 || in_ch % 4) return RW_ERR_UNSUPPORTED;
   const int64_t total = (int64_t)out_ch * in_ch;
-  hipLaunchKernelGGL(pack_wino36_kernel, dim3(rw_stream_grid(total, 256)), dim3(256), 0, rw_s(stream), w, uf, out_ch,
+  hipLaunchKernelGGL(pack_wino36_kernel<0>, dim3(rw_stream_grid(total, 256)), dim3(256), 0, rw_s(stream), w, uf, out_ch,
                      in_ch);
   return RW_LAUNCH_RESULT();
 }
 
-#include <stdlib.h>
-extern "C" int rw_conv3x3_wino4_f32(const float* x, const float* uf, float* y, int batch, int in_ch, int out_ch, int h,
-                                    int w, float w_scale, const rw_conv_epilogue* ep, rw_stream_t stream) {
-  RW_CHECK_ARG(x && uf && y && batch > 0 && in_ch > 0 && out_ch > 0 && h > 0 && w > 0);
-  RW_CHECK_ARG(!ep || ((!ep->noise || ep->noise_w) && (!ep->act || ep->bias)));
-  if (!wino4_shape_ok(out_ch, in_ch, h, w)) return RW_ERR_UNSUPPORTED;
-  Wino4Problem p = {};
-  p.x = x; p.uf = uf; p.y = y;
-  p.style = ep ? ep->style : nullptr; p.demod = ep ? ep->demod : nullptr; p.noise = ep ? ep->noise : nullptr;
-  p.noise_w = ep ? ep->noise_w : nullptr; p.bias = ep ? ep->bias : nullptr; p.act = ep ? ep->act : 0;
-  p.batch = batch; p.in_ch = in_ch; p.out_ch = out_ch; p.h = h; p.w = w; p.w_scale = w_scale;
-  // 32 out-channels x 2 tile rows (8 x 64 pixels) per workgroup
-  p.groups_x = w / 64;
-  p.groups_y = h / 8;
-  const int o_tiles = out_ch / 32;
+static int wino4_gpw(const Wino4Problem& p, int batch, int o_tiles) {
   const char* e = getenv("RW_WINO4_GPW");
   int gpw = e ? atoi(e) : 16;         // whole rows where the launch still has >= 1024 workgroups: +1.5 % over 4
   if (gpw < 1) gpw = 1;
@@ -1177,14 +1446,43 @@ extern "C" int rw_conv3x3_wino4_f32(const float* x, const float* uf, float* y, i
     --gpw;
     while (p.groups_x % gpw) --gpw;
   }
+  return gpw;
+}
+
+static int conv3x3_wino4_launch(const float* x, const float* uf, float* y, int batch, int in_ch, int out_ch, int h,
+                                int w, float w_scale, const rw_conv_epilogue* ep, bool h16, const float* x_amax,
+                                float* y_amax, rw_stream_t stream) {
+  RW_CHECK_ARG(x && uf && y && batch > 0 && in_ch > 0 && out_ch > 0 && h > 0 && w > 0);
+  RW_CHECK_ARG(!ep || ((!ep->noise || ep->noise_w) && (!ep->act || ep->bias)));
+  RW_CHECK_ARG(!h16 || x_amax);
+  if (!wino4_shape_ok(out_ch, in_ch, h, w)) return RW_ERR_UNSUPPORTED;
+  Wino4Problem p = {};
+  p.x = x; p.uf = uf; p.y = y;
+  p.style = ep ? ep->style : nullptr; p.demod = ep ? ep->demod : nullptr; p.noise = ep ? ep->noise : nullptr;
+  p.noise_w = ep ? ep->noise_w : nullptr; p.bias = ep ? ep->bias : nullptr; p.act = ep ? ep->act : 0;
+  p.batch = batch; p.in_ch = in_ch; p.out_ch = out_ch; p.h = h; p.w = w; p.w_scale = w_scale;
+  p.x_amax = x_amax; p.y_amax = y_amax;
+  // 32 out-channels x 2 tile rows (8 x 64 pixels) per workgroup
+  p.groups_x = w / 64;
+  p.groups_y = h / 8;
+  const int o_tiles = out_ch / 32;
+  const int gpw = wino4_gpw(p, batch, o_tiles);
   p.gpw = gpw;
   const int64_t work = (int64_t)batch * p.groups_y * (p.groups_x / gpw) * o_tiles;
   if (work <= 0 || work > 0x7fffffff) return RW_ERR_UNSUPPORTED;
+  if (h16) {
+    if (in_ch > 512) return RW_ERR_UNSUPPORTED;
+    if (y_amax) { const hipError_t me = hipMemsetAsync(y_amax, 0, sizeof(float), rw_s(stream)); if (me != hipSuccess) return (int)me; }
+    if (w4h_point_split(in_ch)) hipLaunchKernelGGL(conv_wino36h_ps_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
+    else hipLaunchKernelGGL(conv_wino36h_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
+    return RW_LAUNCH_RESULT();
+  }
   // versions: 1 = registers / compiler-scheduled loads (256 threads); 2 = <4,3> 512-thread workgroups;
   // 3 (default) = <2,2> two 256-thread workgroups per CU.  RW_WINO4_V overrides for comparison.
   const char* ver = getenv("RW_WINO4_V");
   const int version = ver ? atoi(ver) : 3;
   if (version == 2 && h % 16 == 0 && in_ch <= 512) {
+    const char* e = getenv("RW_WINO4_GPW");
     p.groups_y = h / 16;
     int gpw2 = e ? atoi(e) : 4;
     if (gpw2 < 1) gpw2 = 1;
@@ -1215,6 +1513,36 @@ extern "C" int rw_conv3x3_wino4_f32(const float* x, const float* uf, float* y, i
   return RW_LAUNCH_RESULT();
 }
 
+extern "C" int rw_conv3x3_wino4_f32(const float* x, const float* uf, float* y, int batch, int in_ch, int out_ch, int h,
+                                    int w, float w_scale, const rw_conv_epilogue* ep, rw_stream_t stream) {
+  return conv3x3_wino4_launch(x, uf, y, batch, in_ch, out_ch, h, w, w_scale, ep, false, nullptr, nullptr, stream);
+}
+
+// ---- H16: the same operations with the products on the 16-bit matrix pipe (exact operand split, fp32 accumulation)
+extern "C" long long rw_packed_conv_weight_wino4h_elems(int out_ch, int in_ch) {
+  if (out_ch <= 0 || in_ch <= 0 || out_ch % 16 || in_ch % 4) return -1;
+  return 36LL * out_ch * in_ch + 4;
+}
+
+extern "C" int rw_pack_conv_weight_wino4h_f32(const float* w, float* uf, int out_ch, int in_ch, rw_stream_t stream) {
+  RW_CHECK_ARG(w && uf && out_ch > 0 && in_ch > 0);
+  if (out_ch % 16 || in_ch % 4) return RW_ERR_UNSUPPORTED;
+  const int64_t total = (int64_t)out_ch * in_ch;
+  const hipError_t me = hipMemsetAsync(uf + 36 * total, 0, 4 * sizeof(float), rw_s(stream));
+  if (me != hipSuccess) return (int)me;
+  hipLaunchKernelGGL(pack_wino36_kernel<1>, dim3(rw_stream_grid(total, 256)), dim3(256), 0, rw_s(stream), w, uf, out_ch,
+                     in_ch);
+  hipLaunchKernelGGL(pack_wino36_kernel<2>, dim3(rw_stream_grid(total, 256)), dim3(256), 0, rw_s(stream), w, uf, out_ch,
+                     in_ch);
+  return RW_LAUNCH_RESULT();
+}
+
+extern "C" int rw_conv3x3_wino4h_f32(const float* x, const float* uf, float* y, int batch, int in_ch, int out_ch, int h,
+                                     int w, float w_scale, const rw_conv_epilogue* ep, const float* x_amax,
+                                     float* y_amax, rw_stream_t stream) {
+  return conv3x3_wino4_launch(x, uf, y, batch, in_ch, out_ch, h, w, w_scale, ep, true, x_amax, y_amax, stream);
+}
+
 // ---------------------------------------------------------------------------------------
 // Transposed convolution + blur + noise + bias + leaky ReLU of an upsampling StyledConv in one pass
 // (utils/stylegan2/models.py:313-329 F.conv_transpose2d(stride=2), then Blur(pad 1,1) :289-291, NoiseInjection
@@ -1238,17 +1566,17 @@ extern "C" int rw_pack_conv_transpose_blur_weight_wino4_f32(const float* w, cons
   RW_CHECK_ARG(w && k4 && uf && out_ch > 0 && in_ch > 0);
   if (out_ch % 4 || in_ch % 4) return RW_ERR_UNSUPPORTED;
   const int64_t total = 4LL * out_ch * in_ch;
-  hipLaunchKernelGGL(pack_up_wino36_kernel, dim3(rw_stream_grid(total, 256)), dim3(256), 0, rw_s(stream), w, k4, uf,
+  hipLaunchKernelGGL(pack_up_wino36_kernel<0>, dim3(rw_stream_grid(total, 256)), dim3(256), 0, rw_s(stream), w, k4, uf,
                      out_ch, in_ch);
   return RW_LAUNCH_RESULT();
 }
 
-extern "C" int rw_conv_transpose3x3s2_blur_wino4_f32(const float* x, const float* uf, float* y, int batch, int in_ch,
-                                                     int out_ch, int h, int w, float w_scale,
-                                                     const rw_conv_epilogue* ep, const float* post_scale,
-                                                     rw_stream_t stream) {
+static int up_wino4_launch(const float* x, const float* uf, float* y, int batch, int in_ch, int out_ch, int h, int w,
+                           float w_scale, const rw_conv_epilogue* ep, const float* post_scale, bool h16,
+                           const float* x_amax, float* y_amax, rw_stream_t stream) {
   RW_CHECK_ARG(x && uf && y && batch > 0 && in_ch > 0 && out_ch > 0 && h > 0 && w > 0);
   RW_CHECK_ARG(!ep || ((!ep->noise || ep->noise_w) && (!ep->act || ep->bias)));
+  RW_CHECK_ARG(!h16 || x_amax);
   if (!up_wino4_shape_ok(out_ch, in_ch, h, w)) return RW_ERR_UNSUPPORTED;
   Wino4Problem p = {};
   p.x = x; p.uf = uf; p.y = y;
@@ -1256,21 +1584,19 @@ extern "C" int rw_conv_transpose3x3s2_blur_wino4_f32(const float* x, const float
   p.noise_w = ep ? ep->noise_w : nullptr; p.bias = ep ? ep->bias : nullptr; p.act = ep ? ep->act : 0;
   p.post = post_scale;
   p.batch = batch; p.in_ch = in_ch; p.out_ch = 4 * out_ch; p.h = h; p.w = w; p.w_scale = w_scale;
+  p.x_amax = x_amax; p.y_amax = y_amax;
   p.groups_x = w / 64;
   p.groups_y = h / 8;
   const int o_tiles = p.out_ch / 32;
-  const char* e = getenv("RW_WINO4_GPW");
-  int gpw = e ? atoi(e) : 16;         // whole rows where the launch still has >= 1024 workgroups: +1.5 % over 4
-  if (gpw < 1) gpw = 1;
-  if (gpw > p.groups_x) gpw = p.groups_x;
-  while (p.groups_x % gpw) --gpw;
-  while (gpw > 1 && (int64_t)batch * p.groups_y * (p.groups_x / gpw) * o_tiles < 1024) {
-    --gpw;
-    while (p.groups_x % gpw) --gpw;
-  }
-  p.gpw = gpw;
-  const int64_t work = (int64_t)batch * p.groups_y * (p.groups_x / gpw) * o_tiles;
+  p.gpw = wino4_gpw(p, batch, o_tiles);
+  const int64_t work = (int64_t)batch * p.groups_y * (p.groups_x / p.gpw) * o_tiles;
   if (work <= 0 || work > 0x7fffffff) return RW_ERR_UNSUPPORTED;
+  if (h16) {
+    if (y_amax) { const hipError_t me = hipMemsetAsync(y_amax, 0, sizeof(float), rw_s(stream)); if (me != hipSuccess) return (int)me; }
+    if (w4h_point_split(in_ch)) hipLaunchKernelGGL(conv_up_wino36h_ps_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
+    else hipLaunchKernelGGL(conv_up_wino36h_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
+    return RW_LAUNCH_RESULT();
+  }
 #if W4_PSPLIT
   if (w4_point_split()) {
     if (p.style) hipLaunchKernelGGL(conv_up_wino36_ps_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
@@ -1282,6 +1608,39 @@ extern "C" int rw_conv_transpose3x3s2_blur_wino4_f32(const float* x, const float
   return RW_LAUNCH_RESULT();
 }
 
+extern "C" int rw_conv_transpose3x3s2_blur_wino4_f32(const float* x, const float* uf, float* y, int batch, int in_ch,
+                                                     int out_ch, int h, int w, float w_scale,
+                                                     const rw_conv_epilogue* ep, const float* post_scale,
+                                                     rw_stream_t stream) {
+  return up_wino4_launch(x, uf, y, batch, in_ch, out_ch, h, w, w_scale, ep, post_scale, false, nullptr, nullptr, stream);
+}
+
+extern "C" long long rw_packed_conv_transpose_blur_wino4h_elems(int out_ch, int in_ch) {
+  if (out_ch <= 0 || in_ch <= 0 || out_ch % 4 || in_ch % 4) return -1;
+  return 144LL * out_ch * in_ch + 4;
+}
+
+extern "C" int rw_pack_conv_transpose_blur_weight_wino4h_f32(const float* w, const float* k4, float* uf, int out_ch,
+                                                             int in_ch, rw_stream_t stream) {
+  RW_CHECK_ARG(w && k4 && uf && out_ch > 0 && in_ch > 0);
+  if (out_ch % 4 || in_ch % 4) return RW_ERR_UNSUPPORTED;
+  const int64_t total = 4LL * out_ch * in_ch;
+  const hipError_t me = hipMemsetAsync(uf + 36 * total, 0, 4 * sizeof(float), rw_s(stream));
+  if (me != hipSuccess) return (int)me;
+  hipLaunchKernelGGL(pack_up_wino36_kernel<1>, dim3(rw_stream_grid(total, 256)), dim3(256), 0, rw_s(stream), w, k4, uf,
+                     out_ch, in_ch);
+  hipLaunchKernelGGL(pack_up_wino36_kernel<2>, dim3(rw_stream_grid(total, 256)), dim3(256), 0, rw_s(stream), w, k4, uf,
+                     out_ch, in_ch);
+  return RW_LAUNCH_RESULT();
+}
+
+extern "C" int rw_conv_transpose3x3s2_blur_wino4h_f32(const float* x, const float* uf, float* y, int batch, int in_ch,
+                                                      int out_ch, int h, int w, float w_scale,
+                                                      const rw_conv_epilogue* ep, const float* post_scale,
+                                                      const float* x_amax, float* y_amax, rw_stream_t stream) {
+  return up_wino4_launch(x, uf, y, batch, in_ch, out_ch, h, w, w_scale, ep, post_scale, true, x_amax, y_amax, stream);
+}
+
 // ---------------------------------------------------------------------------------------
 // The last styled convolution of the generator with ToRGB in the epilogue (models.py:639-655), F(4x4,3x3):
 // rgb->out (B, 3, H, W) = ToRGB(act(conv(x) + noise + bias)) + rgb bias + skip; the feature map is not written.
@@ -1290,11 +1649,12 @@ extern "C" int rw_conv3x3_wino4_to_rgb_supported(int out_ch, int in_ch, int h, i
   return out_ch == 32 && in_ch <= 512 && wino4_shape_ok(out_ch, in_ch, h, w) ? 1 : 0;
 }
 
-extern "C" int rw_conv3x3_wino4_to_rgb_f32(const float* x, const float* uf, int batch, int in_ch, int out_ch, int h,
-                                           int w, float w_scale, const rw_conv_epilogue* ep,
-                                           const rw_rgb_epilogue* rgb, rw_stream_t stream) {
+static int wino4_to_rgb_launch(const float* x, const float* uf, int batch, int in_ch, int out_ch, int h, int w,
+                               float w_scale, const rw_conv_epilogue* ep, const rw_rgb_epilogue* rgb, bool h16,
+                               const float* x_amax, rw_stream_t stream) {
   RW_CHECK_ARG(x && uf && rgb && rgb->weight && rgb->style && rgb->out && batch > 0 && in_ch > 0 && out_ch > 0);
   RW_CHECK_ARG(!ep || ((!ep->noise || ep->noise_w) && (!ep->act || ep->bias)));
+  RW_CHECK_ARG(!h16 || x_amax);
   if (!rw_conv3x3_wino4_to_rgb_supported(out_ch, in_ch, h, w)) return RW_ERR_UNSUPPORTED;
   Wino4Problem p = {};
   p.x = x; p.uf = uf; p.y = nullptr;
@@ -1303,20 +1663,17 @@ extern "C" int rw_conv3x3_wino4_to_rgb_f32(const float* x, const float* uf, int 
   p.rgb_weight = rgb->weight; p.rgb_style = rgb->style; p.rgb_bias = rgb->bias; p.rgb_skip = rgb->skip;
   p.rgb_out = rgb->out; p.rgb_scale = rgb->scale;
   p.batch = batch; p.in_ch = in_ch; p.out_ch = out_ch; p.h = h; p.w = w; p.w_scale = w_scale;
+  p.x_amax = x_amax;
   p.groups_x = w / 64;
   p.groups_y = h / 8;
-  const char* e = getenv("RW_WINO4_GPW");
-  int gpw = e ? atoi(e) : 16;         // whole rows where the launch still has >= 1024 workgroups: +1.5 % over 4
-  if (gpw < 1) gpw = 1;
-  if (gpw > p.groups_x) gpw = p.groups_x;
-  while (p.groups_x % gpw) --gpw;
-  while (gpw > 1 && (int64_t)batch * p.groups_y * (p.groups_x / gpw) < 1024) {
-    --gpw;
-    while (p.groups_x % gpw) --gpw;
-  }
-  p.gpw = gpw;
-  const int64_t work = (int64_t)batch * p.groups_y * (p.groups_x / gpw);
+  p.gpw = wino4_gpw(p, batch, 1);
+  const int64_t work = (int64_t)batch * p.groups_y * (p.groups_x / p.gpw);
   if (work <= 0 || work > 0x7fffffff) return RW_ERR_UNSUPPORTED;
+  if (h16) {
+    if (w4h_point_split(in_ch)) hipLaunchKernelGGL(conv_wino36h_rgb_ps_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
+    else hipLaunchKernelGGL(conv_wino36h_rgb_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
+    return RW_LAUNCH_RESULT();
+  }
 #if W4_PSPLIT
   if (w4_point_split()) {
     if (p.style) hipLaunchKernelGGL(conv_wino36_rgb_ps_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
@@ -1326,4 +1683,16 @@ extern "C" int rw_conv3x3_wino4_to_rgb_f32(const float* x, const float* uf, int 
   if (p.style) hipLaunchKernelGGL(conv_wino36_rgb_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
   else hipLaunchKernelGGL(conv_wino36_rgb_ns_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
   return RW_LAUNCH_RESULT();
+}
+
+extern "C" int rw_conv3x3_wino4_to_rgb_f32(const float* x, const float* uf, int batch, int in_ch, int out_ch, int h,
+                                           int w, float w_scale, const rw_conv_epilogue* ep,
+                                           const rw_rgb_epilogue* rgb, rw_stream_t stream) {
+  return wino4_to_rgb_launch(x, uf, batch, in_ch, out_ch, h, w, w_scale, ep, rgb, false, nullptr, stream);
+}
+
+extern "C" int rw_conv3x3_wino4h_to_rgb_f32(const float* x, const float* uf, int batch, int in_ch, int out_ch, int h,
+                                            int w, float w_scale, const rw_conv_epilogue* ep,
+                                            const rw_rgb_epilogue* rgb, const float* x_amax, rw_stream_t stream) {
+  return wino4_to_rgb_launch(x, uf, batch, in_ch, out_ch, h, w, w_scale, ep, rgb, true, x_amax, stream);
 }

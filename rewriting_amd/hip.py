@@ -265,28 +265,75 @@ def wino4_supported(out_ch, in_ch, height, width):
     return bool(lib().rw_conv3x3_wino4_supported(int(out_ch), int(in_ch), int(height), int(width)))
 
 
-def pack_conv_weight_wino4(weight):
+def absmax(x):
+    """max |x| as a one-element device tensor (rw_absmax_f32): the x_amax of the split-operand F(4x4,3x3) kernels
+    where the producer of x did not leave one behind."""
+    x = _dev(x, 'tensor')
+    out = torch.empty(1, device=x.device, dtype=torch.float32)
+    check(lib().rw_absmax_f32(_p(x), x.numel(), _p(out), _stream()))
+    return out
+
+
+def _amax_in(x, x_amax):
+    if x_amax is None:
+        return absmax(x)
+    x_amax = _dev(x_amax, 'x_amax')
+    if x_amax.numel() != 1:
+        raise ValueError('x_amax must hold one float')
+    return x_amax
+
+
+def _amax_out(y_amax):
+    if y_amax is None:
+        return None
+    y_amax = _dev(y_amax, 'y_amax')
+    if y_amax.numel() != 1:
+        raise ValueError('y_amax must hold one float')
+    return y_amax
+
+
+def pack_conv_weight_wino4(weight, split=False):
+    """G g G^T of every filter in the fragment order of the F(4x4,3x3) kernels; split=True: every value as the pair
+    of f16 numbers the kernels on the 16-bit matrix pipe multiply (rw_pack_conv_weight_wino4h_f32) -- the convolution
+    functions tell the two formats apart by their size."""
     weight = _dev(weight, 'weight')
     o, i = weight.shape[-4], weight.shape[-3]
-    n = lib().rw_packed_conv_weight_wino4_elems(o, i)
+    n = (lib().rw_packed_conv_weight_wino4h_elems if split else lib().rw_packed_conv_weight_wino4_elems)(o, i)
     if n <= 0:
         raise ValueError('no F(4x4,3x3) packing for a %d x %d weight' % (o, i))
     uf = torch.empty(n, device=weight.device, dtype=torch.float32)
-    check(lib().rw_pack_conv_weight_wino4_f32(_p(weight), _p(uf), o, i, _stream()))
+    pack = lib().rw_pack_conv_weight_wino4h_f32 if split else lib().rw_pack_conv_weight_wino4_f32
+    check(pack(_p(weight), _p(uf), o, i, _stream()))
     return uf
 
 
-def conv3x3_wino4(x, uf, out_ch, w_scale, style=None, demod=None, noise=None, noise_w=None, bias=None, act=False):
-    """Stride-1 3x3 convolution by Winograd F(4x4,3x3) in fp32 (~1e-5 relative error per layer: the default of the
+def _wino4_split(uf, out_ch, in_ch, what='pack_conv_weight_wino4'):
+    """Is uf the split (f16 pair) packing?  Raises when it is neither packing of this shape."""
+    if uf.numel() == lib().rw_packed_conv_weight_wino4_elems(out_ch, in_ch):
+        return False
+    if uf.numel() == lib().rw_packed_conv_weight_wino4h_elems(out_ch, in_ch):
+        return True
+    raise ValueError('packed weight does not come from %s(%d x %d)' % (what, out_ch, in_ch))
+
+
+def conv3x3_wino4(x, uf, out_ch, w_scale, style=None, demod=None, noise=None, noise_w=None, bias=None, act=False,
+                  x_amax=None, y_amax=None):
+    """Stride-1 3x3 convolution by Winograd F(4x4,3x3) (~1e-5 relative error per layer: the default of the
     un-hooked whole-generator forward, never used by a hooked or sliced model -- models.conv_algo); same arguments
-    and epilogue as conv3x3."""
+    and epilogue as conv3x3.  With weights from pack_conv_weight_wino4(split=True) the products run on the 16-bit
+    matrix pipe (exact f16 operand split, fp32 accumulation): x_amax = a one-element tensor >= max |x| (computed here
+    when None), y_amax = a one-element tensor that receives max |y|."""
     x = _dev(x, 'fmap')
     uf = _dev(uf, 'packed weight')
     b, i, h, w = x.shape
-    if uf.numel() != lib().rw_packed_conv_weight_wino4_elems(out_ch, i):
-        raise ValueError('packed weight does not come from pack_conv_weight_wino4(%d x %d)' % (out_ch, i))
+    split = _wino4_split(uf, out_ch, i)
     y = torch.empty(b, out_ch, h, w, device=x.device, dtype=x.dtype)
     ep, keep = _epilogue(style, demod, noise, noise_w, bias, act)
+    if split:
+        x_amax, y_amax = _amax_in(x, x_amax), _amax_out(y_amax)
+        check(lib().rw_conv3x3_wino4h_f32(_p(x), _p(uf), _p(y), b, i, out_ch, h, w, float(w_scale), ctypes.byref(ep),
+                                          _p(x_amax), _p(y_amax), _stream()))
+        return y
     check(lib().rw_conv3x3_wino4_f32(_p(x), _p(uf), _p(y), b, i, out_ch, h, w, float(w_scale), ctypes.byref(ep),
                                      _stream()))
     return y
@@ -325,9 +372,9 @@ def wino4_to_rgb_supported(out_ch, in_ch, height, width):
 
 
 def conv3x3_wino4_to_rgb(x, uf, out_ch, w_scale, rgb_weight, rgb_style, rgb_bias, rgb_skip, rgb_scale, style=None,
-                         demod=None, noise=None, noise_w=None, bias=None, act=False):
+                         demod=None, noise=None, noise_w=None, bias=None, act=False, x_amax=None):
     """conv3x3_wino4 with ToRGB in the epilogue (out_ch == 32): returns (None, rgb image); the feature map is not
-    written."""
+    written.  Split weights and x_amax as in conv3x3_wino4."""
     x = _dev(x, 'fmap')
     uf = _dev(uf, 'packed weight')
     rgb_weight = _dev(rgb_weight, 'rgb weight').contiguous()
@@ -339,13 +386,17 @@ def conv3x3_wino4_to_rgb(x, uf, out_ch, w_scale, rgb_weight, rgb_style, rgb_bias
         raise ValueError('rgb weight / style shapes')
     if rgb_skip is not None and tuple(rgb_skip.shape) != (b, 3, h, w):
         raise ValueError('rgb skip shape')
-    if uf.numel() != lib().rw_packed_conv_weight_wino4_elems(out_ch, i):
-        raise ValueError('packed weight does not come from pack_conv_weight_wino4(%d x %d)' % (out_ch, i))
+    split = _wino4_split(uf, out_ch, i)
     rgb = torch.empty(b, 3, h, w, device=x.device, dtype=x.dtype)
     ep, keep = _epilogue(style, demod, noise, noise_w, bias, act)
     from ._lib import RgbEpilogue
     re = RgbEpilogue(_p(rgb_weight).value, _p(rgb_style).value, _p(rgb_bias).value, _p(rgb_skip).value,
                      _p(rgb).value, float(rgb_scale))
+    if split:
+        x_amax = _amax_in(x, x_amax)
+        check(lib().rw_conv3x3_wino4h_to_rgb_f32(_p(x), _p(uf), b, i, out_ch, h, w, float(w_scale), ctypes.byref(ep),
+                                                 ctypes.byref(re), _p(x_amax), _stream()))
+        return None, rgb
     check(lib().rw_conv3x3_wino4_to_rgb_f32(_p(x), _p(uf), b, i, out_ch, h, w, float(w_scale), ctypes.byref(ep),
                                             ctypes.byref(re), _stream()))
     return None, rgb
@@ -451,29 +502,38 @@ def conv_transpose_blur_wino4_supported(out_ch, in_ch, height, width):
     return bool(lib().rw_conv_transpose_blur_wino4_supported(int(out_ch), int(in_ch), int(height), int(width)))
 
 
-def pack_conv_transpose_blur_weight_wino4(weight, k4):
-    """F(4x4,3x3) weights of the four output-parity phases of conv_transpose(stride 2) followed by the 4x4 FIR k4."""
+def pack_conv_transpose_blur_weight_wino4(weight, k4, split=False):
+    """F(4x4,3x3) weights of the four output-parity phases of conv_transpose(stride 2) followed by the 4x4 FIR k4;
+    split=True: as f16 pairs (pack_conv_weight_wino4)."""
     weight = _dev(weight, 'weight')
     k4 = _dev(k4, 'blur kernel').contiguous()
     if tuple(k4.shape) != (4, 4):
         raise ValueError('the blur kernel must be 4 x 4')
     o, i = weight.shape[-4], weight.shape[-3]
-    n = lib().rw_packed_conv_transpose_blur_wino4_elems(o, i)
+    n = (lib().rw_packed_conv_transpose_blur_wino4h_elems if split
+         else lib().rw_packed_conv_transpose_blur_wino4_elems)(o, i)
     if n <= 0:
         raise ValueError('no F(4x4,3x3) phase packing for a %d x %d transposed-conv weight' % (o, i))
     uf = torch.empty(n, device=weight.device, dtype=torch.float32)
-    check(lib().rw_pack_conv_transpose_blur_weight_wino4_f32(_p(weight), _p(k4), _p(uf), o, i, _stream()))
+    pack = (lib().rw_pack_conv_transpose_blur_weight_wino4h_f32 if split
+            else lib().rw_pack_conv_transpose_blur_weight_wino4_f32)
+    check(pack(_p(weight), _p(k4), _p(uf), o, i, _stream()))
     return uf
 
 
 def conv_transpose3x3s2_blur_wino4(x, uf, out_ch, w_scale, style=None, demod=None, noise=None, noise_w=None,
-                                   bias=None, act=False, post_scale=None):
+                                   bias=None, act=False, post_scale=None, x_amax=None, y_amax=None):
     """conv_transpose3x3s2 -> blur(pad 1,1) -> noise -> bias + leaky ReLU in one pass: (B,Cin,H,W) -> (B,Cout,2H,2W),
-    the four output-parity phases as virtual channels of the F(4x4,3x3) kernel (its error class: image generation)."""
+    the four output-parity phases as virtual channels of the F(4x4,3x3) kernel (its error class: image generation).
+    Split weights, x_amax and y_amax (max |y|, post_scale included) as in conv3x3_wino4."""
     x = _dev(x, 'fmap')
     uf = _dev(uf, 'packed weight')
     b, i, h, w = x.shape
-    if uf.numel() != lib().rw_packed_conv_transpose_blur_wino4_elems(out_ch, i):
+    if uf.numel() == lib().rw_packed_conv_transpose_blur_wino4_elems(out_ch, i):
+        split = False
+    elif uf.numel() == lib().rw_packed_conv_transpose_blur_wino4h_elems(out_ch, i):
+        split = True
+    else:
         raise ValueError('packed weight does not come from pack_conv_transpose_blur_weight_wino4(%d x %d)'
                          % (out_ch, i))
     y = torch.empty(b, out_ch, 2 * h, 2 * w, device=x.device, dtype=x.dtype)
@@ -481,6 +541,12 @@ def conv_transpose3x3s2_blur_wino4(x, uf, out_ch, w_scale, style=None, demod=Non
     post_scale = _opt(post_scale, 'post scale')
     if post_scale is not None and tuple(post_scale.shape) != (b, out_ch):
         raise ValueError('post_scale must be batch x out_ch')
+    if split:
+        x_amax, y_amax = _amax_in(x, x_amax), _amax_out(y_amax)
+        check(lib().rw_conv_transpose3x3s2_blur_wino4h_f32(_p(x), _p(uf), _p(y), b, i, out_ch, h, w, float(w_scale),
+                                                           ctypes.byref(ep), _p(post_scale), _p(x_amax), _p(y_amax),
+                                                           _stream()))
+        return y
     check(lib().rw_conv_transpose3x3s2_blur_wino4_f32(_p(x), _p(uf), _p(y), b, i, out_ch, h, w, float(w_scale),
                                                       ctypes.byref(ep), _p(post_scale), _stream()))
     return y

@@ -44,8 +44,11 @@ def main(batch=int(os.environ.get('RW_BATCH', '8')), iters=5, impl=int(os.enviro
                       bias=torch.randn(cout, device=dev), act=True)
         if wino:
             uf = hip.pack_conv_weight_wino(w)
+        w4split = os.environ.get('RW_W4_MM', 'f32') != 'f32'        # F(4x4,3x3) on the 16-bit pipe (f16 operand pairs)
         if wino4:
-            uf = hip.pack_conv_weight_wino4(w)
+            uf = hip.pack_conv_weight_wino4(w, split=w4split)
+        amax = hip.absmax(x) if w4split else None                   # as a producer leaves it behind: not timed
+        w4kw = dict(x_amax=amax) if w4split else {}
         upw = os.environ.get('RW_UP_ALGO') == 'wino' and up and hip.conv_transpose_wino_supported(cout, cin, res, res)
         if upw:
             ufu = hip.pack_conv_transpose_weight_wino(w)
@@ -60,7 +63,7 @@ def main(batch=int(os.environ.get('RW_BATCH', '8')), iters=5, impl=int(os.enviro
         upf = upmode == 'fused' and hip.conv_transpose_blur_wino4_supported(cout, cin, res, res)
         upb = upmode == 'wino+blur' and hip.conv_transpose_wino_supported(cout, cin, res, res)
         if upf:
-            uf4 = hip.pack_conv_transpose_blur_weight_wino4(w, k4)
+            uf4 = hip.pack_conv_transpose_blur_weight_wino4(w, k4, split=w4split)
         if upb:
             ufu = hip.pack_conv_transpose_weight_wino(w)
             yout = torch.empty(batch, cout, 2 * res + 1, 2 * res + 1, device=dev)
@@ -69,10 +72,10 @@ def main(batch=int(os.environ.get('RW_BATCH', '8')), iters=5, impl=int(os.enviro
                 hip.conv_transpose3x3s2(x, wp, cout, 1.0, style=style, demod=dm, impl=8, out=yout)
                 hip.conv_transpose3x3s2_wino(x, ufu, cout, 1.0, style=style, demod=dm, out=yout)
                 return hip.blur_noise_act(yout, k4, epu['noise'], epu['noise_w'], epu['bias'])
-        fn = (lambda: hip.conv_transpose3x3s2_blur_wino4(x, uf4, cout, 1.0, style=style, demod=dm, act=True, **epu)) if upf else \
+        fn = (lambda: hip.conv_transpose3x3s2_blur_wino4(x, uf4, cout, 1.0, style=style, demod=dm, act=True, **epu, **w4kw)) if upf else \
              two_pass if upb else \
              (lambda: hip.conv_transpose3x3s2_wino(x, ufu, cout, 1.0, style=style, demod=dm, out=yout)) if upw else \
-             (lambda: hip.conv3x3_wino4(x, uf, cout, 1.0, style=style, demod=dm, **ep)) if wino4 else \
+             (lambda: hip.conv3x3_wino4(x, uf, cout, 1.0, style=style, demod=dm, **ep, **w4kw)) if wino4 else \
              (lambda: hip.conv3x3_wino(x, uf, cout, 1.0, style=style, demod=dm, **ep)) if wino else \
              (lambda: hip.conv3x3_bf16x6(x, wb, cout, 1.0, style=style, demod=dm, **ep)) if split else \
              (lambda: hip.conv_transpose3x3s2(x, wp, cout, 1.0, style=style, demod=dm, impl=impl)) if up else \
@@ -89,7 +92,7 @@ def main(batch=int(os.environ.get('RW_BATCH', '8')), iters=5, impl=int(os.enviro
         flops = 2.0 * 9 * cin * cout * res * res * batch
         out_res = 2 * res + 1 if up else res
         bytes_io = 4.0 * batch * (cin * res * res + cout * out_res * out_res)
-        rows.append(dict(layer=name, cin=cin, cout=cout, res=res, up=up, upmode=upmode, wino=bool(wino) or ('f4' if wino4 else False), ms=round(ms, 4),
+        rows.append(dict(layer=name, cin=cin, cout=cout, res=res, up=up, upmode=upmode, wino=bool(wino) or ('f4' if wino4 else False), mm=os.environ.get('RW_W4_MM', 'f32') if (wino4 or upf) else None, ms=round(ms, 4),
                          tflops=round(flops / ms / 1e9, 2), io_gbs=round(bytes_io / ms / 1e6, 1)))
         print(rows[-1])
         del x, w

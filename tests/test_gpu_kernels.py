@@ -344,8 +344,11 @@ WINO4_CASES = [(1, 8, 32, 8, 64), (2, 64, 64, 16, 64), (1, 128, 128, 32, 64), (2
                (1, 128, 128, 256, 256)]
 
 
+# 'f32': the products on fp32 MFMAs; 'split' / 'split-ps': every operand as an exact pair of f16 numbers on the 16-bit
+# matrix pipe, without / with the 36 points split between the two out-channel waves -- the same bars for all three
+@pytest.mark.parametrize('mm', ['f32', 'split', 'split-ps'])
 @pytest.mark.parametrize('case', WINO4_CASES)
-def test_winograd_f4_conv_matches_oracle_within_its_error_class(case):
+def test_winograd_f4_conv_matches_oracle_within_its_error_class(case, mm, monkeypatch):
     """hip.conv3x3_wino4 (F(4x4,3x3), opt-in) against the direct kernel, the oracle's convolution with the full
     epilogue, and float64: the result of the same convolution, at the accuracy the algorithm has in fp32 -- 1e-5
     relative (Frobenius) and 1e-4 of the output range, an order of magnitude looser than the default kernels."""
@@ -353,6 +356,9 @@ def test_winograd_f4_conv_matches_oracle_within_its_error_class(case):
     from oracle import restatement as R
     b, i, o, h, w = case
     assert hip.wino4_supported(o, i, h, w)
+    split = mm != 'f32'
+    if split:
+        monkeypatch.setenv('RW_W4H_PS', '1' if mm == 'split-ps' else '0')
     x, wt, style = _conv_inputs(*case, seed=41)
     rs = numpy.random.RandomState(42)
     x = x * torch.from_numpy(numpy.exp(1.5 * rs.randn(1, i, 1, 1)).astype('float32'))
@@ -361,11 +367,18 @@ def test_winograd_f4_conv_matches_oracle_within_its_error_class(case):
     noise = torch.from_numpy(rs.randn(b, h * w).astype('float32'))
     s = 1 / math.sqrt(i * 9)
     dm = hip.demod(hip.weight_sqsum(wt.to(DEV), s), style.to(DEV))
-    uf = hip.pack_conv_weight_wino4(wt.to(DEV))
+    uf = hip.pack_conv_weight_wino4(wt.to(DEV), split=split)
     wp = hip.pack_conv_weight(wt.to(DEV), 0)
     plain = hip.conv3x3_wino4(x.to(DEV), uf, o, s, style=style.to(DEV), demod=dm)
     direct = hip.conv3x3(x.to(DEV), wp, o, s, style=style.to(DEV), demod=dm, impl=0 if i % 16 == 0 else 1)
     scale = direct.abs().max().item()
+    if split:
+        # the bound on the input may be loose, and the kernel reports the maximum of what it wrote
+        amax, ymax = hip.absmax(x.to(DEV)), torch.zeros(1, device=DEV)
+        assert amax.item() == x.abs().max().item()
+        loose = hip.conv3x3_wino4(x.to(DEV), uf, o, s, style=style.to(DEV), demod=dm, x_amax=amax * 37.0, y_amax=ymax)
+        assert ymax.item() == loose.abs().max().item()
+        assert rel(loose, plain) < 2e-6, rel(loose, plain)
     assert (plain - direct).abs().max().item() < 1e-4 * scale, (plain - direct).abs().max().item() / scale
     assert rel(plain, direct) < 2e-5, rel(plain, direct)
     args = dict(style=style.to(DEV), demod=dm, noise=noise.to(DEV), noise_w=nw.to(DEV), bias=bias.to(DEV), act=True)
@@ -484,8 +497,9 @@ UP_BLUR_CASES = [(2, 16, 8, 8, 64), (1, 64, 32, 16, 64), (1, 128, 64, 8, 128), (
                  (1, 24, 40, 8, 64), (1, 64, 32, 512, 512)]
 
 
+@pytest.mark.parametrize('mm', ['f32', 'split', 'split-ps'])
 @pytest.mark.parametrize('case', UP_BLUR_CASES)
-def test_one_pass_upsampling_conv_matches_conv_then_blur(case):
+def test_one_pass_upsampling_conv_matches_conv_then_blur(case, mm, monkeypatch):
     """hip.conv_transpose3x3s2_blur_wino4 (the four output-parity phases of conv_transpose (*) blur as virtual channels
     of the F(4x4,3x3) kernel, noise + bias + leaky ReLU in its epilogue) against the two-pass route of the same library
     (direct transposed conv -> blur_noise_act) and the oracle, at the F(4x4,3x3) bars."""
@@ -493,6 +507,9 @@ def test_one_pass_upsampling_conv_matches_conv_then_blur(case):
     from oracle import restatement as R
     b, i, o, h, w = case
     assert hip.conv_transpose_blur_wino4_supported(o, i, h, w)
+    split = mm != 'f32'
+    if split:
+        monkeypatch.setenv('RW_W4H_PS', '1' if mm == 'split-ps' else '0')
     x, wt, style = _conv_inputs(*case, seed=61)
     rs = numpy.random.RandomState(62)
     x = x * torch.from_numpy(numpy.exp(1.0 * rs.randn(1, i, 1, 1)).astype('float32'))
@@ -507,12 +524,15 @@ def test_one_pass_upsampling_conv_matches_conv_then_blur(case):
     wp = hip.pack_conv_weight(wt.to(DEV), 1)
     wide = hip.conv_transpose3x3s2(x.to(DEV), wp, o, s, style=style.to(DEV), demod=dm,
                                    impl=0 if i % 16 == 0 and o % 32 == 0 else 1)
-    uf = hip.pack_conv_transpose_blur_weight_wino4(wt.to(DEV), k4)
+    uf = hip.pack_conv_transpose_blur_weight_wino4(wt.to(DEV), k4, split=split)
     results = []
     for kw in (dict(noise=noise, noise_w=nw, bias=bias, act=True), dict()):
         want = hip.blur_noise_act(wide, k4, kw.get('noise'), kw.get('noise_w'), kw.get('bias'))
-        got = hip.conv_transpose3x3s2_blur_wino4(x.to(DEV), uf, o, s, style=style.to(DEV), demod=dm, **kw)
+        ymax = torch.zeros(1, device=DEV)
+        got = hip.conv_transpose3x3s2_blur_wino4(x.to(DEV), uf, o, s, style=style.to(DEV), demod=dm,
+                                                 **(dict(kw, y_amax=ymax) if split else kw))
         assert got.shape == want.shape == (b, o, 2 * h, 2 * w)
+        assert not split or ymax.item() == got.abs().max().item()
         scale = want.abs().max().item()
         assert (got - want).abs().max().item() < 1e-4 * scale, (got - want).abs().max().item() / scale
         assert rel(got, want) < 3e-5, rel(got, want)
