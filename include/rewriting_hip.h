@@ -302,6 +302,24 @@ int rw_conv_transpose3x3s2_blur_wino4h_f32(const float* x, const float* uf, floa
                                            const float* post_scale, const float* x_amax, float* y_amax,
                                            rw_stream_t stream);
 
+/* rw_conv_transpose3x3s2_wino_f32 (the F(2,2) quads of the stride-2 transposed convolution) with its 25 GEMMs on the
+ * 16-bit matrix pipe and the exact f16 operand split of the wino4h entry points (rw_upwino.hip): one
+ * v_mfma_f32_16x16x32_f16 per point takes the two k-quads of an 8-channel interval (25 MFMAs of ~17 cycles per 8
+ * channels against 50 fp32 MFMAs of 32 that block the vector lanes).  Coefficients 0, +-1 as before: the direct sum's
+ * error class plus <= 2^-21 per product (tested at the fp32 kernel's bars).  Wide maps only: w % 32 == 0, h % 4 == 0,
+ * 16 <= in_ch <= 512, in_ch % 8 == 0, out_ch % 32 == 0.
+ *   uf: rw_packed_conv_transpose_winoh_elems = 16*out_ch*in_ch + 4 floats from rw_pack_conv_transpose_winoh_f32 (the
+ *       25 points carry 16 distinct weights): uf[o / 16][i / 8][wi = 0..15][lane = 16 ((i % 8) % 4) + o % 16]
+ *       [{0: Uh, 1: Ul}], each 32-bit word the f16 pair of channels (i, i + 4) of the interval; trailer
+ *       [2^-eU, 0, max |U|, 0];
+ *   x_amax: device scalar >= max |x| (before the style), as for rw_conv3x3_wino4h_f32. */
+int rw_conv_transpose3x3s2_winoh_supported(int out_ch, int in_ch, int h, int w);
+long long rw_packed_conv_transpose_winoh_elems(int out_ch, int in_ch);
+int rw_pack_conv_transpose_winoh_f32(const float* w, float* uf, int out_ch, int in_ch, rw_stream_t stream);
+int rw_conv_transpose3x3s2_winoh_f32(const float* x, const float* uf, float* y, int batch, int in_ch, int out_ch,
+                                     int h, int w, float w_scale, const float* style, const float* demod,
+                                     const float* x_amax, rw_stream_t stream);
+
 /* NoiseInjectionF (models.py:535-546): y[b][c][p] = x[b][c][p] + noise_w[0] * noise[b][p] */
 int rw_noise_add_f32(const float* x, const float* noise, const float* noise_w, float* y,
                      int batch, int channels, int64_t hw, rw_stream_t stream);

@@ -101,6 +101,11 @@ SIGNATURES = {
     'rw_pack_conv_transpose_wino_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     'rw_conv_transpose3x3s2_wino_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                                 c_float, c_void_p, c_void_p, c_void_p]),
+    'rw_conv_transpose3x3s2_winoh_supported': (c_int, [c_int, c_int, c_int, c_int]),
+    'rw_packed_conv_transpose_winoh_elems': (ctypes.c_longlong, [c_int, c_int]),
+    'rw_pack_conv_transpose_winoh_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    'rw_conv_transpose3x3s2_winoh_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                                 c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     'rw_conv3x3_wino4_to_rgb_supported': (c_int, [c_int, c_int, c_int, c_int]),
     'rw_conv3x3_wino4_to_rgb_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                             POINTER(ConvEpilogue), POINTER(RgbEpilogue), c_void_p]),

@@ -30,10 +30,26 @@
 // are the strip problems of rw_conv.hip (rw_conv_transpose3x3s2_f32 impl 8), as for conv_up_halo_kernel.
 //   weights: uf[o / 16][i / 4][q = 0..6][lane = 16 (i % 4) + o % 16][xi % 4], xi = 4 q + e (25..27 are zero)
 #include "rw_common.h"
-
+//
+// H16 (round 4): the 25 GEMMs on the 16-bit matrix pipe with an exact operand split (the scheme of rw_wino4.hip's H16
+// kernels: T 2^eV = Th + Tl, U 2^eU = Uh + Ul in f16, all four products accumulated in fp32).  This kernel is bound by
+// its fp32 MFMAs (74 % busy, 0.9 VALU per MFMA), so the split pays here: an interval already spans two k-quads, and
+// ONE v_mfma_f32_16x16x32_f16 takes both -- lane group lk holds channels (lk, lk + 4) of the interval,
+//   A = [Uh0, Uh1, Ul0, Ul1, Uh0, Uh1, Ul0, Ul1]    (two weight words, duplicated)
+//   B = [Th0, Th1, Th0, Th1, Tl0, Tl1, Tl0, Tl1]    (v_cvt_pk_f16_f32 converts the pair of channels at once)
+// -- 25 MFMAs of ~17 cycles per 8 channels instead of 50 of 32, the 16 distinct transformed inputs split once per
+// interval (4 VALU per pair) and kept as operand quads.  |T| <= 4 max |x style| and |U| <= 4 max |w|: eV from the
+// caller's x_amax, eU at pack time (trailer, as in rw_wino4.hip).  Packed weights: the 25 points carry 16 distinct values
+// (9 of phase (0,0), 3 + 3 of the mixed phases, 1 of phase (1,1)): uf[o / 16][i / 8][wi = 0..15][lane][{0: Uh pair,
+// 1: Ul pair}] -- 16 KB per interval and workgroup where the fp32 packing streams 28.
+#include <stdlib.h>
 typedef float uw_f32x4 __attribute__((ext_vector_type(4)));
 typedef float uw_f32x2 __attribute__((ext_vector_type(2)));
 typedef int uw_i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned uw_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned uw_u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 uw_f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 uw_f16x8 __attribute__((ext_vector_type(8)));
 
 struct UpWinoProblem {
   const float* x; const float* uf; float* y;
@@ -41,8 +57,13 @@ struct UpWinoProblem {
   int batch, in_ch, out_ch, h, w;
   int groups_x, groups_y, gpw;
   float w_scale;
+  const float* x_amax;          // H16: device scalar >= max |x|
 };
 
+#ifndef UW_ABL
+#define UW_ABL 0          // timing ablations (results WRONG): 2 = no patch pieces, 4 = no weight pieces, 8 = no epilogue;
+                          // H16: 16 = no operand split, 32 = no MFMAs, 64 = no weight reads from LDS
+#endif
 #ifndef UW_NTS
 #define UW_NTS 0          // non-temporal stores of the (2H+1)^2 map (A/B builds)
 #endif
@@ -74,8 +95,9 @@ __device__ __forceinline__ void uw_dma_global_b128_s(unsigned lds_addr, int voff
 // are per lane (registers) instead of per workgroup, and the input arrives ALREADY multiplied by its style (the host
 // side does that on these tiny maps: a per-image style table for 8 images would not fit beside the rings).
 // Everything else is unchanged.
-template <int NRW>
+template <int NRW, bool H16 = false>
 __device__ __forceinline__ void conv_up_wino_body(const UpWinoProblem& p) {
+  static_assert(!H16 || NRW == 0, "the split-operand form is written for the wide maps");
   constexpr int PITCH = NRW == 16 ? 20 : (NRW == 8 ? 10 : (NRW == 4 ? 6 : UW_PITCH));      // row pitch of a patch channel
   constexpr int PROWS = NRW == 16 ? 9 : (NRW == 8 ? 9 : 5);
   constexpr int PCOLS = NRW == 16 ? 17 : (NRW == 8 ? 9 : (NRW == 4 ? 5 : 33));
@@ -84,7 +106,8 @@ __device__ __forceinline__ void conv_up_wino_body(const UpWinoProblem& p) {
   constexpr int UW_PIECES = NRW == 4 ? 4 : 3;     // 64-float pieces per channel
   constexpr int IC = 8;                           // channels per interval: two k-quads
   constexpr int PSZ = IC * UW_PIECES * 64;        // floats per patch ring slot
-  constexpr int USZ = 2 * 2 * 7 * 256;            // floats per weight ring slot: [16-channel half][k-quad][7][256]
+  // floats per weight ring slot: [16-channel half][k-quad][7][256]; H16: [half][16 distinct weights][64 lanes][2 words]
+  constexpr int USZ = H16 ? 2 * 16 * 128 : 2 * 2 * 7 * 256;
   __shared__ __attribute__((aligned(16))) float Ps[3 * PSZ];
   __shared__ __attribute__((aligned(16))) float Us[2 * USZ];
   __shared__ float St[IPW == 1 ? 512 : 1];        // IPW > 1: the input carries its style already
@@ -117,8 +140,25 @@ __device__ __forceinline__ void conv_up_wino_body(const UpWinoProblem& p) {
   const int VT = p.gpw * NC;
 
   if (IPW == 1) {
-    for (int i = tid; i < p.in_ch; i += 256) St[i] = p.style ? p.style[(int64_t)ib * p.in_ch + i] : 1.0f;
-    if (tid < 32) Sc[tid] = p.demod ? p.demod[(int64_t)ib * p.out_ch + o0 + tid] * p.w_scale : p.w_scale;
+    float in_scale = 1.f, out_scale = 1.f;       // H16: 2^eV on the input (style table), 2^-(eU + eV) on the result
+    if (H16) {
+      __shared__ float Red[4];
+      float smax = p.style ? 0.f : 1.f;
+      if (p.style)
+        for (int i = tid; i < p.in_ch; i += 256) smax = fmaxf(smax, fabsf(p.style[(int64_t)ib * p.in_ch + i]));
+#pragma unroll
+      for (int off = 32; off; off >>= 1) smax = fmaxf(smax, __shfl_xor(smax, off));
+      if (lane == 0) Red[wave] = smax;
+      __syncthreads();
+      smax = fmaxf(fmaxf(Red[0], Red[1]), fmaxf(Red[2], Red[3]));
+      const float am = p.x_amax[0] * smax;                        // |T| <= 4 am < 2^(e + 2)
+      int e = (int)((__float_as_uint(am) >> 23) & 0xff) - 126;    // am < 2^e
+      e = e < -100 ? -100 : (e > 100 ? 100 : e);
+      in_scale = __uint_as_float((unsigned)(127 + 12 - e) << 23);
+      out_scale = __uint_as_float((unsigned)(127 + e - 12) << 23) * p.uf[(int64_t)16 * p.out_ch * p.in_ch];
+    }
+    for (int i = tid; i < p.in_ch; i += 256) St[i] = (p.style ? p.style[(int64_t)ib * p.in_ch + i] : 1.0f) * in_scale;
+    if (tid < 32) Sc[tid] = (p.demod ? p.demod[(int64_t)ib * p.out_ch + o0 + tid] * p.w_scale : p.w_scale) * out_scale;
   }
   const bool img_ok = img_l < nimg;
   float scl[4] = {p.w_scale, p.w_scale, p.w_scale, p.w_scale};        // IPW > 1: this lane's demodulation factors
@@ -157,12 +197,22 @@ __device__ __forceinline__ void conv_up_wino_body(const UpWinoProblem& p) {
   };
   // piece s = 0 .. 2 UW_PIECES - 1: channel 2 wave + s / UW_PIECES, piece s % UW_PIECES
   auto pload_piece = [&](int s) __attribute__((always_inline)) {
+    if (UW_ABL & 2) return;
     uw_dma_buffer_b32(p_dst + 256 * s, xoff[s % UW_PIECES], xsrc, p_soff + (s / UW_PIECES) * hw4);
   };
   // weights of an interval: 28 one-KB pieces [half 2][k-quad 2][7]; wave w copies pieces 7 w .. 7 w + 6
   const int kq_total = p.in_ch >> 2;
   const int a_lane = lane * 4;
   auto uload = [&](int slot, int fc) __attribute__((always_inline)) {
+    if (UW_ABL & 4) return;
+    if (H16) {
+      // 16 one-KB pieces [half 2][8]; wave w copies pieces 4 w .. 4 w + 3 (half w / 2)
+      const float* src = p.uf + ((int64_t)((o0 >> 4) + (wave >> 1)) * (p.in_ch >> 3) + fc) * (16 * 128) + (wave & 1) * 1024;
+      const unsigned dst = us_base + (unsigned)((slot * USZ + wave * 1024) * 4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) uw_dma_global_b128_s(dst + q * 1024, a_lane * 4, src + q * 256);
+      return;
+    }
     const int hf = wave >> 1, kql = wave & 1;
     const float* src = p.uf + ((int64_t)((o0 >> 4) + hf) * kq_total + 2 * fc + kql) * (7 * 256);       // uniform
     const unsigned dst = us_base + (unsigned)((slot * USZ + (hf * 2 + kql) * (7 * 256)) * 4);
@@ -217,6 +267,99 @@ __device__ __forceinline__ void conv_up_wino_body(const UpWinoProblem& p) {
             acc[xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[q % 3][e], T[vr][hc], acc[xi], 0, 0, 0);
           }
         }
+      }
+    }
+  };
+
+  // H16: both k-quads of the interval in one K = 32 MFMA per point (see the header)
+  auto compute16 = [&](int ring, int uslot, int c, bool spread) __attribute__((always_inline)) {
+    float T[2][4][4];
+#pragma unroll
+    for (int kql = 0; kql < 2; ++kql) {
+      const float* src = &Ps[ring * PSZ + kql * 4 * (UW_PIECES * 64) + item_off];
+      const float sv = St[IC * c + 4 * kql + lk];
+      float d[3][3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const uw_f32x2 lo = *reinterpret_cast<const uw_f32x2*>(src + r * PITCH);
+        d[r][0] = lo[0] * sv; d[r][1] = lo[1] * sv; d[r][2] = src[r * PITCH + 2] * sv;
+      }
+      float t[4][3];
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) {
+        t[0][cc] = d[0][cc] - d[1][cc]; t[1][cc] = d[1][cc]; t[2][cc] = d[2][cc] - d[1][cc]; t[3][cc] = d[2][cc];
+      }
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        T[kql][v][0] = t[v][0] - t[v][1]; T[kql][v][1] = t[v][1]; T[kql][v][2] = t[v][2] - t[v][1]; T[kql][v][3] = t[v][2];
+      }
+    }
+    // the 16 operand quads (Th pair, Th pair, Tl pair, Tl pair)
+    uw_f16x8 B[4][4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+      for (int hc = 0; hc < 4; ++hc) {
+        const float t0 = T[0][v][hc], t1 = T[1][v][hc];
+        if (UW_ABL & 16) {
+          const uw_f16x2 h0 = __builtin_bit_cast(uw_f16x2, t0), h1 = __builtin_bit_cast(uw_f16x2, t1);
+          B[v][hc] = uw_f16x8{h0[0], h0[1], h1[0], h1[1], h0[0], h0[1], h1[0], h1[1]};
+        } else {
+          const uw_f16x2 hh = __builtin_convertvector(uw_f32x2{t0, t1}, uw_f16x2);
+          float r0, r1;
+          asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hh), "v"(t0));
+          asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hh), "v"(t1));
+          const uw_f16x2 ll = __builtin_convertvector(uw_f32x2{r0, r1}, uw_f16x2);
+          B[v][hc] = uw_f16x8{hh[0], hh[1], hh[0], hh[1], ll[0], ll[1], ll[0], ll[1]};
+        }
+      }
+    // weights: the 25 points carry 16 distinct values (E x O, O x E and O x O repeat theirs), (Uh pair, Ul pair) of
+    // value wi at byte 512 wi + 8 lane (consecutive lanes 8 bytes apart: no bank conflicts -- 16 bytes apart cost
+    // this loop half its time in SQ_WAIT_INST_LDS).  The operand wants the two words twice: the vector ALU binds this
+    // loop and the LDS is a quarter busy, so ds_read2_b64 reads the same eight bytes into both halves of the operand
+    // instead of two v_mov copying them.  The reads are inline assembly (the compiler has no way to say "the same
+    // address twice"), four values per batch, one batch ahead.  The compiler takes an asm's outputs for ready: the
+    // operands reach the MFMAs only through the asm that waits (scripts/check_asm_loads.py checks the assembly).
+    const unsigned ua = us_base + (unsigned)((uslot * USZ + wm * (16 * 128) + 2 * lane) * 4);
+    uw_u32x4 aq[2][4];
+    auto aload = [&](int wi, uw_u32x4& dst) __attribute__((always_inline)) {
+      // offsets of ds_read2_b64 count 8-byte units and stop at 255: one base per four values
+      if (UW_ABL & 64) { dst = uw_u32x4{ua, (unsigned)wi, ua, 1u}; return; }
+      asm volatile("ds_read2_b64 %0, %1 offset0:%2 offset1:%2" : "=&v"(dst) : "v"(ua + (wi >> 2) * 2048), "n"((wi & 3) * 64));
+    };
+    auto point = [&](int xi, const uw_u32x4& a) __attribute__((always_inline)) {
+      const int vr = xi < 9 ? xi / 3 : (xi < 15 ? (xi - 9) / 2 : (xi < 21 ? 1 + 2 * ((xi - 15) / 3) : 1 + 2 * ((xi - 21) / 2)));
+      const int hc = xi < 9 ? xi % 3 : (xi < 15 ? 1 + 2 * ((xi - 9) % 2) : (xi < 21 ? (xi - 15) % 3 : 1 + 2 * ((xi - 21) % 2)));
+      if (UW_ABL & 32) asm volatile("" :: "v"(a), "v"(B[vr][hc]));
+      else acc[xi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(uw_f16x8, a), B[vr][hc], acc[xi], 0, 0, 0);
+    };
+#pragma unroll
+    for (int e = 0; e < 4; ++e) aload(e, aq[0][e]);
+#pragma unroll
+    for (int bt = 0; bt < 4; ++bt) {
+      uw_u32x4 (&cur)[4] = aq[bt & 1];
+      if (bt < 3) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) aload(4 * (bt + 1) + e, aq[(bt + 1) & 1][e]);
+        // this batch's reads are older than the four just issued
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]) :: "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]) :: "memory");
+      }
+      if (spread) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          if (2 * bt + t < 2 * UW_PIECES) pload_piece(2 * bt + t);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int wi = 4 * bt + e;
+        // value wi serves: wi < 9 the point wi of phase (0,0); 9..11 the two columns of row wi - 9 of phase (0,1);
+        // 12..14 column wi - 12 of both rows of phase (1,0); 15 all of phase (1,1)
+        if (wi < 9) point(wi, cur[e]);
+        else if (wi < 12) { point(9 + 2 * (wi - 9), cur[e]); point(10 + 2 * (wi - 9), cur[e]); }
+        else if (wi < 15) { point(15 + (wi - 12), cur[e]); point(18 + (wi - 12), cur[e]); }
+        else { point(21, cur[e]); point(22, cur[e]); point(23, cur[e]); point(24, cur[e]); }
       }
     }
   };
@@ -303,9 +446,9 @@ __device__ __forceinline__ void conv_up_wino_body(const UpWinoProblem& p) {
     uload((v + 1) & 1, c + 1 < NC ? c + 1 : 0);     // weights of interval v + 1 (same slices for every group)
     pload_begin(ring2, fg, fc);                     // patch of interval v + 2: pieces issued between the MFMAs
     advance();
-    compute(ring, v & 1, c, true);
+    if (H16) compute16(ring, v & 1, c, true); else compute(ring, v & 1, c, true);
     const bool last = c == NC - 1;
-    if (last) { group_epilogue(g); c = 0; ++g; } else { ++c; }
+    if (last) { if (!(UW_ABL & 8) || acc[0][0] == 12345.f) group_epilogue(g); c = 0; ++g; } else { ++c; }
     ring = ring == 2 ? 0 : ring + 1;
     sync_interval(last);
   }
@@ -314,23 +457,13 @@ __device__ __forceinline__ void conv_up_wino_body(const UpWinoProblem& p) {
 }
 
 __global__ void __launch_bounds__(256, 2) conv_up_wino_kernel(const UpWinoProblem p) { conv_up_wino_body<0>(p); }
+__global__ void __launch_bounds__(256, 2) conv_up_winoh_kernel(const UpWinoProblem p) { conv_up_wino_body<0, true>(p); }
 __global__ void __launch_bounds__(256, 2) conv_up_wino_narrow_kernel(const UpWinoProblem p) { conv_up_wino_body<16>(p); }
 __global__ void __launch_bounds__(256, 2) conv_up_wino_8x8_kernel(const UpWinoProblem p) { conv_up_wino_body<8>(p); }
 __global__ void __launch_bounds__(256, 2) conv_up_wino_4x4_kernel(const UpWinoProblem p) { conv_up_wino_body<4>(p); }
 
-// One thread: the 25 (+3 zero) values of one (o, i).  W[o][i][ky][kx] as rw_conv_transpose3x3s2_f32 sees it.
-__global__ void __launch_bounds__(256) pack_up_wino_kernel(const float* __restrict__ w, float* __restrict__ uf,
-                                                           int out_ch, int in_ch) {
-  const int64_t total = (int64_t)out_ch * in_ch;
-  const int kqn = in_ch >> 2;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    const int lane = (int)(idx & 63);
-    int64_t rest = idx >> 6;
-    const int kq = (int)(rest % kqn);
-    const int ob = (int)(rest / kqn);
-    const int o = 16 * ob + (lane & 15), i = 4 * kq + (lane >> 4);
-    const float* g = w + ((int64_t)o * in_ch + i) * 9;          // g[3 ky + kx]
+// the 25 (+3 zero) values of one (o, i): g[3 ky + kx] of W[o][i] as rw_conv_transpose3x3s2_f32 sees it
+__device__ __forceinline__ void uw_weight_points(const float* g, float (&u)[28]) {
     // vertical transforms of the three kernel rows: E -> (w[2], w[2] + w[0], w[0]); O -> (w[1], w[1])
     float ve[3][3], vo[2][3];
 #pragma unroll
@@ -338,7 +471,6 @@ __global__ void __launch_bounds__(256) pack_up_wino_kernel(const float* __restri
       ve[0][kx] = g[6 + kx]; ve[1][kx] = g[6 + kx] + g[kx]; ve[2][kx] = g[kx];
       vo[0][kx] = g[3 + kx]; vo[1][kx] = g[3 + kx];
     }
-    float u[28];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       u[3 * a + 0] = ve[a][2]; u[3 * a + 1] = ve[a][2] + ve[a][0]; u[3 * a + 2] = ve[a][0];       // E x E
@@ -350,11 +482,78 @@ __global__ void __launch_bounds__(256) pack_up_wino_kernel(const float* __restri
       u[21 + 2 * a + 0] = vo[a][1]; u[21 + 2 * a + 1] = vo[a][1];                                  // O x O
     }
     u[25] = u[26] = u[27] = 0.f;
+}
+
+// One thread: the values of one (o, i).  W[o][i][ky][kx] as rw_conv_transpose3x3s2_f32 sees it.
+__global__ void __launch_bounds__(256) pack_up_wino_kernel(const float* __restrict__ w, float* __restrict__ uf,
+                                                           int out_ch, int in_ch) {
+  const int64_t total = (int64_t)out_ch * in_ch;
+  const int kqn = in_ch >> 2;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int lane = (int)(idx & 63);
+    int64_t rest = idx >> 6;
+    const int kq = (int)(rest % kqn);
+    const int ob = (int)(rest / kqn);
+    const int o = 16 * ob + (lane & 15), i = 4 * kq + (lane >> 4);
+    float u[28];
+    uw_weight_points(w + ((int64_t)o * in_ch + i) * 9, u);
     float* dst = uf + ((int64_t)ob * kqn + kq) * (7 * 256) + lane * 4;
 #pragma unroll
     for (int q = 0; q < 7; ++q)
       *reinterpret_cast<uw_f32x4*>(dst + q * 256) = uw_f32x4{u[4 * q], u[4 * q + 1], u[4 * q + 2], u[4 * q + 3]};
   }
+}
+
+// H16 packing.  PASS 1: max |U| -> trailer[2] (bits, atomic max).  PASS 2: one thread per (o, channel pair (c, c + 4) of an
+// 8-channel interval): the words Uh pair / Ul pair of U 2^(15 - eu); the first thread writes 2^(eu - 15) to trailer[0].
+__device__ __forceinline__ unsigned uw_f16_bits(float v) { return (unsigned)__builtin_bit_cast(unsigned short, (_Float16)v); }
+template <int PASS>
+__global__ void __launch_bounds__(256) pack_up_winoh_kernel(const float* __restrict__ w, float* __restrict__ uf,
+                                                            int out_ch, int in_ch) {
+  const int ivn = in_ch >> 3;
+  const int64_t total = (int64_t)out_ch * (in_ch >> 1);
+  float* trailer = uf + (int64_t)16 * out_ch * in_ch;
+  float su = 1.f, inv = 1.f, m = 0.f;
+  if (PASS == 2) {
+    const unsigned bits = __float_as_uint(trailer[2]);
+    int eu = (int)((bits >> 23) & 0xff) - 126;
+    if (bits == 0u) eu = 15;
+    eu = eu < -100 ? -100 : (eu > 100 ? 100 : eu);
+    inv = __uint_as_float((unsigned)(127 + eu - 15) << 23);
+    su = __uint_as_float((unsigned)(127 + 15 - eu) << 23);
+  }
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int lane = (int)(idx & 63);
+    int64_t rest = idx >> 6;
+    const int iv = (int)(rest % ivn);
+    const int ob = (int)(rest / ivn);
+    const int o = 16 * ob + (lane & 15), c0 = 8 * iv + (lane >> 4), c1 = c0 + 4;
+    float u0[28], u1[28];
+    uw_weight_points(w + ((int64_t)o * in_ch + c0) * 9, u0);
+    uw_weight_points(w + ((int64_t)o * in_ch + c1) * 9, u1);
+    if (PASS == 1) {
+#pragma unroll
+      for (int i = 0; i < 25; ++i) m = fmaxf(m, fmaxf(fabsf(u0[i]), fabsf(u1[i])));
+    } else {
+      unsigned* dst = reinterpret_cast<unsigned*>(uf) + ((int64_t)ob * ivn + iv) * (16 * 128) + lane * 2;
+#pragma unroll
+      for (int wi = 0; wi < 16; ++wi) {
+        const int xi = wi < 9 ? wi : (wi < 12 ? 9 + 2 * (wi - 9) : (wi < 15 ? 15 + (wi - 12) : 21));    // a point that carries it
+        const float a = u0[xi] * su, b = u1[xi] * su;
+        const _Float16 ah = (_Float16)a, bh = (_Float16)b;
+        *reinterpret_cast<uw_u32x2*>(dst + wi * 128) =
+            uw_u32x2{uw_f16_bits(a) | (uw_f16_bits(b) << 16), uw_f16_bits(a - (float)ah) | (uw_f16_bits(b - (float)bh) << 16)};
+      }
+    }
+  }
+  if (PASS == 1) {
+#pragma unroll
+    for (int off = 32; off; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(trailer + 2), __float_as_uint(m));
+  }
+  if (PASS == 2 && blockIdx.x == 0 && threadIdx.x == 0) trailer[0] = inv;
 }
 
 static bool up_wino_narrow(int h, int w) { return w == 16 && h % 8 == 0; }
@@ -383,20 +582,22 @@ extern "C" int rw_pack_conv_transpose_wino_f32(const float* w, float* uf, int ou
   return RW_LAUNCH_RESULT();
 }
 
-#include <stdlib.h>
 // The quads y < H, x < W of the transposed convolution (everything but output row 2H and column 2W, which
 // rw_conv_transpose3x3s2_f32 impl 8 writes): y (B, out_ch, 2H+1, 2W+1).
-extern "C" int rw_conv_transpose3x3s2_wino_f32(const float* x, const float* uf, float* y, int batch, int in_ch,
-                                               int out_ch, int h, int w, float w_scale, const float* style,
-                                               const float* demod, rw_stream_t stream) {
+static int up_wino_launch(const float* x, const float* uf, float* y, int batch, int in_ch, int out_ch, int h, int w,
+                          float w_scale, const float* style, const float* demod, bool h16, const float* x_amax,
+                          rw_stream_t stream) {
   RW_CHECK_ARG(x && uf && y && batch > 0 && in_ch > 0 && out_ch > 0 && h > 0 && w > 0);
+  RW_CHECK_ARG(!h16 || x_amax);
   if (!up_wino_shape_ok(out_ch, in_ch, h, w)) return RW_ERR_UNSUPPORTED;
   const bool whole = up_wino_whole(h, w);
   if (whole && style) return RW_ERR_UNSUPPORTED;       // 8^2 and 4^2 maps arrive already multiplied by their style
   UpWinoProblem p;
   p.x = x; p.uf = uf; p.y = y; p.style = style; p.demod = demod;
   p.batch = batch; p.in_ch = in_ch; p.out_ch = out_ch; p.h = h; p.w = w; p.w_scale = w_scale;
+  p.x_amax = x_amax;
   const bool narrow = up_wino_narrow(h, w);
+  if (h16 && (whole || narrow || w % 32 != 0)) return RW_ERR_UNSUPPORTED;
   p.groups_x = (narrow || whole) ? 1 : w / 32;
   p.groups_y = whole ? 1 : (narrow ? h / 8 : h / 4);
   const int ipw = whole ? (w == 8 ? 2 : 8) : 1;        // images per workgroup
@@ -414,9 +615,45 @@ extern "C" int rw_conv_transpose3x3s2_wino_f32(const float* x, const float* uf, 
   p.gpw = gpw;
   const int64_t work = (int64_t)wg_batch * p.groups_y * (p.groups_x / gpw) * o_tiles;
   if (work <= 0 || work > 0x7fffffff) return RW_ERR_UNSUPPORTED;
-  if (whole && w == 8) hipLaunchKernelGGL(conv_up_wino_8x8_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
+  if (h16) hipLaunchKernelGGL(conv_up_winoh_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
+  else if (whole && w == 8) hipLaunchKernelGGL(conv_up_wino_8x8_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
   else if (whole) hipLaunchKernelGGL(conv_up_wino_4x4_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
   else if (narrow) hipLaunchKernelGGL(conv_up_wino_narrow_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
   else hipLaunchKernelGGL(conv_up_wino_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
   return RW_LAUNCH_RESULT();
+}
+
+extern "C" int rw_conv_transpose3x3s2_wino_f32(const float* x, const float* uf, float* y, int batch, int in_ch,
+                                               int out_ch, int h, int w, float w_scale, const float* style,
+                                               const float* demod, rw_stream_t stream) {
+  return up_wino_launch(x, uf, y, batch, in_ch, out_ch, h, w, w_scale, style, demod, false, nullptr, stream);
+}
+
+// ---- H16: the same quads with the products on the 16-bit matrix pipe (maps with w % 32 == 0, h % 4 == 0)
+extern "C" int rw_conv_transpose3x3s2_winoh_supported(int out_ch, int in_ch, int h, int w) {
+  return up_wino_shape_ok(out_ch, in_ch, h, w) && w % 32 == 0 && h % 4 == 0 ? 1 : 0;
+}
+
+extern "C" long long rw_packed_conv_transpose_winoh_elems(int out_ch, int in_ch) {
+  if (out_ch <= 0 || in_ch <= 0 || out_ch % 16 || in_ch % 8) return -1;
+  return 16LL * out_ch * in_ch + 4;
+}
+
+extern "C" int rw_pack_conv_transpose_winoh_f32(const float* w, float* uf, int out_ch, int in_ch, rw_stream_t stream) {
+  RW_CHECK_ARG(w && uf && out_ch > 0 && in_ch > 0);
+  if (out_ch % 16 || in_ch % 8) return RW_ERR_UNSUPPORTED;
+  const int64_t total = (int64_t)out_ch * (in_ch >> 1);
+  const hipError_t me = hipMemsetAsync(uf + (int64_t)16 * out_ch * in_ch, 0, 4 * sizeof(float), rw_s(stream));
+  if (me != hipSuccess) return (int)me;
+  hipLaunchKernelGGL(pack_up_winoh_kernel<1>, dim3(rw_stream_grid(total, 256)), dim3(256), 0, rw_s(stream), w, uf,
+                     out_ch, in_ch);
+  hipLaunchKernelGGL(pack_up_winoh_kernel<2>, dim3(rw_stream_grid(total, 256)), dim3(256), 0, rw_s(stream), w, uf,
+                     out_ch, in_ch);
+  return RW_LAUNCH_RESULT();
+}
+
+extern "C" int rw_conv_transpose3x3s2_winoh_f32(const float* x, const float* uf, float* y, int batch, int in_ch,
+                                                int out_ch, int h, int w, float w_scale, const float* style,
+                                                const float* demod, const float* x_amax, rw_stream_t stream) {
+  return up_wino_launch(x, uf, y, batch, in_ch, out_ch, h, w, w_scale, style, demod, true, x_amax, stream);
 }

@@ -1225,6 +1225,8 @@ __global__ void __launch_bounds__(256, 2) conv_wino36h_rgb_kernel(const Wino4Pro
 __global__ void __launch_bounds__(256, 2) conv_wino36h_ps_kernel(const Wino4Problem p) { conv_wino36b_body<2, 2, 0, true, true, true>(p); }
 __global__ void __launch_bounds__(256, 2) conv_up_wino36h_ps_kernel(const Wino4Problem p) { conv_wino36b_body<2, 2, 1, true, true, true>(p); }
 __global__ void __launch_bounds__(256, 2) conv_wino36h_rgb_ps_kernel(const Wino4Problem p) { conv_wino36b_body<2, 2, 2, true, true, true>(p); }
+// <4, 3>: one 512-thread workgroup per CU, 64 tiles per weight slice (RW_W4H_WG8=1; A/B builds)
+__global__ void __launch_bounds__(512, 1) conv_wino36h_wg8_kernel(const Wino4Problem p) { conv_wino36b_body<4, 3, 0, true, false, true>(p); }
 // point split: 0 = never, 1 = always, default = where in_ch >= 128 (RW_W4H_PS overrides)
 static bool w4h_point_split(int in_ch) {
   const char* e = getenv("RW_W4H_PS");
@@ -1473,6 +1475,17 @@ static int conv3x3_wino4_launch(const float* x, const float* uf, float* y, int b
   if (h16) {
     if (in_ch > 512) return RW_ERR_UNSUPPORTED;
     if (y_amax) { const hipError_t me = hipMemsetAsync(y_amax, 0, sizeof(float), rw_s(stream)); if (me != hipSuccess) return (int)me; }
+    const char* wg8 = getenv("RW_W4H_WG8");
+    if (wg8 && wg8[0] == '1' && h % 16 == 0) {
+      p.groups_y = h / 16;
+      int g8 = 4;
+      if (g8 > p.groups_x) g8 = p.groups_x;
+      while (p.groups_x % g8) --g8;
+      p.gpw = g8;
+      const int64_t work8 = (int64_t)batch * p.groups_y * (p.groups_x / g8) * o_tiles;
+      hipLaunchKernelGGL(conv_wino36h_wg8_kernel, dim3((unsigned)work8), dim3(512), 0, rw_s(stream), p);
+      return RW_LAUNCH_RESULT();
+    }
     if (w4h_point_split(in_ch)) hipLaunchKernelGGL(conv_wino36h_ps_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
     else hipLaunchKernelGGL(conv_wino36h_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
     return RW_LAUNCH_RESULT();

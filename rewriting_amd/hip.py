@@ -464,30 +464,49 @@ def conv_transpose_wino_supported(out_ch, in_ch, height, width):
     return bool(lib().rw_conv_transpose3x3s2_wino_supported(int(out_ch), int(in_ch), int(height), int(width)))
 
 
-def pack_conv_transpose_weight_wino(weight):
+def conv_transpose_wino_split_supported(out_ch, in_ch, height, width):
+    """Shapes the split-operand (16-bit matrix pipe) form of conv_transpose3x3s2_wino takes."""
+    return bool(lib().rw_conv_transpose3x3s2_winoh_supported(int(out_ch), int(in_ch), int(height), int(width)))
+
+
+def pack_conv_transpose_weight_wino(weight, split=False):
+    """The 25 F(2,2) points of every filter in fragment order; split=True: as pairs of f16 numbers for the kernel on
+    the 16-bit matrix pipe (rw_pack_conv_transpose_winoh_f32) -- told apart by size."""
     weight = _dev(weight, 'weight')
     o, i = weight.shape[-4], weight.shape[-3]
-    n = lib().rw_packed_conv_transpose_wino_elems(o, i)
+    n = (lib().rw_packed_conv_transpose_winoh_elems if split else lib().rw_packed_conv_transpose_wino_elems)(o, i)
     if n <= 0:
         raise ValueError('no F(2,2) packing for a %d x %d transposed-conv weight' % (o, i))
     uf = torch.empty(n, device=weight.device, dtype=torch.float32)
-    check(lib().rw_pack_conv_transpose_wino_f32(_p(weight), _p(uf), o, i, _stream()))
+    pack = lib().rw_pack_conv_transpose_winoh_f32 if split else lib().rw_pack_conv_transpose_wino_f32
+    check(pack(_p(weight), _p(uf), o, i, _stream()))
     return uf
 
 
-def conv_transpose3x3s2_wino(x, uf, out_ch, w_scale, style=None, demod=None, out=None):
+def conv_transpose3x3s2_wino(x, uf, out_ch, w_scale, style=None, demod=None, out=None, x_amax=None):
     """The quads y < H, x < W of conv_transpose3x3s2 by F(2,2) (25 instead of 36 multiplies per 2x2 block of quads);
-    output row 2H and column 2W are left to conv_transpose3x3s2(..., impl=8, out=...)."""
+    output row 2H and column 2W are left to conv_transpose3x3s2(..., impl=8, out=...).  With weights from
+    pack_conv_transpose_weight_wino(split=True) the products run on the 16-bit matrix pipe (exact f16 operand split,
+    fp32 accumulation; x_amax = a one-element tensor >= max |x|, computed here when None)."""
     x = _dev(x, 'fmap')
     uf = _dev(uf, 'packed weight')
     b, i, h, w = x.shape
-    if uf.numel() != lib().rw_packed_conv_transpose_wino_elems(out_ch, i):
+    if uf.numel() == lib().rw_packed_conv_transpose_wino_elems(out_ch, i):
+        split = False
+    elif uf.numel() == lib().rw_packed_conv_transpose_winoh_elems(out_ch, i):
+        split = True
+    else:
         raise ValueError('packed weight does not come from pack_conv_transpose_weight_wino(%d x %d)' % (out_ch, i))
     y = out if out is not None else torch.empty(b, out_ch, 2 * h + 1, 2 * w + 1, device=x.device, dtype=x.dtype)
     if tuple(y.shape) != (b, out_ch, 2 * h + 1, 2 * w + 1) or not y.is_contiguous():
         raise ValueError('out has the wrong shape')
     style = _opt(style, 'style')
     demod = _opt(demod, 'demod')
+    if split:
+        x_amax = _amax_in(x, x_amax)
+        check(lib().rw_conv_transpose3x3s2_winoh_f32(_p(x), _p(uf), _p(y), b, i, out_ch, h, w, float(w_scale),
+                                                     _p(style), _p(demod), _p(x_amax), _stream()))
+        return y
     if style is not None and w <= 8:
         # whole 8^2 / 4^2 images per wave (several images per workgroup): the kernel takes these maps already
         # multiplied by their style -- the same product, rounded the same way, one tiny launch earlier

@@ -50,8 +50,11 @@ def main(batch=int(os.environ.get('RW_BATCH', '8')), iters=5, impl=int(os.enviro
         amax = hip.absmax(x) if w4split else None                   # as a producer leaves it behind: not timed
         w4kw = dict(x_amax=amax) if w4split else {}
         upw = os.environ.get('RW_UP_ALGO') == 'wino' and up and hip.conv_transpose_wino_supported(cout, cin, res, res)
+        upsplit = os.environ.get('RW_UPW_MM', 'f32') != 'f32' and up and hip.conv_transpose_wino_split_supported(cout, cin, res, res)
+        amax_up = hip.absmax(x) if upsplit else None
+        upkw = dict(x_amax=amax_up) if upsplit else {}
         if upw:
-            ufu = hip.pack_conv_transpose_weight_wino(w)
+            ufu = hip.pack_conv_transpose_weight_wino(w, split=upsplit)
             yout = torch.empty(batch, cout, 2 * res + 1, 2 * res + 1, device=dev)
         upmode = os.environ.get('RW_UP_ALGO') if up else None
         if upmode in ('fused', 'wino+blur'):
@@ -65,16 +68,16 @@ def main(batch=int(os.environ.get('RW_BATCH', '8')), iters=5, impl=int(os.enviro
         if upf:
             uf4 = hip.pack_conv_transpose_blur_weight_wino4(w, k4, split=w4split)
         if upb:
-            ufu = hip.pack_conv_transpose_weight_wino(w)
+            ufu = hip.pack_conv_transpose_weight_wino(w, split=upsplit)
             yout = torch.empty(batch, cout, 2 * res + 1, 2 * res + 1, device=dev)
 
             def two_pass():
                 hip.conv_transpose3x3s2(x, wp, cout, 1.0, style=style, demod=dm, impl=8, out=yout)
-                hip.conv_transpose3x3s2_wino(x, ufu, cout, 1.0, style=style, demod=dm, out=yout)
+                hip.conv_transpose3x3s2_wino(x, ufu, cout, 1.0, style=style, demod=dm, out=yout, **upkw)
                 return hip.blur_noise_act(yout, k4, epu['noise'], epu['noise_w'], epu['bias'])
         fn = (lambda: hip.conv_transpose3x3s2_blur_wino4(x, uf4, cout, 1.0, style=style, demod=dm, act=True, **epu, **w4kw)) if upf else \
              two_pass if upb else \
-             (lambda: hip.conv_transpose3x3s2_wino(x, ufu, cout, 1.0, style=style, demod=dm, out=yout)) if upw else \
+             (lambda: hip.conv_transpose3x3s2_wino(x, ufu, cout, 1.0, style=style, demod=dm, out=yout, **upkw)) if upw else \
              (lambda: hip.conv3x3_wino4(x, uf, cout, 1.0, style=style, demod=dm, **ep, **w4kw)) if wino4 else \
              (lambda: hip.conv3x3_wino(x, uf, cout, 1.0, style=style, demod=dm, **ep)) if wino else \
              (lambda: hip.conv3x3_bf16x6(x, wb, cout, 1.0, style=style, demod=dm, **ep)) if split else \
@@ -92,7 +95,7 @@ def main(batch=int(os.environ.get('RW_BATCH', '8')), iters=5, impl=int(os.enviro
         flops = 2.0 * 9 * cin * cout * res * res * batch
         out_res = 2 * res + 1 if up else res
         bytes_io = 4.0 * batch * (cin * res * res + cout * out_res * out_res)
-        rows.append(dict(layer=name, cin=cin, cout=cout, res=res, up=up, upmode=upmode, wino=bool(wino) or ('f4' if wino4 else False), mm=os.environ.get('RW_W4_MM', 'f32') if (wino4 or upf) else None, ms=round(ms, 4),
+        rows.append(dict(layer=name, cin=cin, cout=cout, res=res, up=up, upmode=upmode, wino=bool(wino) or ('f4' if wino4 else False), mm=os.environ.get('RW_W4_MM', 'f32') if (wino4 or upf) else ('split' if up and upsplit else None), ms=round(ms, 4),
                          tflops=round(flops / ms / 1e9, 2), io_gbs=round(bytes_io / ms / 1e6, 1)))
         print(rows[-1])
         del x, w

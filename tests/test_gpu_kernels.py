@@ -422,8 +422,9 @@ UP_WINO_CASES = [(2, 16, 32, 4, 32), (1, 64, 64, 8, 32), (1, 128, 64, 16, 64), (
                  (1, 48, 96, 4, 4), (250, 64, 64, 4, 4)]
 
 
+@pytest.mark.parametrize('mm', ['f32', 'split'])
 @pytest.mark.parametrize('case', UP_WINO_CASES)
-def test_transposed_conv_f22_matches_direct_kernel_and_oracle(case):
+def test_transposed_conv_f22_matches_direct_kernel_and_oracle(case, mm):
     """hip.conv_transpose3x3s2_wino (F(2,2): 25 instead of 36 multiplies per 2x2 block of quads) + the border strips
     against the direct transposed-conv kernels and the oracle, at the direct kernels' bars (its transforms have
     coefficients 0, +-1); asymmetric random weights, channel scales spread over two decades."""
@@ -431,17 +432,25 @@ def test_transposed_conv_f22_matches_direct_kernel_and_oracle(case):
     from oracle import restatement as R
     b, i, o, h, w = case
     assert hip.conv_transpose_wino_supported(o, i, h, w)
+    split = mm == 'split'           # the products on the 16-bit matrix pipe (exact f16 operand pairs): the same bars
+    if split and not hip.conv_transpose_wino_split_supported(o, i, h, w):
+        pytest.skip('the split-operand form takes the wide maps only')
     x, wt, style = _conv_inputs(*case, seed=51)
     rs = numpy.random.RandomState(52)
     x = x * torch.from_numpy(numpy.exp(1.5 * rs.randn(1, i, 1, 1)).astype('float32'))
     s = 1 / math.sqrt(i * 9)
     dm = hip.demod(hip.weight_sqsum(wt.to(DEV), s), style.to(DEV))
     wp = hip.pack_conv_weight(wt.to(DEV), 1)
-    uf = hip.pack_conv_transpose_weight_wino(wt.to(DEV))
+    uf = hip.pack_conv_transpose_weight_wino(wt.to(DEV), split=split)
     direct = hip.conv_transpose3x3s2(x.to(DEV), wp, o, s, style=style.to(DEV), demod=dm,
                                      impl=0 if i % 16 == 0 else 1)
     out = torch.full_like(direct, float('nan'))
     hip.conv_transpose3x3s2_wino(x.to(DEV), uf, o, s, style=style.to(DEV), demod=dm, out=out)
+    if split:           # a loose bound on the input costs low bits of the smallest values only
+        out2 = torch.full_like(direct, float('nan'))
+        hip.conv_transpose3x3s2_wino(x.to(DEV), uf, o, s, style=style.to(DEV), demod=dm, out=out2,
+                                     x_amax=hip.absmax(x.to(DEV)) * 50.0)
+        assert rel(out2[:, :, :-1, :-1], out[:, :, :-1, :-1]) < 1e-6
     assert torch.isnan(out[:, :, -1, :]).all() and torch.isnan(out[:, :, :, -1]).all()      # strips untouched
     assert torch.isfinite(out[:, :, :-1, :-1]).all()
     if i % 16 == 0:
