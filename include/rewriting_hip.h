@@ -335,6 +335,11 @@ int rw_blur_noise_act_f32(const float* x, const float* k4, const float* noise, c
 int rw_blur_noise_act_scaled_f32(const float* x, const float* k4, const float* noise, const float* noise_w,
                                  const float* bias, const float* post_scale, float* y, int batch, int channels,
                                  int out_h, int out_w, rw_stream_t stream);
+/* ... and y_amax (device scalar, nullable) receives max |y| of the result, post_scale included: the x_amax of a
+ * split-operand (wino4h / winoh) convolution that reads y. */
+int rw_blur_noise_act_amax_f32(const float* x, const float* k4, const float* noise, const float* noise_w,
+                               const float* bias, const float* post_scale, float* y, int batch, int channels,
+                               int out_h, int out_w, float* y_amax, rw_stream_t stream);
 
 /* ToRGBF (models.py:628-655): y[b][c][p] = sum_i (W[c][i]*style[b][i]*w_scale) x[b][i][p]
  * + bias[c] + skip[b][c][p]; out channels = 3, skip nullable. */

@@ -128,6 +128,8 @@ SIGNATURES = {
                                                       c_int, c_float, POINTER(ConvEpilogue), c_void_p, c_void_p]),
     'rw_blur_noise_act_scaled_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                              c_int, c_int, c_int, c_int, c_void_p]),
+    'rw_blur_noise_act_amax_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'rw_solve_ksplit': (c_int, [c_int, c_int, c_int, c_int]),
     'rw_solve_supported': (c_int, [c_int] * 7),
     'rw_solve_scratch_elems': (c_int, [c_int] * 5 + [POINTER(ctypes.c_longlong)]),

@@ -27,6 +27,12 @@ __device__ __forceinline__ float rw_wave_sum(float v) {
   return v;
 }
 
+__device__ __forceinline__ float rw_wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
 // Block-wide sum for 256-thread blocks (4 waves); result valid in every thread.
 __device__ __forceinline__ float rw_block_sum_256(float v, float* lds4) {
   v = rw_wave_sum(v);
@@ -39,3 +45,14 @@ __device__ __forceinline__ float rw_block_sum_256(float v, float* lds4) {
 
 typedef float rw_f32x16 __attribute__((ext_vector_type(16)));
 typedef float rw_f32x4 __attribute__((ext_vector_type(4)));
+
+// max into a device scalar that holds a NON-NEGATIVE float (bit patterns then order like the values).  The scalar is
+// zeroed by a memset, raised by workgroups on all eight XCDs and read by the next launch: the operations carry system
+// scope (sc1: performed at the memory side, not in one XCD's L2), and a workgroup whose value cannot raise it -- almost
+// all of them -- leaves after one coherent load instead of queueing on the same address.
+__device__ __forceinline__ void rw_atomic_max_nonneg(float* addr, float v) {
+  unsigned* a = reinterpret_cast<unsigned*>(addr);
+  const unsigned bits = __float_as_uint(v);
+  if (__hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < bits)
+    __hip_atomic_fetch_max(a, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}

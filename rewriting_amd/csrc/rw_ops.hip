@@ -744,7 +744,8 @@ extern "C" int rw_pack_conv_weight_f32(const float* w, float* wp, int out_ch, in
 __global__ void __launch_bounds__(256) blur_noise_act_kernel(
     const float* __restrict__ x, const float* __restrict__ k4, const float* __restrict__ noise,
     const float* __restrict__ nw_ptr, const float* __restrict__ bias, float* __restrict__ y,
-    int batch, int channels, int out_h, int out_w, int tiles_x, int tiles_y, const float* __restrict__ post) {
+    int batch, int channels, int out_h, int out_w, int tiles_x, int tiles_y, const float* __restrict__ post,
+    float* __restrict__ y_amax) {
   __shared__ float kf[16];
   __shared__ __attribute__((aligned(16))) float tile[BL_TH + 3][BL_PITCH];
   const int tid = threadIdx.x;
@@ -799,7 +800,8 @@ __global__ void __launch_bounds__(256) blur_noise_act_kernel(
   // bound, so wide stores matter more than the (mild, 2-way) LDS bank overlap of this mapping
   const int lx = (tid & 15) * 4;
   const int ox = ox0 + lx;
-  if (ox >= out_w) return;
+  const bool live = ox < out_w;
+  float ymax = 0.f;                             // max |result| of this thread -> y_amax (the next layer's x_amax)
   const float nw = noise ? nw_ptr[0] : 0.f;
   const float bv = bias ? bias[c] : 0.f;
   const float ps = post ? post[bc] : 1.f;       // per (image, channel) factor on the result: the NEXT layer's style
@@ -808,7 +810,7 @@ __global__ void __launch_bounds__(256) blur_noise_act_kernel(
   for (int half = 0; half < BL_TH / 16; ++half) {
     const int ly = (tid >> 4) + 16 * half;
     const int oy = oy0 + ly;
-    if (oy >= out_h) continue;
+    if (oy >= out_h || !live) continue;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -837,6 +839,7 @@ __global__ void __launch_bounds__(256) blur_noise_act_kernel(
       float v = acc[q] + nw * nzv[q];
       if (bias) { v += bv; v = ((v > 0.f) ? v : v * 0.2f) * 1.4142135623730951f; }
       res[q] = post ? v * ps : v;
+      if (ox + q < out_w) ymax = fmaxf(ymax, fabsf(res[q]));
     }
     float* yo = y + (bc * out_h + oy) * (int64_t)out_w + ox;
     if (full) {
@@ -849,6 +852,13 @@ __global__ void __launch_bounds__(256) blur_noise_act_kernel(
 #pragma unroll
       for (int q = 0; q < 4; ++q) if (ox + q < out_w) yo[q] = res[q];
     }
+  }
+  if (y_amax) {       // one coherent load per workgroup, an atomic from the few whose maximum is news
+    ymax = rw_wave_max(ymax);
+    __shared__ float wmax[4];
+    if ((tid & 63) == 0) wmax[tid >> 6] = ymax;
+    __syncthreads();
+    if (tid == 0) rw_atomic_max_nonneg(y_amax, fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])));
   }
 }
 
@@ -923,13 +933,20 @@ __global__ void __launch_bounds__(256) blur_noise_act_small_kernel(
   }
 }
 
-extern "C" int rw_blur_noise_act_scaled_f32(const float* x, const float* k4, const float* noise,
-                                            const float* noise_w, const float* bias, const float* post_scale,
-                                            float* y, int batch, int channels, int out_h, int out_w,
-                                            rw_stream_t stream) {
+extern "C" int rw_absmax_f32(const float* x, long long n, float* out, rw_stream_t stream);
+extern "C" int rw_blur_noise_act_amax_f32(const float* x, const float* k4, const float* noise,
+                                          const float* noise_w, const float* bias, const float* post_scale,
+                                          float* y, int batch, int channels, int out_h, int out_w, float* y_amax,
+                                          rw_stream_t stream) {
   RW_CHECK_ARG(x && k4 && y && batch > 0 && channels > 0 && out_h > 0 && out_w > 0);
   RW_CHECK_ARG(!noise || noise_w);
   if (out_h == out_w && (out_w == 8 || out_w == 16 || out_w == 32)) {
+    if (y_amax) {       // the small maps' kernel has no reduction of its own: one more pass over a tiny map
+      const int rc = rw_blur_noise_act_amax_f32(x, k4, noise, noise_w, bias, post_scale, y, batch, channels, out_h, out_w,
+                                                nullptr, stream);
+      if (rc) return rc;
+      return rw_absmax_f32(y, (long long)batch * channels * out_h * out_w, y_amax, stream);
+    }
     const int64_t planes = (int64_t)batch * channels;
     const int64_t wgs = rw_cdiv(planes, 4096 / (out_w * out_w));
     if (wgs > 0x7fffffff) return RW_ERR_UNSUPPORTED;
@@ -948,9 +965,18 @@ extern "C" int rw_blur_noise_act_scaled_f32(const float* x, const float* k4, con
   const int tiles_x = (int)rw_cdiv(out_w, BL_TW), tiles_y = (int)rw_cdiv(out_h, BL_TH);
   const int64_t blocks = (int64_t)batch * channels * tiles_x * tiles_y;
   if (blocks > 0x7fffffff) return RW_ERR_UNSUPPORTED;
+  if (y_amax) { const hipError_t me = hipMemsetAsync(y_amax, 0, sizeof(float), rw_s(stream)); if (me != hipSuccess) return (int)me; }
   hipLaunchKernelGGL(blur_noise_act_kernel, dim3((unsigned)blocks), dim3(256), 0, rw_s(stream), x, k4,
-                     noise, noise_w, bias, y, batch, channels, out_h, out_w, tiles_x, tiles_y, post_scale);
+                     noise, noise_w, bias, y, batch, channels, out_h, out_w, tiles_x, tiles_y, post_scale, y_amax);
   return RW_LAUNCH_RESULT();
+}
+
+extern "C" int rw_blur_noise_act_scaled_f32(const float* x, const float* k4, const float* noise,
+                                            const float* noise_w, const float* bias, const float* post_scale,
+                                            float* y, int batch, int channels, int out_h, int out_w,
+                                            rw_stream_t stream) {
+  return rw_blur_noise_act_amax_f32(x, k4, noise, noise_w, bias, post_scale, y, batch, channels, out_h, out_w, nullptr,
+                                    stream);
 }
 
 extern "C" int rw_blur_noise_act_f32(const float* x, const float* k4, const float* noise,

@@ -151,7 +151,9 @@ __device__ __forceinline__ void conv_up_wino_body(const UpWinoProblem& p) {
       if (lane == 0) Red[wave] = smax;
       __syncthreads();
       smax = fmaxf(fmaxf(Red[0], Red[1]), fmaxf(Red[2], Red[3]));
-      const float am = p.x_amax[0] * smax;                        // |T| <= 4 am < 2^(e + 2)
+      // (a coherent load: the scalar load the compiler would pick reads through a cache that back-to-back launches do not
+    // invalidate, and the allocator hands the same address to successive layers' bounds)
+    const float am = __hip_atomic_load(p.x_amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) * smax;                        // |T| <= 4 am < 2^(e + 2)
       int e = (int)((__float_as_uint(am) >> 23) & 0xff) - 126;    // am < 2^e
       e = e < -100 ? -100 : (e > 100 ? 100 : e);
       in_scale = __uint_as_float((unsigned)(127 + 12 - e) << 23);
@@ -516,7 +518,7 @@ __global__ void __launch_bounds__(256) pack_up_winoh_kernel(const float* __restr
   float* trailer = uf + (int64_t)16 * out_ch * in_ch;
   float su = 1.f, inv = 1.f, m = 0.f;
   if (PASS == 2) {
-    const unsigned bits = __float_as_uint(trailer[2]);
+    const unsigned bits = __hip_atomic_load(reinterpret_cast<const unsigned*>(trailer + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     int eu = (int)((bits >> 23) & 0xff) - 126;
     if (bits == 0u) eu = 15;
     eu = eu < -100 ? -100 : (eu > 100 ? 100 : eu);
@@ -551,7 +553,7 @@ __global__ void __launch_bounds__(256) pack_up_winoh_kernel(const float* __restr
   if (PASS == 1) {
 #pragma unroll
     for (int off = 32; off; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(trailer + 2), __float_as_uint(m));
+    if ((threadIdx.x & 63) == 0) rw_atomic_max_nonneg(trailer + 2, m);
   }
   if (PASS == 2 && blockIdx.x == 0 && threadIdx.x == 0) trailer[0] = inv;
 }

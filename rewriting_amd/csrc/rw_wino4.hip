@@ -562,7 +562,9 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
     smax = Red[0];
 #pragma unroll
     for (int wv = 1; wv < WAVES; ++wv) smax = fmaxf(smax, Red[wv]);
-    const float am = p.x_amax[0] * smax;                          // >= max |x style|; |B^T d B| <= 100 am < 2^(e + 7)
+    // (a coherent load: the scalar load the compiler would pick reads through a cache that back-to-back launches do not
+    // invalidate, and the allocator hands the same address to successive layers' bounds)
+    const float am = __hip_atomic_load(p.x_amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) * smax;                          // >= max |x style|; |B^T d B| <= 100 am < 2^(e + 7)
     int e = (int)((__float_as_uint(am) >> 23) & 0xff) - 126;      // am < 2^e
     e = e < -100 ? -100 : (e > 100 ? 100 : e);
     in_scale = __uint_as_float((unsigned)(127 + 8 - e) << 23);
@@ -1190,7 +1192,7 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
   if (H16 && !RGB && p.y_amax) {
 #pragma unroll
     for (int off = 32; off; off >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, off));
-    if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(p.y_amax), __float_as_uint(ymax));     // ymax >= 0
+    if (lane == 0) rw_atomic_max_nonneg(p.y_amax, ymax);
   }
 }
 
@@ -1312,7 +1314,7 @@ __device__ __forceinline__ float w4_pack_store(const float* g, float* dst, float
 // H16 packing runs twice: PASS 1 leaves max |U| (as bits, atomic max) in trailer[2]; PASS 2 derives the power of two
 // from it -- max |U| < 2^eu, su = 2^(15 - eu) -- and the first thread writes 2^(eu - 15) to trailer[0].
 __device__ __forceinline__ float w4_weight_scale(const float* trailer, float* inv) {
-  const unsigned bits = __float_as_uint(trailer[2]);
+  const unsigned bits = __hip_atomic_load(reinterpret_cast<const unsigned*>(trailer + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   int eu = (int)((bits >> 23) & 0xff) - 126;
   if (bits == 0u) eu = 15;
   eu = eu < -100 ? -100 : (eu > 100 ? 100 : eu);
@@ -1322,7 +1324,7 @@ __device__ __forceinline__ float w4_weight_scale(const float* trailer, float* in
 __device__ __forceinline__ void w4_report_absmax(float m, float* trailer) {
 #pragma unroll
   for (int off = 32; off; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(trailer + 2), __float_as_uint(m));
+  if ((threadIdx.x & 63) == 0) rw_atomic_max_nonneg(trailer + 2, m);
 }
 
 // One thread: the 36 values of one (o, i).  uf[o / 16][i / 4][xi / 4][16 (i % 4) + o % 16][xi % 4]
@@ -1402,7 +1404,7 @@ __global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(x[(n4 << 2) + threadIdx.x]));
 #pragma unroll
   for (int off = 32; off; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(m));
+  if ((threadIdx.x & 63) == 0) rw_atomic_max_nonneg(out, m);
 }
 
 extern "C" int rw_absmax_f32(const float* x, long long n, float* out, rw_stream_t stream) {

@@ -250,9 +250,10 @@ def conv3x3_wino(x, uf, out_ch, w_scale, style=None, demod=None, noise=None, noi
     if uf.numel() != lib().rw_packed_conv_weight_wino_elems(out_ch, i):
         raise ValueError('packed weight does not come from pack_conv_weight_wino(%d x %d)' % (out_ch, i))
     y = torch.empty(b, out_ch, h, w, device=x.device, dtype=x.dtype)
-    if style is not None and w <= 8:
-        # whole 8^2 / 4^2 images per wave (several images per workgroup): the kernel takes these maps already
-        # multiplied by their style -- the same product, rounded the same way, one tiny launch earlier
+    if style is not None and h == w and w in (4, 8):
+        # whole 8^2 / 4^2 images per wave (several images per workgroup): the library takes exactly these maps already
+        # multiplied by their style (style == NULL, see the header) -- the same product, rounded the same way, one tiny
+        # launch earlier
         x, style = style_mul(x, _dev(style, 'style')), None
     ep, keep = _epilogue(style, demod, noise, noise_w, bias, act)
     check(lib().rw_conv3x3_wino_f32(_p(x), _p(uf), _p(y), b, i, out_ch, h, w, float(w_scale), ctypes.byref(ep),
@@ -507,8 +508,8 @@ def conv_transpose3x3s2_wino(x, uf, out_ch, w_scale, style=None, demod=None, out
         check(lib().rw_conv_transpose3x3s2_winoh_f32(_p(x), _p(uf), _p(y), b, i, out_ch, h, w, float(w_scale),
                                                      _p(style), _p(demod), _p(x_amax), _stream()))
         return y
-    if style is not None and w <= 8:
-        # whole 8^2 / 4^2 images per wave (several images per workgroup): the kernel takes these maps already
+    if style is not None and h == w and w in (4, 8):
+        # whole 8^2 / 4^2 images per wave (several images per workgroup): the library takes exactly these maps already
         # multiplied by their style -- the same product, rounded the same way, one tiny launch earlier
         x, style = style_mul(x, style), None
     check(lib().rw_conv_transpose3x3s2_wino_f32(_p(x), _p(uf), _p(y), b, i, out_ch, h, w, float(w_scale), _p(style),
@@ -581,9 +582,10 @@ def noise_add(x, noise, noise_w):
     return y
 
 
-def blur_noise_act(x, k4, noise, noise_w, bias, post_scale=None):
+def blur_noise_act(x, k4, noise, noise_w, bias, post_scale=None, y_amax=None):
     """Blur(pad 1,1) + noise + bias + leaky ReLU of an upsampling layer in one pass; post_scale (B x C, optional):
-    a factor on the result -- the style of the convolution that consumes it."""
+    a factor on the result -- the style of the convolution that consumes it; y_amax (one-element tensor, optional)
+    receives max |result|."""
     x = _dev(x, 'fmap')
     k4 = _dev(k4, 'blur kernel')
     noise = _opt(noise, 'noise')
@@ -594,8 +596,9 @@ def blur_noise_act(x, k4, noise, noise_w, bias, post_scale=None):
     post_scale = _opt(post_scale, 'post scale')
     if post_scale is not None and tuple(post_scale.shape) != (b, c):
         raise ValueError('post_scale must be batch x channels')
-    check(lib().rw_blur_noise_act_scaled_f32(_p(x), _p(k4), _p(noise), _p(noise_w), _p(bias), _p(post_scale), _p(y),
-                                             b, c, ih - 1, iw - 1, _stream()))
+    y_amax = _amax_out(y_amax)
+    check(lib().rw_blur_noise_act_amax_f32(_p(x), _p(k4), _p(noise), _p(noise_w), _p(bias), _p(post_scale), _p(y),
+                                           b, c, ih - 1, iw - 1, _p(y_amax), _stream()))
     return y
 
 

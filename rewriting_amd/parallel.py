@@ -169,13 +169,26 @@ def allreduce_variance(rv):
 
 
 def gather_images(local_images, seeds_total):
-    """all_gather of per-rank image batches produced with seed i -> rank i mod world; returns the
-    images in seed order on every rank (optional: ranks normally write their own files)."""
+    """all_gather of per-rank image batches produced with seed i -> rank i mod world (this rank holds seeds
+    rank, rank + world, ... in that order); returns all seeds_total images in seed order on every rank (optional:
+    ranks normally write their own files).  The collective wants equal shapes: ranks are padded to
+    ceil(seeds_total / world) images -- the last seeds_total % world ranks hold one image less when the division leaves
+    a remainder."""
     if shard() is None:
+        if local_images.shape[0] != seeds_total:
+            raise ValueError('one process holds all %d images, got %d' % (seeds_total, local_images.shape[0]))
         return local_images
     rank, world = shard()
-    parts = [torch.empty_like(local_images) for _ in range(world)]
-    dist.all_gather(parts, local_images.contiguous())
+    mine = len(range(rank, seeds_total, world))
+    if local_images.shape[0] != mine:
+        raise ValueError('rank %d of %d holds %d of %d images, got %d' % (rank, world, mine, seeds_total,
+                                                                        local_images.shape[0]))
+    per_rank = -(-seeds_total // world)
+    padded = local_images.contiguous()
+    if mine < per_rank:
+        padded = torch.cat([padded, padded.new_zeros((per_rank - mine,) + tuple(padded.shape[1:]))])
+    parts = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded)
     out = torch.empty((seeds_total,) + tuple(local_images.shape[1:]), dtype=local_images.dtype,
                       device=local_images.device)
     for r, part in enumerate(parts):

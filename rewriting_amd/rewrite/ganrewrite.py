@@ -323,6 +323,8 @@ class ProgressiveGanRewriter(object):
 
         def forward_with_lambda(*args, **kwargs):
             owner.weight = weight + torch.einsum(rule, lam, context)
+            sg.bump_weight_epoch()      # a fresh tensor every call: derived (packed) weights must never be looked up by
+            #                             its address and version alone
             return plain_forward(*args, **kwargs)
         owner.forward = forward_with_lambda
         try:

@@ -208,6 +208,35 @@ def up_conv_algo():
     return os.environ.get('RW_UP_ALGO', 'winograd')
 
 
+def matrix_mode():
+    """Which matrix pipe multiplies inside the F(4x4,3x3) and F(2,2) kernels: 'f32' (fp32 MFMAs) or 'split' -- every
+    transformed operand as an exact pair of f16 numbers, all four piece products on the 16-bit pipe, fp32 accumulation
+    (hip.pack_conv_weight_wino4(split=True) ...: per-product error <= 2^-21, the kernels pass their parity tests at the
+    fp32 bars).  Like F(4x4,3x3) itself the split form is the default inside the un-hooked forward of the whole
+    generator only (image generation); hooked / sliced models -- key statistics, goal maps, the solve -- multiply in
+    fp32.  RW_MM=f32|split forces one everywhere."""
+    explicit = os.environ.get('RW_MM')
+    if explicit:
+        return explicit
+    return 'split' if _rgb_branch.image_path else 'f32'
+
+
+def _split_part(kind):
+    """Diagnostics: RW_MM_PARTS=w4,up,up1 restricts the split form to the stride-1 F(4x4,3x3) kernels / the F(2,2)
+    transposed convolutions / the one-pass upsampling layer."""
+    parts = os.environ.get('RW_MM_PARTS')
+    return matrix_mode() == 'split' and (parts is None or kind in parts.split(','))
+
+
+def _amax_of(d, fmap):
+    """The bound max |fmap| its producer left in the bag (key 'amax': (one-element tensor, data_ptr of the map it
+    describes)), or None -- the kernels then measure the map themselves (hip.absmax)."""
+    entry = d.get('amax')
+    if entry is not None and fmap is not None and entry[1] == fmap.data_ptr():
+        return entry[0]
+    return None
+
+
 # Default: F(2x2,3x3) wherever a model is hooked, sliced (nethook.subsequence: the key statistics, the goal maps,
 # the solve's context) or run module by module; F(4x4,3x3) inside the un-hooked forward of the whole generator --
 # image generation, where the measured deviation from the reference image is the same 2e-5 with either.
@@ -415,10 +444,16 @@ class DemodulatedConv2dF(nn.Module):
     def wino_weight(self):
         return self._derived.get('wino', self.weight, lambda: hip.pack_conv_weight_wino(self.weight))
 
-    def up_wino_weight(self):
+    def up_wino_weight(self, split=False):
+        if split:
+            return self._derived.get('upwino_split', self.weight,
+                                     lambda: hip.pack_conv_transpose_weight_wino(self.weight, split=True))
         return self._derived.get('upwino', self.weight, lambda: hip.pack_conv_transpose_weight_wino(self.weight))
 
-    def up_blur_wino4_weight(self, k4):
+    def up_blur_wino4_weight(self, k4, split=False):
+        if split:
+            return self._derived.get('upblur4_split', self.weight,
+                                     lambda: hip.pack_conv_transpose_blur_weight_wino4(self.weight, k4, split=True))
         return self._derived.get('upblur4', self.weight,
                                  lambda: hip.pack_conv_transpose_blur_weight_wino4(self.weight, k4))
 
@@ -441,8 +476,16 @@ class DemodulatedConv2dF(nn.Module):
             return True
         return conv_algo() == 'winograd4' and self.in_channel <= _ONE_PASS_UP_MAX_IN
 
-    def wino4_weight(self):
+    def wino4_weight(self, split=False):
+        if split:
+            return self._derived.get('wino4_split', self.weight,
+                                     lambda: hip.pack_conv_weight_wino4(self.weight, split=True))
         return self._derived.get('wino4', self.weight, lambda: hip.pack_conv_weight_wino4(self.weight))
+
+    def runs_split_wino4(self, h, w):
+        """Will run() on a map of h x w execute the split-operand F(4x4,3x3) kernel (which reports max |result|)?"""
+        return (not self.upsample and _split_part('w4') and conv_algo() == 'winograd4' and conv_impl() == 0
+                and conv_precision() == 'f32' and hip.wino4_supported(self.out_channel, self.in_channel, h, w))
 
     def squared_sums(self):
         return self._derived.get('wsq', self.weight, lambda: hip.weight_sqsum(self.weight, self.scale))
@@ -450,10 +493,14 @@ class DemodulatedConv2dF(nn.Module):
     def demod_factors(self, style):
         return hip.demod(self.squared_sums(), style) if self.demodulate else None
 
-    def run(self, fmap, style, style_on_load, demod=None, **epilogue):
+    def run(self, fmap, style, style_on_load, demod=None, x_amax=None, y_amax=None, **epilogue):
+        """x_amax: a one-element tensor >= max |fmap| if the producer of fmap left one (split-operand kernels; they
+        measure the map themselves otherwise); y_amax: a one-element tensor that receives max |result| where the
+        split-operand F(4x4,3x3) kernel runs (`runs_split_wino4` says whether it will)."""
         if demod is None:
             demod = self.demod_factors(style)
         load_style = style if style_on_load else None
+        split = _split_part('up' if self.upsample else 'w4')
         if self.upsample:
             # the border strips go to an auxiliary stream beside the tiles: the one of the running whole-generator
             # forward, else (a sliced or hooked model: the statistics sweeps, the rewriter's sub-models) the
@@ -475,7 +522,10 @@ class DemodulatedConv2dF(nn.Module):
                 # (latency-bound, 2 % of the step) go to a third stream beside the tiles
                 out = torch.empty(b, self.out_channel, 2 * h + 1, 2 * w + 1, device=fmap.device, dtype=fmap.dtype)
                 wp = self.packed_weight()      # (re)packed on the trunk's stream BEFORE the fork
-                uf = self.up_wino_weight() if f22 else None
+                f22_split = f22 and split and hip.conv_transpose_wino_split_supported(self.out_channel, self.in_channel, h, w)
+                uf = self.up_wino_weight(f22_split) if f22 else None
+                if f22_split and x_amax is None:
+                    x_amax = hip.absmax(fmap)
                 main = torch.cuda.current_stream() if aux is not None else None
                 if aux is not None:
                     aux.wait_stream(main)
@@ -485,7 +535,10 @@ class DemodulatedConv2dF(nn.Module):
                 else:
                     hip.conv_transpose3x3s2(fmap, wp, self.out_channel, self.scale,
                                             style=load_style, demod=demod, impl=8, out=out)
-                if f22:
+                if f22_split:
+                    hip.conv_transpose3x3s2_wino(fmap, uf, self.out_channel, self.scale, style=load_style,
+                                                 demod=demod, out=out, x_amax=x_amax)
+                elif f22:
                     hip.conv_transpose3x3s2_wino(fmap, uf, self.out_channel, self.scale, style=load_style,
                                                  demod=demod, out=out)
                 else:
@@ -498,6 +551,9 @@ class DemodulatedConv2dF(nn.Module):
                                            style=load_style, demod=demod, impl=conv_impl())
         if (conv_algo() == 'winograd4' and conv_impl() == 0 and conv_precision() == 'f32'
                 and hip.wino4_supported(self.out_channel, self.in_channel, fmap.shape[-2], fmap.shape[-1])):
+            if split:
+                return hip.conv3x3_wino4(fmap, self.wino4_weight(True), self.out_channel, self.scale, style=load_style,
+                                         demod=demod, x_amax=x_amax, y_amax=y_amax, **epilogue)
             return hip.conv3x3_wino4(fmap, self.wino4_weight(), self.out_channel, self.scale, style=load_style,
                                      demod=demod, **epilogue)
         if (conv_algo() in ('winograd', 'winograd4') and conv_impl() == 0 and conv_precision() == 'f32'
@@ -738,13 +794,18 @@ class StyledConvSeq(nn.Sequential):
             ('activate', FusedLeakyReLUF(out_channel)),
         ]))
 
-    def _fusable(self):
+    def _fusable(self, d=None):
         if not fusion_enabled() or set(self._modules) != {'mconv', 'noise', 'activate'}:
             return False
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.mconv.dconv.parameters()):
+        if torch.is_grad_enabled() and (
+                any(p.requires_grad for p in self.mconv.dconv.parameters())
+                or (d is not None and any(torch.is_tensor(t) and t.requires_grad for t in (d.get('fmap'), d.get('style'),
+                                                                                           d.get('latent'))))):
             # somebody may differentiate through this layer (an `insert` whose target spans it, rewrite/ganrewrite.py:
-            # 265-283): module by module, where every step carries its adjoint (grad.py).  Image generation and
-            # the statistics sweeps run under no_grad and never come here.
+            # 265-283; a linear_insert that froze every parameter and edits a layer in FRONT of this one: then only
+            # the incoming map carries the graph): module by module, where every step carries its adjoint (grad.py) --
+            # the fused path calls raw-pointer kernels that record no grad_fn.  Image generation and the statistics
+            # sweeps run under no_grad and never come here.
             return False
         mconv = self.mconv
         if not isinstance(mconv, ModulatedConv2dSeq):
@@ -767,7 +828,7 @@ class StyledConvSeq(nn.Sequential):
 
     def forward(self, d):
         pre = d.get('prescaled')
-        if not self._fusable():
+        if not self._fusable(d):
             if pre is not None:
                 raise RuntimeError('a pre-scaled feature map reached a layer that runs module by module')
             return super().forward(d)
@@ -786,9 +847,18 @@ class StyledConvSeq(nn.Sequential):
                 raise RuntimeError('a pre-scaled feature map reached a layer that runs module by module')
             return super().forward(d)
         d_in = d                    # as received (with the hand-over key, if any): what a re-entry must see
-        if pre is not None:
+        x_amax = _amax_of(d, fmap)  # the producer's bound on |fmap| (split-operand kernels), else None
+        if os.environ.get('RW_MM_NO_HANDOVER') == '1':
+            x_amax = None
+        if pre is not None or 'amax' in d:
             d = DataBag(d)
-            del d['prescaled']
+            d.pop('prescaled', None)
+            d.pop('amax', None)
+        split = matrix_mode() == 'split'
+        # ... and this layer's bound for the next one, inside the un-hooked forward only (bags that callers or hooks see
+        # never carry the key; a hooked model under RW_MM=split lets the kernels measure their inputs)
+        y_amax = torch.empty(1, device=fmap.device, dtype=torch.float32) if split and _rgb_branch.image_path else None
+        y_amax_set = False
         post = None
         if mconv.upsample and pre is not None:
             raise RuntimeError('a pre-scaled feature map reached an upsampling layer')
@@ -804,13 +874,19 @@ class StyledConvSeq(nn.Sequential):
             h, w = 2 * fmap.shape[2], 2 * fmap.shape[3]
             noise = self.noise.noise_for(d, b, h, w, fmap.device)
             if dconv.one_pass_upsample(fmap, mconv.blur):
+                split1 = _split_part('up1')
+                mm = dict(x_amax=x_amax, y_amax=y_amax) if split1 else {}
                 out = hip.conv_transpose3x3s2_blur_wino4(
-                    fmap, dconv.up_blur_wino4_weight(mconv.blur.kernel), dconv.out_channel, dconv.scale, style=style,
-                    demod=demod if demod is not None else dconv.demod_factors(style), noise=noise,
-                    noise_w=self.noise.weight, bias=act.bias, act=True, post_scale=post)
+                    fmap, dconv.up_blur_wino4_weight(mconv.blur.kernel, split1), dconv.out_channel, dconv.scale,
+                    style=style, demod=demod if demod is not None else dconv.demod_factors(style), noise=noise,
+                    noise_w=self.noise.weight, bias=act.bias, act=True, post_scale=post, **mm)
+                y_amax_set = split1 and y_amax is not None
             else:
-                wide = dconv.run(fmap, style, style_on_load=True, demod=demod)
-                out = hip.blur_noise_act(wide, mconv.blur.kernel, noise, self.noise.weight, act.bias, post_scale=post)
+                wide = dconv.run(fmap, style, style_on_load=True, demod=demod, x_amax=x_amax)
+                mm = dict(y_amax=y_amax) if y_amax is not None else {}
+                out = hip.blur_noise_act(wide, mconv.blur.kernel, noise, self.noise.weight, act.bias, post_scale=post,
+                                         **mm)
+                y_amax_set = y_amax is not None
         else:
             h, w = fmap.shape[2:]
             noise = self.noise.noise_for(d, b, h, w, fmap.device)
@@ -834,19 +910,27 @@ class StyledConvSeq(nn.Sequential):
                          and hip.wino4_to_rgb_supported(dconv.out_channel, dconv.in_channel, h, w))
                 fused = (hip.conv3x3_wino4_to_rgb if wino4 else
                          hip.conv3x3_wino_to_rgb if wino else hip.conv3x3_to_rgb)
+                split4 = wino4 and _split_part('w4')
+                mm = dict(x_amax=x_amax) if split4 else {}
                 _, rgb = fused(
-                    fmap, dconv.wino4_weight() if wino4 else dconv.wino_weight() if wino else dconv.packed_weight(),
+                    fmap, dconv.wino4_weight(split4) if wino4 else dconv.wino_weight() if wino else dconv.packed_weight(),
                     dconv.out_channel, dconv.scale,
                     torgb.conv.weight.view(3, torgb.conv.in_channel), rgb_style, torgb.bias.view(3), skip,
                     torgb.conv.scale, style=style if on_load else None,
                     demod=demod if demod is not None else dconv.demod_factors(style), noise=noise,
-                    noise_w=self.noise.weight, bias=act.bias, act=True)
+                    noise_w=self.noise.weight, bias=act.bias, act=True, **mm)
                 return DataBag(d, style=style, fmap=None, fused_rgb=rgb)
-            out = dconv.run(fmap, style, style_on_load=on_load, demod=demod, noise=noise,
+            y_amax_set = y_amax is not None and dconv.runs_split_wino4(h, w)
+            out = dconv.run(fmap, style, style_on_load=on_load, demod=demod, x_amax=x_amax,
+                            y_amax=y_amax if y_amax_set else None, noise=noise,
                             noise_w=self.noise.weight, bias=act.bias, act=True)
-        if post is not None:        # only inside the un-hooked forward: bags that callers see never carry the key
-            return DataBag(d, style=style, fmap=out, prescaled=post)
-        return DataBag(d, style=style, fmap=out)
+        # hand-over keys, only inside the un-hooked forward
+        extra = {}
+        if y_amax_set:
+            extra['amax'] = (y_amax, out.data_ptr())
+        if post is not None:        # bags that callers see never carry the key
+            extra['prescaled'] = post
+        return DataBag(d, style=style, fmap=out, **extra)
 
     def _unfused_final(self, d):
         saved, _rgb_branch.final = _rgb_branch.final, None

@@ -149,7 +149,13 @@ def load_request(name='multikey_markandbottom.json'):
 def fold_request(request, nseeds):
     """The request with its seed indices folded into [0, nseeds): lets a reduced sample (smoke runs, launcher
     tests) serve the recorded masks; the identity at the reference's sample size."""
-    return {k: ([[n % nseeds, m] for n, m in v] if k == 'key' else [v[0] % nseeds, v[1]]) for k, v in request.items()}
+    out = dict(request)                 # anything else a request carries (a name, a rank, ...) passes through
+    if 'key' in request:
+        out['key'] = [[n % nseeds, m] for n, m in request['key']]
+    for k in ('object', 'paste'):
+        if k in request:
+            out[k] = [request[k][0] % nseeds, request[k][1]]
+    return out
 
 
 def watermark_job(device, rank=0, world=1, sample_size=1000, niters=2001, size=256, layer=6, variants=None):

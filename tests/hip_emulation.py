@@ -123,18 +123,56 @@ def conv_transpose3x3s2(x, wp, out_ch, w_scale, style=None, demod=None, impl=0, 
     return out
 
 
-def pack_conv_transpose_weight_wino(weight):
-    return pack_conv_weight(weight, 1)                   # opaque handle
+# ---- the split-operand ("H16") kernels: every operand of the matrix products as the sum of two f16 numbers of the value
+# scaled by a power of two (rw_wino4.hip, rw_upwino.hip); the emulation rounds the operands the same way and multiplies
+# in fp32
+class _Split:
+    def __init__(self, handle):
+        self.handle = handle
 
 
-def conv_transpose3x3s2_wino(x, uf, out_ch, w_scale, style=None, demod=None, out=None):
+def _pow2_above(t):
+    """e with max |t| < 2^e (the kernels read it off the exponent field)"""
+    m = float(t.abs().max())
+    return 0 if m == 0 else math.frexp(m)[1]
+
+
+def _f16_pair(t, scale_exp):
+    ts = t * (2.0 ** scale_exp)
+    h = ts.half().float()
+    return (h + (ts - h).half().float()) * (2.0 ** -scale_exp)
+
+
+def absmax(x):
+    return x.detach().abs().max().reshape(1)
+
+
+def conv_transpose_wino_split_supported(out_ch, in_ch, height, width):
+    return width % 32 == 0 and height % 4 == 0 and in_ch % 8 == 0 and 16 <= in_ch <= 512 and out_ch % 32 == 0
+
+
+def pack_conv_transpose_weight_wino(weight, split=False):
+    h = pack_conv_weight(weight, 1)                      # opaque handle
+    return _Split(h) if split else h
+
+
+def conv_transpose3x3s2_wino(x, uf, out_ch, w_scale, style=None, demod=None, out=None, x_amax=None):
     """The arithmetic of rw_upwino.hip in torch fp32: per axis the even outputs by F(2,2) (points d0-d1, d1, d2-d1
     against w2, w2+w0, w0), the odd ones by their single tap; 25 products per 2x2 block of quads.  Writes the
     quads y < H, x < W of `out` only."""
     x = x.detach()
+    split = isinstance(uf, _Split)
+    if split:
+        # |T| <= 4 max |x style| < 2^(e + 2): the kernel scales by 2^(12 - e); the weights by 2^(15 - eu), eu from the
+        # largest of the 25 points (at most 4 max |w|: the exact bound is taken here, one binade cannot matter)
+        smax = 1.0 if style is None else float(style.detach().abs().max())
+        ev = 12 - _pow2_above((x_amax.detach() if x_amax is not None else absmax(x)) * smax)
+        uf = uf.handle
     if style is not None:
         x = x * style.detach()[:, :, None, None]
     w = _unpack(uf, 1)                                   # [o][i][ky][kx]
+    if split:
+        eu = 15 - _pow2_above(w.abs().max().reshape(1) * 4)
     b, c, h, wd = x.shape
     y = out if out is not None else torch.zeros(b, out_ch, 2 * h + 1, 2 * wd + 1)
     xp = F.pad(x, (1, 1, 1, 1))
@@ -154,6 +192,9 @@ def conv_transpose3x3s2_wino(x, uf, out_ch, w_scale, style=None, demod=None, out
             V = [pts(kh, rows[0][a], rows[1][a], rows[2][a]) for a in range(len(rows[0]))]   # V[a][b]
             gv = wts(kv, w[:, :, 0], w[:, :, 1], w[:, :, 2])                              # [a] -> (o,i,kx)
             U = [wts(kh, g[:, :, 0], g[:, :, 1], g[:, :, 2]) for g in gv]                  # U[a][b] (o,i)
+            if split:
+                V = [[_f16_pair(v, ev) for v in row] for row in V]
+                U = [[_f16_pair(u, eu) for u in row] for row in U]
             M = [[torch.einsum('oi,nihw->nohw', U[a][bb], V[a][bb]) for bb in range(len(V[0]))] for a in range(len(V))]
             cols = [outs(kh, M[a]) for a in range(len(M))]
             for bq in range(2):
@@ -171,7 +212,7 @@ def noise_add(x, noise, noise_w):
     return x.detach() + noise_w.detach().reshape(1) * noise.reshape(b, 1, h, w)
 
 
-def blur_noise_act(x, k4, noise, noise_w, bias, post_scale=None):
+def blur_noise_act(x, k4, noise, noise_w, bias, post_scale=None, y_amax=None):
     y = R.upfirdn2d(x.detach(), k4, pad=(1, 1))
     b, c, h, w = y.shape
     if noise is not None:
@@ -180,6 +221,8 @@ def blur_noise_act(x, k4, noise, noise_w, bias, post_scale=None):
         y = F.leaky_relu(y + bias.detach().view(1, -1, 1, 1), 0.2) * SQRT2
     if post_scale is not None:
         y = y * post_scale.detach()[:, :, None, None]
+    if y_amax is not None:
+        y_amax.copy_(absmax(y))
     return y
 
 
@@ -325,8 +368,9 @@ def conv3x3_wino(x, uf, out_ch, w_scale, style=None, demod=None, noise=None, noi
     return y
 
 
-def pack_conv_weight_wino4(weight):
-    return pack_conv_weight(weight, 0)          # opaque handle
+def pack_conv_weight_wino4(weight, split=False):
+    h = pack_conv_weight(weight, 0)             # opaque handle
+    return _Split(h) if split else h
 
 
 _W4G = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6],
@@ -336,9 +380,16 @@ _W4BT = torch.tensor([[4., 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1,
 _W4AT = torch.tensor([[1., 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]])
 
 
-def conv3x3_wino4(x, uf, out_ch, w_scale, style=None, demod=None, noise=None, noise_w=None, bias=None, act=False):
-    """The arithmetic of rw_wino4.hip in torch fp32: F(4x4,3x3) on 6x6 tiles of stride 4."""
+def conv3x3_wino4(x, uf, out_ch, w_scale, style=None, demod=None, noise=None, noise_w=None, bias=None, act=False,
+                  x_amax=None, y_amax=None):
+    """The arithmetic of rw_wino4.hip in torch fp32: F(4x4,3x3) on 6x6 tiles of stride 4; with split weights the
+    transformed operands rounded to pairs of f16 numbers as the kernels on the 16-bit matrix pipe do."""
     x = x.detach()
+    split = isinstance(uf, _Split)
+    if split:
+        smax = 1.0 if style is None else float(style.detach().abs().max())
+        ev = 8 - _pow2_above((x_amax.detach() if x_amax is not None else absmax(x)) * smax)     # |B^T d B| <= 100 max < 2^(e + 7)
+        uf = uf.handle
     if style is not None:
         x = x * style.detach()[:, :, None, None]
     wt = _unpack(uf, 0)
@@ -346,6 +397,8 @@ def conv3x3_wino4(x, uf, out_ch, w_scale, style=None, demod=None, noise=None, no
     U = torch.einsum('ab,oibc,dc->oiad', _W4G, wt, _W4G)
     d = F.pad(x, (1, 1, 1, 1)).unfold(2, 6, 4).unfold(3, 6, 4)
     V = torch.einsum('ab,nithbc,dc->nithad', _W4BT, d, _W4BT)
+    if split:
+        U, V = _f16_pair(U, 15 - _pow2_above(U)), _f16_pair(V, ev)
     M = torch.einsum('oiad,nithad->nothad', U, V)
     Y = torch.einsum('ab,nothbc,dc->nothad', _W4AT, M, _W4AT)
     y = Y.permute(0, 1, 2, 4, 3, 5).reshape(b, out_ch, h, w) * w_scale
@@ -355,18 +408,22 @@ def conv3x3_wino4(x, uf, out_ch, w_scale, style=None, demod=None, noise=None, no
         y = y + noise_w.detach().reshape(1) * noise.reshape(b, 1, h, w)
     if act:
         y = F.leaky_relu(y + bias.detach().view(1, -1, 1, 1), 0.2) * SQRT2
+    if y_amax is not None:
+        y_amax.copy_(absmax(y))
     return y
 
 
-def pack_conv_transpose_blur_weight_wino4(weight, k4):
-    return (pack_conv_weight(weight, 1), k4.detach().clone())          # opaque handle
+def pack_conv_transpose_blur_weight_wino4(weight, k4, split=False):
+    h = (pack_conv_weight(weight, 1), k4.detach().clone())             # opaque handle
+    return _Split(h) if split else h
 
 
 def conv_transpose3x3s2_blur_wino4(x, uf, out_ch, w_scale, style=None, demod=None, noise=None, noise_w=None,
-                                   bias=None, act=False, post_scale=None):
+                                   bias=None, act=False, post_scale=None, x_amax=None, y_amax=None):
     """The arithmetic of rw_wino4.hip's conv_up_wino36_kernel in torch fp32: the four output-parity phases of
     conv_transpose(stride 2) (*) blur as 4 * out_ch virtual channels of the F(4x4,3x3) convolution, pixel-shuffled."""
-    wp, k4 = uf
+    split = isinstance(uf, _Split)
+    wp, k4 = uf.handle if split else uf
     w = _unpack(wp, 1)                                   # [o][i][3][3]
     o, i = w.shape[:2]
     kf = torch.flip(k4, [0, 1])
@@ -381,8 +438,8 @@ def conv_transpose3x3s2_blur_wino4(x, uf, out_ch, w_scale, style=None, demod=Non
             for a in range(3):
                 for b in range(3):
                     wv[2 * py + px::4, :, a, b] = g6[:, :, 4 - 2 * a + py, 4 - 2 * b + px]
-    z = conv3x3_wino4(x, pack_conv_weight(wv.reshape(1, 4 * o, i, 3, 3), 0), 4 * o, w_scale, style=style,
-                      demod=None if demod is None else demod.repeat_interleave(4, dim=1))
+    z = conv3x3_wino4(x, pack_conv_weight_wino4(wv.reshape(1, 4 * o, i, 3, 3), split), 4 * o, w_scale, style=style,
+                      demod=None if demod is None else demod.repeat_interleave(4, dim=1), x_amax=x_amax)
     n, _, h, wd = z.shape
     y = z.reshape(n, o, 2, 2, h, wd).permute(0, 1, 4, 2, 5, 3).reshape(n, o, 2 * h, 2 * wd)
     if noise is not None:
@@ -391,6 +448,8 @@ def conv_transpose3x3s2_blur_wino4(x, uf, out_ch, w_scale, style=None, demod=Non
         y = F.leaky_relu(y + bias.detach().view(1, -1, 1, 1), 0.2) * SQRT2
     if post_scale is not None:
         y = y * post_scale.detach()[:, :, None, None]
+    if y_amax is not None:
+        y_amax.copy_(absmax(y))
     return y
 
 
@@ -423,7 +482,8 @@ def install(monkeypatch):
              'adjust_latent', 'style_mul', 'weight_sqsum', 'demod', 'pack_conv_weight', 'conv3x3',
              'conv_transpose3x3s2', 'noise_add', 'blur_noise_act', 'to_rgb', 'pack_conv_weight_bf16x3',
              'conv3x3_bf16x6', 'pack_conv_weight_wino', 'conv3x3_wino', 'pack_conv_weight_wino4', 'conv3x3_wino4', 'pack_conv_transpose_weight_wino', 'conv_transpose3x3s2_wino',
-             'pack_conv_transpose_blur_weight_wino4', 'conv_transpose3x3s2_blur_wino4',
+             'pack_conv_transpose_blur_weight_wino4', 'conv_transpose3x3s2_blur_wino4', 'absmax',
+             'conv_transpose_wino_split_supported',
              'second_moment_accumulate', 'channel_sums', 'project_weight', 'solve_ksplit',
              'solve_step', 'solve_run', 'conv_wgrad', 'rowdot']
     for n in names:

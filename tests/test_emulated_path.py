@@ -328,6 +328,7 @@ def test_style_handed_over_premultiplied_changes_nothing(emulated_hip, monkeypat
     real = hip.blur_noise_act
     monkeypatch.setattr(hip, 'blur_noise_act',
                         lambda *a, **k: (seen.append(k.get('post_scale') is not None), real(*a, **k))[1])
+    monkeypatch.setenv('RW_MM', 'f32')                   # the fp32 kernels: bit for bit
     with torch.no_grad():
         got = model(z)
     assert any(seen)                                     # the 64 x 64 layer takes F(4x4,3x3)
@@ -337,6 +338,18 @@ def test_style_handed_over_premultiplied_changes_nothing(emulated_hip, monkeypat
         base = model(z)
     assert not any(seen) and torch.equal(got, base)
     monkeypatch.delenv('RW_PRESCALE')
+    # the split-operand kernels (the default of this forward) scale by a power of two taken from the bound on their input:
+    # max |x s| when the style came pre-multiplied, max |x| max |s| otherwise -- a binade apart at most, i.e. other low
+    # bits of the f16 pairs
+    monkeypatch.delenv('RW_MM')
+    with torch.no_grad():
+        got_split = model(z)
+    monkeypatch.setenv('RW_PRESCALE', '0')
+    with torch.no_grad():
+        base_split = model(z)
+    monkeypatch.delenv('RW_PRESCALE')
+    assert (got_split - base_split).abs().max().item() < 2e-6 * got.abs().max().item()
+    assert (got_split - got).abs().max().item() < 1e-5 * got.abs().max().item()
     with nethook.InstrumentedModel(model) as inst:
         inst.retain_layer('layer7', detach=False)
         with torch.no_grad():
@@ -398,6 +411,9 @@ def test_styled_conv_modules_are_differentiable(emulated_hip):
         x = torch.randn(2, 8, 5, 7, requires_grad=True)
         st = (1 + 0.3 * torch.randn(2, 8)).requires_grad_(True)
         y = m(models.DataBag(fmap=x, style=st)).fmap
+        # the graph runs through grad.py's Function (the emulated kernels are torch ops: were they left attached, the
+        # adjoints under test would never be called)
+        assert type(y.grad_fn).__name__.startswith('DemodConv')
         g = torch.randn_like(y)
         (y * g).sum().backward()
         x2, st2, w2 = (t.detach().clone().requires_grad_(True) for t in (x, st, m.weight))
