@@ -473,10 +473,13 @@ __device__ __forceinline__ void w4_at_row(const float (&t)[6], float (&v)[4]) {
 // (f16 denormals: absolute error <= 2^-25 2^-eV) -- no worse than what fp32 accumulation does to them beside the large terms.
 // Per-product error <= 2^-21.x of the product against 2^-24 for an fp32 multiply; measured against float64 the kernel's
 // total error is that of the fp32 F(4x4,3x3) kernel (the transforms' constants dominate both).
-// Packed weights: the layout of rw_pack_conv_weight_wino4_f32 with every float replaced by the 32-bit word
-// Uh | Ul << 16 (same size, same pieces) + 4 trailing floats: [2^-eU, 0, max |U| bits, 0].
-// What it costs: 3 VALU per transformed value (v_cvt_pk_f16_f32, v_fma_mix_f32, v_cvt_pk_f16_f32) + 1 per weight word
-// (v_mov: the pair (w, w)); what it buys: 36 MFMAs of ~17 cycles instead of 32, with vector instructions issuing
+// Packed weights: uf[o / 16][i / 4][position 0..35 (w4_nat)][lane] of 32-bit words Uh | Ul << 16 -- the size and the
+// pieces of rw_pack_conv_weight_wino4_f32, one word per (position, lane) so that consecutive lanes are 4 bytes apart --
+// + 4 trailing floats: [2^-eU, 0, max |U| bits, 0].
+// What it costs: 3 VALU per transformed value (v_cvt_pk_f16_f32, v_fma_mix_f32, v_cvt_pk_f16_f32); the pair (w, w) of a
+// weight word costs none -- ds_read2st64_b32 reads the word into both registers (inline assembly, waits tied to the
+// operands: scripts/check_asm_loads.py) where two v_mov per word were a fifth of the loop's vector instructions.  What
+// it buys: 36 MFMAs of ~17 cycles instead of 32, with vector instructions issuing
 // beside them (profiles/r04a_mfma16_valu_probe.jsonl).  The legacy K = 16 instruction takes as long as the K = 32 one;
 // the K = 32 form needs 8-channel intervals whose rings do not fit two workgroups' LDS.
 // ---------------------------------------------------------------------------------------
@@ -488,8 +491,8 @@ __device__ __forceinline__ void w4_split16(float v, w4_f16x2& hh, w4_f16x2& ll) 
   asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hh), "v"(v));     // v - (float)h, exact
   ll = __builtin_convertvector(w4_f32x2{r, r}, w4_f16x2);
 }
-__device__ __forceinline__ w4_f32x4 w4_mfma16(unsigned w, w4_f16x2 hh, w4_f16x2 ll, w4_f32x4 acc, unsigned w_abl = 0) {
-  const w4_f16x4 a = __builtin_bit_cast(w4_f16x4, (W4_ABL & 128) ? w4_u32x2{w, w_abl} : w4_u32x2{w, w});
+__device__ __forceinline__ w4_f32x4 w4_mfma16(w4_u32x2 ww, w4_f16x2 hh, w4_f16x2 ll, w4_f32x4 acc) {
+  const w4_f16x4 a = __builtin_bit_cast(w4_f16x4, ww);         // (w, w): the word of (position, lane) twice
   const w4_f16x4 b = {hh[0], hh[1], ll[0], ll[1]};
   if (W4_ABL & 64) {
     asm volatile("" :: "v"(a), "v"(b));
@@ -722,16 +725,19 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
   };
 
   // H16: the same interval on v_mfma_f32_16x16x16_f16 (see the note above the body).  Points in the packed order
-  // (w4_nat): a row of B^T d B is finished right before its first point, every value is split where it is used.
+  // (w4_nat): a row of B^T d B is finished right before its first point, every value is split where it is used.  The
+  // weight words come in batches of six, one batch ahead: ds_read2st64_b32 with both offsets equal puts the word of
+  // (position, lane) into both registers of the operand.
+  auto aread = [&](unsigned addr, auto pos_tag, w4_u32x2& dst) __attribute__((always_inline)) {
+    constexpr int POS = decltype(pos_tag)::value;
+    if (W4_ABL & 128) { dst = w4_u32x2{addr, (unsigned)POS}; return; }
+    asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%2" : "=&v"(dst) : "v"(addr), "n"(POS));
+  };
   auto compute16 = [&](int ring, int uring, int kq, auto spread_tag) __attribute__((always_inline)) {
     constexpr bool SPREAD = decltype(spread_tag)::value != 0;
-    const unsigned* base = reinterpret_cast<const unsigned*>(&Us[uring * USZ + wm * (9 * 256) + a_lane]);
+    const unsigned ua = us_base + (unsigned)((uring * USZ + wm * (9 * 256) + lane) * 4);
     const float* src = &Ps[ring * PSZ + item_off];
     const float sv = St[4 * kq + lk];
-    w4_u32x4 a4[3];
-    a4[0] = *reinterpret_cast<const w4_u32x4*>(base);
-    a4[1] = *reinterpret_cast<const w4_u32x4*>(base + 256);
-    a4[2] = *reinterpret_cast<const w4_u32x4*>(base + 512);
     w4_f32x2 c2[6][3];
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
@@ -740,21 +746,35 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
       c2[r][1] = w4_f32x2{lo[2], lo[3]} * sv;
       c2[r][2] = *reinterpret_cast<const w4_f32x2*>(src + r * W4B_PITCH + 4) * sv;
     }
+    w4_u32x2 aq[2][6];
+    aread(ua, w4_int<0>(), aq[0][0]); aread(ua, w4_int<1>(), aq[0][1]); aread(ua, w4_int<2>(), aq[0][2]);
+    aread(ua, w4_int<3>(), aq[0][3]); aread(ua, w4_int<4>(), aq[0][4]); aread(ua, w4_int<5>(), aq[0][5]);
 #pragma unroll
     for (int cp = 0; cp < 3; ++cp)
       if (!(W4_ABL & 1)) w4_bt2(c2[0][cp], c2[1][cp], c2[2][cp], c2[3][cp], c2[4][cp], c2[5][cp]);
     float d[6][6];
-#pragma unroll
-    for (int q = 0; q < 9; ++q) {
-      const w4_u32x4 a = a4[q % 3];
-      if (q + 3 < 9) a4[q % 3] = *reinterpret_cast<const w4_u32x4*>(base + (q + 3) * 256);
+    auto batch = [&](auto bt_tag) __attribute__((always_inline)) {
+      constexpr int BT = decltype(bt_tag)::value;
+      w4_u32x2 (&cur)[6] = aq[BT & 1];
+      if (BT < 5) {
+        w4_u32x2 (&nxt)[6] = aq[(BT + 1) & 1];
+        aread(ua, w4_int<6 * BT + 6>(), nxt[0]); aread(ua, w4_int<6 * BT + 7>(), nxt[1]);
+        aread(ua, w4_int<6 * BT + 8>(), nxt[2]); aread(ua, w4_int<6 * BT + 9>(), nxt[3]);
+        aread(ua, w4_int<6 * BT + 10>(), nxt[4]); aread(ua, w4_int<6 * BT + 11>(), nxt[5]);
+        // this batch's reads are older than the six just issued
+        if (!(W4_ABL & 128))
+          asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5]) :: "memory");
+      } else if (!(W4_ABL & 128)) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5]) :: "memory");
+      }
       if (SPREAD && !(W4_ABL & 2)) {
-        if (2 * q < PPW) pload_piece(2 * q);
-        if (2 * q + 1 < PPW) pload_piece(2 * q + 1);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          if (2 * BT + t < PPW) pload_piece(2 * BT + t);
       }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int pos = 4 * q + e;
+      for (int e = 0; e < 6; ++e) {
+        const int pos = 6 * BT + e;
         const int xi = w4_nat(pos);
         const int ra = xi / 6;
         // first point of a row in the packed order: positions 0, 6, 12 (rows 0, 1, 2), 18 (row 4), 20 (row 5), 26 (row 3)
@@ -768,9 +788,11 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
         }
         w4_f16x2 hh, ll;
         w4_split16(d[ra][xi % 6], hh, ll);
-        acc[xi] = w4_mfma16(a[e], hh, ll, acc[xi], a[e ^ 1]);
+        acc[xi] = w4_mfma16(cur[e], hh, ll, acc[xi]);
       }
-    }
+    };
+    batch(w4_int<0>()); batch(w4_int<1>()); batch(w4_int<2>()); batch(w4_int<3>()); batch(w4_int<4>()); batch(w4_int<5>());
+    static_assert(2 * 6 >= PPW, "two patch pieces per batch cover the wave's share");
   };
 
   // PS: this wave's 18 points against both 16-channel blocks: acc[18 ob + le], le = 6 a + b local (rows (0, 1, 2)[a] of
@@ -838,15 +860,18 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
     }
   };
 
-  // H16 + PS: as compute_ps; every value is split once and meets the weight words of both blocks
+  // H16 + PS: as compute_ps; every value is split once and meets the weight words of both blocks.  Local point le of
+  // wave wm sits at packed position 20 wm + le (le < 16) resp. 16 + 2 wm + (le - 16): two wave-uniform bases, the
+  // position within them an immediate; block 1 is 36 positions further.
   auto compute16_ps = [&](int ring, int uring, int kq, auto spread_tag) __attribute__((always_inline)) {
     constexpr bool SPREAD = decltype(spread_tag)::value != 0;
-    const unsigned* base = reinterpret_cast<const unsigned*>(&Us[uring * USZ + a_lane]);      // block 1: + 9 * 256
+    const unsigned ua = us_base + (unsigned)((uring * USZ + lane) * 4) + (unsigned)(wm * 20 * 256);
+    const unsigned ub = us_base + (unsigned)((uring * USZ + lane) * 4) + (unsigned)(wm * 2 * 256);
     const float* src = &Ps[ring * PSZ + item_off];
     const float sv = St[4 * kq + lk];
-    w4_u32x4 a4[2][2];
-    a4[0][0] = *reinterpret_cast<const w4_u32x4*>(base + ps_quad);
-    a4[0][1] = *reinterpret_cast<const w4_u32x4*>(base + 9 * 256 + ps_quad);
+    w4_u32x2 aq[2][6];                              // three points x two blocks per batch
+    aread(ua, w4_int<0>(), aq[0][0]); aread(ua, w4_int<36>(), aq[0][1]); aread(ua, w4_int<1>(), aq[0][2]);
+    aread(ua, w4_int<37>(), aq[0][3]); aread(ua, w4_int<2>(), aq[0][4]); aread(ua, w4_int<38>(), aq[0][5]);
     w4_f32x2 c2[7][3];
 #pragma unroll
     for (int r = 0; r < 7; ++r) {
@@ -862,33 +887,36 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
       w4_bt2_rows(c2[0][cp], c2[1][cp], c2[2][cp], c2[3][cp], c2[4][cp], c2[5][cp], c2[6][cp], ps_cA, ps_cB, ps_cC,
                   hrow[0][cp], hrow[1][cp], hrow[2][cp]);
     float d[3][6];
-#pragma unroll
-    for (int q = 0; q < 5; ++q) {
-      const w4_u32x4 a0 = a4[q & 1][0], a1 = a4[q & 1][1];
-      if (q + 1 < 4) {
-        a4[(q + 1) & 1][0] = *reinterpret_cast<const w4_u32x4*>(base + ps_quad + (q + 1) * 256);
-        a4[(q + 1) & 1][1] = *reinterpret_cast<const w4_u32x4*>(base + 9 * 256 + ps_quad + (q + 1) * 256);
-      } else if (q + 1 == 4) {
-        const w4_u32x2 h0 = *reinterpret_cast<const w4_u32x2*>(base + ps_half);
-        const w4_u32x2 h1 = *reinterpret_cast<const w4_u32x2*>(base + 9 * 256 + ps_half);
-        a4[0][0] = w4_u32x4{h0[0], h0[1], 0u, 0u};
-        a4[0][1] = w4_u32x4{h1[0], h1[1], 0u, 0u};
+    auto batch = [&](auto bt_tag) __attribute__((always_inline)) {
+      constexpr int BT = decltype(bt_tag)::value;
+      w4_u32x2 (&cur)[6] = aq[BT & 1];
+      if (BT < 5) {
+        w4_u32x2 (&nxt)[6] = aq[(BT + 1) & 1];
+        constexpr int L0 = 3 * BT + 3, L1 = 3 * BT + 4, L2 = 3 * BT + 5;      // the next batch's local points
+        aread(L0 < 16 ? ua : ub, w4_int<L0>(), nxt[0]); aread(L0 < 16 ? ua : ub, w4_int<L0 + 36>(), nxt[1]);
+        aread(L1 < 16 ? ua : ub, w4_int<L1>(), nxt[2]); aread(L1 < 16 ? ua : ub, w4_int<L1 + 36>(), nxt[3]);
+        aread(L2 < 16 ? ua : ub, w4_int<L2>(), nxt[4]); aread(L2 < 16 ? ua : ub, w4_int<L2 + 36>(), nxt[5]);
+        if (!(W4_ABL & 128))
+          asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5]) :: "memory");
+      } else if (!(W4_ABL & 128)) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5]) :: "memory");
       }
       if (SPREAD && !(W4_ABL & 2)) {
 #pragma unroll
-        for (int t = 0; t < 3; ++t)
-          if (3 * q + t < PPW) pload_piece(3 * q + t);
+        for (int t = 0; t < 2; ++t)
+          if (2 * BT + t < PPW) pload_piece(2 * BT + t);
       }
 #pragma unroll
-      for (int e = 0; e < (q < 4 ? 4 : 2); ++e) {
-        const int le = 4 * q + e;
+      for (int e = 0; e < 3; ++e) {
+        const int le = 3 * BT + e;
         if (le % 6 == 0) w4_bt_row(hrow[le / 6][0], hrow[le / 6][1], hrow[le / 6][2], d[le / 6]);
         w4_f16x2 hh, ll;
         w4_split16(d[le / 6][le % 6], hh, ll);
-        acc[le] = w4_mfma16(a0[e], hh, ll, acc[le], a0[e ^ 1]);
-        acc[18 + le] = w4_mfma16(a1[e], hh, ll, acc[18 + le], a1[e ^ 1]);
+        acc[le] = w4_mfma16(cur[2 * e], hh, ll, acc[le]);
+        acc[18 + le] = w4_mfma16(cur[2 * e + 1], hh, ll, acc[18 + le]);
       }
-    }
+    };
+    batch(w4_int<0>()); batch(w4_int<1>()); batch(w4_int<2>()); batch(w4_int<3>()); batch(w4_int<4>()); batch(w4_int<5>());
   };
 
   // ---- the output transform of one accumulator component j: Y[r][k] = (A^T M A)[r][k] of this wave's out-channel block
@@ -1220,7 +1248,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino36_rgb_ns_kernel(const Wino4P
 }
 // H16: the six on the 16-bit matrix pipe (see the note above the body), and the point split for the stride-1 convolution
 // and the upsampling layer (its vector work per interval halves; what it adds -- the partial tiles' swap per group --
-// pays where a group has many intervals: in_ch >= W4H_PS_MIN_IN)
+// pays where a group has many intervals: in_ch >= 64, measured)
 __global__ void __launch_bounds__(256, 2) conv_wino36h_kernel(const Wino4Problem p) { conv_wino36b_body<2, 2, 0, true, false, true>(p); }
 __global__ void __launch_bounds__(256, 2) conv_up_wino36h_kernel(const Wino4Problem p) { conv_wino36b_body<2, 2, 1, true, false, true>(p); }
 __global__ void __launch_bounds__(256, 2) conv_wino36h_rgb_kernel(const Wino4Problem p) { conv_wino36b_body<2, 2, 2, true, false, true>(p); }
@@ -1229,11 +1257,11 @@ __global__ void __launch_bounds__(256, 2) conv_up_wino36h_ps_kernel(const Wino4P
 __global__ void __launch_bounds__(256, 2) conv_wino36h_rgb_ps_kernel(const Wino4Problem p) { conv_wino36b_body<2, 2, 2, true, true, true>(p); }
 // <4, 3>: one 512-thread workgroup per CU, 64 tiles per weight slice (RW_W4H_WG8=1; A/B builds)
 __global__ void __launch_bounds__(512, 1) conv_wino36h_wg8_kernel(const Wino4Problem p) { conv_wino36b_body<4, 3, 0, true, false, true>(p); }
-// point split: 0 = never, 1 = always, default = where in_ch >= 128 (RW_W4H_PS overrides)
+// point split: 0 = never, 1 = always, default = where in_ch >= 64 (RW_W4H_PS overrides)
 static bool w4h_point_split(int in_ch) {
   const char* e = getenv("RW_W4H_PS");
   const int mode = e ? atoi(e) : -1;
-  return mode < 0 ? in_ch >= 128 : mode != 0;
+  return mode < 0 ? in_ch >= 64 : mode != 0;
 }
 
 // The same six with the 36 points split between the two out-channel waves (PS above).  MEASURED FLAT (same box, batch
@@ -1304,9 +1332,11 @@ __device__ __forceinline__ float w4_pack_store(const float* g, float* dst, float
         *reinterpret_cast<w4_f32x4*>(dst + q * 256) =
             w4_f32x4{u[w4_nat(4 * q)], u[w4_nat(4 * q + 1)], u[w4_nat(4 * q + 2)], u[w4_nat(4 * q + 3)]};
       } else {
-        *reinterpret_cast<w4_u32x4*>(dst + q * 256) =
-            w4_u32x4{w4_pack16(u[w4_nat(4 * q)] * su), w4_pack16(u[w4_nat(4 * q + 1)] * su),
-                     w4_pack16(u[w4_nat(4 * q + 2)] * su), w4_pack16(u[w4_nat(4 * q + 3)] * su)};
+        // H16: one word per (position, lane), positions 256 bytes apart -- the kernels read a word into both halves of
+        // an operand pair with ds_read2st64_b32 (dst = the lane's column of the block: + lane instead of + 4 lane)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          reinterpret_cast<unsigned*>(dst)[(4 * q + e) * 64] = w4_pack16(u[w4_nat(4 * q + e)] * su);
       }
     }
     return m;
@@ -1343,7 +1373,8 @@ __global__ void __launch_bounds__(256) pack_wino36_kernel(const float* __restric
     const int kq = (int)(rest % kqn);
     const int ob = (int)(rest / kqn);
     const int o = 16 * ob + (lane & 15), i = 4 * kq + (lane >> 4);
-    m = fmaxf(m, w4_pack_store<PASS>(w + ((int64_t)o * in_ch + i) * 9, uf + ((int64_t)ob * kqn + kq) * (9 * 256) + lane * 4, su));
+    m = fmaxf(m, w4_pack_store<PASS>(w + ((int64_t)o * in_ch + i) * 9,
+                                     uf + ((int64_t)ob * kqn + kq) * (9 * 256) + (PASS == 2 ? lane : lane * 4), su));
   }
   if (PASS == 1) w4_report_absmax(m, trailer);
   if (PASS == 2 && blockIdx.x == 0 && threadIdx.x == 0) trailer[0] = inv;
@@ -1386,7 +1417,7 @@ __global__ void __launch_bounds__(256) pack_up_wino36_kernel(const float* __rest
           }
         h[3 * a + b] = sum;
       }
-    m = fmaxf(m, w4_pack_store<PASS>(h, uf + ((int64_t)ob * kqn + kq) * (9 * 256) + lane * 4, su));
+    m = fmaxf(m, w4_pack_store<PASS>(h, uf + ((int64_t)ob * kqn + kq) * (9 * 256) + (PASS == 2 ? lane : lane * 4), su));
   }
   if (PASS == 1) w4_report_absmax(m, trailer);
   if (PASS == 2 && blockIdx.x == 0 && threadIdx.x == 0) trailer[0] = inv;

@@ -1,6 +1,6 @@
 """Static check of the kernels that read LDS from inline assembly (ds_read2_b64 with register outputs): the compiler
 takes an asm's outputs for ready, so between such a read and the s_waitcnt that covers it nothing may touch the
-destination registers.  Reads hipcc's assembly (-S) of a source file and checks every `ds_read2_b64` inside ASMSTART /
+destination registers.  Reads hipcc's assembly (-S) of a source file and checks every `ds_read2*` inside ASMSTART /
 ASMEND against the instructions up to the wait that retires it (in-order LDS returns: the wait lgkmcnt(n) retires a read
 once at most n LDS instructions were issued after it; scalar memory loads, which return out of order, must not occur
 in between at all).
@@ -40,7 +40,7 @@ def check(path):
         if 'ASMEND' in t:
             in_asm = False
             continue
-        if not (in_asm and t.startswith('ds_read2_b64')):
+        if not (in_asm and t.startswith('ds_read2')):
             continue
         n_reads += 1
         dst = regs(t.split()[1].rstrip(','))
