@@ -43,7 +43,14 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+F16_MFMA_PEAK_TFLOPS = 2500.0     # same guide: dense f16 / bf16 MFMA (the split-operand kernels' pipe)
 HBM_PEAK_GBS = 8000.0
+
+
+def w4h_point_split(in_ch):
+    """rw_wino4.hip's w4h_point_split: which of the two split-operand F(4x4,3x3) kernels a launch picks."""
+    e = os.environ.get('RW_W4H_PS')
+    return in_ch >= 64 if e is None else int(e) != 0
 
 
 def conv_flops(model_size, channel_multiplier=2):
@@ -107,16 +114,27 @@ class ConvTimer:
                 y = fn(x, wp, out_ch, w_scale, *a, **k)
                 e.record()
                 b, i, h, w = x.shape
+                lib = hip.lib()
                 if wino == 'up':
-                    name = {16: 'conv_up_wino_narrow_kernel', 8: 'conv_up_wino_8x8_kernel',
-                            4: 'conv_up_wino_4x4_kernel'}.get(w, 'conv_up_wino_kernel')
+                    if wp.numel() == lib.rw_packed_conv_transpose_winoh_elems(out_ch, i):
+                        name = 'conv_up_winoh_kernel'             # operands split into f16 pairs (16-bit matrix pipe)
+                    else:
+                        name = {16: 'conv_up_wino_narrow_kernel', 8: 'conv_up_wino_8x8_kernel',
+                                4: 'conv_up_wino_4x4_kernel'}.get(w, 'conv_up_wino_kernel')
                 elif wino in ('up4', 'f4rgb', 'f4'):
                     # rw_wino4.hip picks the no-style variants when the input map already carries the style
                     ns = k.get('style') is None
+                    h16 = wp.numel() == (lib.rw_packed_conv_transpose_blur_wino4h_elems(out_ch, i) if wino == 'up4'
+                                         else lib.rw_packed_conv_weight_wino4h_elems(out_ch, i))
+                    ps = '_ps' if h16 and w4h_point_split(i) else ''
                     if wino == 'up4':         # transposed conv + blur + noise + activation in one pass
-                        name = 'conv_up_wino36_ns_kernel' if ns else 'conv_up_wino36_kernel'
+                        name = ('conv_up_wino36h%s_kernel' % ps if h16 else
+                                'conv_up_wino36_ns_kernel' if ns else 'conv_up_wino36_kernel')
                     elif wino == 'f4rgb':
-                        name = 'conv_wino36_rgb_ns_kernel' if ns else 'conv_wino36_rgb_kernel'
+                        name = ('conv_wino36h_rgb%s_kernel' % ps if h16 else
+                                'conv_wino36_rgb_ns_kernel' if ns else 'conv_wino36_rgb_kernel')
+                    elif h16:
+                        name = 'conv_wino36h%s_kernel' % ps
                     elif i > 512:
                         name = 'conv_wino36_kernel<2, 2>'
                     else:
@@ -128,7 +146,17 @@ class ConvTimer:
                 else:
                     name = ('conv_halo_bf16x6_kernel<2, 2, %s>' % ('2, 2' if out_ch % 128 == 0 else '1, 4') if split
                             else conv_kernel_name(out_ch, i, w, upsample))
-                timer.calls.append((name, s, e, 2.0 * 9 * i * out_ch * h * w * b))
+                # algorithmic HBM bytes of the call: the input map once, what it writes once (the (2H+1)^2 map of a
+                # transposed convolution, the (2H)^2 result of the one-pass layer, the RGB image of the fused last layer)
+                if wino == 'up4':
+                    out_elems = b * out_ch * 4 * h * w
+                elif wino == 'f4rgb' or fn is self._orig[3] or fn is self._orig[5]:
+                    out_elems = b * 3 * h * w * 2                  # running image read and written; no feature map
+                elif upsample:
+                    out_elems = b * out_ch * (2 * h + 1) * (2 * w + 1)
+                else:
+                    out_elems = b * out_ch * h * w
+                timer.calls.append((name, s, e, 2.0 * 9 * i * out_ch * h * w * b, 4.0 * (b * i * h * w + out_elems)))
                 return y
             return inner
         hip.conv3x3 = wrap(self._orig[0], False)
@@ -150,66 +178,87 @@ class ConvTimer:
 
     def result(self):
         per = {}
-        for name, s, e, fl in self.calls:
-            d = per.setdefault(name, dict(ms=0.0, flops=0.0, launches=0))
+        for name, s, e, fl, by in self.calls:
+            d = per.setdefault(name, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
             d['ms'] += s.elapsed_time(e)
             d['flops'] += fl
+            d['bytes'] += by
             d['launches'] += 1
         if not per:
             return None
+
+        def rec(n, v):
+            factor, algorithm, pipe, peak = issued_fraction(n)
+            sec = v['ms'] * 1e-3
+            issued = v['flops'] * factor / sec / 1e12
+            return dict(effective_tflops=round(v['flops'] / sec / 1e12, 1), issued_tflops=round(issued, 1), pipe=pipe,
+                        issued_frac=round(issued / peak, 3), hbm_gbs=round(v['bytes'] / sec / 1e9, 1),
+                        hbm_frac=round(v['bytes'] / sec / 1e9 / HBM_PEAK_GBS, 3), ms=round(v['ms'], 2),
+                        launches=v['launches'])
         dom = max(per, key=lambda n: per[n]['ms'])
         d = per[dom]
-        factor, algorithm = issued_fraction(dom)
+        factor, algorithm, pipe, peak = issued_fraction(dom)
         effective = d['flops'] / (d['ms'] * 1e-3) / 1e12          # direct-sum FLOPs per second
         issued = effective * factor                                  # what the matrix pipe executes
         tot_ms = sum(v['ms'] for v in per.values())
         tot_fl = sum(v['flops'] for v in per.values())
-        tot_issued = sum(v['flops'] * issued_fraction(n)[0] for n, v in per.items())
-        out = dict(bound='mfma-issue (fp32 MFMA shares the SIMD lanes with the VALU)',
-                   achieved=round(issued, 2), peak=FP32_MFMA_PEAK_TFLOPS,
-                   unit='TFLOP/s', frac=round(issued / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
-                   kernel=dom, launches=d['launches'],
+        # time the matrix pipes would need at their peaks for what all conv launches issue (fp32 and f16 pipes mixed)
+        pipe_s = sum(v['flops'] * issued_fraction(n)[0] / (issued_fraction(n)[3] * 1e12) for n, v in per.items())
+        out = dict(bound='mfma', achieved=round(issued, 2), peak=peak,
+                   unit='TFLOP/s', frac=round(issued / peak, 4), traffic=None,
+                   kernel=dom, launches=d['launches'], pipe=pipe,
                    avg_launch_us=round(d['ms'] * 1e3 / d['launches'], 2),
                    algorithm=algorithm, mfma_flops_issued_over_direct_sum=round(factor, 4),
                    flops_per_launch=round(d['flops'] / d['launches'] * factor),
                    direct_sum_flops_per_launch=round(d['flops'] / d['launches']),
                    effective_tflops=round(effective, 2),
-                   effective_over_direct_roof=round(effective / FP32_MFMA_PEAK_TFLOPS, 4),
-                   note='`achieved` = matrix FLOPs the kernel ISSUES per second (direct-sum FLOPs of SURVEY 8d x the '
-                        'algorithm\'s multiply count / the direct sum\'s) -- a fraction of the fp32 MFMA peak that cannot '
-                        'exceed 1; `effective_tflops` = the direct sum\'s FLOPs per second, which can',
-                   all_conv_kernels=dict(issued_tflops=round(tot_issued / (tot_ms * 1e-3) / 1e12, 2),
-                                         issued_frac=round(tot_issued / (tot_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                   effective_over_fp32_direct_roof=round(effective / FP32_MFMA_PEAK_TFLOPS, 4),
+                   hbm=dict(algorithmic_bytes_per_launch=round(d['bytes'] / d['launches']),
+                            achieved_gbs=round(d['bytes'] / (d['ms'] * 1e-3) / 1e9, 1), peak_gbs=HBM_PEAK_GBS,
+                            frac=round(d['bytes'] / (d['ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)),
+                   note='`achieved` = matrix FLOPs the kernel ISSUES per second on ITS pipe (direct-sum FLOPs of SURVEY 8d x '
+                        'the algorithm\'s multiply count / the direct sum\'s, x 4 piece products where the operands are '
+                        'split into f16 pairs) against that pipe\'s dense peak; `effective_tflops` = the direct sum\'s '
+                        'FLOPs per second; `hbm` = the launch\'s algorithmic bytes against the HBM roof.  Neither roof binds '
+                        'these kernels: see DESIGN.md section 4 (ablations, SQ counters)',
+                   all_conv_kernels=dict(matrix_pipe_time_frac=round(pipe_s / (tot_ms * 1e-3), 4),
                                          effective_tflops=round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
-                                         effective_over_direct_roof=round(
+                                         effective_over_fp32_direct_roof=round(
                                              tot_fl / (tot_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
                                          ms_per_step=None))
-        out['per_kernel'] = {n: dict(effective_tflops=round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 1),
-                                     issued_tflops=round(v['flops'] * issued_fraction(n)[0] / (v['ms'] * 1e-3) / 1e12, 1),
-                                     issued_frac=round(v['flops'] * issued_fraction(n)[0] / (v['ms'] * 1e-3) / 1e12
-                                                       / FP32_MFMA_PEAK_TFLOPS, 3),
-                                     ms=round(v['ms'], 2), launches=v['launches'])
-                             for n, v in sorted(per.items(), key=lambda kv: -kv[1]['ms'])}
+        out['per_kernel'] = {n: rec(n, v) for n, v in sorted(per.items(), key=lambda kv: -kv[1]['ms'])}
         out['_tot_ms'] = tot_ms
-        out['_issued_flops'] = tot_issued
+        out['_pipe_s'] = pipe_s
         return out
 
 
 def issued_fraction(kernel):
-    """(matrix FLOPs a kernel issues / direct-sum FLOPs of the convolution it computes, what the algorithm is).
-    The minimal-filtering kernels multiply less than the direct sum; the roofline fraction is priced on what they
-    issue (rw_wino.hip, rw_wino4.hip, rw_upwino.hip headers)."""
+    """(matrix FLOPs a kernel issues / direct-sum FLOPs of the convolution it computes, what the algorithm is, the
+    pipe it issues them on, that pipe's dense peak in TFLOP/s).  The minimal-filtering kernels multiply less than the
+    direct sum; the split-operand kernels (…h…) issue FOUR f16 piece products per multiply on the 16-bit pipe
+    (rw_wino.hip, rw_wino4.hip, rw_upwino.hip headers)."""
+    f32 = ('fp32 MFMA', FP32_MFMA_PEAK_TFLOPS)
+    f16 = ('f16 MFMA, 4 piece products per multiply (exact operand split), fp32 accumulate', F16_MFMA_PEAK_TFLOPS)
+    if kernel.startswith('conv_up_wino36h'):
+        return (4.0, 'transposed conv (*) blur as four F(4x4,3x3) phase convolutions: the transposed conv\'s direct-sum '
+                'multiply count, each as 4 f16 piece products') + f16
+    if kernel.startswith('conv_up_winoh'):
+        return (4 * 25.0 / 36.0, 'transposed conv by F(2,2) on the four output-parity phases: 25 multiplies per 2x2 block '
+                'of quads where the direct sum has 36, each as 4 f16 piece products') + f16
+    if kernel.startswith('conv_wino36h'):
+        return (1.0, 'winograd F(4x4,3x3): 36 multiplies per 4x4 output tile where the direct sum has 144, each as 4 f16 '
+                'piece products') + f16
     if kernel.startswith('conv_up_wino36'):
-        return 1.0, ('transposed conv (*) blur as four F(4x4,3x3) phase convolutions, fp32: issues the transposed '
-                     'conv\'s direct-sum FLOP count')
+        return (1.0, 'transposed conv (*) blur as four F(4x4,3x3) phase convolutions, fp32: issues the transposed '
+                'conv\'s direct-sum FLOP count') + f32
     if kernel.startswith('conv_up_wino'):
-        return 25.0 / 36.0, ('transposed conv by F(2,2) on the four output-parity phases, fp32: 25 multiplies per 2x2 '
-                             'block of quads where the direct sum has 36')
+        return (25.0 / 36.0, 'transposed conv by F(2,2) on the four output-parity phases, fp32: 25 multiplies per 2x2 '
+                'block of quads where the direct sum has 36') + f32
     if kernel.startswith('conv_wino36'):
-        return 0.25, 'winograd F(4x4,3x3), fp32: 36 multiplies per 4x4 output tile where the direct sum has 144'
+        return (0.25, 'winograd F(4x4,3x3), fp32: 36 multiplies per 4x4 output tile where the direct sum has 144') + f32
     if kernel.startswith('conv_wino16'):
-        return 1.0 / 2.25, 'winograd F(2x2,3x3), fp32: 16 multiplies per 2x2 output tile where the direct sum has 36'
-    return 1.0, 'direct implicit GEMM, fp32 MFMA'
+        return (1.0 / 2.25, 'winograd F(2x2,3x3), fp32: 16 multiplies per 2x2 output tile where the direct sum has 36') + f32
+    return (1.0, 'direct implicit GEMM, fp32 MFMA') + f32
 
 
 def attach_pmc_traffic(roof, workload, batch):
@@ -347,6 +396,54 @@ def cpu_baseline_forward(size, images=8):
                           best, json.dumps({k: round(v, 3) for k, v in probe.items()}), ncpu))
 
 
+def cpu_baseline_edit(shape, seeds=30, steps=150):
+    """The other half of BASELINE.json's metric on the host cores: key collection (context forward of the 256^2
+    generator up to layer 8 in batches of 10 + the second moment) and the 2001-step rank-1 solve, through the oracle
+    restatement (a port: /root/reference does not exist on the GPU box) -- on a BOUNDED sample (`seeds` of the 1000
+    seeds, `steps` of the 2001 iterations, at the solve's own shapes) extrapolated linearly, at the best of a few thread
+    counts."""
+    from rewriting_amd import synthetic
+    from rewriting_amd.utils import zdataset
+    from rewriting_amd.utils.stylegan2 import models
+    from oracle import restatement as R
+    g = models.SeqStyleGAN2(256, 512, 8, truncation=0.5, mconv='seq')
+    synthetic.randomize_(g, seed=0)
+    sd = {k: v.detach() for k, v in g.state_dict().items()}
+    zds = zdataset.z_dataset_for_model(g, size=seeds)
+    zb = [torch.stack([zds[j][0] for j in range(i, min(i + 10, seeds))]) for i in range(0, seeds, 10)]
+    O, I, h, w = shape.get('out_ch', 512), shape.get('in_ch', 512), shape.get('h', 5), shape.get('w', 8)
+    gen = torch.Generator().manual_seed(0)
+    W0 = torch.randn(1, O, I, 3, 3, generator=gen)
+    key, style = torch.randn(1, I, h, w, generator=gen), 1 + 0.3 * torch.randn(1, I, generator=gen)
+    val, bias = torch.randn(1, O, h, w, generator=gen), torch.zeros(O)
+    ctx = torch.nn.functional.normalize(torch.randn(1, I, generator=gen), dim=1)
+    ncpu = os.cpu_count() or 1
+    saved = torch.get_num_threads()
+    best = None
+    try:
+        with torch.no_grad():
+            for c in sorted({min(t, ncpu) for t in (8, 32, 64)}):
+                torch.set_num_threads(c)
+                R.context_forward(sd, zb[0][:2], 256, 8, truncation=0.5)        # warm-up
+                t0 = time.perf_counter()
+                R.second_moment(R.context_forward(sd, b, 256, 8, truncation=0.5)[0] for b in zb)
+                t_stats = (time.perf_counter() - t0) * 1000.0 / seeds
+                t0 = time.perf_counter()
+                R.insert_explicit(W0, key, style, val, bias, 0.1, ctx, steps)
+                t_solve = (time.perf_counter() - t0) * 2001.0 / steps
+                if best is None or t_stats + t_solve < best[0] + best[1]:
+                    best = (t_stats, t_solve, c)
+    finally:
+        torch.set_num_threads(saved)
+    return dict(value=round(best[0] + best[1], 2), unit='s per edit', cores=best[2], threads=best[2], host_cores=ncpu,
+                kind='port', key_collect_s=round(best[0], 2), solve_s=round(best[1], 2),
+                sample='oracle/restatement.py (a port; the reference itself is not on this box): context_forward + '
+                       'second_moment on %d of the 1000 seeds in batches of 10, insert_explicit for %d of the 2001 '
+                       'iterations on a %d x %d x %d x %d problem (random values, the solve\'s shapes); both extrapolated '
+                       'linearly; best of 8 / 32 / 64 threads (torch %s CPU kernels)' % (seeds, steps, O, I, h, w,
+                                                                                        torch.__version__.split('+')[0]))
+
+
 def bench_device(local):
     """This rank's MI355X.  (tests/bench_cpu_driver.py -- test infrastructure -- substitutes CPU tensors and the
     kernel stand-ins of tests/hip_emulation.py here to drive the launcher and the rank plumbing without a GPU.)"""
@@ -396,38 +493,50 @@ def run_forward(args, rank, world, device, size, batch, name, cpu=True):
         with torch.no_grad():
             last[0] = g(z)
     timed(step, 1, args.warmup, world)                      # warm-up incl. weight repack caches
-    timer = ConvTimer()
-    timer.install()
-    dt = timed(step, args.steps, 0, world)
-    timer.remove()
+    dt = timed(step, args.steps, 0, world)                  # THE number: nothing installed around the kernels
+    from rewriting_amd.utils.stylegan2 import models as sg_models
+    split = sg_models.matrix_mode_of_image_path() == 'split'
     images = batch * world * args.steps
     out = dict(metric='images/sec StyleGANv2-%d fwd' % size, value=round(images / dt, 2), unit='images/sec',
                n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3),
                higher_is_better=True, scaling='weak', vs_baseline=None,
-               dtype='f32' if args.precision == 'f32' else 'f32 via bf16x6 split (stride-1 convs), f32 elsewhere',
+               dtype=('f32 (exact f16 operand split inside the F(4x4,3x3) / F(2,2) kernels: four piece products per '
+                      'multiply on the 16-bit matrix pipe, f32 accumulate; f32 everywhere else)' if split and
+                      args.precision == 'f32' else
+                      'f32' if args.precision == 'f32' else 'f32 via bf16x6 split (stride-1 convs), f32 elsewhere'),
                data='synthetic',
                config=dict(workload=name, batch_per_gpu=batch, truncation=0.5, mconv='seq',
                            weights='synthetic seed 0', parallelism='seeds partitioned per rank, no collective',
-                           conv_gflop_per_image=round(conv_flops(size) / 1e9, 2)))
+                           conv_gflop_per_image=round(conv_flops(size) / 1e9, 2),
+                           matrix_mode='split' if split else 'f32'))
+    # second pass, NOT the headline: HIP events around every convolution call (on torch's current stream, the one the
+    # kernels are launched on) -> the per-kernel table and the dominant kernel's roofline
+    timer = ConvTimer()
+    timer.install()
+    inst_steps = max(1, min(3, args.steps))
+    dt_inst = timed(step, inst_steps, 0, world)
+    timer.remove()
     roof = timer.result()
     tot_ms = roof.pop('_tot_ms')
-    issued = roof.pop('_issued_flops')
-    roof['all_conv_kernels']['ms_per_step'] = round(tot_ms / args.steps, 3)
+    pipe_s = roof.pop('_pipe_s')
+    roof['all_conv_kernels']['ms_per_step'] = round(tot_ms / inst_steps, 3)
+    roof['instrumented_pass'] = dict(steps=inst_steps, ms_per_step=round(dt_inst / inst_steps * 1e3, 3))
     attach_pmc_traffic(roof, 'ffhq%d' % size, batch)
     out['roofline'] = roof
-    # the whole step against both roofs: matrix FLOPs issued by all conv launches / (wall time x fp32 MFMA peak), and
-    # SURVEY 8d's algorithmic bytes (a perfectly block-fused forward) / (wall time x HBM peak); PMC bytes beside them
+    # the whole step against both roofs: time the matrix pipes would need at peak for what all conv launches issue /
+    # wall time, and SURVEY 8d's algorithmic bytes (a perfectly block-fused forward) / (wall time x HBM peak); PMC
+    # bytes beside them
     alg_bytes = {256: 276.3e6, 1024: 1217.7e6}.get(size, 0) * batch
-    step = dict(mfma_issue_frac=round(issued / world / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
-                mfma_issued_tflops=round(issued / world / dt / 1e12, 2),
+    step = dict(matrix_pipe_time_frac=round(pipe_s / inst_steps / (dt / args.steps), 4),
                 direct_sum_tflops=round(conv_flops(size) * batch * args.steps / dt / 1e12, 2),
                 direct_sum_over_fp32_roof=round(conv_flops(size) * batch * args.steps / dt / 1e12
                                                 / FP32_MFMA_PEAK_TFLOPS, 4),
                 hbm_frac=round(alg_bytes * args.steps / dt / 1e9 / HBM_PEAK_GBS, 4),
                 hbm_algorithmic_gbs=round(alg_bytes * args.steps / dt / 1e9, 1),
                 hbm_bytes_algorithmic=round(alg_bytes), hbm_bytes_pmc=None,
-                note='per GPU and step; north_star\'s ">= 60 % of the HBM roofline" presupposes reduced-precision '
-                     'convolutions: in exact fp32 the step is bound by the matrix pipe (SURVEY.md 8d)')
+                note='per GPU and step.  north_star\'s ">= 60 % of the HBM roofline": the step moves its algorithmic '
+                     'bytes at hbm_frac of 8 TB/s; its convolution kernels are bound by neither roof but by their '
+                     'load -> barrier -> transform -> multiply chains (DESIGN.md section 4)')
     attach_pmc_step(step, 'ffhq%d' % size, batch)
     out['step'] = step
     out['parity'] = parity_of_timed_output(last[0], size, z, world)
@@ -460,7 +569,7 @@ def context_flops(model_size, layer, channel_multiplier=2):
     return total, key
 
 
-def measure_edit(device, reps, warmup):
+def measure_edit(device, reps, warmup, cpu=False):
     """configs[2]: horse->hat rank-1 edit at layer 8 of the 256 model.  Every repetition builds a fresh
     rewriter (1000-seed key statistics in batches of 10 + ZCA) and runs apply_edit (goal, context direction,
     2001-step solve)."""
@@ -512,8 +621,29 @@ def measure_edit(device, reps, warmup):
         roof = dict(bound='hbm', achieved=round(solve_bytes / solve_s / 1e9, 1), peak=HBM_PEAK_GBS,
                     unit='GB/s', frac=round(solve_bytes / solve_s / 1e9 / HBM_PEAK_GBS, 4),
                     note='7 x |W| x 4 B per step algorithmic (SURVEY.md 8d); latency-bound')
+    # the same apply_edit as the reference's drivers call it: with an update_callback on every iteration
+    # (rewrite/rewriteapp.py:517-521 prints loss.item() every 50th; metrics/make_watermark_images.py:66-72 ticks a bar) --
+    # unmarked = the reference's contract (the callback runs between the steps and may render the stepped weight: one
+    # launch per iteration), and marked ganrewrite.loss_only (it declares it reads (it, loss) only: the solve is not
+    # interrupted)
+    def ui_callback(it, loss):
+        if it % 50 == 0 or it == 2000:
+            loss.item()
+    with_cb = {}
+    for label, cb in (('reference_contract', ui_callback), ('loss_only', ganrewrite.loss_only(lambda it, loss: ui_callback(it, loss)))):
+        gw = ganrewrite.SeqStyleGanRewriter(g, zds, 8)
+        ts = []
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            gw.apply_edit(req, rank=1, niter=2001, piter=10, lr=0.05, update_callback=cb)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        with_cb[label] = round(min(ts), 4)
+    cpu_rec = cpu_baseline_edit(dict(last)) if cpu else None
     return dict(seconds_per_edit=round(med(times['total']), 4), key_collect_s=round(med(times['stats']), 4),
                 apply_edit_s=round(med(times['edit']), 4), solve_s=round(solve_s, 4), reps=reps,
+                apply_edit_with_update_callback_s=with_cb, cpu_baseline=cpu_rec,
                 workload='stylegan2-256 layer 8, recorded_horse_hat.json: 1000-seed key statistics + ZCA, goal, '
                          'context direction, 2001-step rank-1 solve',
                 solve_path='rw_solve_run_f32' if last.get('one_launch') else 'rw_solve_step_f32',
@@ -553,11 +683,27 @@ def measure_sweep(device, size, layer, nseeds, steps, warmup, world, g=None):
                                              nchw=True, batch_size=launch)
     dt = timed(step, steps, warmup, world)
     flops = (flops_ctx + 2.0 * res * res * cin * cin) * nseeds * steps
-    achieved = flops / dt / 1e12 / world
+    effective = flops / dt / 1e12 / world
+    # the path's one collective, timed on its own: the all-reduce of (mom2, count) in float64 as tally_second_moment
+    # issues it (world == 1: nothing to reduce)
+    launches_total = len(range(0, nseeds, launch))
+    my_launches = len(parallel.batches_for_rank(launches_total, *parallel.shard())) if parallel.shard() else launches_total
+    allreduce_ms = None
+    if world > 1:
+        import torch.distributed as dist
+        buf = torch.zeros(cin * cin + 1, dtype=torch.float64, device=parallel.collective_device())
+        dist.all_reduce(buf)
+        device_sync()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            dist.all_reduce(buf)
+        device_sync()
+        allreduce_ms = round((time.perf_counter() - t0) / 5 * 1e3, 4)
     layers = None
+    issued_frac = None
     if world == 1 and torch.device(device).type == 'cuda':
         # one more context forward of one launch with HIP events around every convolution: the roofline of each layer's
-        # kernel (matrix FLOPs issued / fp32 MFMA peak), as the headline line gives it for the generator's
+        # kernel (matrix FLOPs issued / its pipe's peak), as the headline line gives it for the generator's
         timer = ConvTimer()
         timer.install()
         try:
@@ -569,19 +715,26 @@ def measure_sweep(device, size, layer, nseeds, steps, warmup, world, g=None):
             timer.remove()
         r = timer.result()
         if r is not None:
+            issued_frac = r['all_conv_kernels']['matrix_pipe_time_frac']
             layers = dict(seeds=launch, conv_ms=round(r['_tot_ms'], 3),
-                          conv_issued_frac=r['all_conv_kernels']['issued_frac'], per_kernel=r['per_kernel'],
+                          conv_issued_frac=issued_frac, per_kernel=r['per_kernel'],
                           note='HIP events around each convolution of ONE %d-seed context forward (border strips '
                                'and streaming kernels not included); kernel -> layer: conv_wino16<.., 4 / 8 / 16> = '
                                'layers 2 / 4 / 6, conv_up_wino_4x4 / _8x8 / _narrow = layers 3 / 5 / 7, the un-suffixed '
                                'kernels = the layers from 32 x 32 up' % launch)
     return dict(seeds_per_s=round(nseeds * steps / dt, 1), ms_per_sweep=round(dt / steps * 1e3, 2), size=size,
-                layer=layer, seeds=nseeds, launch=launch, key_map='%d x %d x %d' % (cin, res, res),
+                layer=layer, seeds=nseeds, launch=launch, launches=launches_total, launches_this_rank=my_launches,
+                allreduce_ms=allreduce_ms, key_map='%d x %d x %d' % (cin, res, res),
                 gflop_per_seed=round((flops_ctx + 2.0 * res * res * cin * cin) / 1e9, 3), context_layers=layers,
-                roofline=dict(bound='mfma', achieved=round(achieved, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
-                              frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
-                              note='per GPU: context-forward conv FLOPs of layers 2..%d + 2 H W C^2 of a^T a per seed '
-                                   '(SURVEY.md 8d) / wall time; the key map itself (%.1f MB per seed) is read once'
+                roofline=dict(bound='mfma', achieved=None if issued_frac is None else round(issued_frac * FP32_MFMA_PEAK_TFLOPS, 2),
+                              peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=issued_frac, traffic=None,
+                              effective_tflops=round(effective, 2),
+                              effective_over_fp32_direct_roof=round(effective / FP32_MFMA_PEAK_TFLOPS, 4),
+                              note='per GPU.  `frac` = the headline\'s definition: matrix FLOPs the context forward\'s '
+                                   'convolution kernels ISSUE / the fp32 MFMA peak over their own time (one launch under '
+                                   'HIP events; null when not measured: N > 1).  `effective_*` = direct-sum conv FLOPs of '
+                                   'layers 2..%d + 2 H W C^2 of a^T a per seed (SURVEY.md 8d) / wall time -- the minimal-'
+                                   'filtering kernels issue fewer; the key map itself (%.1f MB per seed) is read once'
                                    % (layer - 1, per_seed_bytes / 1e6)))
 
 
@@ -594,7 +747,8 @@ def run_sweep(args, rank, world, device):
                 config=dict(workload='%d-seed second-moment sweep, launches of %d seeds (reference batches of 10 '
                                      'inside) dealt round-robin, one all-reduce' % (args.seeds, m['launch']),
                             key_map=m['key_map'], gflop_per_seed=m['gflop_per_seed'],
-                            context_layers=m['context_layers']),
+                            launches=m['launches'], launches_this_rank=m['launches_this_rank'],
+                            allreduce_ms=m['allreduce_ms'], context_layers=m['context_layers']),
                 roofline=m['roofline'])
 
 
@@ -611,13 +765,35 @@ def extras(args, rank, world, device):
     out = {}
     torch.cuda.empty_cache()
     g = build_generator(1024, device)
-    for layer, seeds in ((8, 2000), (10, 1000), (14, 500)):      # configs[3]: the three sweep layers of SURVEY 8d
-        n = 10000 if world > 1 else seeds
-        out['sweep_ffhq1024_layer%d' % layer] = measure_sweep(device, 1024, layer, n, 2, 1, world, g=g)
+    for layer in (8, 10, 14):      # configs[3]: the three sweep layers of SURVEY 8d, on its own 10 000 seeds at every N
+        out['sweep_ffhq1024_layer%d' % layer] = measure_sweep(device, 1024, layer, 10000, 1 if layer == 14 else 2, 1, world,
+                                                              g=g)
         torch.cuda.empty_cache()
+    if world == 1:
+        # the headline's forward on the fp32 matrix pipe (RW_MM=f32), same process, same box: what the operand split buys
+        from rewriting_amd.utils import zdataset
+        z = zdataset.standard_z_sample(64, 512, seed=1).to(device)
+        saved_mm = os.environ.get('RW_MM')
+
+        def fwd():
+            with torch.no_grad():
+                g(z)
+        rates = {}
+        for mm in ('f32', 'split'):
+            os.environ['RW_MM'] = mm
+            timed(fwd, 1, 1, world)
+            rates[mm] = round(64 * 5 / timed(fwd, 5, 0, world), 2)
+        if saved_mm is None:
+            del os.environ['RW_MM']
+        else:
+            os.environ['RW_MM'] = saved_mm
+        out['forward_ffhq1024_by_matrix_mode'] = dict(images_per_s=rates, batch=64, steps=5,
+                                                      note='f32 = every product on fp32 MFMAs (round 3\'s kernels); '
+                                                           'split = the default of the un-hooked forward')
+        del z
     del g
     if world == 1:
-        out['edit_horse256_layer8'] = measure_edit(device, 3, 1)
+        out['edit_horse256_layer8'] = measure_edit(device, 3, 1, cpu=not args.no_cpu_baseline)
         torch.cuda.empty_cache()
         saved = (args.steps, args.warmup)
         args.steps, args.warmup = 5, 2
@@ -636,7 +812,24 @@ def extras(args, rank, world, device):
     args.steps, args.warmup, args.seeds = saved
     out['watermark_church256'] = dict(seconds_per_job=w['value'], images_per_s=w['config']['images_per_s'],
                                       variants=w['config']['variants'], scaling=w['scaling'],
-                                      workload=w['config']['workload'])
+                                      workload=w['config']['workload'],
+                                      update_callback='the driver\'s progress-bar hook on every iteration, marked '
+                                                      'ganrewrite.loss_only (it reads `it` only); the variants share '
+                                                      'one statistics cache, as watermark.sh\'s runs share their '
+                                                      'results directory')
+    if world == 1:
+        # the erase solves of the first variant (2 x 2001 steps) under the three callback contracts
+        from rewriting_amd import workloads
+        req = workloads.fold_request(workloads.load_request(), 1000)
+        modes = {}
+        for mode in ('none', 'loss_only', 'reference'):
+            t, _, _ = workloads.run_watermark_variant(workloads.WATERMARK_VARIANTS[0], device, req, sample_size=1000,
+                                                      callback=mode)
+            modes[mode] = round(t['edit_s'], 4)
+        out['watermark_church256']['edit_s_of_variant_0_by_update_callback'] = dict(
+            modes, note='none = no callback; loss_only = the marked hook (callbacks delivered after the solve); '
+                        'reference = the unmarked hook: called between the steps as rewrite/ganrewrite.py:288-289 does, '
+                        'one launch per iteration')
     return out
 
 
@@ -725,7 +918,10 @@ def main():
         import torch.distributed as dist
         if dist.get_world_size() != args.gpus:
             raise SystemExit('bench.py: process group of %d ranks for --gpus %d' % (dist.get_world_size(), args.gpus))
-        out['rccl'] = dict(backend=dist.get_backend(), world_size=dist.get_world_size())
+        out['rccl'] = dict(backend=dist.get_backend(), world_size=dist.get_world_size(),
+                           note='seeds / launches / variants are partitioned per rank; the only data-path collective is '
+                                'the sweeps\' all-reduce of (mom2, count) (extra.sweep_*: allreduce_ms, launches, '
+                                'launches_this_rank = rank 0\'s share)')
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

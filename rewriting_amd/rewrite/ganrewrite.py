@@ -817,6 +817,16 @@ def crop_clip_to_bounds(source, target, bounds):
             (st, sl, sb, sr), (tt, tl, tb, tr))
 
 
+def loss_only(callback):
+    """Marks an `update_callback(it, loss)` as one that looks at its two arguments only (a progress bar, a loss
+    printout -- metrics/make_watermark_images.py:66-72, rewrite/rewriteapp.py:517-521 are of this kind) and never at
+    the model: the solvers then run without interruption and deliver the callbacks afterwards, in order, with the loss
+    of every iteration.  An unmarked callback is called after each step and sees the stepped, not yet projected weight,
+    as in the reference (rewrite/ganrewrite.py:288-289) -- at one kernel launch per iteration."""
+    callback.loss_only = True
+    return callback
+
+
 def projected_conv(weight, direction):
     """P(W)[.., o, i, y, x] = sum_d (sum_j W[.., o, j, y, x] d[d, j]) d[d, i]   (:806-813)"""
     if hip.on_device(weight) and weight.dtype == torch.float32 and weight.dim() in (4, 5) \

@@ -148,6 +148,14 @@ class Solver:
 
     def _run(self, update_callback):
         niter, piter = self.niter, self.piter
+        if update_callback is not None and getattr(update_callback, 'loss_only', False):
+            # a callback that DECLARES it looks at (it, loss) only -- a progress bar, a loss printout: the solve runs as
+            # if there were none (one launch, or the replayed graph) and the callbacks are delivered afterwards, in
+            # order, against the loss buffer.  Callbacks without the mark keep the reference's contract below.
+            self._run(None)
+            for it in range(niter):
+                update_callback(it, self.losses[it])
+            return
         if self.one_launch and update_callback is None:
             self.run_range(0, niter)
             return

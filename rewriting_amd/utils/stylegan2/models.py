@@ -221,6 +221,11 @@ def matrix_mode():
     return 'split' if _rgb_branch.image_path else 'f32'
 
 
+def matrix_mode_of_image_path():
+    """matrix_mode() as the un-hooked forward of a whole generator sees it (bench.py labels its line with it)."""
+    return os.environ.get('RW_MM') or 'split'
+
+
 def _split_part(kind):
     """Diagnostics: RW_MM_PARTS=w4,up,up1 restricts the split form to the stride-1 F(4x4,3x3) kernels / the F(2,2)
     transposed convolutions / the one-pass upsampling layer."""

@@ -52,32 +52,23 @@ def pooled_rgb_features(images):
     return torch.nn.functional.adaptive_avg_pool2d(images, 8).reshape(images.shape[0], -1)
 
 
-_synthetic_states = {}
-
-
 _templates = {}
 
 
 def build_model(size, truncation, device, seed=0):
-    """The "checkpoint" of this offline build: seeded synthetic weights.  The state dict is generated once per
-    (size, seed) and kept on the host -- every variant then loads it like a driver loads its checkpoint file.  The
-    module tree is built once per size and copied: constructing a generator draws 30 M random initial weights on the
-    host that the load overwrites (cProfile of a watermark variant, scripts/probe/wm_host_profile.py: 0.17 of its 1.42 s
-    in the two constructors, 0.03 s in a copy)."""
-    key = (size, seed)
-    if key not in _synthetic_states:
+    """The "checkpoint" of this offline build: seeded synthetic weights.  The module tree is built and its weights are
+    drawn ONCE per (size, seed, device) and kept as a template ON THE DEVICE; every variant then takes a copy -- a
+    device-to-device copy of 120 MB where constructing a generator draws 30 M random initial weights on the host and a
+    host-resident checkpoint pays the PCIe transfer again (0.25 - 0.30 s of the 0.4 s a watermark variant spent before
+    its first kernel: profiles/r04j_bench.json, build_models_s)."""
+    key = (size, seed, str(device))
+    if key not in _templates:
         g = models.SeqStyleGAN2(size, 512, 8, truncation=truncation, mconv='seq')
         synthetic.randomize_(g, seed=seed)
-        _synthetic_states[key] = ({k: v.detach().clone() for k, v in g.state_dict().items()},
-                                  g.latents.latent_avg.detach().clone())
-        _templates[size] = copy.deepcopy(g)
-        return g.eval().to(device)
-    g = copy.deepcopy(_templates[size])
+        _templates[key] = g.eval().to(device)
+    g = copy.deepcopy(_templates[key])
     g.latents.truncation = truncation
-    sd, avg = _synthetic_states[key]
-    g.latents.latent_avg = avg.clone()
-    g.load_state_dict(sd)
-    return g.eval().to(device)
+    return g
 
 
 def sample_set_statistics(model, zds, batch=250, feature_fn=pooled_rgb_features, stats=None):
@@ -99,31 +90,48 @@ def sample_set_statistics(model, zds, batch=250, feature_fn=pooled_rgb_features,
 
 
 def run_watermark_variant(variant, device, request, size=256, layer=6, sample_size=1000, niters=2001, piters=10,
-                          lr=0.05, cachedir=None, feature_fn=pooled_rgb_features, weight_seed=0):
-    """One invocation of metrics/make_watermark_images.py main(); returns (timings, FeatureStatistics, rewriter)."""
+                          lr=0.05, cachedir=None, feature_fn=pooled_rgb_features, weight_seed=0, callback='loss_only'):
+    """One invocation of metrics/make_watermark_images.py main(); returns (timings, FeatureStatistics, rewriter).
+    callback: the driver passes a progress-bar hook as update_callback on every iteration (:66-72, `pbar_hook(it)`):
+    'loss_only' = that hook, marked ganrewrite.loss_only (it reads `it` only: the solve runs uninterrupted),
+    'reference' = the same hook unmarked (the reference's contract: called between the steps, one launch per iteration),
+    'none' = no callback."""
     from .rewrite import ganrewrite
     own_cache = cachedir is None
     cachedir = cachedir or tempfile.mkdtemp(prefix='rw_watermark_')
+    sync = (lambda: torch.cuda.synchronize(device)) if torch.device(device).type == 'cuda' else (lambda: None)
     t = {}
     t0 = time.perf_counter()
     model_for_covariance = build_model(size, 1.00, device, weight_seed)
     model = build_model(size, 0.50, device, weight_seed)
     zds = zdataset.z_dataset_for_model(model, size=sample_size)
+    sync()
+    t['build_models_s'] = time.perf_counter() - t0
     gw = None
     for m in (model_for_covariance, model):
+        ta = time.perf_counter()
         gw = ganrewrite.SeqStyleGanRewriter(
             m, zds, layer, cachedir=cachedir, low_rank_insert=True, low_rank_gradient=True,
             key_method={'ours': 'zca', 'gandissect': 'gandissect', 'none': 'zca'}[variant['erasemethod']],
             tight_paste=True)
         if m is model_for_covariance:
             gw.collect_2nd_moment()
-    torch.cuda.synchronize(device) if torch.device(device).type == 'cuda' else None
+        sync()
+        # the first rewriter sweeps (or finds the sweep in the cache directory the job's variants share, as the five
+        # invocations of watermark.sh share their results directory) and factorises; the second loads and factorises
+        t['rewriter_covariance_model_s' if m is model_for_covariance else 'rewriter_edited_model_s'] = time.perf_counter() - ta
     t['statistics_s'] = time.perf_counter() - t0
     t1 = time.perf_counter()
     if variant['erasemethod'] == 'ours':
+        ticks = [0]
+
+        def pbar_cb(it, loss):
+            ticks[0] += 1
+        cb = {'none': None, 'reference': pbar_cb, 'loss_only': ganrewrite.loss_only(lambda it, loss: pbar_cb(it, loss))}[callback]
         for _ in range(variant.get('nreps', 2)):
             gw.apply_erase(request, rank=variant.get('rank', 1), drank=variant['drank'], niter=niters, piter=piters,
-                           lr=lr)
+                           lr=lr, update_callback=cb)
+        t['callback'] = callback
     elif variant['erasemethod'] == 'gandissect':
         mkey = gw.multi_key_from_selection(request['key'], rank=variant['drank'])
         gw.zero(mkey)
@@ -158,18 +166,27 @@ def fold_request(request, nseeds):
     return out
 
 
-def watermark_job(device, rank=0, world=1, sample_size=1000, niters=2001, size=256, layer=6, variants=None):
-    """The five variants, variant i on rank i mod world.  Returns {variant name: (timings, stats)} of this rank."""
+def watermark_job(device, rank=0, world=1, sample_size=1000, niters=2001, size=256, layer=6, variants=None,
+                  callback='loss_only', share_cache=True):
+    """The five variants, variant i on rank i mod world.  Returns {variant name: (timings, stats)} of this rank.
+    share_cache: the variants of a rank share one statistics cache directory, as the five invocations of watermark.sh
+    share their results directory (utils/tally.py:703-730: the first computes the 1000-seed sweep, the others load
+    it) -- one sweep per rank instead of one per variant."""
     request = fold_request(load_request(), sample_size)
     variants = WATERMARK_VARIANTS if variants is None else variants
     out = {}
-    with parallel.replicas():
-        for i, v in enumerate(variants):
-            if i % world != rank:
-                continue
-            t, stats, _ = run_watermark_variant(v, device, request, size=size, layer=layer, sample_size=sample_size,
-                                                niters=niters)
-            out[variant_name(v)] = (t, stats)
+    cachedir = tempfile.mkdtemp(prefix='rw_watermark_job_') if share_cache else None
+    try:
+        with parallel.replicas():
+            for i, v in enumerate(variants):
+                if i % world != rank:
+                    continue
+                t, stats, _ = run_watermark_variant(v, device, request, size=size, layer=layer, sample_size=sample_size,
+                                                    niters=niters, cachedir=cachedir, callback=callback)
+                out[variant_name(v)] = (t, stats)
+    finally:
+        if cachedir is not None:
+            shutil.rmtree(cachedir, ignore_errors=True)
     return out
 
 

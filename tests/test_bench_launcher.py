@@ -28,7 +28,9 @@ def test_bench_self_launch_runs_the_sharded_sweep_on_two_ranks():
     rc, out, err = _run(['--gpus', '2', '--workload', 'sweep', '--size', '32', '--layer', '6', '--seeds', '40',
                          '--steps', '1', '--warmup', '0'])
     assert rc == 0, err[-2000:]
-    assert out['n_gpus'] == 2 and out['rccl'] == dict(backend='gloo', world_size=2)
+    assert out['n_gpus'] == 2 and (out['rccl']['backend'], out['rccl']['world_size']) == ('gloo', 2)
+    # the collective is timed on its own and the launch counts are in the line (a SCALE line can be audited)
+    assert out['config']['allreduce_ms'] > 0 and out['config']['launches'] == 2 and out['config']['launches_this_rank'] == 1
     assert out['unit'] == 'seeds/sec' and out['value'] > 0 and out['scaling'] == 'strong'
     assert out['steps'] == 1 and out['warmup'] == 0 and out['ms_per_step'] > 0
     assert out['data'] == 'emulated kernels on CPU'               # the driver marks its line: never a bench number
