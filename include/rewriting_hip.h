@@ -39,6 +39,13 @@ const char* rw_error_string(int code);
 
 /* ---------------------------------------------------------------------------------------
  * L1 native ops -- replace the two pybind entry points of utils/stylegan2/op/
+ *
+ * fp32 ONLY.  The reference's modules dispatch float, double and half (AT_DISPATCH_FLOATING_TYPES_AND_HALF,
+ * fused_bias_act_kernel.cu:79, upfirdn2d_kernel.cu:225); every entry of this library takes `float` pointers -- the
+ * path it accelerates runs in fp32 end to end (BASELINE.json: "images within 1e-3 L-inf fp32").  A model cast with
+ * .double() or .half() does not reach these entries: the Python wrappers (rewriting_amd/hip.py, the ctypes stub of
+ * INTEGRATION.md) refuse any other dtype with an error that names this limit (the status of the refusal is
+ * RW_ERR_UNSUPPORTED: nothing was launched), they never convert silently.
  * ------------------------------------------------------------------------------------- */
 
 /* fused_bias_act(input, bias, refer, act, grad, alpha, scale)

@@ -40,10 +40,10 @@ def save(name, **arrays):
     print('wrote', path, '%.1f KB' % (os.path.getsize(path) / 1024))
 
 
-def build_stylegan(ref, size, truncation, channel_multiplier=2, seed=0):
+def build_stylegan(ref, size, truncation, channel_multiplier=2, seed=0, tails='normal'):
     g = ref.models.SeqStyleGAN2(size, 512, 8, channel_multiplier=channel_multiplier,
                                 truncation=truncation, mconv='seq')
-    synthetic.randomize_(g, seed=seed)
+    synthetic.randomize_(g, seed=seed, tails=tails)
     g.eval()
     return g
 
@@ -115,10 +115,11 @@ def image_digest(img, stride, crop=64):
                 norm=numpy.float64(d.norm().item()), shape=numpy.array(img.shape))
 
 
-def golden_generator_full(ref, name, size, batch, stride):
+def golden_generator_full(ref, name, size, batch, stride, tails='normal'):
     """BASELINE.json's own generator sizes (utils/stylegan2/models.py:41-141): image digest + strided
-    sub-samples of every leaf module's output."""
-    g = build_stylegan(ref, size, 0.5)
+    sub-samples of every leaf module's output.  tails='heavy': Student-t / log-normal-gain weights
+    (rewriting_amd/synthetic.py:_heavy) -- what trained checkpoints' weight and activation statistics look like."""
+    g = build_stylegan(ref, size, 0.5, tails=tails)
     z = ref.zdataset.standard_z_sample(batch, 512, seed=1)
     store, handles = capture_stages(g)
     with torch.no_grad():
@@ -126,7 +127,7 @@ def golden_generator_full(ref, name, size, batch, stride):
     for h in handles:
         h.remove()
     arrays = dict(z=z.numpy(), meta=json.dumps(dict(size=size, truncation=0.5, channel_multiplier=2,
-                                                    batch=batch, weight_seed=0)))
+                                                    batch=batch, weight_seed=0, tails=tails)))
     for k, v in image_digest(img, stride).items():
         arrays['image/' + k] = v
     for lname, out in store.items():
@@ -1187,6 +1188,8 @@ def main():
         # BASELINE.json's own sizes (minutes of CPU each)
         'gen_s256_full': lambda: golden_generator_full(ref, 'gen_s256_full', 256, 4, 4),
         'gen_s1024_full': lambda: golden_generator_full(ref, 'gen_s1024_full', 1024, 2, 8),
+        'gen_s256_heavy': lambda: golden_generator_full(ref, 'gen_s256_heavy', 256, 4, 4, tails='heavy'),
+        'gen_s1024_heavy': lambda: golden_generator_full(ref, 'gen_s1024_heavy', 1024, 2, 8, tails='heavy'),
         'rw_s256_l8_horsehat_1000': lambda: golden_edit_full(ref, 'rw_s256_l8_horsehat_1000'),
         'rw_s256_l8_horsehat_1000_keys': lambda: golden_edit_full_keys(ref, 'rw_s256_l8_horsehat_1000_keys'),
         'sweep_s1024': lambda: golden_sweep_1024(ref, 'sweep_s1024'),

@@ -27,7 +27,9 @@ def _dev(t, name='tensor'):
         raise RuntimeError('rewriting_amd: %s is on %s; the HIP kernels need a GPU tensor '
                            '(there is no CPU fallback)' % (name, t.device))
     if t.dtype != torch.float32:
-        raise RuntimeError('rewriting_amd: %s must be float32, got %s' % (name, t.dtype))
+        raise RuntimeError('rewriting_amd: %s is %s; the C ABI is fp32 only (RW_ERR_UNSUPPORTED, include/rewriting_hip.h: '
+                           'the reference\'s pybind modules also dispatch half and double, this library does not) -- '
+                           'cast the model / tensor with .float()' % (name, t.dtype))
     return t.detach().contiguous()
 
 

@@ -28,8 +28,28 @@ def _normal(key, shape, seed, std=1.0, mean=0.0):
     return torch.from_numpy((a * std + mean).astype('float32'))
 
 
-def stylegan2_state_dict(reference_state, seed=0):
-    """Returns a dict with the keys/shapes of ``reference_state`` filled deterministically."""
+def _heavy(key, shape, seed):
+    """Convolution / modulation weights as trained checkpoints have them: Student-t (nu = 3) entries -- a few per
+    thousand are 5 - 20 sigma -- times per-out-channel and per-in-channel log-normal gains (sigma 0.5), scaled back to
+    unit RMS.  Activations downstream are heavy-tailed too: the fixture for tolerances that scale with the output
+    range (the F(4x4,3x3) error class, the f16 operand pairs of the split kernels)."""
+    r = _rng(key + '/heavy', seed)
+    n = int(numpy.prod(shape))
+    a = r.standard_t(3, size=n).reshape(shape) / numpy.sqrt(3.0)          # variance of t(3) is 3
+    if len(shape) >= 4:                                                     # (1, O, I, k, k) or (O, I, k, k)
+        o_ax, i_ax = len(shape) - 4, len(shape) - 3
+        go = numpy.exp(0.5 * r.standard_normal(shape[o_ax])).reshape([-1 if d == o_ax else 1 for d in range(len(shape))])
+        gi = numpy.exp(0.5 * r.standard_normal(shape[i_ax])).reshape([-1 if d == i_ax else 1 for d in range(len(shape))])
+        a = a * go * gi
+    elif len(shape) == 2:                                                   # modulation: (in_channel, style_dim)
+        a = a * numpy.exp(0.5 * r.standard_normal(shape[0]))[:, None]
+    a = a / numpy.sqrt((a * a).mean())
+    return torch.from_numpy(a.astype('float32'))
+
+
+def stylegan2_state_dict(reference_state, seed=0, tails='normal'):
+    """Returns a dict with the keys/shapes of ``reference_state`` filled deterministically.  tails='heavy': the
+    convolution and modulation weights from _heavy instead of N(0, 1)."""
     out = {}
     for key, val in reference_state.items():
         shape = tuple(val.shape)
@@ -49,6 +69,9 @@ def stylegan2_state_dict(reference_state, seed=0):
             out[key] = torch.full(shape, 0.1)
         elif key.endswith('activate.bias') or key.endswith('rgb.bias'):
             out[key] = _normal(key, shape, seed, std=0.1)
+        elif tails == 'heavy' and (key.endswith('dconv.weight') or key.endswith('modulation.weight')
+                                   or key.endswith('conv.weight')):
+            out[key] = _heavy(key, shape, seed)
         else:                                   # conv / modulation / constant input
             out[key] = _normal(key, shape, seed)
     return out
@@ -66,9 +89,11 @@ def proggan_state_dict(reference_state, seed=0):
     return out
 
 
-def randomize_(model, seed=0, kind='stylegan2'):
-    fill = stylegan2_state_dict if kind == 'stylegan2' else proggan_state_dict
-    sd = fill(model.state_dict(), seed)
+def randomize_(model, seed=0, kind='stylegan2', tails='normal'):
+    if kind == 'stylegan2':
+        sd = stylegan2_state_dict(model.state_dict(), seed, tails=tails)
+    else:
+        sd = proggan_state_dict(model.state_dict(), seed)
     if kind == 'stylegan2' and sd['latents.latent_avg'].shape != model.state_dict()['latents.latent_avg'].shape:
         # latent_avg is registered as a 0-d placeholder (models.py:575); replace the buffer.
         model.latents.latent_avg = sd.pop('latents.latent_avg').to(model.latents.latent_avg.device)

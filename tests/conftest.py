@@ -57,12 +57,12 @@ def emulated_hip(monkeypatch):
     yield
 
 
-def build_stylegan(size, truncation, channel_multiplier=2, seed=0, device='cpu'):
+def build_stylegan(size, truncation, channel_multiplier=2, seed=0, device='cpu', tails='normal'):
     from rewriting_amd.utils.stylegan2 import models
     from rewriting_amd import synthetic
     g = models.SeqStyleGAN2(size, 512, 8, channel_multiplier=channel_multiplier,
                             truncation=truncation, mconv='seq')
-    synthetic.randomize_(g, seed=seed)
+    synthetic.randomize_(g, seed=seed, tails=tails)
     return g.eval().to(device)
 
 

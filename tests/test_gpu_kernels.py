@@ -845,3 +845,15 @@ def test_conv_weight_and_input_gradients_match_autograd_of_the_oracle(case, upsa
     assert rel(a, c) < 1e-6
     r = hip.rowdot(y.detach(), g.to(DEV))
     assert rel(r, (y2.detach() * g).sum((2, 3))) < 1e-5
+
+
+def test_other_dtypes_are_refused_with_the_fp32_only_message():
+    """The B3 boundary is fp32 only (the reference's pybind modules also dispatch half and double): the wrappers say so
+    instead of converting."""
+    from rewriting_amd import hip
+    x = torch.randn(2, 4, 8, 8, device=DEV)
+    for bad in (x.double(), x.half()):
+        with pytest.raises(RuntimeError, match='fp32 only'):
+            hip.fused_bias_act(bad, torch.zeros(4, device=DEV, dtype=bad.dtype), None, 3, 0, 0.2, 1.0)
+        with pytest.raises(RuntimeError, match='fp32 only'):
+            hip.pixel_norm(bad.reshape(2, -1))
