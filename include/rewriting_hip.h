@@ -445,9 +445,15 @@ int rw_solve_step_f32(const rw_solve_problem* p, int project, rw_stream_t stream
  * lpart (niter * out_ch floats) is used, the step counter is not touched, losses[it] is written for the iterations
  * run, state is read from / written back to weight, exp_avg, exp_avg_sq (consecutive calls continue each other).
  * rw_solve_run_supported: 1 for stride-1 targets (with or without bias), in_ch % 64 == 0, in_ch <= 512,
- * out_ch % 2 == 0, rank <= 8, no linear_insert, in_ch * ((h*w + 1) | 1) floats + scratch within 160 KB of LDS; else 0 and
- * rw_solve_step_f32 is the way. */
+ * out_ch % 2 == 0, rank <= 8, no linear_insert, and either in_ch * ((h+2)(w+1) + 3 | 1) floats + scratch within 160 KB of
+ * LDS (the crop resident) or w <= 16 (the crop streamed, see below); else 0 and rw_solve_step_f32 is the way. */
 int rw_solve_run_supported(int out_ch, int in_ch, int h, int w, int rank, int upsample, int linear_insert);
+/* Round 4: crops that do not fit the LDS (w <= 16: the watermark erase's whole 16 x 16 maps of 512 channels) run in one
+ * launch too -- every thread streams ITS channel's crop row by row from a position-major copy (built in `lpart`'s tail),
+ * and with low_rank_gradient the gradient phase needs no key at all (it correlates g with the one-channel maps
+ * d_r^T key).  rw_solve_run_scratch_elems: floats of `lpart` = niter * out_ch (rounded up to 4) + that copy where the
+ * crop is streamed. */
+long long rw_solve_run_scratch_elems(int out_ch, int in_ch, int h, int w, int niter);
 int rw_solve_run_f32(const rw_solve_problem* p, int it_begin, int it_end, int niter, int piter, int low_rank_insert,
                      float* lpart, rw_stream_t stream);
 /* W <- W - P(W) + amount*P(1)  (zero(), ganrewrite.py:190-195) and ortho = W - P(W) helpers */

@@ -135,6 +135,7 @@ SIGNATURES = {
     'rw_solve_scratch_elems': (c_int, [c_int] * 5 + [POINTER(ctypes.c_longlong)]),
     'rw_solve_step_f32': (c_int, [POINTER(SolveProblem), c_int, c_void_p]),
     'rw_solve_run_supported': (c_int, [c_int] * 7),
+    'rw_solve_run_scratch_elems': (ctypes.c_longlong, [c_int] * 5),
     'rw_solve_run_f32': (c_int, [POINTER(SolveProblem), c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'rw_project_weight_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                       c_int, c_float, c_void_p]),

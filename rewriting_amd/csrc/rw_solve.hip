@@ -14,6 +14,7 @@
 // device-side step counter, so ten iterations can be captured in one HIP graph and replayed
 // with no host synchronisation; losses are written to a device array.
 #include "rw_common.h"
+#include <stdlib.h>
 
 #define SV_KC 16
 #define SV_BM 64        // out channels per workgroup (both GEMMs)
@@ -838,6 +839,326 @@ __global__ void __launch_bounds__(512) solve_persistent_kernel(const rw_solve_pr
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// The same solve for key crops that do NOT fit the LDS (round 4: the watermark erase solves on whole 16 x 16 maps of
+// 512 channels, 633 KB of key).  Thread i of a workgroup reads only ITS channel's crop, so the crop need not be shared
+// at all: it is streamed from a position-major, zero-padded copy in global memory (keyT[e][i], e = the padded index of
+// the resident kernel's layout; built once per launch range by solve_key_transpose_kernel, L2-resident: every
+// workgroup reads the same 0.6 MB) ROW BY ROW into registers -- four row buffers of w + 4 values, the row three ahead in
+// flight while a row is convolved, every load 256 contiguous bytes per wave.  Positions are paired within a padded row
+// (the last pair of an odd row re-computes the first position of the next one: the same value to the same place in
+// the forward phase, masked out of the gradient phase).
+// With low_rank_gradient (the erase's setting) the gradient phase needs no key at all: the projected gradient is
+//   P(dW)[o][i][t] = sum_r (s sum_n g[o][n] kd_r[n + t] - c2[o] sum_j W[o][j][t] sig2[j] d_r[j]) d_r[i],
+//   kd_r[e] = sum_i d_r[i] key[i][e]   (a one-channel map per context row, computed once per launch),
+// i.e. 18 correlations of 256 positions per context row instead of 2.4 M multiply-adds per out-channel pair.
+// Everything else -- phase B, Adam, the projections, the per-channel loss parts -- is the resident kernel's.
+// Limits: as solve_persistent_kernel but w <= 16 and the (small) LDS footprint below instead of the crop's.
+// ---------------------------------------------------------------------------------------
+#define SVS_WP_MAX 17
+#define SVS_ROW (SVS_WP_MAX + 3)
+
+__global__ void __launch_bounds__(256) solve_key_transpose_kernel(const float* __restrict__ key, float* __restrict__ keyT,
+                                                                  int in_ch, int h, int w) {
+  const int PS = svp_row_pitch(h, w), WP = w + 1;
+  const int64_t total = (int64_t)PS * in_ch;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int e = (int)(idx / in_ch), i = (int)(idx - (int64_t)e * in_ch);
+    const int yy = e / WP - 1, xx = e - (e / WP) * WP - 1;        // crop coordinates of padded index e
+    keyT[idx] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? key[((int64_t)i * h + yy) * w + xx] : 0.f;
+  }
+}
+
+__global__ void __launch_bounds__(512) solve_stream_kernel(const rw_solve_problem p, int it0, int it1, int niter, int piter,
+                                                            int low_rank_insert, float* lpart_all,
+                                                            const float* __restrict__ keyT) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nth = blockDim.x, NW = nth >> 6;
+  const int P = p.h * p.w, WP = p.w + 1;
+  const int PS = svp_row_pitch(p.h, p.w);
+  const int NP = svp_positions(p.h, p.w);
+  const int PA = svp_pair_row(p.h, p.w);
+  const bool lrg = p.low_rank_gradient != 0;
+  float* part = lds;                                // [NW][PA]      per-wave conv sums (n, o); the projection's scratch
+  float* gds = part + svp_part_floats(NW, p.h, p.w);   // [PA]       g_pre * demod at (n, o); 0 at pad positions
+  float* vals = gds + PA;
+  float* nz = vals + PA;
+  float* wq = nz + PA;                              // [NW][2]
+  float* chn = wq + 16;                             // [2][4]
+  float* cgs = chn + 8;                             // [SVP_RMAX][18]  s * correlation of g with kd_r, per (tap, out-channel)
+  int* nmap = reinterpret_cast<int*>(cgs + SVP_RMAX * 18);   // [P]
+  float* kd = reinterpret_cast<float*>(nmap + P);   // [rank][PS]    low_rank_gradient only
+  // Adam's moments of my 18 weights live in LDS (column tid of [36][threads]): the four row buffers need the registers
+  float* mv = kd + (lrg ? p.rank : 0) * PS + tid;   // [2 * 18][nth]
+  float* red = part;
+  const int o0 = 2 * blockIdx.x;
+  const int i = tid;
+  const int K = 9 * p.in_ch;
+  const bool plain = p.bias == nullptr;
+  const bool constrained = p.context != nullptr && p.rank > 0;
+  const bool odd = lane & 1, hi = lane & 2;
+
+  for (int e = tid; e < 3 * PA; e += nth) gds[e] = 0.f;       // gds, vals, nz
+  __syncthreads();
+  for (int q = tid; q < P; q += nth) {
+    const int y = q / p.w, n = y * WP + (q - y * p.w);
+    nmap[q] = n;
+    vals[2 * n] = p.val[(int64_t)o0 * P + q];
+    vals[2 * n + 1] = p.val[(int64_t)(o0 + 1) * P + q];
+    if (!plain) nz[n] = p.noise_w[0] * p.noise[q];
+  }
+  if (lrg) {
+    // kd_r[e] = sum_j d_r[j] key[j][e]: thread e walks the channels of its position (consecutive floats of keyT)
+    for (int e = tid; e < PS; e += nth) {
+      const svp_f4* row = reinterpret_cast<const svp_f4*>(keyT + (int64_t)e * p.in_ch);
+      for (int r = 0; r < p.rank; ++r) {
+        const svp_f4* d4 = reinterpret_cast<const svp_f4*>(p.context + (int64_t)r * p.in_ch);
+        float acc = 0.f;
+        for (int j = 0; j < p.in_ch / 4; ++j) {
+          const svp_f4 kv = row[j], dv = d4[j];
+          acc += kv[0] * dv[0] + kv[1] * dv[1] + kv[2] * dv[2] + kv[3] * dv[3];
+        }
+        kd[r * PS + e] = acc;
+      }
+    }
+  }
+  svp_f2 W[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+      const int64_t idx = (int64_t)(o0 + o) * K + i * 9 + t;
+      W[t][o] = p.weight[idx];
+      mv[(2 * t + o) * nth] = p.exp_avg[idx];
+      mv[(18 + 2 * t + o) * nth] = p.exp_avg_sq[idx];
+    }
+  float dctx[SVP_RMAX];
+#pragma unroll
+  for (int r = 0; r < SVP_RMAX; ++r) dctx[r] = (constrained && r < p.rank) ? p.context[(int64_t)r * p.in_ch + i] : 0.f;
+  const float sg = p.style[i], sig2 = sg * sg, s = p.w_scale;
+  const float inv_numel = 1.0f / ((float)p.out_ch * (float)P);
+  const float bias0 = plain ? 0.f : p.bias[o0], bias1 = plain ? 0.f : p.bias[o0 + 1];
+  __syncthreads();
+
+  // sums over the workgroup's channels of x[t][o] d_r: red[(wave * RMAX + r) * 18 + 2 t + o] (one barrier to publish)
+  auto reduce_rows = [&](const svp_f2 (&x)[9], bool weighted) __attribute__((always_inline)) {
+    for (int r = 0; r < p.rank; ++r) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+          const float sum = svp_wave_sum63(x[t][o] * (weighted ? dctx[r] * sig2 : dctx[r]));
+          if (lane == 63) red[(wave * SVP_RMAX + r) * 18 + 2 * t + o] = sum;
+        }
+    }
+    __syncthreads();
+  };
+  auto project_rows = [&](svp_f2 (&x)[9]) __attribute__((always_inline)) {
+    reduce_rows(x, false);
+    svp_f2 out[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) out[t] = svp_f2{0.f, 0.f};
+    for (int r = 0; r < p.rank; ++r) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        svp_f2 c = {0.f, 0.f};
+        for (int w2 = 0; w2 < NW; ++w2) c += *reinterpret_cast<const svp_f2*>(red + (w2 * SVP_RMAX + r) * 18 + 2 * t);
+        out[t] += c * dctx[r];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) x[t] = out[t];
+    __syncthreads();
+  };
+  // padded row r of this thread's channel -> registers (entries beyond the row / the crop's padded extent are 0)
+  // (buffer loads: one vector register of lane offsets and a scalar offset per element -- twenty 64-bit vector
+  // addresses per row spilled the kernel --, and an element past the copy's end reads 0 by the range check)
+  const __amdgpu_buffer_rsrc_t ksrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(keyT), 0, (int)((int64_t)PS * p.in_ch * 4), 0x00020000);
+  const int klane = i * 4, krow4 = p.in_ch * 4;
+  auto load_row = [&](int r, float (&Kr)[SVS_ROW]) __attribute__((always_inline)) {
+    const int s0 = r * WP * krow4;
+#pragma unroll
+    for (int j = 0; j < SVS_ROW; ++j)
+      Kr[j] = j < WP + 3 ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ksrc, klane, s0 + j * krow4, 0)) : 0.f;
+  };
+
+  float ss_next = p.step_size[it0 < it1 ? it0 : 0], bc_next = p.bc2_sqrt[it0 < it1 ? it0 : 0];
+  for (int it = it0; it < it1; ++it) {
+    const float step_size = ss_next, bc2s = bc_next;
+    if (it + 1 < it1) { ss_next = p.step_size[it + 1]; bc_next = p.bc2_sqrt[it + 1]; }
+    // ---- A: partial convolution of my channel (rows streamed), the demodulation partial
+    {
+      svp_f2 wq2 = {0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const svp_f2 a = (s * W[t]) * sg;
+        wq2 += a * a;
+      }
+      const float wq0 = svp_wave_sum63(wq2[0]), wq1 = svp_wave_sum63(wq2[1]);
+      if (lane == 63) { wq[wave * 2] = wq0; wq[wave * 2 + 1] = wq1; }
+      auto conv_row = [&](int y, const float (&R0)[SVS_ROW], const float (&R1)[SVS_ROW], const float (&R2)[SVS_ROW])
+          __attribute__((always_inline)) {
+#pragma unroll
+        for (int x = 0; x < SVS_WP_MAX; x += 2) {
+          if (x < WP) {
+            svp_f2 a = {0.f, 0.f}, b = {0.f, 0.f};
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+              const float (&R)[SVS_ROW] = ky == 0 ? R0 : (ky == 1 ? R1 : R2);
+              const float k0 = R[x], k1 = R[x + 1], k2 = R[x + 2], k3 = R[x + 3];
+              a = __builtin_elementwise_fma(W[3 * ky], svp_f2{k0, k0}, a);
+              b = __builtin_elementwise_fma(W[3 * ky], svp_f2{k1, k1}, b);
+              a = __builtin_elementwise_fma(W[3 * ky + 1], svp_f2{k1, k1}, a);
+              b = __builtin_elementwise_fma(W[3 * ky + 1], svp_f2{k2, k2}, b);
+              a = __builtin_elementwise_fma(W[3 * ky + 2], svp_f2{k2, k2}, a);
+              b = __builtin_elementwise_fma(W[3 * ky + 2], svp_f2{k3, k3}, b);
+            }
+            const float v = svp_wave_sum4(a, b, odd, hi);
+            const int n2 = 2 * (y * WP + x) + lane;
+            if (lane < 4 && n2 < 2 * NP) part[wave * PA + n2] = v;
+          }
+        }
+      };
+      float KA[SVS_ROW], KB[SVS_ROW], KC[SVS_ROW], KD[SVS_ROW];
+      load_row(0, KA); load_row(1, KB); load_row(2, KC); load_row(3, KD);
+      for (int y = 0; y < p.h; y += 4) {
+        conv_row(y, KA, KB, KC);
+        if (y + 4 <= p.h + 1) load_row(y + 4, KA);
+        if (y + 1 < p.h) { conv_row(y + 1, KB, KC, KD); if (y + 5 <= p.h + 1) load_row(y + 5, KB); }
+        if (y + 2 < p.h) { conv_row(y + 2, KC, KD, KA); if (y + 6 <= p.h + 1) load_row(y + 6, KC); }
+        if (y + 3 < p.h) { conv_row(y + 3, KD, KA, KB); if (y + 7 <= p.h + 1) load_row(y + 7, KD); }
+      }
+    }
+    __syncthreads();
+    // ---- B: wave o finishes out-channel o0 + o
+    for (int o = wave; o < 2; o += NW) {
+      float wsq = 0.f;
+      for (int w2 = 0; w2 < NW; ++w2) wsq += wq[w2 * 2 + o];
+      const float demod = rsqrtf(wsq + 1e-8f);
+      const float bv = o ? bias1 : bias0;
+      float lsum = 0.f, tsum = 0.f;
+      for (int q = lane; q < P; q += 64) {
+        const int n2 = 2 * nmap[q] + o;
+        float conv = 0.f;
+        for (int w2 = 0; w2 < NW; ++w2) conv += part[w2 * PA + n2];
+        conv *= s;
+        float out, pre;
+        if (plain) { pre = conv * demod; out = pre; }
+        else {
+          pre = conv * demod + nz[n2 >> 1] + bv;
+          out = 1.4142135623730951f * ((pre > 0.f) ? pre : 0.2f * pre);
+        }
+        const float diff = out - vals[n2];
+        lsum += fabsf(diff);
+        const float sgn = (diff > 0.f) ? 1.f : ((diff < 0.f) ? -1.f : 0.f);
+        const float g_out = sgn * inv_numel;
+        const float g_pre = plain ? g_out : ((pre > 0.f) ? g_out : g_out * 0.2f) * 1.4142135623730951f;
+        gds[n2] = g_pre * demod;
+        tsum += g_pre * conv;
+      }
+      lsum = svp_wave_sum63(lsum);
+      tsum = svp_wave_sum63(tsum);
+      if (lane == 63) {
+        chn[o * 4] = s * s * demod * demod * demod * tsum;
+        lpart_all[(int64_t)it * p.out_ch + o0 + o] = lsum * inv_numel;
+      }
+    }
+    __syncthreads();
+    // ---- C: gradient of my 18 weights, Adam, projections
+    {
+      svp_f2 G[9];
+      const svp_f2 c2 = {chn[0], chn[4]};
+      if (lrg) {
+        // s * sum_n g[n][o] kd_r[n + tap]: wave w takes the (context row, tap) pairs w, w + NW, ...
+        for (int idx = wave; idx < p.rank * 9; idx += NW) {
+          const int r = idx / 9, t = idx - 9 * r;
+          const float* kr = kd + r * PS + (t / 3) * WP + (t % 3);
+          svp_f2 acc = {0.f, 0.f};
+          for (int n = lane; n < NP; n += 64) acc += *reinterpret_cast<const svp_f2*>(gds + 2 * n) * kr[n];
+          const float a0 = svp_wave_sum63(acc[0]), a1 = svp_wave_sum63(acc[1]);
+          if (lane == 63) { cgs[r * 18 + 2 * t] = s * a0; cgs[r * 18 + 2 * t + 1] = s * a1; }
+        }
+        reduce_rows(W, true);                       // sum_j W[t][o][j] sig2[j] d_r[j] (publishes cgs too)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) G[t] = svp_f2{0.f, 0.f};
+        for (int r = 0; r < p.rank; ++r) {
+#pragma unroll
+          for (int t = 0; t < 9; ++t) {
+            svp_f2 wsd = {0.f, 0.f};
+            for (int w2 = 0; w2 < NW; ++w2) wsd += *reinterpret_cast<const svp_f2*>(red + (w2 * SVP_RMAX + r) * 18 + 2 * t);
+            const svp_f2 cg = *reinterpret_cast<const svp_f2*>(cgs + r * 18 + 2 * t);
+            G[t] += (cg - c2 * wsd) * dctx[r];
+          }
+        }
+        __syncthreads();                            // red (= part) and cgs are free again
+      } else {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) G[t] = svp_f2{0.f, 0.f};
+        auto grad_row = [&](int y, const float (&R0)[SVS_ROW], const float (&R1)[SVS_ROW], const float (&R2)[SVS_ROW])
+            __attribute__((always_inline)) {
+#pragma unroll
+          for (int x = 0; x < SVS_WP_MAX; x += 2) {
+            if (x < WP) {
+              const int n = y * WP + x;
+              const svp_f2 ga = *reinterpret_cast<const svp_f2*>(gds + 2 * n);
+              // the second position of a row's last pair belongs to the next row (its first pair counts it)
+              const svp_f2 gb = (x + 1 < WP && n + 1 < NP) ? *reinterpret_cast<const svp_f2*>(gds + 2 * n + 2) : svp_f2{0.f, 0.f};
+#pragma unroll
+              for (int ky = 0; ky < 3; ++ky) {
+                const float (&R)[SVS_ROW] = ky == 0 ? R0 : (ky == 1 ? R1 : R2);
+                const float k0 = R[x], k1 = R[x + 1], k2 = R[x + 2], k3 = R[x + 3];
+                G[3 * ky] = __builtin_elementwise_fma(ga, svp_f2{k0, k0}, G[3 * ky]);
+                G[3 * ky] = __builtin_elementwise_fma(gb, svp_f2{k1, k1}, G[3 * ky]);
+                G[3 * ky + 1] = __builtin_elementwise_fma(ga, svp_f2{k1, k1}, G[3 * ky + 1]);
+                G[3 * ky + 1] = __builtin_elementwise_fma(gb, svp_f2{k2, k2}, G[3 * ky + 1]);
+                G[3 * ky + 2] = __builtin_elementwise_fma(ga, svp_f2{k2, k2}, G[3 * ky + 2]);
+                G[3 * ky + 2] = __builtin_elementwise_fma(gb, svp_f2{k3, k3}, G[3 * ky + 2]);
+              }
+            }
+          }
+        };
+        float KA[SVS_ROW], KB[SVS_ROW], KC[SVS_ROW], KD[SVS_ROW];
+        load_row(0, KA); load_row(1, KB); load_row(2, KC); load_row(3, KD);
+        for (int y = 0; y < p.h; y += 4) {
+          grad_row(y, KA, KB, KC);
+          if (y + 4 <= p.h + 1) load_row(y + 4, KA);
+          if (y + 1 < p.h) { grad_row(y + 1, KB, KC, KD); if (y + 5 <= p.h + 1) load_row(y + 5, KB); }
+          if (y + 2 < p.h) { grad_row(y + 2, KC, KD, KA); if (y + 6 <= p.h + 1) load_row(y + 6, KC); }
+          if (y + 3 < p.h) { grad_row(y + 3, KD, KA, KB); if (y + 7 <= p.h + 1) load_row(y + 7, KD); }
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) G[t] = s * G[t] - c2 * W[t] * sig2;
+        if (p.low_rank_gradient) project_rows(G);
+      }
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+          float wv = W[t][o], mm = mv[(2 * t + o) * nth], vv = mv[(18 + 2 * t + o) * nth];
+          adam_update(G[t][o], wv, mm, vv, p.one_minus_beta1, p.beta2, p.one_minus_beta2, p.eps, step_size, bc2s);
+          W[t][o] = wv; mv[(2 * t + o) * nth] = mm; mv[(18 + 2 * t + o) * nth] = vv;
+        }
+      if (low_rank_insert && (it % piter == 0 || it == niter - 1)) {
+        svp_f2 pw[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) pw[t] = W[t];
+        project_rows(pw);
+#pragma unroll
+        for (int t = 0; t < 9; ++t)          // ortho part: read where it is used (every piter-th iteration)
+          W[t] = svp_f2{p.ortho[(int64_t)o0 * K + i * 9 + t], p.ortho[(int64_t)(o0 + 1) * K + i * 9 + t]} + pw[t];
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+      const int64_t idx = (int64_t)(o0 + o) * K + i * 9 + t;
+      p.weight[idx] = W[t][o]; p.exp_avg[idx] = mv[(2 * t + o) * nth]; p.exp_avg_sq[idx] = mv[(18 + 2 * t + o) * nth];
+    }
+}
+
 // losses[it] = sum over out-channels of the per-channel parts, in channel order (deterministic)
 __global__ void __launch_bounds__(64) solve_loss_sum_kernel(const float* __restrict__ lpart_all, float* __restrict__ losses,
                                                             int out_ch, int it0, int it1) {
@@ -854,18 +1175,47 @@ static size_t svp_lds_bytes(int in_ch, int h, int w) {
   return ((size_t)in_ch * svp_row_pitch(h, w) + svp_part_floats(NW, h, w) + 3 * (size_t)svp_pair_row(h, w) + 16 + 8 +
           (size_t)h * w) * sizeof(float);
 }
+// the streaming form: no crop in the LDS; kd maps of the context rows for low_rank_gradient
+static size_t svs_lds_bytes(int in_ch, int h, int w, int rank) {
+  const int NW = in_ch / 64;
+  return ((size_t)svp_part_floats(NW, h, w) + 3 * (size_t)svp_pair_row(h, w) + 16 + 8 + SVP_RMAX * 18 + (size_t)h * w +
+          (size_t)rank * svp_row_pitch(h, w) + 36 * (size_t)in_ch) * sizeof(float);
+}
+static bool svp_common_ok(int out_ch, int in_ch, int h, int w, int rank, int upsample, int linear_insert) {
+  if (out_ch <= 0 || in_ch <= 0 || h <= 0 || w <= 0 || upsample || linear_insert) return false;
+  return !(out_ch % 2 || in_ch % 64 || in_ch > 512 || rank > SVP_RMAX);
+}
+static bool svp_resident(int in_ch, int h, int w) { return svp_lds_bytes(in_ch, h, w) <= 160 * 1024; }
+static bool svs_streamable(int in_ch, int h, int w, int rank) {
+  return w + 1 <= SVS_WP_MAX && in_ch % 4 == 0 && svs_lds_bytes(in_ch, h, w, rank) <= 150 * 1024;
+}
+
+// which kernel a launch takes: the streaming one where the crop does not fit, or everywhere it can run under
+// RW_SOLVE_STREAM=1 (tests) -- ONE statement, used by the scratch size and by the launch
+static bool svs_use_stream(int in_ch, int h, int w, int rank) {
+  const char* force = getenv("RW_SOLVE_STREAM");
+  return !svp_resident(in_ch, h, w) || (force && force[0] == '1' && svs_streamable(in_ch, h, w, rank));
+}
 
 // 1 when rw_solve_run_f32 takes the target, 0 otherwise (then rw_solve_step_f32 is the way)
 extern "C" int rw_solve_run_supported(int out_ch, int in_ch, int h, int w, int rank, int upsample, int linear_insert) {
-  if (out_ch <= 0 || in_ch <= 0 || h <= 0 || w <= 0 || upsample || linear_insert) return 0;
-  if (out_ch % 2 || in_ch % 64 || in_ch > 512 || rank > SVP_RMAX) return 0;
-  return svp_lds_bytes(in_ch, h, w) <= 160 * 1024 ? 1 : 0;
+  if (!svp_common_ok(out_ch, in_ch, h, w, rank, upsample, linear_insert)) return 0;
+  return (svp_resident(in_ch, h, w) || svs_streamable(in_ch, h, w, rank)) ? 1 : 0;
+}
+
+// floats of `lpart` rw_solve_run_f32 needs: niter * out_ch loss parts + (crops beyond the LDS) the position-major copy
+// of the key crop the streaming kernel reads
+extern "C" long long rw_solve_run_scratch_elems(int out_ch, int in_ch, int h, int w, int niter) {
+  if (out_ch <= 0 || in_ch <= 0 || h <= 0 || w <= 0 || niter < 0) return -1;
+  long long n = ((long long)niter * out_ch + 3) / 4 * 4;
+  if (svs_use_stream(in_ch, h, w, 0)) n += (long long)svp_row_pitch(h, w) * in_ch;
+  return n;
 }
 
 // Iterations [it_begin, it_end) of the niter-iteration solve in one launch (state is read from and written back to
 // weight / exp_avg / exp_avg_sq, so consecutive calls continue each other); project on the iterations the reference
-// projects on (it % piter == 0 or it == niter - 1) when low_rank_insert != 0.  lpart: (niter, out_ch) floats of
-// scratch; losses[it] is written for the iterations run.  Uses no other scratch of rw_solve_problem and not its
+// projects on (it % piter == 0 or it == niter - 1) when low_rank_insert != 0.  lpart: rw_solve_run_scratch_elems floats
+// of scratch; losses[it] is written for the iterations run.  Uses no other scratch of rw_solve_problem and not its
 // step counter.
 extern "C" int rw_solve_run_f32(const rw_solve_problem* pr, int it_begin, int it_end, int niter, int piter,
                                 int low_rank_insert, float* lpart, rw_stream_t stream) {
@@ -879,13 +1229,25 @@ extern "C" int rw_solve_run_f32(const rw_solve_problem* pr, int it_begin, int it
   RW_CHECK_ARG(!low_rank_insert || p.ortho);
   if (!rw_solve_run_supported(p.out_ch, p.in_ch, p.h, p.w, p.rank, p.upsample, p.linear_insert)) return RW_ERR_UNSUPPORTED;
   if (it_begin == it_end) return 0;
-  const size_t ldsb = svp_lds_bytes(p.in_ch, p.h, p.w);
   hipStream_t s = rw_s(stream);
-  hipError_t e = hipFuncSetAttribute((const void*)solve_persistent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)ldsb);
-  if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(solve_persistent_kernel, dim3(p.out_ch / 2), dim3(p.in_ch), ldsb, s, p, it_begin, it_end, niter, piter,
-                     low_rank_insert, lpart);
+  if (svs_use_stream(p.in_ch, p.h, p.w, p.rank)) {
+    float* keyT = lpart + ((long long)niter * p.out_ch + 3) / 4 * 4;
+    const int64_t total = (int64_t)svp_row_pitch(p.h, p.w) * p.in_ch;
+    hipLaunchKernelGGL(solve_key_transpose_kernel, dim3(rw_stream_grid(total, 256)), dim3(256), 0, s, p.key, keyT, p.in_ch,
+                       p.h, p.w);
+    const size_t ldsb = svs_lds_bytes(p.in_ch, p.h, p.w, p.low_rank_gradient ? p.rank : 0);
+    hipError_t e = hipFuncSetAttribute((const void*)solve_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(solve_stream_kernel, dim3(p.out_ch / 2), dim3(p.in_ch), ldsb, s, p, it_begin, it_end, niter, piter,
+                       low_rank_insert, lpart, (const float*)keyT);
+  } else {
+    const size_t ldsb = svp_lds_bytes(p.in_ch, p.h, p.w);
+    hipError_t e = hipFuncSetAttribute((const void*)solve_persistent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)ldsb);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(solve_persistent_kernel, dim3(p.out_ch / 2), dim3(p.in_ch), ldsb, s, p, it_begin, it_end, niter,
+                       piter, low_rank_insert, lpart);
+  }
   hipLaunchKernelGGL(solve_loss_sum_kernel, dim3(it_end - it_begin), dim3(64), 0, s, (const float*)lpart, p.losses,
                      p.out_ch, it_begin, it_end);
   return RW_LAUNCH_RESULT();

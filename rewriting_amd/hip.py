@@ -702,6 +702,14 @@ def solve_run_supported(out_ch, in_ch, h, w, rank, upsample, linear):
     return lib().rw_solve_run_supported(out_ch, in_ch, h, w, int(rank), int(bool(upsample)), int(bool(linear))) == 1
 
 
+def solve_run_scratch_elems(out_ch, in_ch, h, w, niter):
+    """Floats of the scratch rw_solve_run_f32 needs (per-channel loss parts + the streamed crop's copy)."""
+    n = lib().rw_solve_run_scratch_elems(int(out_ch), int(in_ch), int(h), int(w), int(niter))
+    if n < 0:
+        raise ValueError('rw_solve_run_scratch_elems(%d, %d, %d, %d, %d)' % (out_ch, in_ch, h, w, niter))
+    return n
+
+
 def solve_run(problem, it_begin, it_end, niter, piter, low_rank_insert, lpart):
     check(lib().rw_solve_run_f32(ctypes.byref(problem), int(it_begin), int(it_end), int(niter), int(piter),
                                  int(bool(low_rank_insert)), _p(lpart), _stream()))

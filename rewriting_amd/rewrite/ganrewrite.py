@@ -321,6 +321,8 @@ class ProgressiveGanRewriter(object):
         plain_forward = owner.forward
         del owner._parameters['weight']
 
+        from ..utils.stylegan2 import models as sg
+
         def forward_with_lambda(*args, **kwargs):
             owner.weight = weight + torch.einsum(rule, lam, context)
             sg.bump_weight_epoch()      # a fresh tensor every call: derived (packed) weights must never be looked up by

@@ -117,7 +117,7 @@ class Solver:
         # the one-launch path: decided once per solve, so the step counter and the tables stay consistent
         self.one_launch = (os.environ.get('RW_SOLVE_ONE_LAUNCH', '1') != '0'
                            and hip.solve_run_supported(O, I, h, wd, p.rank, upsample, linear))
-        self.lpart = torch.empty(niter * O, **f32) if self.one_launch else None
+        self.lpart = torch.empty(hip.solve_run_scratch_elems(O, I, h, wd, niter), **f32) if self.one_launch else None
         LAST.clear()
         LAST.update(one_launch=bool(self.one_launch), out_ch=O, in_ch=I, h=h, w=wd, niter=niter,
                     upsample=bool(upsample), linear=bool(linear))

@@ -16,7 +16,10 @@ def main(niter=int(os.environ.get('RW_NITER', '2001'))):
     dev = 'cuda'
     gen = torch.Generator().manual_seed(0)
     rows = []
-    for (O, I, h, w) in [(512, 512, 5, 8), (512, 512, 12, 12), (256, 256, 8, 8)]:
+    # (out, in, h, w, low_rank_gradient); the last three: crops beyond the LDS (streamed); 16 x 16 with low_rank_gradient is
+    # the watermark erase's solve
+    for (O, I, h, w, lrg) in [(512, 512, 5, 8, False), (512, 512, 12, 12, False), (256, 256, 8, 8, False),
+                              (512, 512, 16, 16, True), (512, 512, 16, 16, False), (512, 512, 12, 12, True)]:
         weight = torch.nn.Parameter(torch.randn(1, O, I, 3, 3, generator=gen).to(dev))
         key = torch.randn(1, I, h, w, generator=gen).to(dev)
         style = (1 + 0.3 * torch.randn(1, I, generator=gen)).to(dev)
@@ -29,11 +32,11 @@ def main(niter=int(os.environ.get('RW_NITER', '2001'))):
             wt = torch.nn.Parameter(weight.detach().clone())
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            hipsolve.run(wt, key, style, val, bias, noise_w, ctx, niter=niter, piter=10, lr=0.05)
+            solver = hipsolve.run(wt, key, style, val, bias, noise_w, ctx, niter=niter, piter=10, lr=0.05, low_rank_gradient=lrg)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
-        rows.append(dict(out_ch=O, in_ch=I, crop=[h, w], steps=niter, seconds=round(best, 4),
+        rows.append(dict(out_ch=O, in_ch=I, crop=[h, w], low_rank_gradient=lrg, one_launch=bool(solver.one_launch), steps=niter, seconds=round(best, 4),
                          us_per_iter=round(best / niter * 1e6, 2), checksum=float(wt.detach().double().sum())))
         print(rows[-1], flush=True)
     os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)

@@ -277,11 +277,19 @@ def test_solver_against_oracle_explicit_arithmetic():
     os.environ.pop('RW_SOLVE_ONE_LAUNCH', None)
 
 
-@pytest.mark.parametrize('O,I,h,w,rank,plain', [(512, 512, 5, 8, 1, False), (256, 512, 6, 8, 3, False),
-                                                 (64, 64, 1, 1, 1, False), (128, 256, 4, 4, 8, True),
-                                                 (64, 192, 3, 17, 2, False), (128, 256, 8, 12, 1, False),
-                                                 (64, 128, 7, 1, 2, False)])
-def test_one_launch_solver_equals_step_solver(O, I, h, w, rank, plain):
+# the last four: crops beyond the LDS (streamed row by row: round 4), the watermark erase's own shape first;
+# lrg = low_rank_gradient (the erase's setting: the gradient phase then needs no key at all); 'stream': the streaming
+# kernel forced on a crop that would fit (RW_SOLVE_STREAM=1) -- odd and even widths, one row, rank 8
+@pytest.mark.parametrize('O,I,h,w,rank,plain,lrg,stream', [
+    (512, 512, 5, 8, 1, False, False, False), (256, 512, 6, 8, 3, False, False, False),
+    (64, 64, 1, 1, 1, False, False, False), (128, 256, 4, 4, 8, True, False, False),
+    (64, 192, 3, 17, 2, False, False, False), (128, 256, 8, 12, 1, False, False, False),
+    (64, 128, 7, 1, 2, False, False, False),
+    (512, 512, 16, 16, 1, False, True, False), (512, 512, 16, 16, 2, False, False, False),
+    (128, 512, 12, 12, 3, False, True, False), (64, 256, 13, 15, 1, True, False, False),
+    (128, 256, 4, 4, 8, True, True, True), (64, 128, 7, 1, 2, False, False, True), (64, 192, 3, 16, 2, False, True, True),
+    (128, 256, 8, 12, 1, False, False, True)])
+def test_one_launch_solver_equals_step_solver(O, I, h, w, rank, plain, lrg, stream, monkeypatch):
     """rw_solve_run_f32 (one workgroup per pair of out-channels, the whole solve in one launch) against the step
     kernels on the same problem: the same update in another summation order, so 11 iterations agree to rounding;
     a per-iteration callback drives the same kernel one iteration per launch (state round-trips through HBM) with the
@@ -297,6 +305,8 @@ def test_one_launch_solver_equals_step_solver(O, I, h, w, rank, plain):
     nw = None if plain else torch.tensor([0.1], device=DEV)
     ctx = torch.linalg.qr(torch.from_numpy(rs.randn(I, rank).astype('float32')))[0].t().contiguous().to(DEV)
     assert hip.solve_run_supported(O, I, h, w, rank, False, False)
+    if stream:
+        monkeypatch.setenv('RW_SOLVE_STREAM', '1')
     res = {}
     for mode in ('one_launch', 'step', 'callback'):
         os.environ['RW_SOLVE_ONE_LAUNCH'] = '0' if mode == 'step' else '1'
@@ -304,7 +314,8 @@ def test_one_launch_solver_equals_step_solver(O, I, h, w, rank, plain):
         seen = []
         cb = (lambda it, loss: seen.append(float(loss))) if mode == 'callback' else None
         s = hipsolve.run(Wd, key, style, val, bias, nw, ctx, niter=11, piter=10, lr=0.05, low_rank_insert=True,
-                         upsample=False, update_callback=cb)
+                         low_rank_gradient=lrg, upsample=False, update_callback=cb)
+        assert s.one_launch == (mode != 'step')
         res[mode] = (Wd, s.losses.clone())
         if mode == 'callback':
             assert numpy.array_equal(numpy.array(seen, dtype='float32'), s.losses.cpu().numpy())
@@ -320,8 +331,11 @@ def test_one_launch_solver_limits():
     from rewriting_amd import hip
     assert hip.solve_run_supported(512, 512, 6, 8, 1, False, False)          # 8 x 9 padded rows: within the LDS
     assert hip.solve_run_supported(256, 256, 8, 12, 1, False, False)
-    assert not hip.solve_run_supported(512, 512, 8, 9, 1, False, False)      # not at 512 channels
-    assert not hip.solve_run_supported(512, 512, 16, 16, 1, False, False)
+    assert hip.solve_run_supported(512, 512, 8, 9, 1, False, False)          # beyond the LDS: streamed (w <= 16)
+    assert hip.solve_run_supported(512, 512, 16, 16, 8, False, False)
+    assert not hip.solve_run_supported(512, 512, 16, 17, 1, False, False)     # wider than the row buffers
+    assert hip.solve_run_scratch_elems(512, 512, 5, 8, 2001) == 2001 * 512
+    assert hip.solve_run_scratch_elems(512, 512, 16, 16, 2001) == 2001 * 512 + 309 * 512
     assert not hip.solve_run_supported(512, 512, 4, 4, 1, True, False)       # upsampling targets: step path
     assert not hip.solve_run_supported(512, 512, 4, 4, 1, False, True)       # linear_insert: step path
     assert not hip.solve_run_supported(512, 1024, 2, 2, 1, False, False)
