@@ -779,17 +779,21 @@ def extras(args, rank, world, device):
             with torch.no_grad():
                 g(z)
         rates = {}
-        for mm in ('f32', 'split'):
-            os.environ['RW_MM'] = mm
+        for mm in ('f32', 'split', 'split+direct16'):
+            os.environ['RW_MM'] = mm.split('+')[0]
+            os.environ['RW_MM_DIRECT16'] = '1' if mm.endswith('direct16') else '0'
             timed(fwd, 1, 1, world)
             rates[mm] = round(64 * 5 / timed(fwd, 5, 0, world), 2)
+        del os.environ['RW_MM_DIRECT16']
         if saved_mm is None:
             del os.environ['RW_MM']
         else:
             os.environ['RW_MM'] = saved_mm
-        out['forward_ffhq1024_by_matrix_mode'] = dict(images_per_s=rates, batch=64, steps=5,
-                                                      note='f32 = every product on fp32 MFMAs (round 3\'s kernels); '
-                                                           'split = the default of the un-hooked forward')
+        out['forward_ffhq1024_by_matrix_mode'] = dict(
+            images_per_s=rates, batch=64, steps=5,
+            note='f32 = every product on fp32 MFMAs (round 3\'s kernels); split = the default of the un-hooked forward; '
+                 'split+direct16 (opt-in, RW_MM_DIRECT16=1) = the layers from 64^2 up as direct sums on the 16-bit pipe '
+                 '(csrc/rw_dconv.hip) instead of F(4x4,3x3)')
         del z
     del g
     if world == 1:

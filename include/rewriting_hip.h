@@ -309,6 +309,36 @@ int rw_conv_transpose3x3s2_blur_wino4h_f32(const float* x, const float* uf, floa
                                            const float* post_scale, const float* x_amax, float* y_amax,
                                            rw_stream_t stream);
 
+/* The same three operations as DIRECT sums on the 16-bit matrix pipe (rw_dconv.hip, round 4): no transform at all -- an
+ * input value is scaled by style 2^eV and split into its f16 pair ONCE per workgroup while it is staged into LDS, and read
+ * nine times as a ready operand of v_mfma_f32_16x16x32_f16 (a lane's eight k values = [Vh c0..c3, Vl c0..c3] of four input
+ * channels against [Uh c0..c3] twice, then [Ul c0..c3] twice: all four piece products, fp32 accumulation).  4x the
+ * multiplies of F(4x4,3x3) but none of its chains: the faster kernel where channels are few and maps large (the 512^2 and
+ * 1024^2 layers of the generators).  Error class: the direct fp32 kernels' (per-product 2^-21, no transform constants).
+ * Shapes: in_ch % 16 == 0 (<= 512), w % 32 == 0; rw_dconv3x3: out_ch % 32 == 0, h % 16 == 0; the transposed form:
+ * out_ch % 16 == 0, h % 8 == 0; to_rgb: out_ch == 32.
+ *   wp: rw_packed_dconv_*_elems floats from rw_pack_dconv_*_f32: wp[o / 16][9 (i / 16) + tap][Uh | Ul][lane = 16 ((i % 16) / 4)
+ *       + o % 16][8 halves: channels 4 ((i % 16) / 4) + (0..3), twice] + 4 trailing floats [2^-eU, 0, max |U|, 0].  The
+ *       transposed form packs the four output-parity phases of conv_transpose (*) blur as blocks of 16 virtual channels:
+ *       block 4 (o / 16) + 2 py + px.
+ * x_amax / y_amax / ep / post_scale / rgb: as in the wino4h entry points. */
+int rw_dconv3x3_supported(int out_ch, int in_ch, int h, int w);
+long long rw_packed_dconv_weight_elems(int out_ch, int in_ch);
+int rw_pack_dconv_weight_f32(const float* w, float* wp, int out_ch, int in_ch, rw_stream_t stream);
+int rw_dconv3x3_f32(const float* x, const float* wp, float* y, int batch, int in_ch, int out_ch, int h, int w,
+                    float w_scale, const rw_conv_epilogue* ep, const float* x_amax, float* y_amax, rw_stream_t stream);
+int rw_dconv3x3_to_rgb_supported(int out_ch, int in_ch, int h, int w);
+int rw_dconv3x3_to_rgb_f32(const float* x, const float* wp, int batch, int in_ch, int out_ch, int h, int w,
+                           float w_scale, const rw_conv_epilogue* ep, const rw_rgb_epilogue* rgb, const float* x_amax,
+                           rw_stream_t stream);
+int rw_dconv_transpose_blur_supported(int out_ch, int in_ch, int h, int w);
+long long rw_packed_dconv_transpose_blur_weight_elems(int out_ch, int in_ch);
+int rw_pack_dconv_transpose_blur_weight_f32(const float* w, const float* k4, float* wp, int out_ch, int in_ch,
+                                            rw_stream_t stream);
+int rw_dconv_transpose3x3s2_blur_f32(const float* x, const float* wp, float* y, int batch, int in_ch, int out_ch, int h,
+                                     int w, float w_scale, const rw_conv_epilogue* ep, const float* post_scale,
+                                     const float* x_amax, float* y_amax, rw_stream_t stream);
+
 /* rw_conv_transpose3x3s2_wino_f32 (the F(2,2) quads of the stride-2 transposed convolution) with its 25 GEMMs on the
  * 16-bit matrix pipe and the exact f16 operand split of the wino4h entry points (rw_upwino.hip): one
  * v_mfma_f32_16x16x32_f16 per point takes the two k-quads of an 8-channel interval (25 MFMAs of ~17 cycles per 8

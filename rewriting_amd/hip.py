@@ -574,6 +574,115 @@ def conv_transpose3x3s2_blur_wino4(x, uf, out_ch, w_scale, style=None, demod=Non
     return y
 
 
+def dconv_supported(out_ch, in_ch, height, width):
+    """Shapes conv3x3_direct16 takes (rw_dconv3x3_supported)."""
+    return bool(lib().rw_dconv3x3_supported(int(out_ch), int(in_ch), int(height), int(width)))
+
+
+def dconv_to_rgb_supported(out_ch, in_ch, height, width):
+    return bool(lib().rw_dconv3x3_to_rgb_supported(int(out_ch), int(in_ch), int(height), int(width)))
+
+
+def dconv_transpose_blur_supported(out_ch, in_ch, height, width):
+    return bool(lib().rw_dconv_transpose_blur_supported(int(out_ch), int(in_ch), int(height), int(width)))
+
+
+def pack_conv_weight_direct16(weight):
+    """The weights as f16 pairs in the operand order of the direct kernels on the 16-bit matrix pipe
+    (rw_pack_dconv_weight_f32)."""
+    weight = _dev(weight, 'weight')
+    o, i = weight.shape[-4], weight.shape[-3]
+    n = lib().rw_packed_dconv_weight_elems(o, i)
+    if n <= 0:
+        raise ValueError('no direct-16 packing for a %d x %d weight' % (o, i))
+    wp = torch.empty(n, device=weight.device, dtype=torch.float32)
+    check(lib().rw_pack_dconv_weight_f32(_p(weight), _p(wp), o, i, _stream()))
+    return wp
+
+
+def _direct16_check(wp, n, what):
+    if wp.numel() != n:
+        raise ValueError('packed weight does not come from %s' % what)
+
+
+def conv3x3_direct16(x, wp, out_ch, w_scale, style=None, demod=None, noise=None, noise_w=None, bias=None, act=False,
+                     x_amax=None, y_amax=None):
+    """Stride-1 3x3 convolution as a direct sum on the 16-bit matrix pipe (exact f16 operand split, fp32 accumulation:
+    rw_dconv3x3_f32); arguments, epilogue, x_amax and y_amax as conv3x3_wino4 with split weights."""
+    x = _dev(x, 'fmap')
+    wp = _dev(wp, 'packed weight')
+    b, i, h, w = x.shape
+    _direct16_check(wp, lib().rw_packed_dconv_weight_elems(out_ch, i), 'pack_conv_weight_direct16(%d x %d)' % (out_ch, i))
+    y = torch.empty(b, out_ch, h, w, device=x.device, dtype=x.dtype)
+    ep, keep = _epilogue(style, demod, noise, noise_w, bias, act)
+    x_amax, y_amax = _amax_in(x, x_amax), _amax_out(y_amax)
+    check(lib().rw_dconv3x3_f32(_p(x), _p(wp), _p(y), b, i, out_ch, h, w, float(w_scale), ctypes.byref(ep),
+                                _p(x_amax), _p(y_amax), _stream()))
+    return y
+
+
+def conv3x3_direct16_to_rgb(x, wp, out_ch, w_scale, rgb_weight, rgb_style, rgb_bias, rgb_skip, rgb_scale, style=None,
+                            demod=None, noise=None, noise_w=None, bias=None, act=False, x_amax=None):
+    """conv3x3_direct16 with ToRGB in the epilogue (out_ch == 32): returns (None, rgb image)."""
+    x = _dev(x, 'fmap')
+    wp = _dev(wp, 'packed weight')
+    rgb_weight = _dev(rgb_weight, 'rgb weight').contiguous()
+    rgb_style = _dev(rgb_style, 'rgb style').contiguous()
+    rgb_bias = _opt(rgb_bias, 'rgb bias')
+    rgb_skip = _opt(rgb_skip, 'rgb skip')
+    b, i, h, w = x.shape
+    if tuple(rgb_weight.shape) != (3, out_ch) or tuple(rgb_style.shape) != (b, out_ch):
+        raise ValueError('rgb weight / style shapes')
+    if rgb_skip is not None and tuple(rgb_skip.shape) != (b, 3, h, w):
+        raise ValueError('rgb skip shape')
+    _direct16_check(wp, lib().rw_packed_dconv_weight_elems(out_ch, i), 'pack_conv_weight_direct16(%d x %d)' % (out_ch, i))
+    rgb = torch.empty(b, 3, h, w, device=x.device, dtype=x.dtype)
+    ep, keep = _epilogue(style, demod, noise, noise_w, bias, act)
+    from ._lib import RgbEpilogue
+    re = RgbEpilogue(_p(rgb_weight).value, _p(rgb_style).value, _p(rgb_bias).value, _p(rgb_skip).value,
+                     _p(rgb).value, float(rgb_scale))
+    x_amax = _amax_in(x, x_amax)
+    check(lib().rw_dconv3x3_to_rgb_f32(_p(x), _p(wp), b, i, out_ch, h, w, float(w_scale), ctypes.byref(ep),
+                                       ctypes.byref(re), _p(x_amax), _stream()))
+    return None, rgb
+
+
+def pack_conv_transpose_blur_weight_direct16(weight, k4):
+    """The four output-parity phases of conv_transpose(stride 2) followed by the 4x4 FIR k4, as f16 pairs in the operand
+    order of the direct kernel (rw_pack_dconv_transpose_blur_weight_f32)."""
+    weight = _dev(weight, 'weight')
+    k4 = _dev(k4, 'blur kernel').contiguous()
+    if tuple(k4.shape) != (4, 4):
+        raise ValueError('the blur kernel must be 4 x 4')
+    o, i = weight.shape[-4], weight.shape[-3]
+    n = lib().rw_packed_dconv_transpose_blur_weight_elems(o, i)
+    if n <= 0:
+        raise ValueError('no direct-16 phase packing for a %d x %d transposed-conv weight' % (o, i))
+    wp = torch.empty(n, device=weight.device, dtype=torch.float32)
+    check(lib().rw_pack_dconv_transpose_blur_weight_f32(_p(weight), _p(k4), _p(wp), o, i, _stream()))
+    return wp
+
+
+def conv_transpose3x3s2_blur_direct16(x, wp, out_ch, w_scale, style=None, demod=None, noise=None, noise_w=None,
+                                      bias=None, act=False, post_scale=None, x_amax=None, y_amax=None):
+    """conv_transpose3x3s2 -> blur(pad 1,1) -> noise -> bias + leaky ReLU in one pass as a direct sum on the 16-bit matrix
+    pipe: (B,Cin,H,W) -> (B,Cout,2H,2W); arguments as conv_transpose3x3s2_blur_wino4 with split weights."""
+    x = _dev(x, 'fmap')
+    wp = _dev(wp, 'packed weight')
+    b, i, h, w = x.shape
+    _direct16_check(wp, lib().rw_packed_dconv_transpose_blur_weight_elems(out_ch, i),
+                    'pack_conv_transpose_blur_weight_direct16(%d x %d)' % (out_ch, i))
+    y = torch.empty(b, out_ch, 2 * h, 2 * w, device=x.device, dtype=x.dtype)
+    ep, keep = _epilogue(style, demod, noise, noise_w, bias, act)
+    post_scale = _opt(post_scale, 'post scale')
+    if post_scale is not None and tuple(post_scale.shape) != (b, out_ch):
+        raise ValueError('post_scale must be batch x out_ch')
+    x_amax, y_amax = _amax_in(x, x_amax), _amax_out(y_amax)
+    check(lib().rw_dconv_transpose3x3s2_blur_f32(_p(x), _p(wp), _p(y), b, i, out_ch, h, w, float(w_scale),
+                                                 ctypes.byref(ep), _p(post_scale), _p(x_amax), _p(y_amax), _stream()))
+    return y
+
+
 def noise_add(x, noise, noise_w):
     x = _dev(x, 'fmap')
     noise = _dev(noise, 'noise')

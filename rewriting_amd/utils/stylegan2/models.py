@@ -233,6 +233,20 @@ def _split_part(kind):
     return matrix_mode() == 'split' and (parts is None or kind in parts.split(','))
 
 
+def _direct16(dconv, h, w, kind):
+    """Opt-in (RW_MM_DIRECT16=1, with the split form): the DIRECT sums on the 16-bit matrix pipe (csrc/rw_dconv.hip) in
+    place of the split-operand F(4x4,3x3) kernels where the shape allows -- kind 'conv' / 'up' / 'rgb'.  Measured equal
+    in time on the 512^2 / 1024^2 layers (profiles/r04s) and closer to the fp32 direct sum (4e-7 against 1e-6), so not
+    the default: see DESIGN.md section 4.4."""
+    if os.environ.get('RW_MM_DIRECT16') != '1' or dconv.in_channel < 32:
+        return False
+    if kind == 'up':
+        return hip.dconv_transpose_blur_supported(dconv.out_channel, dconv.in_channel, h, w)
+    if kind == 'rgb':
+        return hip.dconv_to_rgb_supported(dconv.out_channel, dconv.in_channel, h, w)
+    return hip.dconv_supported(dconv.out_channel, dconv.in_channel, h, w)
+
+
 def _amax_of(d, fmap):
     """The bound max |fmap| its producer left in the bag (key 'amax': (one-element tensor, data_ptr of the map it
     describes)), or None -- the kernels then measure the map themselves (hip.absmax)."""
@@ -481,6 +495,13 @@ class DemodulatedConv2dF(nn.Module):
             return True
         return conv_algo() == 'winograd4' and self.in_channel <= _ONE_PASS_UP_MAX_IN
 
+    def direct16_weight(self):
+        return self._derived.get('direct16', self.weight, lambda: hip.pack_conv_weight_direct16(self.weight))
+
+    def up_blur_direct16_weight(self, k4):
+        return self._derived.get('upblur_direct16', self.weight,
+                                 lambda: hip.pack_conv_transpose_blur_weight_direct16(self.weight, k4))
+
     def wino4_weight(self, split=False):
         if split:
             return self._derived.get('wino4_split', self.weight,
@@ -556,6 +577,9 @@ class DemodulatedConv2dF(nn.Module):
                                            style=load_style, demod=demod, impl=conv_impl())
         if (conv_algo() == 'winograd4' and conv_impl() == 0 and conv_precision() == 'f32'
                 and hip.wino4_supported(self.out_channel, self.in_channel, fmap.shape[-2], fmap.shape[-1])):
+            if split and _direct16(self, fmap.shape[-2], fmap.shape[-1], 'conv'):
+                return hip.conv3x3_direct16(fmap, self.direct16_weight(), self.out_channel, self.scale, style=load_style,
+                                            demod=demod, x_amax=x_amax, y_amax=y_amax, **epilogue)
             if split:
                 return hip.conv3x3_wino4(fmap, self.wino4_weight(True), self.out_channel, self.scale, style=load_style,
                                          demod=demod, x_amax=x_amax, y_amax=y_amax, **epilogue)
@@ -881,8 +905,12 @@ class StyledConvSeq(nn.Sequential):
             if dconv.one_pass_upsample(fmap, mconv.blur):
                 split1 = _split_part('up1')
                 mm = dict(x_amax=x_amax, y_amax=y_amax) if split1 else {}
-                out = hip.conv_transpose3x3s2_blur_wino4(
-                    fmap, dconv.up_blur_wino4_weight(mconv.blur.kernel, split1), dconv.out_channel, dconv.scale,
+                if split1 and _direct16(dconv, fmap.shape[2], fmap.shape[3], 'up'):
+                    one_pass, packed = hip.conv_transpose3x3s2_blur_direct16, dconv.up_blur_direct16_weight(mconv.blur.kernel)
+                else:
+                    one_pass, packed = hip.conv_transpose3x3s2_blur_wino4, dconv.up_blur_wino4_weight(mconv.blur.kernel, split1)
+                out = one_pass(
+                    fmap, packed, dconv.out_channel, dconv.scale,
                     style=style, demod=demod if demod is not None else dconv.demod_factors(style), noise=noise,
                     noise_w=self.noise.weight, bias=act.bias, act=True, post_scale=post, **mm)
                 y_amax_set = split1 and y_amax is not None
@@ -917,8 +945,12 @@ class StyledConvSeq(nn.Sequential):
                          hip.conv3x3_wino_to_rgb if wino else hip.conv3x3_to_rgb)
                 split4 = wino4 and _split_part('w4')
                 mm = dict(x_amax=x_amax) if split4 else {}
+                direct = split4 and _direct16(dconv, h, w, 'rgb')
+                if direct:
+                    fused = hip.conv3x3_direct16_to_rgb
                 _, rgb = fused(
-                    fmap, dconv.wino4_weight(split4) if wino4 else dconv.wino_weight() if wino else dconv.packed_weight(),
+                    fmap, dconv.direct16_weight() if direct else dconv.wino4_weight(split4) if wino4 else dconv.wino_weight() if wino
+                    else dconv.packed_weight(),
                     dconv.out_channel, dconv.scale,
                     torgb.conv.weight.view(3, torgb.conv.in_channel), rgb_style, torgb.bias.view(3), skip,
                     torgb.conv.scale, style=style if on_load else None,

@@ -857,3 +857,122 @@ def test_other_dtypes_are_refused_with_the_fp32_only_message():
             hip.fused_bias_act(bad, torch.zeros(4, device=DEV, dtype=bad.dtype), None, 3, 0, 0.2, 1.0)
         with pytest.raises(RuntimeError, match='fp32 only'):
             hip.pixel_norm(bad.reshape(2, -1))
+
+
+# ---- direct sums on the 16-bit matrix pipe (rw_dconv.hip): the direct fp32 kernels' bars, not the F(4x4,3x3) ones
+DIRECT16_CASES = [(1, 16, 32, 16, 32), (2, 64, 64, 16, 64), (1, 32, 32, 48, 96), (1, 128, 128, 32, 64), (3, 48, 96, 16, 32),
+                  (1, 512, 128, 16, 32), (1, 64, 64, 512, 512), (1, 32, 32, 1024, 1024), (1, 128, 128, 256, 256)]
+
+
+@pytest.mark.parametrize('ver', ['one-role', 'specialised'])
+@pytest.mark.parametrize('wm', [0, 1, 2, 4])
+@pytest.mark.parametrize('case', DIRECT16_CASES)
+def test_direct16_conv_matches_direct_fp32_kernel_and_oracle(case, wm, ver, monkeypatch):
+    """hip.conv3x3_direct16 (direct sum, operands split into exact f16 pairs, v_mfma_f32_16x16x32_f16) against the direct
+    fp32 kernel, the oracle with the full epilogue and float64 -- every workgroup shape (32 / 64 / 128 out-channels)."""
+    from rewriting_amd import hip
+    from oracle import restatement as R
+    b, i, o, h, w = case
+    assert hip.dconv_supported(o, i, h, w)
+    monkeypatch.setenv('RW_DCONV_V', '1' if ver == 'one-role' else '2')
+    if ver == 'specialised' and b == 3:
+        monkeypatch.setenv('RW_DCONV_GRID', '5')           # runs of several tiles, across images, ragged
+    if wm:
+        if o % (32 * wm):
+            pytest.skip('out_ch not a multiple of the workgroup shape')
+        monkeypatch.setenv('RW_DCONV_WM', str(wm))
+    x, wt, style = _conv_inputs(*case, seed=141)
+    rs = numpy.random.RandomState(142)
+    x = x * torch.from_numpy(numpy.exp(1.5 * rs.randn(1, i, 1, 1)).astype('float32'))
+    bias = torch.from_numpy(rs.randn(o).astype('float32'))
+    nw = torch.tensor([0.2])
+    noise = torch.from_numpy(rs.randn(b, h * w).astype('float32'))
+    s = 1 / math.sqrt(i * 9)
+    dm = hip.demod(hip.weight_sqsum(wt.to(DEV), s), style.to(DEV))
+    pk = hip.pack_conv_weight_direct16(wt.to(DEV))
+    wp = hip.pack_conv_weight(wt.to(DEV), 0)
+    ymax = torch.zeros(1, device=DEV)
+    plain = hip.conv3x3_direct16(x.to(DEV), pk, o, s, style=style.to(DEV), demod=dm, y_amax=ymax)
+    assert ymax.item() == plain.abs().max().item()
+    direct = hip.conv3x3(x.to(DEV), wp, o, s, style=style.to(DEV), demod=dm, impl=0)
+    scale = direct.abs().max().item()
+    assert (plain - direct).abs().max().item() < 2e-5 * scale, (plain - direct).abs().max().item() / scale
+    assert rel(plain, direct) < 3e-6, rel(plain, direct)
+    loose = hip.conv3x3_direct16(x.to(DEV), pk, o, s, style=style.to(DEV), demod=dm, x_amax=hip.absmax(x.to(DEV)) * 37.0)
+    assert rel(loose, plain) < 2e-6, rel(loose, plain)
+    args = dict(style=style.to(DEV), demod=dm, noise=noise.to(DEV), noise_w=nw.to(DEV), bias=bias.to(DEV), act=True)
+    got = hip.conv3x3_direct16(x.to(DEV), pk, o, s, **args)
+    same = hip.conv3x3(x.to(DEV), wp, o, s, impl=0, **args)
+    assert (got - same).abs().max().item() < 2e-5 * max(1.0, same.abs().max().item())
+    if b * i * o * h * w <= 2 ** 32:
+        key = style[:, :, None, None] * x
+        conv = R.demod_conv(key, style, wt, upsample=False)
+        want = R.fused_leaky_relu(conv + nw * noise.view(b, 1, h, w), bias)
+        assert rel(got, want) < 3e-6, rel(got, want)
+        ref = torch.nn.functional.conv2d(key.double(), wt[0].double(), padding=1) * s * dm.cpu().double()[:, :, None, None]
+        e_w = ((plain.cpu().double() - ref).norm() / ref.norm()).item()
+        assert e_w < 3e-6, e_w
+    if o == 32 and wm in (0, 1):                            # ToRGB in the epilogue (the feature map is not written)
+        assert hip.dconv_to_rgb_supported(o, i, h, w)
+        wrgb = torch.from_numpy(rs.randn(3, o).astype('float32')).to(DEV)
+        srgb = torch.from_numpy((1 + 0.3 * rs.randn(b, o)).astype('float32')).to(DEV)
+        brgb = torch.from_numpy(rs.randn(3).astype('float32')).to(DEV)
+        skip = torch.from_numpy(rs.randn(b, 3, h, w).astype('float32')).to(DEV)
+        want_rgb = hip.to_rgb(got, wrgb, srgb, brgb, skip, 1 / math.sqrt(o))
+        y, rgb = hip.conv3x3_direct16_to_rgb(x.to(DEV), pk, o, s, wrgb, srgb, brgb, skip, 1 / math.sqrt(o), **args)
+        assert y is None and rel(rgb, want_rgb) < 2e-6, rel(rgb, want_rgb)
+        _, rgb2 = hip.conv3x3_direct16_to_rgb(x.to(DEV), pk, o, s, wrgb, srgb, None, None, 1 / math.sqrt(o), **args)
+        assert rel(rgb2, want_rgb - skip - brgb.view(1, 3, 1, 1)) < 1e-5
+
+
+UP_DIRECT16_CASES = [(2, 16, 16, 8, 32), (1, 64, 32, 16, 64), (1, 128, 64, 8, 128), (3, 32, 16, 24, 64), (1, 512, 64, 8, 64),
+                     (1, 48, 48, 8, 32), (1, 64, 32, 512, 512)]
+
+
+@pytest.mark.parametrize('ver', ['one-role', 'specialised'])
+@pytest.mark.parametrize('case', UP_DIRECT16_CASES)
+def test_direct16_one_pass_upsampling_conv_matches_conv_then_blur(case, ver, monkeypatch):
+    """hip.conv_transpose3x3s2_blur_direct16 (the four output-parity phases of conv_transpose (*) blur as direct sums on the
+    16-bit matrix pipe, noise + bias + leaky ReLU + post scale in the epilogue) against the two-pass route of the same
+    library (direct transposed conv -> blur_noise_act) and the oracle, at the direct kernels' bars."""
+    from rewriting_amd import hip
+    from oracle import restatement as R
+    b, i, o, h, w = case
+    assert hip.dconv_transpose_blur_supported(o, i, h, w)
+    monkeypatch.setenv('RW_DCONV_V', '1' if ver == 'one-role' else '2')
+    if ver == 'specialised' and b > 1:
+        monkeypatch.setenv('RW_DCONV_GRID', '7')
+    x, wt, style = _conv_inputs(*case, seed=161)
+    rs = numpy.random.RandomState(162)
+    x = x * torch.from_numpy(numpy.exp(1.0 * rs.randn(1, i, 1, 1)).astype('float32'))
+    s = 1 / math.sqrt(i * 9)
+    k1 = torch.tensor([1., 3., 3., 1.])
+    k4 = k1[:, None] * k1[None, :]
+    k4 = (k4 / k4.sum() * 4).to(DEV)
+    noise = torch.from_numpy(rs.randn(b, 1, 2 * h, 2 * w).astype('float32')).to(DEV)
+    nw = torch.tensor([0.37], device=DEV)
+    bias = torch.from_numpy(rs.randn(o).astype('float32')).to(DEV)
+    post = torch.from_numpy((1 + 0.3 * rs.randn(b, o)).astype('float32')).to(DEV)
+    dm = hip.demod(hip.weight_sqsum(wt.to(DEV), s), style.to(DEV))
+    wp = hip.pack_conv_weight(wt.to(DEV), 1)
+    wide = hip.conv_transpose3x3s2(x.to(DEV), wp, o, s, style=style.to(DEV), demod=dm,
+                                   impl=0 if i % 16 == 0 and o % 32 == 0 else 1)
+    pk = hip.pack_conv_transpose_blur_weight_direct16(wt.to(DEV), k4)
+    results = []
+    for kw in (dict(noise=noise, noise_w=nw, bias=bias, act=True), dict(), dict(post_scale=post)):
+        want = hip.blur_noise_act(wide, k4, kw.get('noise'), kw.get('noise_w'), kw.get('bias'), kw.get('post_scale'))
+        ymax = torch.zeros(1, device=DEV)
+        got = hip.conv_transpose3x3s2_blur_direct16(x.to(DEV), pk, o, s, style=style.to(DEV), demod=dm, y_amax=ymax, **kw)
+        assert got.shape == want.shape == (b, o, 2 * h, 2 * w)
+        assert ymax.item() == got.abs().max().item()
+        scale = want.abs().max().item()
+        assert (got - want).abs().max().item() < 2e-5 * scale, (got - want).abs().max().item() / scale
+        assert rel(got, want) < 3e-6, rel(got, want)
+        results.append((kw, got.cpu()))
+    assert b * i * o * h * w <= 2 ** 29
+    key = style[:, :, None, None] * x
+    blur = R.upfirdn2d(R.demod_conv(key, style, wt, upsample=True), k4.cpu(), pad=(1, 1))
+    for kw, got in results[:2]:
+        ref = R.fused_leaky_relu(blur + nw.cpu() * noise.cpu(), bias.cpu()) if kw else blur
+        assert rel(got, ref) < 5e-6, rel(got, ref)
+        assert (got - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
