@@ -313,14 +313,18 @@ int rw_conv_transpose3x3s2_blur_wino4h_f32(const float* x, const float* uf, floa
  * input value is scaled by style 2^eV and split into its f16 pair ONCE per workgroup while it is staged into LDS, and read
  * nine times as a ready operand of v_mfma_f32_16x16x32_f16 (a lane's eight k values = [Vh c0..c3, Vl c0..c3] of four input
  * channels against [Uh c0..c3] twice, then [Ul c0..c3] twice: all four piece products, fp32 accumulation).  4x the
- * multiplies of F(4x4,3x3) but none of its chains: the faster kernel where channels are few and maps large (the 512^2 and
- * 1024^2 layers of the generators).  Error class: the direct fp32 kernels' (per-product 2^-21, no transform constants).
+ * multiplies of F(4x4,3x3) and none of its transforms.  Error class: the direct fp32 kernels' (per-product 2^-21, no transform constants).
  * Shapes: in_ch % 16 == 0 (<= 512), w % 32 == 0; rw_dconv3x3: out_ch % 32 == 0, h % 16 == 0; the transposed form:
  * out_ch % 16 == 0, h % 8 == 0; to_rgb: out_ch == 32.
  *   wp: rw_packed_dconv_*_elems floats from rw_pack_dconv_*_f32: wp[o / 16][9 (i / 16) + tap][Uh | Ul][lane = 16 ((i % 16) / 4)
- *       + o % 16][8 halves: channels 4 ((i % 16) / 4) + (0..3), twice] + 4 trailing floats [2^-eU, 0, max |U|, 0].  The
- *       transposed form packs the four output-parity phases of conv_transpose (*) blur as blocks of 16 virtual channels:
- *       block 4 (o / 16) + 2 py + px.
+ *       + o % 16][4 halves: channels 4 ((i % 16) / 4) + (0..3)] (the kernels double them into the operand) + 4 trailing
+ *       floats [2^-eU, 0, max |U|, 0].  The transposed form packs the four output-parity phases of conv_transpose (*) blur as
+ *       blocks of 16 virtual channels: block 4 (o / 16) + 2 py + px.
+ * Two kernel families behind the same entry points: one-role workgroups (two per CU), and -- where in_ch >= 32, the
+ * epilogue carries a style, w % 64 == 0 and (rw_dconv3x3_f32) out_ch % 64 == 0, h % 8 == 0 -- workgroups of eight
+ * multiplying and four staging waves (RW_DCONV_V=1 forces the first).  Measured on MI355X: as fast as the split F(4x4,3x3)
+ * kernels on the 512^2 / 1024^2 layers, not faster (the 16-bit pipe retires an MFMA per 20 cycles and SIMD at ~1.7 GHz
+ * under this load: DESIGN.md section 4.4) -- the Python host leaves them opt-in (RW_MM_DIRECT16=1).
  * x_amax / y_amax / ep / post_scale / rgb: as in the wino4h entry points. */
 int rw_dconv3x3_supported(int out_ch, int in_ch, int h, int w);
 long long rw_packed_dconv_weight_elems(int out_ch, int in_ch);

@@ -414,19 +414,24 @@ __device__ __forceinline__ void dconv_body(const DconvProblem& p) {
 // Second version: the waves of a workgroup SPECIALISE.  Measured on the kernel above (profiles/r04p): every part of it
 // costs about a millisecond of the 4.6 per layer and nothing overlaps -- staging loads (HBM latency), weights (L2), the
 // MFMAs and the epilogue take turns, because one wave does all four and its loads return in order: a wait for weights
-// (L2, short) also waits for the window loads (HBM, long) issued before them.  Here a workgroup has six waves:
-//   waves 0..3 (one per SIMD) only multiply: pixel operands from LDS (two reads ahead), weight operands from L2 (one kernel
-//     column = 96 MFMAs ahead -- their only vector loads, so the in-order counter never ties them to HBM), the epilogue of
-//     a tile from tables and noise that sit in LDS, 16-byte stores;
-//   waves 4, 5 only stage (two channel quads each): the window of chunk n + 2 is requested while chunk n is multiplied,
-//     converted and written (with the next tile's tables and noise) during chunk n + 1 -- a full chunk of MFMAs hides the
-//     HBM latency.
-// One raw s_barrier per chunk joins the two (LDS writes waited for, loads in flight across it).  Two workgroups per CU: a
-// SIMD holds two multiplying waves (one wave alone issues an MFMA every 20 cycles, not 16, and every other instruction
-// of its stream is a bubble: cycle counters in the kernel, profiles/r04q) that drift apart, so one's epilogue runs under
-// the other's MFMAs; 168 registers per wave.  A workgroup takes every (grid)th tile, those of one XCD being neighbours.
-// in_ch >= 32 (the tables of a tile are double-buffered by tile parity; one chunk per tile would overwrite a table under
-// the epilogue that reads it).
+// (L2, short) also waits for the window loads (HBM, long) issued before them.  Here ONE workgroup of twelve waves owns a CU:
+//   waves 0..7 (two per SIMD: a workgroup's waves are dealt to the SIMDs in turn) only multiply: pixel operands AND
+//     weight operands from LDS (the weights one half-step = 48 MFMAs ahead; through the L1 they were 288 loads per chunk
+//     and CU), the tile's noise requested a chunk ahead, the epilogue from tables in LDS, 16-byte stores;
+//   waves 8..11 only stage, one channel quad and one weight block each: piece s (a 16-byte aligned run of four columns
+//     per lane and channel + three 1-KB tap pieces of weights) of chunk n + 1 is converted and written, then piece s of
+//     chunk n + 2 requested into the same registers -- loads are in flight all the time, a whole interval ahead;
+//     everything the compiler can count (LDS-direct loads from inline assembly made its waits nine loads too strict,
+//     loop-carried assembly outputs are not safe against its copies).
+// One raw s_barrier per chunk joins them (LDS writes waited for, loads in flight across it).  A workgroup takes every
+// (grid)th tile -- those running at the same time are neighbours, the 32 of an XCD consecutive.  Tiles are 8 rows x 64
+// columns x 64 out-channels; in_ch >= 32 (tables double-buffered by tile parity), a style on load, w % 64 == 0.
+// What it reaches (profiles/r04s: cycle counters inside the kernel): the multiplying waves are never short of operands,
+// and the two of a SIMD retire an MFMA every 20.5 cycles -- the rate ONE wave issues them at (scripts/probe: 20 - 21.6
+// cycles alone, 17.2 - 18.7 with a second wave's MFMAs between) -- at the 1.7 GHz the chip sustains under this load:
+// 302 M MFMAs x 20.5 / 1024 SIMDs = 3.6 ms + the tiles' epilogues = 4.2 ms, where the 2.5 PFLOP/s the pipe is priced at
+// (16 cycles, 2.4 GHz) would be 2.0.  That is the same 4.2 - 4.4 ms the split F(4x4,3x3) kernel takes with a quarter of
+// the multiplies; the direct sums stay an opt-in (closer to the fp32 sum: 4e-7 against 1.1e-6).
 // ---------------------------------------------------------------------------------------
 // MW multiplying waves (wave < MW) = WM pairs of out-channel blocks x (MW / WM) strips of 4 rows x 32 columns, WC of them side
 // by side (a tile is 4 MW / (WM WC) rows x 32 WC columns: the wider, the fewer 128-byte lines its window touches per

@@ -4,6 +4,5 @@ import sys, json
 for l in sys.stdin:
     if 'layer' not in l: continue
     d = json.loads(l); print(d['layer'], {k: v for k, v in d.items() if k.endswith('_ms') or k.startswith('rel')})"; }
-PYTEST_ARGS="-k direct16" bash scripts/gpu_dconv.sh r04q tests
 echo "== product"; python scripts/dconv_bench.py | show
 RW_HIP_LIB=$PWD/scripts/probe/abl/lib_dcprof.so python scripts/dconv_prof.py
