@@ -102,7 +102,8 @@ class ConvTimer:
         from rewriting_amd import hip
         self._orig = (hip.conv3x3, hip.conv_transpose3x3s2, hip.conv3x3_bf16x6, hip.conv3x3_to_rgb,
                       hip.conv3x3_wino, hip.conv3x3_wino_to_rgb, hip.conv3x3_wino4, hip.conv_transpose3x3s2_wino,
-                      hip.conv_transpose3x3s2_blur_wino4, hip.conv3x3_wino4_to_rgb)
+                      hip.conv_transpose3x3s2_blur_wino4, hip.conv3x3_wino4_to_rgb,
+                      hip.conv3x3_direct16, hip.conv_transpose3x3s2_blur_direct16, hip.conv3x3_direct16_to_rgb)
         timer = self
 
         def wrap(fn, upsample, split=False, wino=None):
@@ -115,7 +116,18 @@ class ConvTimer:
                 e.record()
                 b, i, h, w = x.shape
                 lib = hip.lib()
-                if wino == 'up':
+                if wino in ('d16', 'd16up', 'd16rgb'):
+                    # rw_dconv.hip: the specialised kernels take a style on load, >= 32 channels, maps 64 columns wide
+                    ws = k.get('style') is not None and i >= 32 and w % 64 == 0 and os.environ.get('RW_DCONV_V') != '1'
+                    if wino == 'd16up':
+                        name = 'dconv_ws_up_kernel' if ws else 'dconv_up_kernel'
+                    elif wino == 'd16rgb':
+                        name = 'dconv_rgb_kernel'
+                    elif ws and out_ch % 64 == 0 and h % 8 == 0:
+                        name = 'dconv_ws_w2_kernel'
+                    else:
+                        name = 'dconv_w%d_kernel' % (4 if out_ch % 128 == 0 else 2 if out_ch % 64 == 0 else 1)
+                elif wino == 'up':
                     if wp.numel() == lib.rw_packed_conv_transpose_winoh_elems(out_ch, i):
                         name = 'conv_up_winoh_kernel'             # operands split into f16 pairs (16-bit matrix pipe)
                     else:
@@ -148,9 +160,9 @@ class ConvTimer:
                             else conv_kernel_name(out_ch, i, w, upsample))
                 # algorithmic HBM bytes of the call: the input map once, what it writes once (the (2H+1)^2 map of a
                 # transposed convolution, the (2H)^2 result of the one-pass layer, the RGB image of the fused last layer)
-                if wino == 'up4':
+                if wino in ('up4', 'd16up'):
                     out_elems = b * out_ch * 4 * h * w
-                elif wino == 'f4rgb' or fn is self._orig[3] or fn is self._orig[5]:
+                elif wino in ('f4rgb', 'd16rgb') or fn is self._orig[3] or fn is self._orig[5]:
                     out_elems = b * 3 * h * w * 2                  # running image read and written; no feature map
                 elif upsample:
                     out_elems = b * out_ch * (2 * h + 1) * (2 * w + 1)
@@ -169,12 +181,16 @@ class ConvTimer:
         hip.conv_transpose3x3s2_wino = wrap(self._orig[7], True, wino='up')
         hip.conv_transpose3x3s2_blur_wino4 = wrap(self._orig[8], True, wino='up4')
         hip.conv3x3_wino4_to_rgb = wrap(self._orig[9], False, wino='f4rgb')
+        hip.conv3x3_direct16 = wrap(self._orig[10], False, wino='d16')
+        hip.conv_transpose3x3s2_blur_direct16 = wrap(self._orig[11], True, wino='d16up')
+        hip.conv3x3_direct16_to_rgb = wrap(self._orig[12], False, wino='d16rgb')
 
     def remove(self):
         from rewriting_amd import hip
         (hip.conv3x3, hip.conv_transpose3x3s2, hip.conv3x3_bf16x6, hip.conv3x3_to_rgb, hip.conv3x3_wino,
          hip.conv3x3_wino_to_rgb, hip.conv3x3_wino4, hip.conv_transpose3x3s2_wino,
-         hip.conv_transpose3x3s2_blur_wino4, hip.conv3x3_wino4_to_rgb) = self._orig
+         hip.conv_transpose3x3s2_blur_wino4, hip.conv3x3_wino4_to_rgb, hip.conv3x3_direct16,
+         hip.conv_transpose3x3s2_blur_direct16, hip.conv3x3_direct16_to_rgb) = self._orig
 
     def result(self):
         per = {}
@@ -239,6 +255,11 @@ def issued_fraction(kernel):
     (rw_wino.hip, rw_wino4.hip, rw_upwino.hip headers)."""
     f32 = ('fp32 MFMA', FP32_MFMA_PEAK_TFLOPS)
     f16 = ('f16 MFMA, 4 piece products per multiply (exact operand split), fp32 accumulate', F16_MFMA_PEAK_TFLOPS)
+    if kernel.startswith('dconv') and '_up_' in kernel:
+        return (16.0, 'transposed conv (*) blur as four DIRECT 3x3 phase convolutions: 4x the transposed conv\'s direct-sum '
+                'multiplies, each as 4 f16 piece products') + f16
+    if kernel.startswith('dconv'):
+        return (4.0, 'direct sum, each multiply as 4 f16 piece products') + f16
     if kernel.startswith('conv_up_wino36h'):
         return (4.0, 'transposed conv (*) blur as four F(4x4,3x3) phase convolutions: the transposed conv\'s direct-sum '
                 'multiply count, each as 4 f16 piece products') + f16
@@ -508,7 +529,8 @@ def run_forward(args, rank, world, device, size, batch, name, cpu=True):
                config=dict(workload=name, batch_per_gpu=batch, truncation=0.5, mconv='seq',
                            weights='synthetic seed 0', parallelism='seeds partitioned per rank, no collective',
                            conv_gflop_per_image=round(conv_flops(size) / 1e9, 2),
-                           matrix_mode='split' if split else 'f32'))
+                           matrix_mode='split' if split else 'f32',
+                           direct_sums=os.environ.get('RW_MM_DIRECT16', '0') if split else None))
     # second pass, NOT the headline: HIP events around every convolution call (on torch's current stream, the one the
     # kernels are launched on) -> the per-kernel table and the dominant kernel's roofline
     timer = ConvTimer()
@@ -779,21 +801,24 @@ def extras(args, rank, world, device):
             with torch.no_grad():
                 g(z)
         rates = {}
-        for mm in ('f32', 'split', 'split+direct16'):
-            os.environ['RW_MM'] = mm.split('+')[0]
-            os.environ['RW_MM_DIRECT16'] = '1' if mm.endswith('direct16') else '0'
+        modes = {'f32': ('f32', '0'), 'split': ('split', '0'), 'split, direct sums on layers 10-17': ('split', 'auto'),
+                 'split, direct sums on layers 10-18': ('split', '1')}
+        saved_d16 = os.environ.get('RW_MM_DIRECT16')
+        for mm, (pipe, d16) in modes.items():
+            os.environ['RW_MM'], os.environ['RW_MM_DIRECT16'] = pipe, d16
             timed(fwd, 1, 1, world)
             rates[mm] = round(64 * 5 / timed(fwd, 5, 0, world), 2)
-        del os.environ['RW_MM_DIRECT16']
-        if saved_mm is None:
-            del os.environ['RW_MM']
-        else:
-            os.environ['RW_MM'] = saved_mm
+        for key, val in (('RW_MM', saved_mm), ('RW_MM_DIRECT16', saved_d16)):
+            if val is None:
+                del os.environ[key]
+            else:
+                os.environ[key] = val
         out['forward_ffhq1024_by_matrix_mode'] = dict(
             images_per_s=rates, batch=64, steps=5,
-            note='f32 = every product on fp32 MFMAs (round 3\'s kernels); split = the default of the un-hooked forward; '
-                 'split+direct16 (opt-in, RW_MM_DIRECT16=1) = the layers from 64^2 up as direct sums on the 16-bit pipe '
-                 '(csrc/rw_dconv.hip) instead of F(4x4,3x3)')
+            note='f32 = every product on fp32 MFMAs (round 3\'s kernels); split = the default of the un-hooked forward: '
+                 'f16 operand pairs on the 16-bit pipe in the F(4x4,3x3) and F(2,2) kernels; the other two rows (opt-in, '
+                 'RW_MM_DIRECT16=auto / 1) replace the F(4x4,3x3) kernels of the stride-1 layers from 64^2 up and of the '
+                 'one-pass upsampling layer / also of the last layer by DIRECT sums on the 16-bit pipe (csrc/rw_dconv.hip)')
         del z
     del g
     if world == 1:

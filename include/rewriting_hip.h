@@ -293,6 +293,9 @@ int rw_conv_transpose3x3s2_blur_wino4_f32(const float* x, const float* uf, float
  *   y_amax (device scalar, nullable): receives max |y| of the result (zeroed, then atomic max).
  * Everything else as in the fp32 entry points. */
 int rw_absmax_f32(const float* x, long long n, float* out, rw_stream_t stream);
+/* dst[0] = the bound in src[0] (a y_amax that a producer raised with atomics), fetched by one atomic and stored plainly:
+ * what a consumer's x_amax should point to when producer and consumer run back to back beside work on other streams. */
+int rw_publish_scalar_f32(float* src, float* dst, rw_stream_t stream);
 long long rw_packed_conv_weight_wino4h_elems(int out_ch, int in_ch);
 int rw_pack_conv_weight_wino4h_f32(const float* w, float* uf, int out_ch, int in_ch, rw_stream_t stream);
 int rw_conv3x3_wino4h_f32(const float* x, const float* uf, float* y, int batch, int in_ch, int out_ch, int h,

@@ -14,7 +14,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('RW_HIP_LIB') or os.path.join(_HERE, 'librewriting_hip.so')    # RW_HIP_LIB: tuning builds
 
-ABI_VERSION = 5        # 5: rw_dconv* (direct sums on the 16-bit pipe); 4: rw_*_wino4h_* (operands split into f16 pairs), rw_absmax_f32; 3: rw_solve_run_*, the 8x8 / 4x4 shapes (style == NULL), packed F(4x4,3x3) point order w4_nat; 2: rw_solve_supported 1/0, sizes[6]
+ABI_VERSION = 6        # 6: rw_publish_scalar_f32; 5: rw_dconv* (direct sums on the 16-bit pipe); 4: rw_*_wino4h_* (operands split into f16 pairs), rw_absmax_f32; 3: rw_solve_run_*, the 8x8 / 4x4 shapes (style == NULL), packed F(4x4,3x3) point order w4_nat; 2: rw_solve_supported 1/0, sizes[6]
 
 
 class ConvEpilogue(Structure):
@@ -110,6 +110,7 @@ SIGNATURES = {
     'rw_conv3x3_wino4_to_rgb_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                             POINTER(ConvEpilogue), POINTER(RgbEpilogue), c_void_p]),
     'rw_absmax_f32': (c_int, [c_void_p, ctypes.c_longlong, c_void_p, c_void_p]),
+    'rw_publish_scalar_f32': (c_int, [c_void_p, c_void_p, c_void_p]),
     'rw_packed_conv_weight_wino4h_elems': (ctypes.c_longlong, [c_int, c_int]),
     'rw_pack_conv_weight_wino4h_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     'rw_conv3x3_wino4h_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,

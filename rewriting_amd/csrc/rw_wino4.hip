@@ -1449,6 +1449,23 @@ extern "C" int rw_absmax_f32(const float* x, long long n, float* out, rw_stream_
   return RW_LAUNCH_RESULT();
 }
 
+// A bound that workgroups on all XCDs raised with memory-side atomics (y_amax of a producer) -> a scalar the next launch
+// may read like any other tensor: ONE thread fetches it with an atomic (performed where the producers' were, so it is
+// the final value whatever an L2 still holds for that address) and stores it plainly; the launch boundary publishes the
+// store.  Found at round 4: with the RGB branch running on a second stream, a forward that was immediately followed by
+// another forward occasionally came out 0.01 - 0.05 off (some workgroups of a consumer had read a stale bound of the
+// recycled address and multiplied with fewer bits); never with RW_MM_NO_HANDOVER=1, RW_RGB_STREAM=0 or a host sync.
+__global__ void publish_scalar_kernel(float* __restrict__ src, float* __restrict__ dst) {
+  const unsigned bits = __hip_atomic_fetch_max(reinterpret_cast<unsigned*>(src), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  dst[0] = __uint_as_float(bits);
+}
+
+extern "C" int rw_publish_scalar_f32(float* src, float* dst, rw_stream_t stream) {
+  RW_CHECK_ARG(src && dst && src != dst);
+  hipLaunchKernelGGL(publish_scalar_kernel, dim3(1), dim3(1), 0, rw_s(stream), src, dst);
+  return RW_LAUNCH_RESULT();
+}
+
 static bool wino4_shape_ok(int out_ch, int in_ch, int h, int w) {
   return out_ch > 0 && in_ch > 0 && out_ch % 32 == 0 && in_ch % 8 == 0 && w % 64 == 0 && h % 8 == 0;
 }

@@ -6,6 +6,7 @@ library and returns the torch tensor -- the ownership rule of SURVEY.md section 
 must be float32 tensors on a HIP device; anything else raises (no CPU path).
 """
 import ctypes
+import os
 import math
 
 import torch
@@ -278,12 +279,20 @@ def absmax(x):
 
 
 def _amax_in(x, x_amax):
+    """The bound a split-operand kernel gets: measured here when the caller has none; a handed-over one (raised by the
+    producer's workgroups with atomics) is first PUBLISHED into a fresh scalar by rw_publish_scalar_f32 -- one thread, one
+    atomic fetch, one plain store -- so that every workgroup of the consumer reads the same, final value (RW_MM_PUBLISH=0:
+    pass the producer's scalar itself, as before)."""
     if x_amax is None:
         return absmax(x)
     x_amax = _dev(x_amax, 'x_amax')
     if x_amax.numel() != 1:
         raise ValueError('x_amax must hold one float')
-    return x_amax
+    if os.environ.get('RW_MM_PUBLISH', '1') == '0':
+        return x_amax
+    out = torch.empty(1, device=x_amax.device, dtype=torch.float32)
+    check(lib().rw_publish_scalar_f32(_p(x_amax), _p(out), _stream()))
+    return out
 
 
 def _amax_out(y_amax):

@@ -234,11 +234,17 @@ def _split_part(kind):
 
 
 def _direct16(dconv, h, w, kind):
-    """Opt-in (RW_MM_DIRECT16=1, with the split form): the DIRECT sums on the 16-bit matrix pipe (csrc/rw_dconv.hip) in
-    place of the split-operand F(4x4,3x3) kernels where the shape allows -- kind 'conv' / 'up' / 'rgb'.  Measured equal
-    in time on the 512^2 / 1024^2 layers (profiles/r04s) and closer to the fp32 direct sum (4e-7 against 1e-6), so not
-    the default: see DESIGN.md section 4.4."""
-    if os.environ.get('RW_MM_DIRECT16') != '1' or dconv.in_channel < 32:
+    """Opt-in inside the split form: the DIRECT sums on the 16-bit matrix pipe (csrc/rw_dconv.hip) in place of the
+    split-operand F(4x4,3x3) kernels, kind 'conv' / 'up' / 'rgb'.  RW_MM_DIRECT16=1 turns all three on, a comma-separated
+    list of kinds selects, 'auto' = 'conv,up': the two that measured faster INSIDE the forward of the 1024 generator
+    (profiles/r04v, ms per launch at batch 64: the stride-1 layers 3.2 - 3.6 / 4.3 against 3.7 - 4.7, the one-pass upsampling
+    layer 9.6 - 10.0 against 10.4; +4.7 % on the forward; the last layer + ToRGB is slower: 7.0 against 5.8).  NOT the
+    default: with the one-pass direct kernel in the forward, repeated forwards of the 1024 generator were not
+    reproducible (rows differing by up to 0.5 with identical inputs and bounds; every kernel-level and full-size parity
+    case passes) -- an interaction that is not understood yet."""
+    mode = os.environ.get('RW_MM_DIRECT16', '0')
+    kinds = ('conv', 'up') if mode == 'auto' else ('conv', 'up', 'rgb') if mode == '1' else mode.split(',')
+    if dconv.in_channel < 32 or kind not in kinds:
         return False
     if kind == 'up':
         return hip.dconv_transpose_blur_supported(dconv.out_channel, dconv.in_channel, h, w)

@@ -453,6 +453,82 @@ def conv_transpose3x3s2_blur_wino4(x, uf, out_ch, w_scale, style=None, demod=Non
     return y
 
 
+# ---- the direct sums on the 16-bit matrix pipe (rw_dconv.hip): the operands rounded to f16 pairs (|x style| scaled below
+# 2^14, the weights below 2^15), the sum itself in fp32
+class _Direct16:
+    def __init__(self, handle):
+        self.handle = handle
+
+
+def pack_conv_weight_direct16(weight):
+    return _Direct16(pack_conv_weight(weight, 0))
+
+
+def conv3x3_direct16(x, wp, out_ch, w_scale, style=None, demod=None, noise=None, noise_w=None, bias=None, act=False,
+                     x_amax=None, y_amax=None):
+    x = x.detach()
+    smax = 1.0 if style is None else float(style.detach().abs().max())
+    ev = 14 - _pow2_above((x_amax.detach() if x_amax is not None else absmax(x)) * smax)
+    if style is not None:
+        x = x * style.detach()[:, :, None, None]
+    wt = _unpack(wp.handle, 0)
+    b, i, h, w = x.shape
+    y = F.conv2d(_f16_pair(x, ev), _f16_pair(wt, 15 - _pow2_above(wt)), padding=1) * w_scale
+    if demod is not None:
+        y = y * demod[:, :, None, None]
+    if noise is not None:
+        y = y + noise_w.detach().reshape(1) * noise.reshape(b, 1, h, w)
+    if act:
+        y = F.leaky_relu(y + bias.detach().view(1, -1, 1, 1), 0.2) * SQRT2
+    if y_amax is not None:
+        y_amax.copy_(absmax(y))
+    return y
+
+
+def conv3x3_direct16_to_rgb(x, wp, out_ch, w_scale, rgb_weight, rgb_style, rgb_bias, rgb_skip, rgb_scale, style=None,
+                            demod=None, noise=None, noise_w=None, bias=None, act=False, x_amax=None):
+    y = conv3x3_direct16(x, wp, out_ch, w_scale, style=style, demod=demod, noise=noise, noise_w=noise_w, bias=bias, act=act,
+                         x_amax=x_amax)
+    return None, to_rgb(y, rgb_weight, rgb_style, rgb_bias, rgb_skip, rgb_scale)
+
+
+def pack_conv_transpose_blur_weight_direct16(weight, k4):
+    return _Direct16((pack_conv_weight(weight, 1), k4.detach().clone()))
+
+
+def conv_transpose3x3s2_blur_direct16(x, wp, out_ch, w_scale, style=None, demod=None, noise=None, noise_w=None,
+                                      bias=None, act=False, post_scale=None, x_amax=None, y_amax=None):
+    """rw_dconv.hip's one-pass upsampling layer: the four output-parity phases of conv_transpose(stride 2) (*) blur as
+    4 * out_ch virtual channels of a direct 3x3 convolution, pixel-shuffled."""
+    packed, k4 = wp.handle
+    w = _unpack(packed, 1)                               # [o][i][3][3]
+    o, i = w.shape[:2]
+    kf = torch.flip(k4, [0, 1])
+    g6 = torch.zeros(o, i, 6, 6)
+    for c in range(4):
+        for d in range(4):
+            g6[:, :, 3 - c:6 - c, 3 - d:6 - d] += kf[c, d] * w
+    wv = torch.zeros(4 * o, i, 3, 3)
+    for py in range(2):
+        for px in range(2):
+            for a in range(3):
+                for b in range(3):
+                    wv[2 * py + px::4, :, a, b] = g6[:, :, 4 - 2 * a + py, 4 - 2 * b + px]
+    z = conv3x3_direct16(x, pack_conv_weight_direct16(wv.reshape(1, 4 * o, i, 3, 3)), 4 * o, w_scale, style=style,
+                         demod=None if demod is None else demod.repeat_interleave(4, dim=1), x_amax=x_amax)
+    n, _, h, wd = z.shape
+    y = z.reshape(n, o, 2, 2, h, wd).permute(0, 1, 4, 2, 5, 3).reshape(n, o, 2 * h, 2 * wd)
+    if noise is not None:
+        y = y + noise_w.detach().reshape(1) * noise.reshape(n, 1, 2 * h, 2 * wd)
+    if act:
+        y = F.leaky_relu(y + bias.detach().view(1, -1, 1, 1), 0.2) * SQRT2
+    if post_scale is not None:
+        y = y * post_scale.detach()[:, :, None, None]
+    if y_amax is not None:
+        y_amax.copy_(absmax(y))
+    return y
+
+
 def conv_wgrad(g, x, upsample, scale=1.0, gscale=None, xscale=None):
     """d W of conv2d(x, W, pad 1) / conv_transpose2d(x, W^T, stride 2) given g = d L / d y, through torch's own
     autograd of the same op (rw_conv_wgrad_f32's definition)."""
@@ -483,6 +559,8 @@ def install(monkeypatch):
              'conv_transpose3x3s2', 'noise_add', 'blur_noise_act', 'to_rgb', 'pack_conv_weight_bf16x3',
              'conv3x3_bf16x6', 'pack_conv_weight_wino', 'conv3x3_wino', 'pack_conv_weight_wino4', 'conv3x3_wino4', 'pack_conv_transpose_weight_wino', 'conv_transpose3x3s2_wino',
              'pack_conv_transpose_blur_weight_wino4', 'conv_transpose3x3s2_blur_wino4', 'absmax',
+             'pack_conv_weight_direct16', 'conv3x3_direct16', 'conv3x3_direct16_to_rgb',
+             'pack_conv_transpose_blur_weight_direct16', 'conv_transpose3x3s2_blur_direct16',
              'conv_transpose_wino_split_supported',
              'second_moment_accumulate', 'channel_sums', 'project_weight', 'solve_ksplit',
              'solve_step', 'solve_run', 'conv_wgrad', 'rowdot']

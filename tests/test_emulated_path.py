@@ -276,10 +276,12 @@ def test_generator_with_f4_winograd_is_inside_the_image_tolerance(emulated_hip, 
     assert (base - want).abs().max().item() < 1e-4 and not torch.equal(base, got)
 
 
-def test_one_pass_upsampling_layers_stay_inside_the_image_tolerance(emulated_hip, monkeypatch):
-    """RW_UP_ALGO=winograd4: the upsampling StyledConvs as ONE pass (transposed conv (*) blur as four F(4x4,3x3) phase
-    convolutions, noise + bias + activation in the epilogue) instead of conv -> (2H+1)^2 map -> blur pass: same
-    generator, reference golden, image tolerance; a hooked layer falls back to the module-by-module route."""
+@pytest.mark.parametrize('direct16', ['0', 'auto'])       # the default / the opt-in direct sums
+def test_one_pass_upsampling_layers_stay_inside_the_image_tolerance(emulated_hip, monkeypatch, direct16):
+    """RW_UP_ALGO=winograd4: the upsampling StyledConvs as ONE pass (transposed conv (*) blur as four phase convolutions
+    -- F(4x4,3x3), or, with RW_MM_DIRECT16, direct sums on the 16-bit pipe where the shape allows --, noise + bias + activation in
+    the epilogue) instead of conv -> (2H+1)^2 map -> blur pass: same generator, reference golden, image tolerance; a
+    hooked layer falls back to the module-by-module route."""
     from rewriting_amd import hip
     from rewriting_amd.utils import nethook
     g = load_golden('gen_s64_cm1')
@@ -287,14 +289,18 @@ def test_one_pass_upsampling_layers_stay_inside_the_image_tolerance(emulated_hip
     model = build_stylegan(meta['size'], meta['truncation'], meta['channel_multiplier'])
     z = torch.from_numpy(g['z'])
     want = torch.from_numpy(g['image'])
-    calls = []
-    real = hip.conv_transpose3x3s2_blur_wino4
+    calls, direct = [], []
+    real, real16 = hip.conv_transpose3x3s2_blur_wino4, hip.conv_transpose3x3s2_blur_direct16
     monkeypatch.setattr(hip, 'conv_transpose_blur_wino4_supported', lambda o, i, h, w: True)
     monkeypatch.setattr(hip, 'conv_transpose3x3s2_blur_wino4', lambda *a, **k: (calls.append(a[0].shape), real(*a, **k))[1])
+    monkeypatch.setattr(hip, 'conv_transpose3x3s2_blur_direct16',
+                        lambda *a, **k: (calls.append(a[0].shape), direct.append(a[0].shape), real16(*a, **k))[2])
     monkeypatch.setenv('RW_UP_ALGO', 'winograd4')
+    monkeypatch.setenv('RW_MM_DIRECT16', direct16)
     with torch.no_grad():
         got = model(z)
     assert len(calls) == 4                              # 4 -> 8 -> 16 -> 32 -> 64
+    assert [tuple(sh[2:]) for sh in direct] == ([] if direct16 == '0' else [(32, 32)])       # w % 32 == 0, h % 8 == 0
     assert (got - want).abs().max().item() < 1e-3
     monkeypatch.setenv('RW_UP_ALGO', 'winograd')
     del calls[:]
