@@ -508,6 +508,42 @@ def test_premultiplied_style_and_one_pass_layers_on_the_image_path(monkeypatch):
     assert (got - exact).abs().max().item() < 1e-4
 
 
+@pytest.mark.xfail(strict=False, reason='OPEN ISSUE of round 4 (DESIGN.md section 9, item 0): intermittent, about one sequence in '
+                                        'thirty after rw_publish_scalar_f32 (one in three before)')
+def test_forwards_issued_back_to_back_equal_their_synced_twins(monkeypatch):
+    """Round 4: a forward that another forward followed WITHOUT a host sync is occasionally 0.01 - 0.05 off (split-operand
+    kernels with the bound hand-over, beside the RGB branch's second stream; every single forward, and the last one of a
+    sequence, is right, so no other test sees it; never with RW_MM_NO_HANDOVER=1, RW_RGB_STREAM=0, RW_MM=f32 or a host
+    sync).  Publishing the bounds by one thread before a consumer reads them (hip._amax_in, rw_publish_scalar_f32)
+    took it from 5 of 12 sequences to 1 of 44, not to zero -- the producers' side of the hand-over (memset + filtered
+    memory-side atomics on a recycled address) is the remaining suspect.  Twelve sequences of four differently configured
+    forwards, unsynced, against the same four with a sync after each: bit-identical when the issue does not strike
+    (scripts/forward_repro.py is the stand-alone form)."""
+    model = build_stylegan(256, 0.7, device=DEV)
+    z = torch.randn(4, 512, generator=torch.Generator().manual_seed(9)).to(DEV)
+    configs = [{}, {'RW_PRESCALE': '0'}, {'RW_PRESCALE': '0', 'RW_UP_FUSED': '0', 'RW_RGB_F4': '0'},
+               {'RW_PRESCALE': '0', 'RW_UP_FUSED': '0', 'RW_RGB_F4': '0', 'RW_CONV_ALGO': 'winograd'}]
+
+    def run(sync):
+        outs = []
+        with torch.no_grad():
+            for env in configs:
+                for k, v in env.items():
+                    monkeypatch.setenv(k, v)
+                outs.append(model(z))
+                if sync:
+                    torch.cuda.synchronize()
+                for k in env:
+                    monkeypatch.delenv(k)
+        torch.cuda.synchronize()
+        return outs
+    ref = run(True)
+    for rep in range(12):
+        got = run(False)
+        for i, (a, b) in enumerate(zip(got, ref)):
+            assert torch.equal(a, b), (rep, i, (a - b).abs().max().item())
+
+
 @pytest.mark.parametrize('hook', [False, True])
 def test_insert_on_a_two_layer_target_matches_reference_golden(hook):
     """The autograd path on the kernels: a target of two styled convolutions (and the same with a hooked module),
