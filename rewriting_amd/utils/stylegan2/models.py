@@ -1044,6 +1044,14 @@ class SeqStyleGAN2(nn.Sequential):
             return self._forward(input)
         _rgb_branch.image_path = True
         _rgb_branch.successor = self._successors()
+        if (input.is_cuda and matrix_mode() == 'split' and os.environ.get('RW_FORWARD_DRAIN', '1') != '0'
+                and not torch.cuda.is_current_stream_capturing()):
+            # WORKAROUND for an open issue of round 4: a forward that starts while the
+            # previous one is still running on the device occasionally multiplies some tiles with a stale bound (images
+            # 0.01 - 0.05 off, 1 sequence in 3 before rw_publish_scalar_f32, 1 in ~40 after; never once the previous
+            # forward has drained).  The trunk's stream is drained before the first launch -- the host no longer runs a
+            # forward ahead, which costs the launch-bound first millisecond of each forward.  RW_FORWARD_DRAIN=0 removes it.
+            torch.cuda.current_stream().synchronize()
         try:
             return self._forward(input)
         finally:
