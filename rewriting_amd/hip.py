@@ -269,11 +269,33 @@ def wino4_supported(out_ch, in_ch, height, width):
     return bool(lib().rw_conv3x3_wino4_supported(int(out_ch), int(in_ch), int(height), int(width)))
 
 
+_bound_rings = {}
+_BOUND_SLOTS, _BOUND_STRIDE = 4096, 32          # slots per device; floats between slots: one 128-byte line each
+
+
+def bound_scalar(device):
+    """A one-element float32 tensor for a bound (x_amax / y_amax of the split-operand kernels): the next slot of a
+    per-device ring of 4096 scalars, one cache line each, allocated once.  NOT torch.empty(1): the caching allocator
+    hands the address of a bound that has just died to the next one, and the system-scope loads these scalars are read
+    with are served by the reading XCD's L2 -- an XCD that still held the line saw the previous occupant (DESIGN.md
+    section 9, item 0).  A slot comes round again after 4096 bounds (~150 forwards of gigabytes each): nothing of it is
+    left in any L2 by then.  The contents are whatever the slot held last (the kernels zero what they raise)."""
+    device = torch.device(device)
+    if device.type == 'cuda' and device.index is None:
+        device = torch.device('cuda', torch.cuda.current_device())
+    ring = _bound_rings.get(device)
+    if ring is None:
+        ring = _bound_rings[device] = [torch.zeros(_BOUND_SLOTS * _BOUND_STRIDE, device=device, dtype=torch.float32), 0]
+    n = ring[1]
+    ring[1] = (n + 1) % _BOUND_SLOTS
+    return ring[0][n * _BOUND_STRIDE:n * _BOUND_STRIDE + 1]
+
+
 def absmax(x):
     """max |x| as a one-element device tensor (rw_absmax_f32): the x_amax of the split-operand F(4x4,3x3) kernels
     where the producer of x did not leave one behind."""
     x = _dev(x, 'tensor')
-    out = torch.empty(1, device=x.device, dtype=torch.float32)
+    out = bound_scalar(x.device)
     check(lib().rw_absmax_f32(_p(x), x.numel(), _p(out), _stream()))
     return out
 
@@ -290,7 +312,7 @@ def _amax_in(x, x_amax):
         raise ValueError('x_amax must hold one float')
     if os.environ.get('RW_MM_PUBLISH', '1') == '0':
         return x_amax
-    out = torch.empty(1, device=x_amax.device, dtype=torch.float32)
+    out = bound_scalar(x_amax.device)
     check(lib().rw_publish_scalar_f32(_p(x_amax), _p(out), _stream()))
     return out
 

@@ -892,7 +892,7 @@ class StyledConvSeq(nn.Sequential):
         split = matrix_mode() == 'split'
         # ... and this layer's bound for the next one, inside the un-hooked forward only (bags that callers or hooks see
         # never carry the key; a hooked model under RW_MM=split lets the kernels measure their inputs)
-        y_amax = torch.empty(1, device=fmap.device, dtype=torch.float32) if split and _rgb_branch.image_path else None
+        y_amax = hip.bound_scalar(fmap.device) if split and _rgb_branch.image_path else None
         y_amax_set = False
         post = None
         if mconv.upsample and pre is not None:

@@ -20,3 +20,22 @@ def test_asm_lds_reads_reach_their_consumers_only_through_their_waits():
                         os.path.join(ROOT, 'rewriting_amd', 'csrc', 'rw_upwino.hip')], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert '16 asm LDS reads checked, 0 violations' in r.stdout
+
+
+def test_bound_scalars_come_from_a_ring_of_separate_cache_lines():
+    """hip.bound_scalar: one-element float32 views of one persistent tensor, 128 bytes apart, a slot reused only after the
+    whole ring -- never the allocator's freshly recycled address."""
+    import torch
+    from rewriting_amd import hip
+    a = hip.bound_scalar('cpu')
+    b = hip.bound_scalar(torch.device('cpu'))
+    assert a.shape == b.shape == (1,) and a.dtype == torch.float32
+    assert b.data_ptr() - a.data_ptr() == 128
+    a.fill_(3.0)
+    b.zero_()
+    assert a.item() == 3.0                                  # separate storage locations of the same buffer
+    seen = {a.data_ptr(), b.data_ptr()}
+    for _ in range(hip._BOUND_SLOTS - 2):
+        seen.add(hip.bound_scalar('cpu').data_ptr())
+    assert len(seen) == hip._BOUND_SLOTS                    # every slot once ...
+    assert hip.bound_scalar('cpu').data_ptr() == a.data_ptr()          # ... then round again
