@@ -530,8 +530,7 @@ def run_forward(args, rank, world, device, size, batch, name, cpu=True):
                            weights='synthetic seed 0', parallelism='seeds partitioned per rank, no collective',
                            conv_gflop_per_image=round(conv_flops(size) / 1e9, 2),
                            matrix_mode='split' if split else 'f32',
-                           direct_sums=os.environ.get('RW_MM_DIRECT16', '0') if split else None,
-                           forward_drain=os.environ.get('RW_FORWARD_DRAIN', '1') if split else None))
+                           direct_sums=os.environ.get('RW_MM_DIRECT16', '0') if split else None))
     # second pass, NOT the headline: HIP events around every convolution call (on torch's current stream, the one the
     # kernels are launched on) -> the per-kernel table and the dominant kernel's roofline
     timer = ConvTimer()
@@ -801,13 +800,12 @@ def extras(args, rank, world, device):
             with torch.no_grad():
                 g(z)
         rates = {}
-        modes = {'f32': ('f32', '0', '1'), 'split': ('split', '0', '1'),
-                 'split, a forward may start while the previous one runs (RW_FORWARD_DRAIN=0)': ('split', '0', '0'),
-                 'split, direct sums on layers 10-17': ('split', 'auto', '1'),
-                 'split, direct sums on layers 10-18': ('split', '1', '1')}
-        saved = {k: os.environ.get(k) for k in ('RW_MM', 'RW_MM_DIRECT16', 'RW_FORWARD_DRAIN')}
-        for mm, (pipe, d16, drain) in modes.items():
-            os.environ['RW_MM'], os.environ['RW_MM_DIRECT16'], os.environ['RW_FORWARD_DRAIN'] = pipe, d16, drain
+        modes = {'f32': ('f32', '0'), 'split': ('split', '0'),
+                 'split, direct sums on layers 10-17': ('split', 'auto'),
+                 'split, direct sums on layers 10-18': ('split', '1')}
+        saved = {k: os.environ.get(k) for k in ('RW_MM', 'RW_MM_DIRECT16')}
+        for mm, (pipe, d16) in modes.items():
+            os.environ['RW_MM'], os.environ['RW_MM_DIRECT16'] = pipe, d16
             timed(fwd, 1, 1, world)
             rates[mm] = round(64 * 5 / timed(fwd, 5, 0, world), 2)
         for key, val in saved.items():
@@ -820,9 +818,8 @@ def extras(args, rank, world, device):
             note='f32 = every product on fp32 MFMAs (round 3\'s kernels); split = the default of the un-hooked forward: '
                  'f16 operand pairs on the 16-bit pipe in the F(4x4,3x3) and F(2,2) kernels; the other two rows (opt-in, '
                  'RW_MM_DIRECT16=auto / 1) replace the F(4x4,3x3) kernels of the stride-1 layers from 64^2 up and of the '
-                 'one-pass upsampling layer / also of the last layer by DIRECT sums on the 16-bit pipe (csrc/rw_dconv.hip); '
-                 'RW_FORWARD_DRAIN=0 removes the stream drain in front of every forward (the workaround of DESIGN.md '
-                 'section 4.1 iii for forwards that start while the previous one runs: results then occasionally 0.01-0.05 off)')
+                 'one-pass upsampling layer / also of the last layer by DIRECT sums on the 16-bit pipe (csrc/rw_dconv.hip). '
+                 'No forward drains a stream: round 4\'s RW_FORWARD_DRAIN workaround is gone with the device scalars it covered')
         del z
     del g
     if world == 1:

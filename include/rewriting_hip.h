@@ -32,8 +32,11 @@ typedef void* rw_stream_t; /* hipStream_t */
 #define RW_ERR_BAD_ARGUMENT 10001
 #define RW_ERR_UNSUPPORTED  10002
 
-/* 3 since round 3: rw_solve_run_*, the whole-image 8x8 / 4x4 shapes, a new point order inside the packed F(4x4,3x3)
- * weights (buffers packed by an older library do not fit this one: repack, as the Python side does per weight version). */
+/* 7 since round 5: the split-operand ("H16") entry points take their bounds as RW_BOUND_LANES-float vectors written
+ * by plain stores (no memset, no atomic, no device scalar that one launch raises and the next reads) and their weight
+ * scale BY VALUE (rw_split_weight_scale); rw_publish_scalar_f32 is gone.  (3: rw_solve_run_*, the whole-image 8x8 / 4x4
+ * shapes, the point order of the packed F(4x4,3x3) weights; 4: rw_*_wino4h_*; 5: rw_dconv*; 6: rw_publish_scalar_f32.)
+ * Buffers packed by an older library do not fit this one: repack, as the Python side does per weight version. */
 int rw_abi_version(void);
 const char* rw_error_string(int code);
 
@@ -283,34 +286,58 @@ int rw_conv_transpose3x3s2_blur_wino4_f32(const float* x, const float* uf, float
  * v_mfma_f32_16x16x16_f16.  Per-product error <= 2^-21 of the product (fp32 multiply: 2^-24); accumulation, transforms
  * and epilogue are the fp32 kernels' -- same shapes, same results within the F(4x4,3x3) error class (tested at the same
  * bars), 36 MFMAs of ~17 cycles per k-quad instead of 32-cycle fp32 MFMAs that block the vector lanes.
- * Powers of two keep the pieces inside f16's normal range:
+ * Powers of two keep the pieces inside f16's normal range.  Neither of them is ever handed from one launch to the next
+ * through a device scalar (round 4 did: a 4-byte value zeroed by a memset, raised with atomics and read back by the next
+ * launch was occasionally read stale -- images 0.01 - 0.05 off; the forward of the reference is a pure function of its
+ * inputs, utils/stylegan2/models.py:126-141, and so is this one now):
  *   uf: rw_packed_*_wino4h_elems floats from rw_pack_*_wino4h_f32: the wino4 layout with every float replaced by the
- *       32-bit word Uh | Ul << 16 of U 2^eU, + 4 trailing floats [2^-eU, 0, max |U|, 0];
- *   x_amax (device scalar, required): a bound max |x| <= x_amax[0] on the input map (without the on-load style; the
- *       kernel multiplies by the style's largest factor itself) -- what the producer of x left in its y_amax, or
- *       rw_absmax_f32(x).  A bound that is too small overflows f16 (inf/NaN in the result); a bound that is 2^k too
- *       large costs k low bits of the smallest values only;
- *   y_amax (device scalar, nullable): receives max |y| of the result (zeroed, then atomic max).
+ *       32-bit word Uh | Ul << 16 of U * u_scale, + 4 trailing floats [1 / u_scale, u_scale, 0, 0] that NO kernel reads
+ *       (they tell the format from the fp32 packing by size and let a host inspect what a buffer was packed with);
+ *   u_scale (BY VALUE, pack entry points) / u_inv = 1 / u_scale (BY VALUE, convolution entry points): the power of two
+ *       that rw_split_weight_scale() derives from max |U|; max |U| comes from rw_*_absmax_f32 (a bound, below), read
+ *       back by the host ONCE per weight version;
+ *   a BOUND on a map: RW_BOUND_LANES floats whose maximum is >= max |x| -- every wave of a consumer loads the vector
+ *       (one float per lane, an ordinary vector load of data the previous launch stored plainly) and reduces it;
+ *   x_amax (required): the bound of the input map (without the on-load style; the kernel multiplies by the style's
+ *       largest factor itself) -- what the producer of x left in its y_amax, or rw_absmax_f32(x).  A bound that is too
+ *       small overflows f16 (inf/NaN in the result); a bound that is 2^k too large costs k low bits of the smallest
+ *       values only;
+ *   y_amax (nullable): rw_bound_floats(elements of y) floats.  Every wave (or workgroup) of the producer stores ITS
+ *       maximum into its own slot behind the first RW_BOUND_LANES floats -- plain stores, nothing is zeroed first,
+ *       every slot that is read is written by the same launch -- and one 64-workgroup launch reduces the slots into
+ *       y_amax[0 .. RW_BOUND_LANES): the bound of y.  Kernel boundaries order all of it like any feature map.
  * Everything else as in the fp32 entry points. */
+#define RW_BOUND_LANES 64
+/* floats of a y_amax buffer for a result of n_elems floats (64 + slots: every producer needs at most
+ * 2048 + n_elems / 1024 + 1 of them; one that would need more measures its result with rw_absmax_f32 instead) */
+long long rw_bound_floats(long long n_elems);
+/* out (rw_bound_floats(n) floats) <- the bound of x[0 .. n) */
 int rw_absmax_f32(const float* x, long long n, float* out, rw_stream_t stream);
-/* dst[0] = the bound in src[0] (a y_amax that a producer raised with atomics), fetched by one atomic and stored plainly:
- * what a consumer's x_amax should point to when producer and consumer run back to back beside work on other streams. */
-int rw_publish_scalar_f32(float* src, float* dst, rw_stream_t stream);
+/* u_scale = 2^(15 - e) with max |U| < 2^e (1 for max |U| == 0): |U u_scale| < 2^15 */
+float rw_split_weight_scale(float u_absmax);
+/* bound (rw_bound_floats(0) floats) <- max |U| over the transformed weights the matching rw_pack_* would store */
+int rw_conv_weight_wino4h_absmax_f32(const float* w, int out_ch, int in_ch, float* bound, rw_stream_t stream);
+int rw_conv_transpose_blur_weight_wino4h_absmax_f32(const float* w, const float* k4, int out_ch, int in_ch, float* bound,
+                                                    rw_stream_t stream);
+int rw_conv_transpose_weight_winoh_absmax_f32(const float* w, int out_ch, int in_ch, float* bound, rw_stream_t stream);
+int rw_dconv_weight_absmax_f32(const float* w, int out_ch, int in_ch, float* bound, rw_stream_t stream);
+int rw_dconv_transpose_blur_weight_absmax_f32(const float* w, const float* k4, int out_ch, int in_ch, float* bound,
+                                              rw_stream_t stream);
 long long rw_packed_conv_weight_wino4h_elems(int out_ch, int in_ch);
-int rw_pack_conv_weight_wino4h_f32(const float* w, float* uf, int out_ch, int in_ch, rw_stream_t stream);
+int rw_pack_conv_weight_wino4h_f32(const float* w, float* uf, int out_ch, int in_ch, float u_scale, rw_stream_t stream);
 int rw_conv3x3_wino4h_f32(const float* x, const float* uf, float* y, int batch, int in_ch, int out_ch, int h,
-                          int w, float w_scale, const rw_conv_epilogue* ep, const float* x_amax, float* y_amax,
-                          rw_stream_t stream);
+                          int w, float w_scale, const rw_conv_epilogue* ep, float u_inv, const float* x_amax,
+                          float* y_amax, rw_stream_t stream);
 int rw_conv3x3_wino4h_to_rgb_f32(const float* x, const float* uf, int batch, int in_ch, int out_ch, int h, int w,
-                                 float w_scale, const rw_conv_epilogue* ep, const rw_rgb_epilogue* rgb,
+                                 float w_scale, const rw_conv_epilogue* ep, const rw_rgb_epilogue* rgb, float u_inv,
                                  const float* x_amax, rw_stream_t stream);
 long long rw_packed_conv_transpose_blur_wino4h_elems(int out_ch, int in_ch);
 int rw_pack_conv_transpose_blur_weight_wino4h_f32(const float* w, const float* k4, float* uf, int out_ch, int in_ch,
-                                                  rw_stream_t stream);
+                                                  float u_scale, rw_stream_t stream);
 int rw_conv_transpose3x3s2_blur_wino4h_f32(const float* x, const float* uf, float* y, int batch, int in_ch,
                                            int out_ch, int h, int w, float w_scale, const rw_conv_epilogue* ep,
-                                           const float* post_scale, const float* x_amax, float* y_amax,
-                                           rw_stream_t stream);
+                                           const float* post_scale, float u_inv, const float* x_amax,
+                                           float* y_amax, rw_stream_t stream);
 
 /* The same three operations as DIRECT sums on the 16-bit matrix pipe (rw_dconv.hip, round 4): no transform at all -- an
  * input value is scaled by style 2^eV and split into its f16 pair ONCE per workgroup while it is staged into LDS, and read
@@ -321,30 +348,31 @@ int rw_conv_transpose3x3s2_blur_wino4h_f32(const float* x, const float* uf, floa
  * out_ch % 16 == 0, h % 8 == 0; to_rgb: out_ch == 32.
  *   wp: rw_packed_dconv_*_elems floats from rw_pack_dconv_*_f32: wp[o / 16][9 (i / 16) + tap][Uh | Ul][lane = 16 ((i % 16) / 4)
  *       + o % 16][4 halves: channels 4 ((i % 16) / 4) + (0..3)] (the kernels double them into the operand) + 4 trailing
- *       floats [2^-eU, 0, max |U|, 0].  The transposed form packs the four output-parity phases of conv_transpose (*) blur as
+ *       floats [1 / u_scale, u_scale, 0, 0] (not read by any kernel).  The transposed form packs the four output-parity phases of conv_transpose (*) blur as
  *       blocks of 16 virtual channels: block 4 (o / 16) + 2 py + px.
  * Two kernel families behind the same entry points: one-role workgroups (two per CU), and -- where in_ch >= 32, the
  * epilogue carries a style, w % 64 == 0 and (rw_dconv3x3_f32) out_ch % 64 == 0, h % 8 == 0 -- workgroups of eight
  * multiplying and four staging waves (RW_DCONV_V=1 forces the first).  Measured on MI355X: as fast as the split F(4x4,3x3)
  * kernels on the 512^2 / 1024^2 layers, not faster (the 16-bit pipe retires an MFMA per 20 cycles and SIMD at ~1.7 GHz
  * under this load: DESIGN.md section 4.4) -- the Python host leaves them opt-in (RW_MM_DIRECT16=1).
- * x_amax / y_amax / ep / post_scale / rgb: as in the wino4h entry points. */
+ * u_scale / u_inv / x_amax / y_amax / ep / post_scale / rgb: as in the wino4h entry points. */
 int rw_dconv3x3_supported(int out_ch, int in_ch, int h, int w);
 long long rw_packed_dconv_weight_elems(int out_ch, int in_ch);
-int rw_pack_dconv_weight_f32(const float* w, float* wp, int out_ch, int in_ch, rw_stream_t stream);
+int rw_pack_dconv_weight_f32(const float* w, float* wp, int out_ch, int in_ch, float u_scale, rw_stream_t stream);
 int rw_dconv3x3_f32(const float* x, const float* wp, float* y, int batch, int in_ch, int out_ch, int h, int w,
-                    float w_scale, const rw_conv_epilogue* ep, const float* x_amax, float* y_amax, rw_stream_t stream);
+                    float w_scale, const rw_conv_epilogue* ep, float u_inv, const float* x_amax, float* y_amax,
+                    rw_stream_t stream);
 int rw_dconv3x3_to_rgb_supported(int out_ch, int in_ch, int h, int w);
 int rw_dconv3x3_to_rgb_f32(const float* x, const float* wp, int batch, int in_ch, int out_ch, int h, int w,
-                           float w_scale, const rw_conv_epilogue* ep, const rw_rgb_epilogue* rgb, const float* x_amax,
-                           rw_stream_t stream);
+                           float w_scale, const rw_conv_epilogue* ep, const rw_rgb_epilogue* rgb, float u_inv,
+                           const float* x_amax, rw_stream_t stream);
 int rw_dconv_transpose_blur_supported(int out_ch, int in_ch, int h, int w);
 long long rw_packed_dconv_transpose_blur_weight_elems(int out_ch, int in_ch);
 int rw_pack_dconv_transpose_blur_weight_f32(const float* w, const float* k4, float* wp, int out_ch, int in_ch,
-                                            rw_stream_t stream);
+                                            float u_scale, rw_stream_t stream);
 int rw_dconv_transpose3x3s2_blur_f32(const float* x, const float* wp, float* y, int batch, int in_ch, int out_ch, int h,
                                      int w, float w_scale, const rw_conv_epilogue* ep, const float* post_scale,
-                                     const float* x_amax, float* y_amax, rw_stream_t stream);
+                                     float u_inv, const float* x_amax, float* y_amax, rw_stream_t stream);
 
 /* rw_conv_transpose3x3s2_wino_f32 (the F(2,2) quads of the stride-2 transposed convolution) with its 25 GEMMs on the
  * 16-bit matrix pipe and the exact f16 operand split of the wino4h entry points (rw_upwino.hip): one
@@ -355,13 +383,13 @@ int rw_dconv_transpose3x3s2_blur_f32(const float* x, const float* wp, float* y, 
  *   uf: rw_packed_conv_transpose_winoh_elems = 16*out_ch*in_ch + 4 floats from rw_pack_conv_transpose_winoh_f32 (the
  *       25 points carry 16 distinct weights): uf[o / 16][i / 8][wi = 0..15][lane = 16 ((i % 8) % 4) + o % 16]
  *       [{0: Uh, 1: Ul}], each 32-bit word the f16 pair of channels (i, i + 4) of the interval; trailer
- *       [2^-eU, 0, max |U|, 0];
- *   x_amax: device scalar >= max |x| (before the style), as for rw_conv3x3_wino4h_f32. */
+ *       [1 / u_scale, u_scale, 0, 0] (not read by any kernel);
+ *   u_scale / u_inv / x_amax (the bound of x before the style): as for rw_conv3x3_wino4h_f32. */
 int rw_conv_transpose3x3s2_winoh_supported(int out_ch, int in_ch, int h, int w);
 long long rw_packed_conv_transpose_winoh_elems(int out_ch, int in_ch);
-int rw_pack_conv_transpose_winoh_f32(const float* w, float* uf, int out_ch, int in_ch, rw_stream_t stream);
+int rw_pack_conv_transpose_winoh_f32(const float* w, float* uf, int out_ch, int in_ch, float u_scale, rw_stream_t stream);
 int rw_conv_transpose3x3s2_winoh_f32(const float* x, const float* uf, float* y, int batch, int in_ch, int out_ch,
-                                     int h, int w, float w_scale, const float* style, const float* demod,
+                                     int h, int w, float w_scale, const float* style, const float* demod, float u_inv,
                                      const float* x_amax, rw_stream_t stream);
 
 /* NoiseInjectionF (models.py:535-546): y[b][c][p] = x[b][c][p] + noise_w[0] * noise[b][p] */
@@ -379,8 +407,8 @@ int rw_blur_noise_act_f32(const float* x, const float* k4, const float* noise, c
 int rw_blur_noise_act_scaled_f32(const float* x, const float* k4, const float* noise, const float* noise_w,
                                  const float* bias, const float* post_scale, float* y, int batch, int channels,
                                  int out_h, int out_w, rw_stream_t stream);
-/* ... and y_amax (device scalar, nullable) receives max |y| of the result, post_scale included: the x_amax of a
- * split-operand (wino4h / winoh) convolution that reads y. */
+/* ... and y_amax (nullable, rw_bound_floats(batch * channels * out_h * out_w) floats) receives the bound of the result,
+ * post_scale included: the x_amax of a split-operand (wino4h / winoh) convolution that reads y. */
 int rw_blur_noise_act_amax_f32(const float* x, const float* k4, const float* noise, const float* noise_w,
                                const float* bias, const float* post_scale, float* y, int batch, int channels,
                                int out_h, int out_w, float* y_amax, rw_stream_t stream);

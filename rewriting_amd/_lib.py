@@ -14,7 +14,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('RW_HIP_LIB') or os.path.join(_HERE, 'librewriting_hip.so')    # RW_HIP_LIB: tuning builds
 
-ABI_VERSION = 6        # 6: rw_publish_scalar_f32; 5: rw_dconv* (direct sums on the 16-bit pipe); 4: rw_*_wino4h_* (operands split into f16 pairs), rw_absmax_f32; 3: rw_solve_run_*, the 8x8 / 4x4 shapes (style == NULL), packed F(4x4,3x3) point order w4_nat; 2: rw_solve_supported 1/0, sizes[6]
+ABI_VERSION = 7        # 7: bounds as RW_BOUND_LANES-float vectors written by plain stores, weight scales by value (rw_split_weight_scale, rw_*_absmax_f32), no rw_publish_scalar_f32; 6: rw_publish_scalar_f32; 5: rw_dconv* (direct sums on the 16-bit pipe); 4: rw_*_wino4h_* (operands split into f16 pairs), rw_absmax_f32; 3: rw_solve_run_*, the 8x8 / 4x4 shapes (style == NULL), packed F(4x4,3x3) point order w4_nat; 2: rw_solve_supported 1/0, sizes[6]
 
 
 class ConvEpilogue(Structure):
@@ -103,38 +103,45 @@ SIGNATURES = {
                                                 c_float, c_void_p, c_void_p, c_void_p]),
     'rw_conv_transpose3x3s2_winoh_supported': (c_int, [c_int, c_int, c_int, c_int]),
     'rw_packed_conv_transpose_winoh_elems': (ctypes.c_longlong, [c_int, c_int]),
-    'rw_pack_conv_transpose_winoh_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    'rw_pack_conv_transpose_winoh_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     'rw_conv_transpose3x3s2_winoh_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
-                                                 c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                                 c_float, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
     'rw_conv3x3_wino4_to_rgb_supported': (c_int, [c_int, c_int, c_int, c_int]),
     'rw_conv3x3_wino4_to_rgb_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                             POINTER(ConvEpilogue), POINTER(RgbEpilogue), c_void_p]),
     'rw_absmax_f32': (c_int, [c_void_p, ctypes.c_longlong, c_void_p, c_void_p]),
-    'rw_publish_scalar_f32': (c_int, [c_void_p, c_void_p, c_void_p]),
+    'rw_bound_floats': (ctypes.c_longlong, [ctypes.c_longlong]),
+    'rw_split_weight_scale': (c_float, [c_float]),
+    'rw_conv_weight_wino4h_absmax_f32': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    'rw_conv_transpose_blur_weight_wino4h_absmax_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    'rw_conv_transpose_weight_winoh_absmax_f32': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    'rw_dconv_weight_absmax_f32': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    'rw_dconv_transpose_blur_weight_absmax_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'rw_packed_conv_weight_wino4h_elems': (ctypes.c_longlong, [c_int, c_int]),
-    'rw_pack_conv_weight_wino4h_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    'rw_pack_conv_weight_wino4h_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     'rw_conv3x3_wino4h_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
-                                      POINTER(ConvEpilogue), c_void_p, c_void_p, c_void_p]),
+                                      POINTER(ConvEpilogue), c_float, c_void_p, c_void_p, c_void_p]),
     'rw_conv3x3_wino4h_to_rgb_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
-                                             POINTER(ConvEpilogue), POINTER(RgbEpilogue), c_void_p, c_void_p]),
+                                             POINTER(ConvEpilogue), POINTER(RgbEpilogue), c_float, c_void_p, c_void_p]),
     'rw_packed_conv_transpose_blur_wino4h_elems': (ctypes.c_longlong, [c_int, c_int]),
-    'rw_pack_conv_transpose_blur_weight_wino4h_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    'rw_pack_conv_transpose_blur_weight_wino4h_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float,
+                                                              c_void_p]),
     'rw_conv_transpose3x3s2_blur_wino4h_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                                                       c_int, c_float, POINTER(ConvEpilogue), c_void_p, c_void_p,
-                                                       c_void_p, c_void_p]),
+                                                       c_int, c_float, POINTER(ConvEpilogue), c_void_p, c_float,
+                                                       c_void_p, c_void_p, c_void_p]),
     'rw_dconv3x3_supported': (c_int, [c_int, c_int, c_int, c_int]),
     'rw_packed_dconv_weight_elems': (ctypes.c_longlong, [c_int, c_int]),
-    'rw_pack_dconv_weight_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    'rw_pack_dconv_weight_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     'rw_dconv3x3_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
-                                POINTER(ConvEpilogue), c_void_p, c_void_p, c_void_p]),
+                                POINTER(ConvEpilogue), c_float, c_void_p, c_void_p, c_void_p]),
     'rw_dconv3x3_to_rgb_supported': (c_int, [c_int, c_int, c_int, c_int]),
     'rw_dconv3x3_to_rgb_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
-                                       POINTER(ConvEpilogue), POINTER(RgbEpilogue), c_void_p, c_void_p]),
+                                       POINTER(ConvEpilogue), POINTER(RgbEpilogue), c_float, c_void_p, c_void_p]),
     'rw_dconv_transpose_blur_supported': (c_int, [c_int, c_int, c_int, c_int]),
     'rw_packed_dconv_transpose_blur_weight_elems': (ctypes.c_longlong, [c_int, c_int]),
-    'rw_pack_dconv_transpose_blur_weight_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    'rw_pack_dconv_transpose_blur_weight_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     'rw_dconv_transpose3x3s2_blur_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
-                                                 c_float, POINTER(ConvEpilogue), c_void_p, c_void_p, c_void_p,
+                                                 c_float, POINTER(ConvEpilogue), c_void_p, c_float, c_void_p, c_void_p,
                                                  c_void_p]),
     'rw_conv_transpose_blur_wino4_supported': (c_int, [c_int, c_int, c_int, c_int]),
     'rw_packed_conv_transpose_blur_wino4_elems': (ctypes.c_longlong, [c_int, c_int]),

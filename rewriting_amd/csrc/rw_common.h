@@ -46,13 +46,50 @@ __device__ __forceinline__ float rw_block_sum_256(float v, float* lds4) {
 typedef float rw_f32x16 __attribute__((ext_vector_type(16)));
 typedef float rw_f32x4 __attribute__((ext_vector_type(4)));
 
-// max into a device scalar that holds a NON-NEGATIVE float (bit patterns then order like the values).  The scalar is
-// zeroed by a memset, raised by workgroups on all eight XCDs and read by the next launch: the operations carry system
-// scope (sc1: performed at the memory side, not in one XCD's L2), and a workgroup whose value cannot raise it -- almost
-// all of them -- leaves after one coherent load instead of queueing on the same address.
-__device__ __forceinline__ void rw_atomic_max_nonneg(float* addr, float v) {
-  unsigned* a = reinterpret_cast<unsigned*>(addr);
-  const unsigned bits = __float_as_uint(v);
-  if (__hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < bits)
-    __hip_atomic_fetch_max(a, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+// ---------------------------------------------------------------------------------------
+// Bounds (max |map|) handed from a launch to the next one -- see "a BOUND on a map" in include/rewriting_hip.h.
+// Round 4 kept them in 4-byte device scalars: zeroed by a memset, raised by the producer's workgroups with (filtered,
+// system-scope) atomics, read by the consumer with a system-scope load.  Occasionally a consumer read a stale value
+// (images 0.01 - 0.05 off; GPUTEST_r04).  Nothing of that mechanism is left: a producer's wave (or workgroup) stores its
+// maximum PLAINLY into ITS OWN slot, rw_bound_finish() reduces the slots of the launch into RW_BOUND_LANES floats with
+// one small launch, and a consumer's wave loads those floats with an ordinary per-lane vector load.  No location is
+// written by more than one workgroup, nothing is zeroed first, every slot that is read was written by the launch in
+// front: what orders it is what orders every feature map -- the launch boundary.
+// ---------------------------------------------------------------------------------------
+// slots a producer may use for a result of n floats (rw_bound_floats(n) - RW_BOUND_LANES)
+static inline int64_t rw_bound_slot_capacity(int64_t n_elems) { return 2048 + n_elems / 1024 + 1; }
+
+// host: bound[0 .. RW_BOUND_LANES) <- the maxima of bound[RW_BOUND_LANES .. RW_BOUND_LANES + nslots)   (rw_bound.hip)
+int rw_bound_finish(float* bound, int64_t nslots, hipStream_t stream);
+
+// consumer: the bound (uniform over the wave).  ALL 64 lanes of the wave must be active.
+__device__ __forceinline__ float rw_bound_load(const float* __restrict__ bound) {
+  return rw_wave_max(bound[threadIdx.x & 63]);
+}
+
+// producer, one slot per WAVE: slot = workgroup * waves per workgroup + wave.  v = the wave's maximum (any lane's copy
+// of the reduced value); every wave of the launch must call it exactly once.
+__device__ __forceinline__ void rw_bound_store_wave(float* __restrict__ bound, float v) {
+  if ((threadIdx.x & 63) == 0)
+    bound[RW_BOUND_LANES + (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = v;
+}
+
+// producer, one slot per WORKGROUP of 256 threads: v = this thread's maximum; every thread of the workgroup calls it.
+__device__ __forceinline__ void rw_bound_store_block_256(float* __restrict__ bound, float v, float* lds4) {
+  v = rw_wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) bound[RW_BOUND_LANES + blockIdx.x] = fmaxf(fmaxf(lds4[0], lds4[1]), fmaxf(lds4[2], lds4[3]));
+}
+
+// u_scale = 2^(15 - e), max |U| < 2^e  (rw_split_weight_scale in the header; one definition for host and tests)
+static inline float rw_weight_scale_of(float u_absmax) {
+  union { float f; unsigned u; } b;
+  b.f = u_absmax;
+  int eu = (int)((b.u >> 23) & 0xff) - 126;
+  if ((b.u & 0x7fffffffu) == 0u) eu = 15;
+  eu = eu < -100 ? -100 : (eu > 100 ? 100 : eu);
+  b.u = (unsigned)(127 + 15 - eu) << 23;
+  return b.f;
 }

@@ -53,8 +53,8 @@ struct DconvProblem {
   int tiles_x, tiles_y, o_tiles;
   int strided;                                      // specialised kernels: tile k of workgroup b = k * grid + b' instead of a contiguous run
   float w_scale;
-  const float* trailer;                             // the 4 floats behind the packed weights
-  const float* x_amax; float* y_amax;
+  float u_inv;                                      // 1 / (the packed weights' scale), by value
+  const float* x_amax; float* y_amax;               // bounds (RW_BOUND_LANES floats; y: + slots), rw_common.h
 };
 
 #ifndef DC_ABL
@@ -151,12 +151,11 @@ __device__ __forceinline__ void dconv_body(const DconvProblem& p) {
     if (lane == 0) Red[wave] = smax;
     __syncthreads();
     smax = fmaxf(fmaxf(Red[0], Red[1]), fmaxf(Red[2], Red[3]));
-    // (coherent loads: see rw_wino4.hip -- the bound's address is recycled from launch to launch)
-    const float am = __hip_atomic_load(p.x_amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) * smax;
+    const float am = rw_bound_load(p.x_amax) * smax;
     int e = (int)((__float_as_uint(am) >> 23) & 0xff) - 126;      // am < 2^e
     e = e < -100 ? -100 : (e > 100 ? 100 : e);
     in_scale = __uint_as_float((unsigned)(127 + 14 - e) << 23);
-    out_scale = __uint_as_float((unsigned)(127 + e - 14) << 23) * p.trailer[0];
+    out_scale = __uint_as_float((unsigned)(127 + e - 14) << 23) * p.u_inv;
   }
   const float gain = p.act ? 1.4142135623730951f : 1.f, slope = p.act ? 0.2f : 1.f;
   for (int i = tid; i < p.in_ch; i += 256) St[i] = (p.style ? p.style[(int64_t)ib * p.in_ch + i] : 1.0f) * in_scale;
@@ -404,10 +403,7 @@ __device__ __forceinline__ void dconv_body(const DconvProblem& p) {
       }
     }
   }
-  if (!RGB && p.y_amax) {
-    ymax = rw_wave_max(ymax);
-    if (lane == 0) rw_atomic_max_nonneg(p.y_amax, ymax);
-  }
+  if (!RGB && p.y_amax) rw_bound_store_wave(p.y_amax, rw_wave_max(ymax));       // this wave's slot
 }
 
 // ---------------------------------------------------------------------------------------
@@ -473,7 +469,10 @@ __device__ __forceinline__ void dconv_ws_body(const DconvProblem& p) {
   const int t0 = p.strided ? 0 : bx * per;
   const int t1 = p.strided ? (int)((total - bx + gridDim.x - 1) / gridDim.x)
                            : (int)((int64_t)t0 + per < total ? t0 + per : total);       // run = positions [t0, t1)
-  if (t0 >= t1) return;
+  if (t0 >= t1) {                                  // (every wave of the launch owns a slot of the bound: rw_common.h)
+    if (!RGB && p.y_amax) rw_bound_store_wave(p.y_amax, 0.f);
+    return;
+  }
   const int N = (t1 - t0) * NC;                    // chunks of the run
   const int t_mul = p.strided ? gridDim.x : 1, t_add = p.strided ? bx : 0;            // tile id of run position k
   auto decode = [&](int pos, int& ot, int& tx, int& ty, int& ib) __attribute__((always_inline)) {
@@ -494,7 +493,7 @@ __device__ __forceinline__ void dconv_ws_body(const DconvProblem& p) {
   if (wave >= MW) {
     // =========================== staging waves: channel quad g of every chunk ===========================
     const int g2 = QW * (wave - MW), lid = (wave - MW) * 64 + lane;    // quads g2 .. g2 + QW - 1
-    const float xam = __hip_atomic_load(p.x_amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const float xam = rw_bound_load(p.x_amax);
     const int hw4 = (int)hw * 4;
     int loff[SI];                                   // LDS byte offset of the item's window column 4 j - 3 (may lie left of the row)
 #pragma unroll
@@ -543,7 +542,7 @@ __device__ __forceinline__ void dconv_ws_body(const DconvProblem& p) {
           int e = (int)((__float_as_uint(am) >> 23) & 0xff) - 126;      // am < 2^e
           e = e < -100 ? -100 : (e > 100 ? 100 : e);
           in_scale = __uint_as_float((unsigned)(127 + 14 - e) << 23);
-          out_scale = __uint_as_float((unsigned)(127 + e - 14) << 23) * p.trailer[0];
+          out_scale = __uint_as_float((unsigned)(127 + e - 14) << 23) * p.u_inv;
           xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (int64_t)ib * p.in_ch * hw), 0,
                                                    (int)((int64_t)p.in_ch * hw * 4), 0x00020000);
         }
@@ -683,6 +682,7 @@ __device__ __forceinline__ void dconv_ws_body(const DconvProblem& p) {
       o[8] = DC_T() - pt_all; o[9] = pt_del; o[10] = pt_req; o[11] = pt_bar; o[12] = N;
     }
 #endif
+    if (!RGB && p.y_amax) rw_bound_store_wave(p.y_amax, 0.f);       // a staging wave produced nothing: its slot says so
     return;
   }
 
@@ -886,10 +886,7 @@ __device__ __forceinline__ void dconv_ws_body(const DconvProblem& p) {
     o[0] = DC_T() - pt_all; o[1] = pt_mm; o[2] = pt_bar; o[3] = pt_epi; o[4] = N;
   }
 #endif
-  if (!RGB && p.y_amax) {
-    ymax = rw_wave_max(ymax);
-    if (lane == 0) rw_atomic_max_nonneg(p.y_amax, ymax);
-  }
+  if (!RGB && p.y_amax) rw_bound_store_wave(p.y_amax, rw_wave_max(ymax));       // this wave's slot
 }
 
 // one workgroup per CU: 8 multiplying waves (two per SIMD: the waves of a workgroup are dealt to the SIMDs in turn) + 4 staging;
@@ -904,28 +901,19 @@ __global__ void __launch_bounds__(256, 2) dconv_up_kernel(const DconvProblem p) 
 __global__ void __launch_bounds__(256, 2) dconv_rgb_kernel(const DconvProblem p) { dconv_body<2, 1>(p); }
 
 // ---------------------------------------------------------------------------------------
-// Packing.  PASS 1: max |U| -> trailer[2] (bits, atomic max); PASS 2: the f16 pieces of U 2^eU in operand order.
+// Packing.  PASS 1 (rw_dconv_*_absmax_f32): max |U| as a bound; PASS 2: the f16 pieces of U su in operand order, su BY VALUE
+// (rw_split_weight_scale of the maximum the host read back: see rw_wino4.hip).
 // One thread per (virtual out-channel v, input channel i): nine taps.  UP: v's block vb = 4 ot + 2 py + px is phase (py, px)
 // of the real channels 16 ot + (v % 16); its 3x3 kernel is rw_wino4.hip's composition of the transposed convolution with the
 // blur: h[a][b] = g6[2 - 2a + py][2 - 2b + px], g6 = k' (*) w.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ float dc_weight_scale(const float* trailer, float* inv) {
-  const unsigned bits = __hip_atomic_load(reinterpret_cast<const unsigned*>(trailer + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  int eu = (int)((bits >> 23) & 0xff) - 126;        // max |U| < 2^eu
-  if (bits == 0u) eu = 15;
-  eu = eu < -100 ? -100 : (eu > 100 ? 100 : eu);
-  *inv = __uint_as_float((unsigned)(127 + eu - 15) << 23);
-  return __uint_as_float((unsigned)(127 + 15 - eu) << 23);
-}
-
 template <int PASS, bool UP>
 __global__ void __launch_bounds__(256) pack_dconv_kernel(const float* __restrict__ w, const float* __restrict__ k4,
                                                          unsigned char* __restrict__ wp, float* __restrict__ trailer,
-                                                         int vch, int in_ch) {
+                                                         int vch, int in_ch, float su, float* __restrict__ bound) {
   const int64_t total = (int64_t)vch * in_ch;
   const int NC = in_ch >> 4, T = 9 * NC;
-  float su = 1.f, inv = 1.f, m = 0.f;
-  if (PASS == 2) su = dc_weight_scale(trailer, &inv);
+  float m = 0.f;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     const int i = (int)(idx % in_ch), v = (int)(idx / in_ch);
     const int vb = v >> 4, n = v & 15;
@@ -970,11 +958,10 @@ __global__ void __launch_bounds__(256) pack_dconv_kernel(const float* __restrict
       d[256] = lo;                                  // part 1: + 512 bytes
     }
   }
-  if (PASS == 1) {
-    m = rw_wave_max(m);
-    if ((threadIdx.x & 63) == 0) rw_atomic_max_nonneg(trailer + 2, m);
-  }
-  if (PASS == 2 && blockIdx.x == 0 && threadIdx.x == 0) trailer[0] = inv;
+  __shared__ float red[4];
+  if (PASS == 1) rw_bound_store_block_256(bound, m, red);
+  if (PASS == 2 && blockIdx.x == 0 && threadIdx.x < 4)       // for inspection only: no kernel reads the trailer
+    trailer[threadIdx.x] = threadIdx.x == 0 ? 1.f / su : (threadIdx.x == 1 ? su : 0.f);
 }
 
 // RW_DCONV_V=1: the one-role kernels (two workgroups per CU); default: the specialised ones (in_ch >= 32)
@@ -1002,29 +989,49 @@ extern "C" long long rw_packed_dconv_weight_elems(int out_ch, int in_ch) {
 }
 
 template <bool UP>
-static int dconv_pack(const float* w, const float* k4, float* wp, int vch, int in_ch, rw_stream_t stream) {
+static int dconv_absmax(const float* w, const float* k4, int vch, int in_ch, float* bound, rw_stream_t stream) {
+  const int64_t total = (int64_t)vch * in_ch;
+  const int grid = rw_stream_grid(total, 256);
+  hipLaunchKernelGGL((pack_dconv_kernel<1, UP>), dim3(grid), dim3(256), 0, rw_s(stream), w, k4, (unsigned char*)nullptr,
+                     (float*)nullptr, vch, in_ch, 1.f, bound);
+  const int rc = RW_LAUNCH_RESULT();
+  if (rc) return rc;
+  return rw_bound_finish(bound, grid, rw_s(stream));
+}
+
+template <bool UP>
+static int dconv_pack(const float* w, const float* k4, float* wp, int vch, int in_ch, float u_scale, rw_stream_t stream) {
   const int64_t total = (int64_t)vch * in_ch;
   float* trailer = wp + 9 * total;
-  const hipError_t me = hipMemsetAsync(trailer, 0, 4 * sizeof(float), rw_s(stream));
-  if (me != hipSuccess) return (int)me;
   unsigned char* bytes = reinterpret_cast<unsigned char*>(wp);
-  hipLaunchKernelGGL((pack_dconv_kernel<1, UP>), dim3(rw_stream_grid(total, 256)), dim3(256), 0, rw_s(stream), w, k4, bytes,
-                     trailer, vch, in_ch);
   hipLaunchKernelGGL((pack_dconv_kernel<2, UP>), dim3(rw_stream_grid(total, 256)), dim3(256), 0, rw_s(stream), w, k4, bytes,
-                     trailer, vch, in_ch);
+                     trailer, vch, in_ch, u_scale, (float*)nullptr);
   return RW_LAUNCH_RESULT();
 }
 
-extern "C" int rw_pack_dconv_weight_f32(const float* w, float* wp, int out_ch, int in_ch, rw_stream_t stream) {
-  RW_CHECK_ARG(w && wp && out_ch > 0 && in_ch > 0);
+extern "C" int rw_dconv_weight_absmax_f32(const float* w, int out_ch, int in_ch, float* bound, rw_stream_t stream) {
+  RW_CHECK_ARG(w && bound && out_ch > 0 && in_ch > 0);
   if (out_ch % 16 || in_ch % 16) return RW_ERR_UNSUPPORTED;
-  return dconv_pack<false>(w, nullptr, wp, out_ch, in_ch, stream);
+  return dconv_absmax<false>(w, nullptr, out_ch, in_ch, bound, stream);
+}
+
+extern "C" int rw_pack_dconv_weight_f32(const float* w, float* wp, int out_ch, int in_ch, float u_scale, rw_stream_t stream) {
+  RW_CHECK_ARG(w && wp && out_ch > 0 && in_ch > 0 && u_scale > 0.f);
+  if (out_ch % 16 || in_ch % 16) return RW_ERR_UNSUPPORTED;
+  return dconv_pack<false>(w, nullptr, wp, out_ch, in_ch, u_scale, stream);
+}
+
+// after a launch whose waves stored their maxima: the bound of the result
+static int dconv_finish(float* y_amax, int64_t nslots, rw_stream_t stream) {
+  const int rc = RW_LAUNCH_RESULT();
+  if (rc || !y_amax) return rc;
+  return rw_bound_finish(y_amax, nslots, rw_s(stream));
 }
 
 static void dconv_fill(DconvProblem& p, const float* x, const float* wp, int batch, int in_ch, int vch, int h, int w,
-                       float w_scale, const rw_conv_epilogue* ep, const float* x_amax, float* y_amax) {
+                       float w_scale, const rw_conv_epilogue* ep, float u_inv, const float* x_amax, float* y_amax) {
   p.x = x; p.wp = reinterpret_cast<const unsigned char*>(wp);
-  p.trailer = wp + 9LL * vch * in_ch;
+  p.u_inv = u_inv;
   p.style = ep ? ep->style : nullptr; p.demod = ep ? ep->demod : nullptr; p.noise = ep ? ep->noise : nullptr;
   p.noise_w = ep ? ep->noise_w : nullptr; p.bias = ep ? ep->bias : nullptr; p.act = ep ? ep->act : 0;
   p.batch = batch; p.in_ch = in_ch; p.out_ch = vch; p.h = h; p.w = w; p.w_scale = w_scale;
@@ -1035,16 +1042,16 @@ static void dconv_fill(DconvProblem& p, const float* x, const float* wp, int bat
 }
 
 extern "C" int rw_dconv3x3_f32(const float* x, const float* wp, float* y, int batch, int in_ch, int out_ch, int h, int w,
-                               float w_scale, const rw_conv_epilogue* ep, const float* x_amax, float* y_amax,
+                               float w_scale, const rw_conv_epilogue* ep, float u_inv, const float* x_amax, float* y_amax,
                                rw_stream_t stream) {
-  RW_CHECK_ARG(x && wp && y && x_amax && batch > 0 && in_ch > 0 && out_ch > 0 && h > 0 && w > 0);
+  RW_CHECK_ARG(x && wp && y && x_amax && u_inv > 0.f && batch > 0 && in_ch > 0 && out_ch > 0 && h > 0 && w > 0);
   RW_CHECK_ARG(!ep || ((!ep->noise || ep->noise_w) && (!ep->act || ep->bias)));
   if (!dconv_shape_ok(out_ch, in_ch, h, w)) return RW_ERR_UNSUPPORTED;
   if ((int64_t)in_ch * h * w * 4 > 0x7fffffffLL) return RW_ERR_UNSUPPORTED;
   DconvProblem p = {};
-  dconv_fill(p, x, wp, batch, in_ch, out_ch, h, w, w_scale, ep, x_amax, y_amax);
+  dconv_fill(p, x, wp, batch, in_ch, out_ch, h, w, w_scale, ep, u_inv, x_amax, y_amax);
   p.y = y;
-  if (y_amax) { const hipError_t me = hipMemsetAsync(y_amax, 0, sizeof(float), rw_s(stream)); if (me != hipSuccess) return (int)me; }
+  const int64_t cap = rw_bound_slot_capacity((int64_t)batch * out_ch * h * w);
   // out-channels of a workgroup: 128 / 64 / 32 -- the widest that divides (the window is staged once for all of them)
   const char* e = getenv("RW_DCONV_WM");
   int wm = out_ch % 128 == 0 ? 4 : (out_ch % 64 == 0 ? 2 : 1);
@@ -1058,13 +1065,15 @@ extern "C" int rw_dconv3x3_f32(const float* x, const float* wp, float* y, int ba
     // 128 out-channels per workgroup would not fit, 32 would need twice the pixels)
     p.o_tiles = out_ch / 64; p.tiles_y = h / 8; p.tiles_x = w / 64;
     const unsigned grid = dconv_ws_grid((int64_t)batch * p.tiles_y * p.tiles_x * p.o_tiles);
+    if (y_amax && 12LL * grid > cap) return RW_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(dconv_ws_w2_kernel, dim3(grid), dim3(768), 0, rw_s(stream), p);
-    return RW_LAUNCH_RESULT();
+    return dconv_finish(y_amax, 12LL * grid, stream);
   }
+  if (y_amax && 4 * work > cap) return RW_ERR_UNSUPPORTED;
   if (wm == 4) hipLaunchKernelGGL(dconv_w4_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
   else if (wm == 2) hipLaunchKernelGGL(dconv_w2_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
   else hipLaunchKernelGGL(dconv_w1_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
-  return RW_LAUNCH_RESULT();
+  return dconv_finish(y_amax, 4 * work, stream);
 }
 
 // ---- conv_transpose(stride 2) + blur + noise + bias + leaky ReLU in one pass (rw_conv_transpose3x3s2_blur_wino4_f32's operation)
@@ -1078,36 +1087,44 @@ extern "C" long long rw_packed_dconv_transpose_blur_weight_elems(int out_ch, int
   if (out_ch <= 0 || in_ch <= 0 || out_ch % 16 || in_ch % 16) return -1;
   return 36LL * out_ch * in_ch + 4;
 }
-extern "C" int rw_pack_dconv_transpose_blur_weight_f32(const float* w, const float* k4, float* wp, int out_ch, int in_ch,
-                                                       rw_stream_t stream) {
-  RW_CHECK_ARG(w && k4 && wp && out_ch > 0 && in_ch > 0);
+extern "C" int rw_dconv_transpose_blur_weight_absmax_f32(const float* w, const float* k4, int out_ch, int in_ch,
+                                                         float* bound, rw_stream_t stream) {
+  RW_CHECK_ARG(w && k4 && bound && out_ch > 0 && in_ch > 0);
   if (out_ch % 16 || in_ch % 16) return RW_ERR_UNSUPPORTED;
-  return dconv_pack<true>(w, k4, wp, 4 * out_ch, in_ch, stream);
+  return dconv_absmax<true>(w, k4, 4 * out_ch, in_ch, bound, stream);
+}
+extern "C" int rw_pack_dconv_transpose_blur_weight_f32(const float* w, const float* k4, float* wp, int out_ch, int in_ch,
+                                                       float u_scale, rw_stream_t stream) {
+  RW_CHECK_ARG(w && k4 && wp && out_ch > 0 && in_ch > 0 && u_scale > 0.f);
+  if (out_ch % 16 || in_ch % 16) return RW_ERR_UNSUPPORTED;
+  return dconv_pack<true>(w, k4, wp, 4 * out_ch, in_ch, u_scale, stream);
 }
 extern "C" int rw_dconv_transpose3x3s2_blur_f32(const float* x, const float* wp, float* y, int batch, int in_ch, int out_ch,
                                                 int h, int w, float w_scale, const rw_conv_epilogue* ep,
-                                                const float* post_scale, const float* x_amax, float* y_amax,
+                                                const float* post_scale, float u_inv, const float* x_amax, float* y_amax,
                                                 rw_stream_t stream) {
-  RW_CHECK_ARG(x && wp && y && x_amax && batch > 0 && in_ch > 0 && out_ch > 0 && h > 0 && w > 0);
+  RW_CHECK_ARG(x && wp && y && x_amax && u_inv > 0.f && batch > 0 && in_ch > 0 && out_ch > 0 && h > 0 && w > 0);
   RW_CHECK_ARG(!ep || ((!ep->noise || ep->noise_w) && (!ep->act || ep->bias)));
   if (!dconv_up_shape_ok(out_ch, in_ch, h, w)) return RW_ERR_UNSUPPORTED;
   if ((int64_t)in_ch * h * w * 4 > 0x7fffffffLL) return RW_ERR_UNSUPPORTED;
   DconvProblem p = {};
-  dconv_fill(p, x, wp, batch, in_ch, 4 * out_ch, h, w, w_scale, ep, x_amax, y_amax);
+  dconv_fill(p, x, wp, batch, in_ch, 4 * out_ch, h, w, w_scale, ep, u_inv, x_amax, y_amax);
   p.y = y; p.post = post_scale;
-  if (y_amax) { const hipError_t me = hipMemsetAsync(y_amax, 0, sizeof(float), rw_s(stream)); if (me != hipSuccess) return (int)me; }
+  const int64_t cap = rw_bound_slot_capacity((int64_t)batch * out_ch * 4 * h * w);
   p.o_tiles = out_ch / 16;
   p.tiles_y = h / 8;
   const int64_t work = (int64_t)batch * p.tiles_y * p.tiles_x * p.o_tiles;
   if (work <= 0 || work > 0x7fffffff) return RW_ERR_UNSUPPORTED;
   if (dconv_specialised(in_ch, ep) && w % 64 == 0) {
     p.tiles_y = h / 8; p.tiles_x = w / 64;
-    hipLaunchKernelGGL(dconv_ws_up_kernel, dim3(dconv_ws_grid((int64_t)batch * p.tiles_y * p.tiles_x * p.o_tiles)), dim3(768), 0,
-                       rw_s(stream), p);
-    return RW_LAUNCH_RESULT();
+    const unsigned grid = dconv_ws_grid((int64_t)batch * p.tiles_y * p.tiles_x * p.o_tiles);
+    if (y_amax && 12LL * grid > cap) return RW_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(dconv_ws_up_kernel, dim3(grid), dim3(768), 0, rw_s(stream), p);
+    return dconv_finish(y_amax, 12LL * grid, stream);
   }
+  if (y_amax && 4 * work > cap) return RW_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(dconv_up_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
-  return RW_LAUNCH_RESULT();
+  return dconv_finish(y_amax, 4 * work, stream);
 }
 
 // ---- the last styled convolution with ToRGB in the epilogue (rw_conv3x3_wino4_to_rgb_f32's operation)
@@ -1115,14 +1132,14 @@ extern "C" int rw_dconv3x3_to_rgb_supported(int out_ch, int in_ch, int h, int w)
   return out_ch == 32 && dconv_shape_ok(out_ch, in_ch, h, w) ? 1 : 0;
 }
 extern "C" int rw_dconv3x3_to_rgb_f32(const float* x, const float* wp, int batch, int in_ch, int out_ch, int h, int w,
-                                      float w_scale, const rw_conv_epilogue* ep, const rw_rgb_epilogue* rgb,
+                                      float w_scale, const rw_conv_epilogue* ep, const rw_rgb_epilogue* rgb, float u_inv,
                                       const float* x_amax, rw_stream_t stream) {
-  RW_CHECK_ARG(x && wp && rgb && rgb->weight && rgb->style && rgb->out && x_amax && batch > 0 && in_ch > 0 && out_ch > 0);
+  RW_CHECK_ARG(x && wp && rgb && rgb->weight && rgb->style && rgb->out && x_amax && u_inv > 0.f && batch > 0 && in_ch > 0 && out_ch > 0);
   RW_CHECK_ARG(!ep || ((!ep->noise || ep->noise_w) && (!ep->act || ep->bias)));
   if (!rw_dconv3x3_to_rgb_supported(out_ch, in_ch, h, w)) return RW_ERR_UNSUPPORTED;
   if ((int64_t)in_ch * h * w * 4 > 0x7fffffffLL) return RW_ERR_UNSUPPORTED;
   DconvProblem p = {};
-  dconv_fill(p, x, wp, batch, in_ch, out_ch, h, w, w_scale, ep, x_amax, nullptr);
+  dconv_fill(p, x, wp, batch, in_ch, out_ch, h, w, w_scale, ep, u_inv, x_amax, nullptr);
   p.rgb_weight = rgb->weight; p.rgb_style = rgb->style; p.rgb_bias = rgb->bias; p.rgb_skip = rgb->skip;
   p.rgb_out = rgb->out; p.rgb_scale = rgb->scale;
   p.o_tiles = 1;

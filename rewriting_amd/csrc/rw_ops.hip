@@ -12,7 +12,7 @@
 #include <stdlib.h>
 #include <stdint.h>
 
-extern "C" int rw_abi_version(void) { return 6; }
+extern "C" int rw_abi_version(void) { return 7; }
 
 extern "C" const char* rw_error_string(int code) {
   if (code == 0) return "success";
@@ -853,12 +853,9 @@ __global__ void __launch_bounds__(256) blur_noise_act_kernel(
       for (int q = 0; q < 4; ++q) if (ox + q < out_w) yo[q] = res[q];
     }
   }
-  if (y_amax) {       // one coherent load per workgroup, an atomic from the few whose maximum is news
-    ymax = rw_wave_max(ymax);
+  if (y_amax) {       // the workgroup's maximum -> its own slot of the bound (plain store: rw_common.h)
     __shared__ float wmax[4];
-    if ((tid & 63) == 0) wmax[tid >> 6] = ymax;
-    __syncthreads();
-    if (tid == 0) rw_atomic_max_nonneg(y_amax, fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])));
+    rw_bound_store_block_256(y_amax, ymax, wmax);
   }
 }
 
@@ -965,10 +962,18 @@ extern "C" int rw_blur_noise_act_amax_f32(const float* x, const float* k4, const
   const int tiles_x = (int)rw_cdiv(out_w, BL_TW), tiles_y = (int)rw_cdiv(out_h, BL_TH);
   const int64_t blocks = (int64_t)batch * channels * tiles_x * tiles_y;
   if (blocks > 0x7fffffff) return RW_ERR_UNSUPPORTED;
-  if (y_amax) { const hipError_t me = hipMemsetAsync(y_amax, 0, sizeof(float), rw_s(stream)); if (me != hipSuccess) return (int)me; }
+  const int64_t n_out = (int64_t)batch * channels * out_h * out_w;
+  if (y_amax && blocks > rw_bound_slot_capacity(n_out)) {     // tiles too small for a slot each: measure the result instead
+    const int rc = rw_blur_noise_act_amax_f32(x, k4, noise, noise_w, bias, post_scale, y, batch, channels, out_h, out_w,
+                                              nullptr, stream);
+    if (rc) return rc;
+    return rw_absmax_f32(y, (long long)n_out, y_amax, stream);
+  }
   hipLaunchKernelGGL(blur_noise_act_kernel, dim3((unsigned)blocks), dim3(256), 0, rw_s(stream), x, k4,
                      noise, noise_w, bias, y, batch, channels, out_h, out_w, tiles_x, tiles_y, post_scale, y_amax);
-  return RW_LAUNCH_RESULT();
+  const int rc = RW_LAUNCH_RESULT();
+  if (rc || !y_amax) return rc;
+  return rw_bound_finish(y_amax, blocks, rw_s(stream));
 }
 
 extern "C" int rw_blur_noise_act_scaled_f32(const float* x, const float* k4, const float* noise,

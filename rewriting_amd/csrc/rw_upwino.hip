@@ -57,7 +57,8 @@ struct UpWinoProblem {
   int batch, in_ch, out_ch, h, w;
   int groups_x, groups_y, gpw;
   float w_scale;
-  const float* x_amax;          // H16: device scalar >= max |x|
+  const float* x_amax;          // H16: the bound of x (RW_BOUND_LANES floats, rw_common.h)
+  float u_inv;                  // H16: 1 / (the packed weights' scale), by value
 };
 
 #ifndef UW_ABL
@@ -151,13 +152,11 @@ __device__ __forceinline__ void conv_up_wino_body(const UpWinoProblem& p) {
       if (lane == 0) Red[wave] = smax;
       __syncthreads();
       smax = fmaxf(fmaxf(Red[0], Red[1]), fmaxf(Red[2], Red[3]));
-      // (a coherent load: the scalar load the compiler would pick reads through a cache that back-to-back launches do not
-    // invalidate, and the allocator hands the same address to successive layers' bounds)
-    const float am = __hip_atomic_load(p.x_amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) * smax;                        // |T| <= 4 am < 2^(e + 2)
+      const float am = rw_bound_load(p.x_amax) * smax;            // |T| <= 4 am < 2^(e + 2)
       int e = (int)((__float_as_uint(am) >> 23) & 0xff) - 126;    // am < 2^e
       e = e < -100 ? -100 : (e > 100 ? 100 : e);
       in_scale = __uint_as_float((unsigned)(127 + 12 - e) << 23);
-      out_scale = __uint_as_float((unsigned)(127 + e - 12) << 23) * p.uf[(int64_t)16 * p.out_ch * p.in_ch];
+      out_scale = __uint_as_float((unsigned)(127 + e - 12) << 23) * p.u_inv;
     }
     for (int i = tid; i < p.in_ch; i += 256) St[i] = (p.style ? p.style[(int64_t)ib * p.in_ch + i] : 1.0f) * in_scale;
     if (tid < 32) Sc[tid] = (p.demod ? p.demod[(int64_t)ib * p.out_ch + o0 + tid] * p.w_scale : p.w_scale) * out_scale;
@@ -507,24 +506,16 @@ __global__ void __launch_bounds__(256) pack_up_wino_kernel(const float* __restri
   }
 }
 
-// H16 packing.  PASS 1: max |U| -> trailer[2] (bits, atomic max).  PASS 2: one thread per (o, channel pair (c, c + 4) of an
-// 8-channel interval): the words Uh pair / Ul pair of U 2^(15 - eu); the first thread writes 2^(eu - 15) to trailer[0].
+// H16 packing.  PASS 1 (rw_conv_transpose_weight_winoh_absmax_f32): max |U| as a bound, one slot per workgroup.  PASS 2:
+// one thread per (o, channel pair (c, c + 4) of an 8-channel interval): the words Uh pair / Ul pair of U su, su BY VALUE
+// (rw_split_weight_scale of the maximum the host read back: see rw_wino4.hip); the trailer is for inspection only.
 __device__ __forceinline__ unsigned uw_f16_bits(float v) { return (unsigned)__builtin_bit_cast(unsigned short, (_Float16)v); }
 template <int PASS>
 __global__ void __launch_bounds__(256) pack_up_winoh_kernel(const float* __restrict__ w, float* __restrict__ uf,
-                                                            int out_ch, int in_ch) {
+                                                            int out_ch, int in_ch, float su, float* __restrict__ bound) {
   const int ivn = in_ch >> 3;
   const int64_t total = (int64_t)out_ch * (in_ch >> 1);
-  float* trailer = uf + (int64_t)16 * out_ch * in_ch;
-  float su = 1.f, inv = 1.f, m = 0.f;
-  if (PASS == 2) {
-    const unsigned bits = __hip_atomic_load(reinterpret_cast<const unsigned*>(trailer + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    int eu = (int)((bits >> 23) & 0xff) - 126;
-    if (bits == 0u) eu = 15;
-    eu = eu < -100 ? -100 : (eu > 100 ? 100 : eu);
-    inv = __uint_as_float((unsigned)(127 + eu - 15) << 23);
-    su = __uint_as_float((unsigned)(127 + 15 - eu) << 23);
-  }
+  float m = 0.f;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
     const int lane = (int)(idx & 63);
@@ -550,12 +541,10 @@ __global__ void __launch_bounds__(256) pack_up_winoh_kernel(const float* __restr
       }
     }
   }
-  if (PASS == 1) {
-#pragma unroll
-    for (int off = 32; off; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-    if ((threadIdx.x & 63) == 0) rw_atomic_max_nonneg(trailer + 2, m);
-  }
-  if (PASS == 2 && blockIdx.x == 0 && threadIdx.x == 0) trailer[0] = inv;
+  __shared__ float red[4];
+  if (PASS == 1) rw_bound_store_block_256(bound, m, red);
+  if (PASS == 2 && blockIdx.x == 0 && threadIdx.x < 4)
+    uf[(int64_t)16 * out_ch * in_ch + threadIdx.x] = threadIdx.x == 0 ? 1.f / su : (threadIdx.x == 1 ? su : 0.f);
 }
 
 static bool up_wino_narrow(int h, int w) { return w == 16 && h % 8 == 0; }
@@ -587,17 +576,17 @@ extern "C" int rw_pack_conv_transpose_wino_f32(const float* w, float* uf, int ou
 // The quads y < H, x < W of the transposed convolution (everything but output row 2H and column 2W, which
 // rw_conv_transpose3x3s2_f32 impl 8 writes): y (B, out_ch, 2H+1, 2W+1).
 static int up_wino_launch(const float* x, const float* uf, float* y, int batch, int in_ch, int out_ch, int h, int w,
-                          float w_scale, const float* style, const float* demod, bool h16, const float* x_amax,
-                          rw_stream_t stream) {
+                          float w_scale, const float* style, const float* demod, bool h16, float u_inv,
+                          const float* x_amax, rw_stream_t stream) {
   RW_CHECK_ARG(x && uf && y && batch > 0 && in_ch > 0 && out_ch > 0 && h > 0 && w > 0);
-  RW_CHECK_ARG(!h16 || x_amax);
+  RW_CHECK_ARG(!h16 || (x_amax && u_inv > 0.f));
   if (!up_wino_shape_ok(out_ch, in_ch, h, w)) return RW_ERR_UNSUPPORTED;
   const bool whole = up_wino_whole(h, w);
   if (whole && style) return RW_ERR_UNSUPPORTED;       // 8^2 and 4^2 maps arrive already multiplied by their style
   UpWinoProblem p;
   p.x = x; p.uf = uf; p.y = y; p.style = style; p.demod = demod;
   p.batch = batch; p.in_ch = in_ch; p.out_ch = out_ch; p.h = h; p.w = w; p.w_scale = w_scale;
-  p.x_amax = x_amax;
+  p.x_amax = x_amax; p.u_inv = u_inv;
   const bool narrow = up_wino_narrow(h, w);
   if (h16 && (whole || narrow || w % 32 != 0)) return RW_ERR_UNSUPPORTED;
   p.groups_x = (narrow || whole) ? 1 : w / 32;
@@ -628,7 +617,7 @@ static int up_wino_launch(const float* x, const float* uf, float* y, int batch, 
 extern "C" int rw_conv_transpose3x3s2_wino_f32(const float* x, const float* uf, float* y, int batch, int in_ch,
                                                int out_ch, int h, int w, float w_scale, const float* style,
                                                const float* demod, rw_stream_t stream) {
-  return up_wino_launch(x, uf, y, batch, in_ch, out_ch, h, w, w_scale, style, demod, false, nullptr, stream);
+  return up_wino_launch(x, uf, y, batch, in_ch, out_ch, h, w, w_scale, style, demod, false, 1.f, nullptr, stream);
 }
 
 // ---- H16: the same quads with the products on the 16-bit matrix pipe (maps with w % 32 == 0, h % 4 == 0)
@@ -641,21 +630,32 @@ extern "C" long long rw_packed_conv_transpose_winoh_elems(int out_ch, int in_ch)
   return 16LL * out_ch * in_ch + 4;
 }
 
-extern "C" int rw_pack_conv_transpose_winoh_f32(const float* w, float* uf, int out_ch, int in_ch, rw_stream_t stream) {
-  RW_CHECK_ARG(w && uf && out_ch > 0 && in_ch > 0);
+extern "C" int rw_conv_transpose_weight_winoh_absmax_f32(const float* w, int out_ch, int in_ch, float* bound,
+                                                         rw_stream_t stream) {
+  RW_CHECK_ARG(w && bound && out_ch > 0 && in_ch > 0);
   if (out_ch % 16 || in_ch % 8) return RW_ERR_UNSUPPORTED;
   const int64_t total = (int64_t)out_ch * (in_ch >> 1);
-  const hipError_t me = hipMemsetAsync(uf + (int64_t)16 * out_ch * in_ch, 0, 4 * sizeof(float), rw_s(stream));
-  if (me != hipSuccess) return (int)me;
-  hipLaunchKernelGGL(pack_up_winoh_kernel<1>, dim3(rw_stream_grid(total, 256)), dim3(256), 0, rw_s(stream), w, uf,
-                     out_ch, in_ch);
+  const int grid = rw_stream_grid(total, 256);
+  hipLaunchKernelGGL(pack_up_winoh_kernel<1>, dim3(grid), dim3(256), 0, rw_s(stream), w, (float*)nullptr, out_ch, in_ch, 1.f,
+                     bound);
+  const int rc = RW_LAUNCH_RESULT();
+  if (rc) return rc;
+  return rw_bound_finish(bound, grid, rw_s(stream));
+}
+
+extern "C" int rw_pack_conv_transpose_winoh_f32(const float* w, float* uf, int out_ch, int in_ch, float u_scale,
+                                                rw_stream_t stream) {
+  RW_CHECK_ARG(w && uf && out_ch > 0 && in_ch > 0 && u_scale > 0.f);
+  if (out_ch % 16 || in_ch % 8) return RW_ERR_UNSUPPORTED;
+  const int64_t total = (int64_t)out_ch * (in_ch >> 1);
   hipLaunchKernelGGL(pack_up_winoh_kernel<2>, dim3(rw_stream_grid(total, 256)), dim3(256), 0, rw_s(stream), w, uf,
-                     out_ch, in_ch);
+                     out_ch, in_ch, u_scale, (float*)nullptr);
   return RW_LAUNCH_RESULT();
 }
 
 extern "C" int rw_conv_transpose3x3s2_winoh_f32(const float* x, const float* uf, float* y, int batch, int in_ch,
                                                 int out_ch, int h, int w, float w_scale, const float* style,
-                                                const float* demod, const float* x_amax, rw_stream_t stream) {
-  return up_wino_launch(x, uf, y, batch, in_ch, out_ch, h, w, w_scale, style, demod, true, x_amax, stream);
+                                                const float* demod, float u_inv, const float* x_amax,
+                                                rw_stream_t stream) {
+  return up_wino_launch(x, uf, y, batch, in_ch, out_ch, h, w, w_scale, style, demod, true, u_inv, x_amax, stream);
 }

@@ -66,9 +66,10 @@ struct Wino4Problem {
   const float* rgb_weight; const float* rgb_style; const float* rgb_bias; const float* rgb_skip; float* rgb_out;
   float rgb_scale;
   const float* post;            // UP: (batch x real out_ch) factor on the result (the next layer's style), nullable
-  // H16 kernels (operands split into f16 pairs, see conv_wino36b_body): device scalar >= max |x| of the input map;
-  // nullable device scalar that receives (atomic max) max |result| -- the next layer's x_amax
+  // H16 kernels (operands split into f16 pairs, see conv_wino36b_body): the bound of the input map (RW_BOUND_LANES floats,
+  // rw_common.h); nullable: the slots + bound of the result -- the next layer's x_amax; 1 / (the packed weights' scale)
   const float* x_amax; float* y_amax;
+  float u_inv;
 };
 
 #define W4_PC 66                // patch columns: 64 + 2
@@ -466,16 +467,16 @@ __device__ __forceinline__ void w4_at_row(const float (&t)[6], float (&v)[4]) {
 // and v_mfma_f32_16x16x16_f16 accumulates all FOUR products in fp32: its k index within a lane group holds
 // A = [Uh, Ul, Uh, Ul], B = [Vh, Vh, Vl, Vl] of ONE input channel -- the lane <-> (channel, tile) / (channel, out-channel)
 // assignment of v_mfma_f32_16x16x4_f32 carries over unchanged, so does everything around the loop (rings, pieces,
-// waits, epilogues).  The powers of two keep the operands inside f16's normal range: eU from max |U| at pack time (stored
-// behind the packed weights), eV from a device scalar x_amax >= max |x| that the producer of the map left behind (or
-// rw_absmax_f32), the style's largest factor and the transform's gain (<= 100): |V 2^eV| < 25600.  Both leave the result
+// waits, epilogues).  The powers of two keep the operands inside f16's normal range: eU from max |U| at pack time (read
+// back by the host once per weight version and passed by value), eV from the bound x_amax >= max |x| that the producer of
+// the map left behind (or rw_absmax_f32), the style's largest factor and the transform's gain (<= 100): |V 2^eV| < 25600.  Both leave the result
 // through the epilogue's per-channel factor (exact).  Values more than 2^17 below the map's maximum lose low bits of Vl
 // (f16 denormals: absolute error <= 2^-25 2^-eV) -- no worse than what fp32 accumulation does to them beside the large terms.
 // Per-product error <= 2^-21.x of the product against 2^-24 for an fp32 multiply; measured against float64 the kernel's
 // total error is that of the fp32 F(4x4,3x3) kernel (the transforms' constants dominate both).
 // Packed weights: uf[o / 16][i / 4][position 0..35 (w4_nat)][lane] of 32-bit words Uh | Ul << 16 -- the size and the
 // pieces of rw_pack_conv_weight_wino4_f32, one word per (position, lane) so that consecutive lanes are 4 bytes apart --
-// + 4 trailing floats: [2^-eU, 0, max |U| bits, 0].
+// + 4 trailing floats [2^-eU, 2^eU, 0, 0] that no kernel reads: 2^-eU arrives BY VALUE (Wino4Problem::u_inv).
 // What it costs: 3 VALU per transformed value (v_cvt_pk_f16_f32, v_fma_mix_f32, v_cvt_pk_f16_f32); the pair (w, w) of a
 // weight word costs none -- ds_read2st64_b32 reads the word into both registers (inline assembly, waits tied to the
 // operands: scripts/check_asm_loads.py) where two v_mov per word were a fifth of the loop's vector instructions.  What
@@ -565,13 +566,11 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
     smax = Red[0];
 #pragma unroll
     for (int wv = 1; wv < WAVES; ++wv) smax = fmaxf(smax, Red[wv]);
-    // (a coherent load: the scalar load the compiler would pick reads through a cache that back-to-back launches do not
-    // invalidate, and the allocator hands the same address to successive layers' bounds)
-    const float am = __hip_atomic_load(p.x_amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) * smax;                          // >= max |x style|; |B^T d B| <= 100 am < 2^(e + 7)
+    const float am = rw_bound_load(p.x_amax) * smax;              // >= max |x style|; |B^T d B| <= 100 am < 2^(e + 7)
     int e = (int)((__float_as_uint(am) >> 23) & 0xff) - 126;      // am < 2^e
     e = e < -100 ? -100 : (e > 100 ? 100 : e);
     in_scale = __uint_as_float((unsigned)(127 + 8 - e) << 23);
-    out_scale = __uint_as_float((unsigned)(127 + e - 8) << 23) * p.uf[(int64_t)36 * p.out_ch * p.in_ch];
+    out_scale = __uint_as_float((unsigned)(127 + e - 8) << 23) * p.u_inv;
   }
   for (int i = tid; i < p.in_ch; i += THREADS) St[i] = (p.style ? p.style[(int64_t)ib * p.in_ch + i] : 1.0f) * in_scale;
   if (tid < 16 * WGM) {
@@ -1217,11 +1216,7 @@ __device__ __forceinline__ void conv_wino36b_body(const Wino4Problem& p) {
   }
   __builtin_amdgcn_s_waitcnt(0x0070);               // nothing in flight into LDS when the workgroup retires
 #undef W4_WAIT
-  if (H16 && !RGB && p.y_amax) {
-#pragma unroll
-    for (int off = 32; off; off >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, off));
-    if (lane == 0) rw_atomic_max_nonneg(p.y_amax, ymax);
-  }
+  if (H16 && !RGB && p.y_amax) rw_bound_store_wave(p.y_amax, rw_wave_max(ymax));      // this wave's slot
 }
 
 template <int WGN, int UDEPTH>
@@ -1341,31 +1336,18 @@ __device__ __forceinline__ float w4_pack_store(const float* g, float* dst, float
     }
     return m;
 }
-// H16 packing runs twice: PASS 1 leaves max |U| (as bits, atomic max) in trailer[2]; PASS 2 derives the power of two
-// from it -- max |U| < 2^eu, su = 2^(15 - eu) -- and the first thread writes 2^(eu - 15) to trailer[0].
-__device__ __forceinline__ float w4_weight_scale(const float* trailer, float* inv) {
-  const unsigned bits = __hip_atomic_load(reinterpret_cast<const unsigned*>(trailer + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  int eu = (int)((bits >> 23) & 0xff) - 126;
-  if (bits == 0u) eu = 15;
-  eu = eu < -100 ? -100 : (eu > 100 ? 100 : eu);
-  *inv = __uint_as_float((unsigned)(127 + eu - 15) << 23);
-  return __uint_as_float((unsigned)(127 + 15 - eu) << 23);
-}
-__device__ __forceinline__ void w4_report_absmax(float m, float* trailer) {
-#pragma unroll
-  for (int off = 32; off; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-  if ((threadIdx.x & 63) == 0) rw_atomic_max_nonneg(trailer + 2, m);
-}
-
+// H16 packing runs as two entry points: rw_*_absmax_f32 (PASS 1) leaves max |U| as a bound (one slot per workgroup +
+// rw_bound_finish); the host reads it ONCE per weight version, derives the power of two -- max |U| < 2^eu,
+// su = 2^(15 - eu): rw_split_weight_scale -- and hands it BY VALUE to rw_pack_* (PASS 2) and, inverted, to every
+// convolution launch.  (Round 4 kept max |U| and 2^-eU in device scalars behind the packed weights: zeroed by a memset,
+// raised with atomics, read by the next launches -- the first forward after a pack occasionally read a stale one.)
 // One thread: the 36 values of one (o, i).  uf[o / 16][i / 4][xi / 4][16 (i % 4) + o % 16][xi % 4]
 template <int PASS>
 __global__ void __launch_bounds__(256) pack_wino36_kernel(const float* __restrict__ w, float* __restrict__ uf,
-                                                          int out_ch, int in_ch) {
+                                                          int out_ch, int in_ch, float su, float* __restrict__ bound) {
   const int64_t total = (int64_t)out_ch * in_ch;
   const int kqn = in_ch >> 2;
-  float* trailer = uf + 36 * total;
-  float su = 1.f, inv = 1.f, m = 0.f;
-  if (PASS == 2) su = w4_weight_scale(trailer, &inv);
+  float m = 0.f;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
     const int lane = (int)(idx & 63);
@@ -1376,8 +1358,10 @@ __global__ void __launch_bounds__(256) pack_wino36_kernel(const float* __restric
     m = fmaxf(m, w4_pack_store<PASS>(w + ((int64_t)o * in_ch + i) * 9,
                                      uf + ((int64_t)ob * kqn + kq) * (9 * 256) + (PASS == 2 ? lane : lane * 4), su));
   }
-  if (PASS == 1) w4_report_absmax(m, trailer);
-  if (PASS == 2 && blockIdx.x == 0 && threadIdx.x == 0) trailer[0] = inv;
+  __shared__ float red[4];
+  if (PASS == 1) rw_bound_store_block_256(bound, m, red);
+  if (PASS == 2 && blockIdx.x == 0 && threadIdx.x < 4)       // for inspection only: no kernel reads the trailer
+    uf[36 * total + threadIdx.x] = threadIdx.x == 0 ? 1.f / su : (threadIdx.x == 1 ? su : 0.f);
 }
 
 // The same for the transposed convolution + blur problem: virtual channel v = 4 o + 2 py + px carries the phase
@@ -1385,13 +1369,12 @@ __global__ void __launch_bounds__(256) pack_wino36_kernel(const float* __restric
 // k' = the blur kernel as upfirdn2d applies it (flipped).  w[o][i][ky][kx] as rw_conv_transpose3x3s2_f32 sees it.
 template <int PASS>
 __global__ void __launch_bounds__(256) pack_up_wino36_kernel(const float* __restrict__ w, const float* __restrict__ k4,
-                                                             float* __restrict__ uf, int out_ch, int in_ch) {
+                                                             float* __restrict__ uf, int out_ch, int in_ch, float su,
+                                                             float* __restrict__ bound) {
   const int vch = 4 * out_ch;
   const int64_t total = (int64_t)vch * in_ch;
   const int kqn = in_ch >> 2;
-  float* trailer = uf + 36 * total;
-  float su = 1.f, inv = 1.f, m = 0.f;
-  if (PASS == 2) su = w4_weight_scale(trailer, &inv);
+  float m = 0.f;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
     const int lane = (int)(idx & 63);
@@ -1419,51 +1402,10 @@ __global__ void __launch_bounds__(256) pack_up_wino36_kernel(const float* __rest
       }
     m = fmaxf(m, w4_pack_store<PASS>(h, uf + ((int64_t)ob * kqn + kq) * (9 * 256) + (PASS == 2 ? lane : lane * 4), su));
   }
-  if (PASS == 1) w4_report_absmax(m, trailer);
-  if (PASS == 2 && blockIdx.x == 0 && threadIdx.x == 0) trailer[0] = inv;
-}
-
-// max |x| over n floats -> out[0] (zeroed first): the x_amax of the H16 kernels where no producer left one behind
-__global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
-  float m = 0.f;
-  const int64_t n4 = n >> 2;
-  const w4_f32x4* x4 = reinterpret_cast<const w4_f32x4*>(x);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-    const w4_f32x4 v = x4[i];
-    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
-  }
-  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(x[(n4 << 2) + threadIdx.x]));
-#pragma unroll
-  for (int off = 32; off; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-  if ((threadIdx.x & 63) == 0) rw_atomic_max_nonneg(out, m);
-}
-
-extern "C" int rw_absmax_f32(const float* x, long long n, float* out, rw_stream_t stream) {
-  RW_CHECK_ARG(x && out && n > 0);
-  if (((size_t)x & 15) != 0) return RW_ERR_UNSUPPORTED;
-  { const hipError_t me = hipMemsetAsync(out, 0, sizeof(float), rw_s(stream)); if (me != hipSuccess) return (int)me; }
-  int grid = (int)((n / 4 + 255) / 256);
-  if (grid > 2048) grid = 2048;
-  if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, rw_s(stream), x, (int64_t)n, out);
-  return RW_LAUNCH_RESULT();
-}
-
-// A bound that workgroups on all XCDs raised with memory-side atomics (y_amax of a producer) -> a scalar the next launch
-// may read like any other tensor: ONE thread fetches it with an atomic (performed where the producers' were, so it is
-// the final value whatever an L2 still holds for that address) and stores it plainly; the launch boundary publishes the
-// store.  Found at round 4: with the RGB branch running on a second stream, a forward that was immediately followed by
-// another forward occasionally came out 0.01 - 0.05 off (some workgroups of a consumer had read a stale bound of the
-// recycled address and multiplied with fewer bits); never with RW_MM_NO_HANDOVER=1, RW_RGB_STREAM=0 or a host sync.
-__global__ void publish_scalar_kernel(float* __restrict__ src, float* __restrict__ dst) {
-  const unsigned bits = __hip_atomic_fetch_max(reinterpret_cast<unsigned*>(src), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  dst[0] = __uint_as_float(bits);
-}
-
-extern "C" int rw_publish_scalar_f32(float* src, float* dst, rw_stream_t stream) {
-  RW_CHECK_ARG(src && dst && src != dst);
-  hipLaunchKernelGGL(publish_scalar_kernel, dim3(1), dim3(1), 0, rw_s(stream), src, dst);
-  return RW_LAUNCH_RESULT();
+  __shared__ float red[4];
+  if (PASS == 1) rw_bound_store_block_256(bound, m, red);
+  if (PASS == 2 && blockIdx.x == 0 && threadIdx.x < 4)
+    uf[36 * total + threadIdx.x] = threadIdx.x == 0 ? 1.f / su : (threadIdx.x == 1 ? su : 0.f);
 }
 
 static bool wino4_shape_ok(int out_ch, int in_ch, int h, int w) {
@@ -1484,7 +1426,7 @@ extern "C" int rw_pack_conv_weight_wino4_f32(const float* w, float* uf, int out_
   if (out_ch % 16 || in_ch % 4) return RW_ERR_UNSUPPORTED;
   const int64_t total = (int64_t)out_ch * in_ch;
   hipLaunchKernelGGL(pack_wino36_kernel<0>, dim3(rw_stream_grid(total, 256)), dim3(256), 0, rw_s(stream), w, uf, out_ch,
-                     in_ch);
+                     in_ch, 1.f, (float*)nullptr);
   return RW_LAUNCH_RESULT();
 }
 
@@ -1501,19 +1443,26 @@ static int wino4_gpw(const Wino4Problem& p, int batch, int o_tiles) {
   return gpw;
 }
 
+// after an H16 launch whose waves stored their maxima: the bound of the result
+static int w4h_finish(float* y_amax, int64_t nslots, rw_stream_t stream) {
+  const int rc = RW_LAUNCH_RESULT();
+  if (rc || !y_amax) return rc;
+  return rw_bound_finish(y_amax, nslots, rw_s(stream));
+}
+
 static int conv3x3_wino4_launch(const float* x, const float* uf, float* y, int batch, int in_ch, int out_ch, int h,
-                                int w, float w_scale, const rw_conv_epilogue* ep, bool h16, const float* x_amax,
-                                float* y_amax, rw_stream_t stream) {
+                                int w, float w_scale, const rw_conv_epilogue* ep, bool h16, float u_inv,
+                                const float* x_amax, float* y_amax, rw_stream_t stream) {
   RW_CHECK_ARG(x && uf && y && batch > 0 && in_ch > 0 && out_ch > 0 && h > 0 && w > 0);
   RW_CHECK_ARG(!ep || ((!ep->noise || ep->noise_w) && (!ep->act || ep->bias)));
-  RW_CHECK_ARG(!h16 || x_amax);
+  RW_CHECK_ARG(!h16 || (x_amax && u_inv > 0.f));
   if (!wino4_shape_ok(out_ch, in_ch, h, w)) return RW_ERR_UNSUPPORTED;
   Wino4Problem p = {};
   p.x = x; p.uf = uf; p.y = y;
   p.style = ep ? ep->style : nullptr; p.demod = ep ? ep->demod : nullptr; p.noise = ep ? ep->noise : nullptr;
   p.noise_w = ep ? ep->noise_w : nullptr; p.bias = ep ? ep->bias : nullptr; p.act = ep ? ep->act : 0;
   p.batch = batch; p.in_ch = in_ch; p.out_ch = out_ch; p.h = h; p.w = w; p.w_scale = w_scale;
-  p.x_amax = x_amax; p.y_amax = y_amax;
+  p.x_amax = x_amax; p.y_amax = y_amax; p.u_inv = u_inv;
   // 32 out-channels x 2 tile rows (8 x 64 pixels) per workgroup
   p.groups_x = w / 64;
   p.groups_y = h / 8;
@@ -1524,7 +1473,7 @@ static int conv3x3_wino4_launch(const float* x, const float* uf, float* y, int b
   if (work <= 0 || work > 0x7fffffff) return RW_ERR_UNSUPPORTED;
   if (h16) {
     if (in_ch > 512) return RW_ERR_UNSUPPORTED;
-    if (y_amax) { const hipError_t me = hipMemsetAsync(y_amax, 0, sizeof(float), rw_s(stream)); if (me != hipSuccess) return (int)me; }
+    const int64_t n_out = (int64_t)batch * out_ch * h * w;
     const char* wg8 = getenv("RW_W4H_WG8");
     if (wg8 && wg8[0] == '1' && h % 16 == 0) {
       p.groups_y = h / 16;
@@ -1533,12 +1482,14 @@ static int conv3x3_wino4_launch(const float* x, const float* uf, float* y, int b
       while (p.groups_x % g8) --g8;
       p.gpw = g8;
       const int64_t work8 = (int64_t)batch * p.groups_y * (p.groups_x / g8) * o_tiles;
+      if (y_amax && 8 * work8 > rw_bound_slot_capacity(n_out)) return RW_ERR_UNSUPPORTED;
       hipLaunchKernelGGL(conv_wino36h_wg8_kernel, dim3((unsigned)work8), dim3(512), 0, rw_s(stream), p);
-      return RW_LAUNCH_RESULT();
+      return w4h_finish(y_amax, 8 * work8, stream);
     }
+    if (y_amax && 4 * work > rw_bound_slot_capacity(n_out)) return RW_ERR_UNSUPPORTED;
     if (w4h_point_split(in_ch)) hipLaunchKernelGGL(conv_wino36h_ps_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
     else hipLaunchKernelGGL(conv_wino36h_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
-    return RW_LAUNCH_RESULT();
+    return w4h_finish(y_amax, 4 * work, stream);
   }
   // versions: 1 = registers / compiler-scheduled loads (256 threads); 2 = <4,3> 512-thread workgroups;
   // 3 (default) = <2,2> two 256-thread workgroups per CU.  RW_WINO4_V overrides for comparison.
@@ -1578,7 +1529,7 @@ static int conv3x3_wino4_launch(const float* x, const float* uf, float* y, int b
 
 extern "C" int rw_conv3x3_wino4_f32(const float* x, const float* uf, float* y, int batch, int in_ch, int out_ch, int h,
                                     int w, float w_scale, const rw_conv_epilogue* ep, rw_stream_t stream) {
-  return conv3x3_wino4_launch(x, uf, y, batch, in_ch, out_ch, h, w, w_scale, ep, false, nullptr, nullptr, stream);
+  return conv3x3_wino4_launch(x, uf, y, batch, in_ch, out_ch, h, w, w_scale, ep, false, 1.f, nullptr, nullptr, stream);
 }
 
 // ---- H16: the same operations with the products on the 16-bit matrix pipe (exact operand split, fp32 accumulation)
@@ -1587,23 +1538,30 @@ extern "C" long long rw_packed_conv_weight_wino4h_elems(int out_ch, int in_ch) {
   return 36LL * out_ch * in_ch + 4;
 }
 
-extern "C" int rw_pack_conv_weight_wino4h_f32(const float* w, float* uf, int out_ch, int in_ch, rw_stream_t stream) {
-  RW_CHECK_ARG(w && uf && out_ch > 0 && in_ch > 0);
+extern "C" int rw_conv_weight_wino4h_absmax_f32(const float* w, int out_ch, int in_ch, float* bound, rw_stream_t stream) {
+  RW_CHECK_ARG(w && bound && out_ch > 0 && in_ch > 0);
   if (out_ch % 16 || in_ch % 4) return RW_ERR_UNSUPPORTED;
   const int64_t total = (int64_t)out_ch * in_ch;
-  const hipError_t me = hipMemsetAsync(uf + 36 * total, 0, 4 * sizeof(float), rw_s(stream));
-  if (me != hipSuccess) return (int)me;
-  hipLaunchKernelGGL(pack_wino36_kernel<1>, dim3(rw_stream_grid(total, 256)), dim3(256), 0, rw_s(stream), w, uf, out_ch,
-                     in_ch);
+  const int grid = rw_stream_grid(total, 256);
+  hipLaunchKernelGGL(pack_wino36_kernel<1>, dim3(grid), dim3(256), 0, rw_s(stream), w, (float*)nullptr, out_ch, in_ch, 1.f,
+                     bound);
+  return w4h_finish(bound, grid, stream);
+}
+
+extern "C" int rw_pack_conv_weight_wino4h_f32(const float* w, float* uf, int out_ch, int in_ch, float u_scale,
+                                              rw_stream_t stream) {
+  RW_CHECK_ARG(w && uf && out_ch > 0 && in_ch > 0 && u_scale > 0.f);
+  if (out_ch % 16 || in_ch % 4) return RW_ERR_UNSUPPORTED;
+  const int64_t total = (int64_t)out_ch * in_ch;
   hipLaunchKernelGGL(pack_wino36_kernel<2>, dim3(rw_stream_grid(total, 256)), dim3(256), 0, rw_s(stream), w, uf, out_ch,
-                     in_ch);
+                     in_ch, u_scale, (float*)nullptr);
   return RW_LAUNCH_RESULT();
 }
 
 extern "C" int rw_conv3x3_wino4h_f32(const float* x, const float* uf, float* y, int batch, int in_ch, int out_ch, int h,
-                                     int w, float w_scale, const rw_conv_epilogue* ep, const float* x_amax,
+                                     int w, float w_scale, const rw_conv_epilogue* ep, float u_inv, const float* x_amax,
                                      float* y_amax, rw_stream_t stream) {
-  return conv3x3_wino4_launch(x, uf, y, batch, in_ch, out_ch, h, w, w_scale, ep, true, x_amax, y_amax, stream);
+  return conv3x3_wino4_launch(x, uf, y, batch, in_ch, out_ch, h, w, w_scale, ep, true, u_inv, x_amax, y_amax, stream);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1630,16 +1588,16 @@ extern "C" int rw_pack_conv_transpose_blur_weight_wino4_f32(const float* w, cons
   if (out_ch % 4 || in_ch % 4) return RW_ERR_UNSUPPORTED;
   const int64_t total = 4LL * out_ch * in_ch;
   hipLaunchKernelGGL(pack_up_wino36_kernel<0>, dim3(rw_stream_grid(total, 256)), dim3(256), 0, rw_s(stream), w, k4, uf,
-                     out_ch, in_ch);
+                     out_ch, in_ch, 1.f, (float*)nullptr);
   return RW_LAUNCH_RESULT();
 }
 
 static int up_wino4_launch(const float* x, const float* uf, float* y, int batch, int in_ch, int out_ch, int h, int w,
-                           float w_scale, const rw_conv_epilogue* ep, const float* post_scale, bool h16,
+                           float w_scale, const rw_conv_epilogue* ep, const float* post_scale, bool h16, float u_inv,
                            const float* x_amax, float* y_amax, rw_stream_t stream) {
   RW_CHECK_ARG(x && uf && y && batch > 0 && in_ch > 0 && out_ch > 0 && h > 0 && w > 0);
   RW_CHECK_ARG(!ep || ((!ep->noise || ep->noise_w) && (!ep->act || ep->bias)));
-  RW_CHECK_ARG(!h16 || x_amax);
+  RW_CHECK_ARG(!h16 || (x_amax && u_inv > 0.f));
   if (!up_wino4_shape_ok(out_ch, in_ch, h, w)) return RW_ERR_UNSUPPORTED;
   Wino4Problem p = {};
   p.x = x; p.uf = uf; p.y = y;
@@ -1647,7 +1605,7 @@ static int up_wino4_launch(const float* x, const float* uf, float* y, int batch,
   p.noise_w = ep ? ep->noise_w : nullptr; p.bias = ep ? ep->bias : nullptr; p.act = ep ? ep->act : 0;
   p.post = post_scale;
   p.batch = batch; p.in_ch = in_ch; p.out_ch = 4 * out_ch; p.h = h; p.w = w; p.w_scale = w_scale;
-  p.x_amax = x_amax; p.y_amax = y_amax;
+  p.x_amax = x_amax; p.y_amax = y_amax; p.u_inv = u_inv;
   p.groups_x = w / 64;
   p.groups_y = h / 8;
   const int o_tiles = p.out_ch / 32;
@@ -1655,10 +1613,10 @@ static int up_wino4_launch(const float* x, const float* uf, float* y, int batch,
   const int64_t work = (int64_t)batch * p.groups_y * (p.groups_x / p.gpw) * o_tiles;
   if (work <= 0 || work > 0x7fffffff) return RW_ERR_UNSUPPORTED;
   if (h16) {
-    if (y_amax) { const hipError_t me = hipMemsetAsync(y_amax, 0, sizeof(float), rw_s(stream)); if (me != hipSuccess) return (int)me; }
+    if (y_amax && 4 * work > rw_bound_slot_capacity((int64_t)batch * out_ch * 4 * h * w)) return RW_ERR_UNSUPPORTED;
     if (w4h_point_split(in_ch)) hipLaunchKernelGGL(conv_up_wino36h_ps_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
     else hipLaunchKernelGGL(conv_up_wino36h_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
-    return RW_LAUNCH_RESULT();
+    return w4h_finish(y_amax, 4 * work, stream);
   }
 #if W4_PSPLIT
   if (w4_point_split()) {
@@ -1675,7 +1633,7 @@ extern "C" int rw_conv_transpose3x3s2_blur_wino4_f32(const float* x, const float
                                                      int out_ch, int h, int w, float w_scale,
                                                      const rw_conv_epilogue* ep, const float* post_scale,
                                                      rw_stream_t stream) {
-  return up_wino4_launch(x, uf, y, batch, in_ch, out_ch, h, w, w_scale, ep, post_scale, false, nullptr, nullptr, stream);
+  return up_wino4_launch(x, uf, y, batch, in_ch, out_ch, h, w, w_scale, ep, post_scale, false, 1.f, nullptr, nullptr, stream);
 }
 
 extern "C" long long rw_packed_conv_transpose_blur_wino4h_elems(int out_ch, int in_ch) {
@@ -1683,25 +1641,32 @@ extern "C" long long rw_packed_conv_transpose_blur_wino4h_elems(int out_ch, int 
   return 144LL * out_ch * in_ch + 4;
 }
 
-extern "C" int rw_pack_conv_transpose_blur_weight_wino4h_f32(const float* w, const float* k4, float* uf, int out_ch,
-                                                             int in_ch, rw_stream_t stream) {
-  RW_CHECK_ARG(w && k4 && uf && out_ch > 0 && in_ch > 0);
+extern "C" int rw_conv_transpose_blur_weight_wino4h_absmax_f32(const float* w, const float* k4, int out_ch, int in_ch,
+                                                               float* bound, rw_stream_t stream) {
+  RW_CHECK_ARG(w && k4 && bound && out_ch > 0 && in_ch > 0);
   if (out_ch % 4 || in_ch % 4) return RW_ERR_UNSUPPORTED;
   const int64_t total = 4LL * out_ch * in_ch;
-  const hipError_t me = hipMemsetAsync(uf + 36 * total, 0, 4 * sizeof(float), rw_s(stream));
-  if (me != hipSuccess) return (int)me;
-  hipLaunchKernelGGL(pack_up_wino36_kernel<1>, dim3(rw_stream_grid(total, 256)), dim3(256), 0, rw_s(stream), w, k4, uf,
-                     out_ch, in_ch);
+  const int grid = rw_stream_grid(total, 256);
+  hipLaunchKernelGGL(pack_up_wino36_kernel<1>, dim3(grid), dim3(256), 0, rw_s(stream), w, k4, (float*)nullptr, out_ch, in_ch,
+                     1.f, bound);
+  return w4h_finish(bound, grid, stream);
+}
+
+extern "C" int rw_pack_conv_transpose_blur_weight_wino4h_f32(const float* w, const float* k4, float* uf, int out_ch,
+                                                             int in_ch, float u_scale, rw_stream_t stream) {
+  RW_CHECK_ARG(w && k4 && uf && out_ch > 0 && in_ch > 0 && u_scale > 0.f);
+  if (out_ch % 4 || in_ch % 4) return RW_ERR_UNSUPPORTED;
+  const int64_t total = 4LL * out_ch * in_ch;
   hipLaunchKernelGGL(pack_up_wino36_kernel<2>, dim3(rw_stream_grid(total, 256)), dim3(256), 0, rw_s(stream), w, k4, uf,
-                     out_ch, in_ch);
+                     out_ch, in_ch, u_scale, (float*)nullptr);
   return RW_LAUNCH_RESULT();
 }
 
 extern "C" int rw_conv_transpose3x3s2_blur_wino4h_f32(const float* x, const float* uf, float* y, int batch, int in_ch,
                                                       int out_ch, int h, int w, float w_scale,
-                                                      const rw_conv_epilogue* ep, const float* post_scale,
+                                                      const rw_conv_epilogue* ep, const float* post_scale, float u_inv,
                                                       const float* x_amax, float* y_amax, rw_stream_t stream) {
-  return up_wino4_launch(x, uf, y, batch, in_ch, out_ch, h, w, w_scale, ep, post_scale, true, x_amax, y_amax, stream);
+  return up_wino4_launch(x, uf, y, batch, in_ch, out_ch, h, w, w_scale, ep, post_scale, true, u_inv, x_amax, y_amax, stream);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1714,10 +1679,10 @@ extern "C" int rw_conv3x3_wino4_to_rgb_supported(int out_ch, int in_ch, int h, i
 
 static int wino4_to_rgb_launch(const float* x, const float* uf, int batch, int in_ch, int out_ch, int h, int w,
                                float w_scale, const rw_conv_epilogue* ep, const rw_rgb_epilogue* rgb, bool h16,
-                               const float* x_amax, rw_stream_t stream) {
+                               float u_inv, const float* x_amax, rw_stream_t stream) {
   RW_CHECK_ARG(x && uf && rgb && rgb->weight && rgb->style && rgb->out && batch > 0 && in_ch > 0 && out_ch > 0);
   RW_CHECK_ARG(!ep || ((!ep->noise || ep->noise_w) && (!ep->act || ep->bias)));
-  RW_CHECK_ARG(!h16 || x_amax);
+  RW_CHECK_ARG(!h16 || (x_amax && u_inv > 0.f));
   if (!rw_conv3x3_wino4_to_rgb_supported(out_ch, in_ch, h, w)) return RW_ERR_UNSUPPORTED;
   Wino4Problem p = {};
   p.x = x; p.uf = uf; p.y = nullptr;
@@ -1726,7 +1691,7 @@ static int wino4_to_rgb_launch(const float* x, const float* uf, int batch, int i
   p.rgb_weight = rgb->weight; p.rgb_style = rgb->style; p.rgb_bias = rgb->bias; p.rgb_skip = rgb->skip;
   p.rgb_out = rgb->out; p.rgb_scale = rgb->scale;
   p.batch = batch; p.in_ch = in_ch; p.out_ch = out_ch; p.h = h; p.w = w; p.w_scale = w_scale;
-  p.x_amax = x_amax;
+  p.x_amax = x_amax; p.u_inv = u_inv;
   p.groups_x = w / 64;
   p.groups_y = h / 8;
   p.gpw = wino4_gpw(p, batch, 1);
@@ -1751,11 +1716,12 @@ static int wino4_to_rgb_launch(const float* x, const float* uf, int batch, int i
 extern "C" int rw_conv3x3_wino4_to_rgb_f32(const float* x, const float* uf, int batch, int in_ch, int out_ch, int h,
                                            int w, float w_scale, const rw_conv_epilogue* ep,
                                            const rw_rgb_epilogue* rgb, rw_stream_t stream) {
-  return wino4_to_rgb_launch(x, uf, batch, in_ch, out_ch, h, w, w_scale, ep, rgb, false, nullptr, stream);
+  return wino4_to_rgb_launch(x, uf, batch, in_ch, out_ch, h, w, w_scale, ep, rgb, false, 1.f, nullptr, stream);
 }
 
 extern "C" int rw_conv3x3_wino4h_to_rgb_f32(const float* x, const float* uf, int batch, int in_ch, int out_ch, int h,
                                             int w, float w_scale, const rw_conv_epilogue* ep,
-                                            const rw_rgb_epilogue* rgb, const float* x_amax, rw_stream_t stream) {
-  return wino4_to_rgb_launch(x, uf, batch, in_ch, out_ch, h, w, w_scale, ep, rgb, true, x_amax, stream);
+                                            const rw_rgb_epilogue* rgb, float u_inv, const float* x_amax,
+                                            rw_stream_t stream) {
+  return wino4_to_rgb_launch(x, uf, batch, in_ch, out_ch, h, w, w_scale, ep, rgb, true, u_inv, x_amax, stream);
 }

@@ -188,7 +188,7 @@ def _epilogue(style=None, demod=None, noise=None, noise_w=None, bias=None, act=F
 def conv3x3(x, wp, out_ch, w_scale, style=None, demod=None, noise=None, noise_w=None, bias=None,
             act=False, impl=0):
     x = _dev(x, 'fmap')
-    wp = _dev(wp, 'packed weight')
+    packed, wp = wp, _dev(wp, 'packed weight')
     b, i, h, w = x.shape
     y = torch.empty(b, out_ch, h, w, device=x.device, dtype=x.dtype)
     ep, keep = _epilogue(style, demod, noise, noise_w, bias, act)
@@ -207,7 +207,7 @@ def conv3x3_to_rgb(x, wp, out_ch, w_scale, rgb_weight, rgb_style, rgb_bias, rgb_
                    demod=None, noise=None, noise_w=None, bias=None, act=False, store_fmap=False):
     """The styled convolution with ToRGB fused into its epilogue: returns (fmap or None, rgb image)."""
     x = _dev(x, 'fmap')
-    wp = _dev(wp, 'packed weight')
+    packed, wp = wp, _dev(wp, 'packed weight')
     rgb_weight = _dev(rgb_weight, 'rgb weight').contiguous()
     rgb_style = _dev(rgb_style, 'rgb style').contiguous()
     rgb_bias = _opt(rgb_bias, 'rgb bias')
@@ -248,7 +248,7 @@ def pack_conv_weight_wino(weight):
 def conv3x3_wino(x, uf, out_ch, w_scale, style=None, demod=None, noise=None, noise_w=None, bias=None, act=False):
     """Stride-1 3x3 convolution by Winograd F(2x2,3x3) in fp32; same arguments and epilogue as conv3x3."""
     x = _dev(x, 'fmap')
-    uf = _dev(uf, 'packed weight')
+    packed, uf = uf, _dev(uf, 'packed weight')      # (the scale of a split packing rides on the caller's tensor)
     b, i, h, w = x.shape
     if uf.numel() != lib().rw_packed_conv_weight_wino_elems(out_ch, i):
         raise ValueError('packed weight does not come from pack_conv_weight_wino(%d x %d)' % (out_ch, i))
@@ -269,61 +269,75 @@ def wino4_supported(out_ch, in_ch, height, width):
     return bool(lib().rw_conv3x3_wino4_supported(int(out_ch), int(in_ch), int(height), int(width)))
 
 
-_bound_rings = {}
-_BOUND_SLOTS, _BOUND_STRIDE = 4096, 32          # slots per device; floats between slots: one 128-byte line each
+BOUND_LANES = 64                # RW_BOUND_LANES of include/rewriting_hip.h
 
 
-def bound_scalar(device):
-    """A one-element float32 tensor for a bound (x_amax / y_amax of the split-operand kernels): the next slot of a
-    per-device ring of 4096 scalars, one cache line each, allocated once.  NOT torch.empty(1): the caching allocator
-    hands the address of a bound that has just died to the next one, and the system-scope loads these scalars are read
-    with are served by the reading XCD's L2 -- an XCD that still held the line saw the previous occupant (DESIGN.md
-    section 9, item 0).  A slot comes round again after 4096 bounds (~150 forwards of gigabytes each): nothing of it is
-    left in any L2 by then.  The contents are whatever the slot held last (the kernels zero what they raise)."""
-    device = torch.device(device)
-    if device.type == 'cuda' and device.index is None:
-        device = torch.device('cuda', torch.cuda.current_device())
-    ring = _bound_rings.get(device)
-    if ring is None:
-        ring = _bound_rings[device] = [torch.zeros(_BOUND_SLOTS * _BOUND_STRIDE, device=device, dtype=torch.float32), 0]
-    n = ring[1]
-    ring[1] = (n + 1) % _BOUND_SLOTS
-    return ring[0][n * _BOUND_STRIDE:n * _BOUND_STRIDE + 1]
+def bound_floats(n_elems):
+    """Floats of the y_amax buffer of a producer whose result has n_elems floats (rw_bound_floats)."""
+    return int(lib().rw_bound_floats(int(n_elems)))
+
+
+def new_bound(n_elems, device):
+    """An (uninitialised) y_amax buffer for a result of n_elems floats: BOUND_LANES floats that will hold the bound --
+    their maximum is >= max |result| -- followed by the producer's per-wave slots ("a BOUND on a map" in
+    include/rewriting_hip.h).  The same tensor is the x_amax of the convolution that reads the result.  Nothing in it is
+    zeroed, raised with atomics or read back by a later launch through a device scalar: a producer's waves store their
+    own slots plainly, one small launch reduces them, the launch boundary publishes the floats like any feature map."""
+    return torch.empty(bound_floats(n_elems), device=device, dtype=torch.float32)
+
+
+def bound_value(bound):
+    """The number a bound stands for (host sync; tests and the packing of split weights, never the forward)."""
+    return float(bound[:BOUND_LANES].max())
 
 
 def absmax(x):
-    """max |x| as a one-element device tensor (rw_absmax_f32): the x_amax of the split-operand F(4x4,3x3) kernels
-    where the producer of x did not leave one behind."""
+    """The bound of x (rw_absmax_f32): the x_amax of the split-operand kernels where the producer of x did not leave one
+    behind."""
     x = _dev(x, 'tensor')
-    out = bound_scalar(x.device)
+    out = new_bound(0, x.device)            # at most 2048 slots
     check(lib().rw_absmax_f32(_p(x), x.numel(), _p(out), _stream()))
     return out
 
 
 def _amax_in(x, x_amax):
-    """The bound a split-operand kernel gets: measured here when the caller has none; a handed-over one (raised by the
-    producer's workgroups with atomics) is first PUBLISHED into a fresh scalar by rw_publish_scalar_f32 -- one thread, one
-    atomic fetch, one plain store -- so that every workgroup of the consumer reads the same, final value (RW_MM_PUBLISH=0:
-    pass the producer's scalar itself, as before)."""
+    """The bound a split-operand kernel gets: the caller's, or measured here."""
     if x_amax is None:
         return absmax(x)
     x_amax = _dev(x_amax, 'x_amax')
-    if x_amax.numel() != 1:
-        raise ValueError('x_amax must hold one float')
-    if os.environ.get('RW_MM_PUBLISH', '1') == '0':
-        return x_amax
-    out = bound_scalar(x_amax.device)
-    check(lib().rw_publish_scalar_f32(_p(x_amax), _p(out), _stream()))
-    return out
+    if x_amax.numel() < BOUND_LANES:
+        raise ValueError('x_amax must be a bound: at least %d floats (hip.new_bound / hip.absmax)' % BOUND_LANES)
+    return x_amax
 
 
-def _amax_out(y_amax):
+def _amax_out(y_amax, n_elems):
     if y_amax is None:
         return None
     y_amax = _dev(y_amax, 'y_amax')
-    if y_amax.numel() != 1:
-        raise ValueError('y_amax must hold one float')
+    if y_amax.numel() < bound_floats(n_elems):
+        raise ValueError('y_amax must come from hip.new_bound(%d, device): %d floats' % (n_elems, bound_floats(n_elems)))
     return y_amax
+
+
+def _split_scale(measure, *args):
+    """(u_scale, u_inv) of a split-operand packing: `measure` (a rw_*_absmax_f32 entry) leaves max |U| as a bound, the
+    host reads it -- ONE sync per weight version, never inside a forward whose weights are packed -- and
+    rw_split_weight_scale turns it into the power of two that the pack kernel and every convolution launch then get BY
+    VALUE."""
+    device = args[0].device
+    bound = new_bound(0, device)
+    check(measure(*[_p(a) if torch.is_tensor(a) else a for a in args], _p(bound), _stream()))
+    u_scale = float(lib().rw_split_weight_scale(bound_value(bound)))
+    return u_scale, 1.0 / u_scale
+
+
+def _u_inv(packed):
+    """1 / u_scale of a split-operand packing: it travels with the tensor the pack function returned."""
+    try:
+        return float(packed.rw_u_inv)
+    except AttributeError:
+        raise ValueError('split-operand packed weights must be the tensor a hip.pack_*(split=True) / pack_*_direct16 call '
+                         'returned (its scale travels as the attribute rw_u_inv; a copy does not carry it)') from None
 
 
 def pack_conv_weight_wino4(weight, split=False):
@@ -336,8 +350,11 @@ def pack_conv_weight_wino4(weight, split=False):
     if n <= 0:
         raise ValueError('no F(4x4,3x3) packing for a %d x %d weight' % (o, i))
     uf = torch.empty(n, device=weight.device, dtype=torch.float32)
-    pack = lib().rw_pack_conv_weight_wino4h_f32 if split else lib().rw_pack_conv_weight_wino4_f32
-    check(pack(_p(weight), _p(uf), o, i, _stream()))
+    if split:
+        u_scale, uf.rw_u_inv = _split_scale(lib().rw_conv_weight_wino4h_absmax_f32, weight, o, i)
+        check(lib().rw_pack_conv_weight_wino4h_f32(_p(weight), _p(uf), o, i, u_scale, _stream()))
+    else:
+        check(lib().rw_pack_conv_weight_wino4_f32(_p(weight), _p(uf), o, i, _stream()))
     return uf
 
 
@@ -355,18 +372,18 @@ def conv3x3_wino4(x, uf, out_ch, w_scale, style=None, demod=None, noise=None, no
     """Stride-1 3x3 convolution by Winograd F(4x4,3x3) (~1e-5 relative error per layer: the default of the
     un-hooked whole-generator forward, never used by a hooked or sliced model -- models.conv_algo); same arguments
     and epilogue as conv3x3.  With weights from pack_conv_weight_wino4(split=True) the products run on the 16-bit
-    matrix pipe (exact f16 operand split, fp32 accumulation): x_amax = a one-element tensor >= max |x| (computed here
-    when None), y_amax = a one-element tensor that receives max |y|."""
+    matrix pipe (exact f16 operand split, fp32 accumulation): x_amax = the bound of x (hip.absmax(x), or the y_amax its
+    producer filled; measured here when None), y_amax = hip.new_bound(y.numel(), device), which receives the bound of y."""
     x = _dev(x, 'fmap')
-    uf = _dev(uf, 'packed weight')
+    packed, uf = uf, _dev(uf, 'packed weight')      # (the scale of a split packing rides on the caller's tensor)
     b, i, h, w = x.shape
     split = _wino4_split(uf, out_ch, i)
     y = torch.empty(b, out_ch, h, w, device=x.device, dtype=x.dtype)
     ep, keep = _epilogue(style, demod, noise, noise_w, bias, act)
     if split:
-        x_amax, y_amax = _amax_in(x, x_amax), _amax_out(y_amax)
+        x_amax, y_amax = _amax_in(x, x_amax), _amax_out(y_amax, y.numel())
         check(lib().rw_conv3x3_wino4h_f32(_p(x), _p(uf), _p(y), b, i, out_ch, h, w, float(w_scale), ctypes.byref(ep),
-                                          _p(x_amax), _p(y_amax), _stream()))
+                                          _u_inv(packed), _p(x_amax), _p(y_amax), _stream()))
         return y
     check(lib().rw_conv3x3_wino4_f32(_p(x), _p(uf), _p(y), b, i, out_ch, h, w, float(w_scale), ctypes.byref(ep),
                                      _stream()))
@@ -377,7 +394,7 @@ def conv3x3_wino_to_rgb(x, uf, out_ch, w_scale, rgb_weight, rgb_style, rgb_bias,
                         demod=None, noise=None, noise_w=None, bias=None, act=False, store_fmap=False):
     """conv3x3_wino with ToRGB in the epilogue (out_ch == 32): returns (fmap or None, rgb image)."""
     x = _dev(x, 'fmap')
-    uf = _dev(uf, 'packed weight')
+    packed, uf = uf, _dev(uf, 'packed weight')      # (the scale of a split packing rides on the caller's tensor)
     rgb_weight = _dev(rgb_weight, 'rgb weight').contiguous()
     rgb_style = _dev(rgb_style, 'rgb style').contiguous()
     rgb_bias = _opt(rgb_bias, 'rgb bias')
@@ -410,7 +427,7 @@ def conv3x3_wino4_to_rgb(x, uf, out_ch, w_scale, rgb_weight, rgb_style, rgb_bias
     """conv3x3_wino4 with ToRGB in the epilogue (out_ch == 32): returns (None, rgb image); the feature map is not
     written.  Split weights and x_amax as in conv3x3_wino4."""
     x = _dev(x, 'fmap')
-    uf = _dev(uf, 'packed weight')
+    packed, uf = uf, _dev(uf, 'packed weight')      # (the scale of a split packing rides on the caller's tensor)
     rgb_weight = _dev(rgb_weight, 'rgb weight').contiguous()
     rgb_style = _dev(rgb_style, 'rgb style').contiguous()
     rgb_bias = _opt(rgb_bias, 'rgb bias')
@@ -429,7 +446,7 @@ def conv3x3_wino4_to_rgb(x, uf, out_ch, w_scale, rgb_weight, rgb_style, rgb_bias
     if split:
         x_amax = _amax_in(x, x_amax)
         check(lib().rw_conv3x3_wino4h_to_rgb_f32(_p(x), _p(uf), b, i, out_ch, h, w, float(w_scale), ctypes.byref(ep),
-                                                 ctypes.byref(re), _p(x_amax), _stream()))
+                                                 ctypes.byref(re), _u_inv(packed), _p(x_amax), _stream()))
         return None, rgb
     check(lib().rw_conv3x3_wino4_to_rgb_f32(_p(x), _p(uf), b, i, out_ch, h, w, float(w_scale), ctypes.byref(ep),
                                             ctypes.byref(re), _stream()))
@@ -481,7 +498,7 @@ def up_strips_applicable(out_ch, in_ch):
 
 def conv_transpose3x3s2(x, wp, out_ch, w_scale, style=None, demod=None, impl=0, out=None):
     x = _dev(x, 'fmap')
-    wp = _dev(wp, 'packed weight')
+    packed, wp = wp, _dev(wp, 'packed weight')
     b, i, h, w = x.shape
     y = out if out is not None else torch.empty(b, out_ch, 2 * h + 1, 2 * w + 1, device=x.device, dtype=x.dtype)
     if tuple(y.shape) != (b, out_ch, 2 * h + 1, 2 * w + 1) or not y.is_contiguous():
@@ -512,8 +529,11 @@ def pack_conv_transpose_weight_wino(weight, split=False):
     if n <= 0:
         raise ValueError('no F(2,2) packing for a %d x %d transposed-conv weight' % (o, i))
     uf = torch.empty(n, device=weight.device, dtype=torch.float32)
-    pack = lib().rw_pack_conv_transpose_winoh_f32 if split else lib().rw_pack_conv_transpose_wino_f32
-    check(pack(_p(weight), _p(uf), o, i, _stream()))
+    if split:
+        u_scale, uf.rw_u_inv = _split_scale(lib().rw_conv_transpose_weight_winoh_absmax_f32, weight, o, i)
+        check(lib().rw_pack_conv_transpose_winoh_f32(_p(weight), _p(uf), o, i, u_scale, _stream()))
+    else:
+        check(lib().rw_pack_conv_transpose_wino_f32(_p(weight), _p(uf), o, i, _stream()))
     return uf
 
 
@@ -521,9 +541,9 @@ def conv_transpose3x3s2_wino(x, uf, out_ch, w_scale, style=None, demod=None, out
     """The quads y < H, x < W of conv_transpose3x3s2 by F(2,2) (25 instead of 36 multiplies per 2x2 block of quads);
     output row 2H and column 2W are left to conv_transpose3x3s2(..., impl=8, out=...).  With weights from
     pack_conv_transpose_weight_wino(split=True) the products run on the 16-bit matrix pipe (exact f16 operand split,
-    fp32 accumulation; x_amax = a one-element tensor >= max |x|, computed here when None)."""
+    fp32 accumulation; x_amax = the bound of x as in conv3x3_wino4, measured here when None)."""
     x = _dev(x, 'fmap')
-    uf = _dev(uf, 'packed weight')
+    packed, uf = uf, _dev(uf, 'packed weight')      # (the scale of a split packing rides on the caller's tensor)
     b, i, h, w = x.shape
     if uf.numel() == lib().rw_packed_conv_transpose_wino_elems(out_ch, i):
         split = False
@@ -539,7 +559,7 @@ def conv_transpose3x3s2_wino(x, uf, out_ch, w_scale, style=None, demod=None, out
     if split:
         x_amax = _amax_in(x, x_amax)
         check(lib().rw_conv_transpose3x3s2_winoh_f32(_p(x), _p(uf), _p(y), b, i, out_ch, h, w, float(w_scale),
-                                                     _p(style), _p(demod), _p(x_amax), _stream()))
+                                                     _p(style), _p(demod), _u_inv(packed), _p(x_amax), _stream()))
         return y
     if style is not None and h == w and w in (4, 8):
         # whole 8^2 / 4^2 images per wave (several images per workgroup): the library takes exactly these maps already
@@ -568,9 +588,11 @@ def pack_conv_transpose_blur_weight_wino4(weight, k4, split=False):
     if n <= 0:
         raise ValueError('no F(4x4,3x3) phase packing for a %d x %d transposed-conv weight' % (o, i))
     uf = torch.empty(n, device=weight.device, dtype=torch.float32)
-    pack = (lib().rw_pack_conv_transpose_blur_weight_wino4h_f32 if split
-            else lib().rw_pack_conv_transpose_blur_weight_wino4_f32)
-    check(pack(_p(weight), _p(k4), _p(uf), o, i, _stream()))
+    if split:
+        u_scale, uf.rw_u_inv = _split_scale(lib().rw_conv_transpose_blur_weight_wino4h_absmax_f32, weight, k4, o, i)
+        check(lib().rw_pack_conv_transpose_blur_weight_wino4h_f32(_p(weight), _p(k4), _p(uf), o, i, u_scale, _stream()))
+    else:
+        check(lib().rw_pack_conv_transpose_blur_weight_wino4_f32(_p(weight), _p(k4), _p(uf), o, i, _stream()))
     return uf
 
 
@@ -580,7 +602,7 @@ def conv_transpose3x3s2_blur_wino4(x, uf, out_ch, w_scale, style=None, demod=Non
     the four output-parity phases as virtual channels of the F(4x4,3x3) kernel (its error class: image generation).
     Split weights, x_amax and y_amax (max |y|, post_scale included) as in conv3x3_wino4."""
     x = _dev(x, 'fmap')
-    uf = _dev(uf, 'packed weight')
+    packed, uf = uf, _dev(uf, 'packed weight')      # (the scale of a split packing rides on the caller's tensor)
     b, i, h, w = x.shape
     if uf.numel() == lib().rw_packed_conv_transpose_blur_wino4_elems(out_ch, i):
         split = False
@@ -595,10 +617,10 @@ def conv_transpose3x3s2_blur_wino4(x, uf, out_ch, w_scale, style=None, demod=Non
     if post_scale is not None and tuple(post_scale.shape) != (b, out_ch):
         raise ValueError('post_scale must be batch x out_ch')
     if split:
-        x_amax, y_amax = _amax_in(x, x_amax), _amax_out(y_amax)
+        x_amax, y_amax = _amax_in(x, x_amax), _amax_out(y_amax, y.numel())
         check(lib().rw_conv_transpose3x3s2_blur_wino4h_f32(_p(x), _p(uf), _p(y), b, i, out_ch, h, w, float(w_scale),
-                                                           ctypes.byref(ep), _p(post_scale), _p(x_amax), _p(y_amax),
-                                                           _stream()))
+                                                           ctypes.byref(ep), _p(post_scale), _u_inv(packed), _p(x_amax),
+                                                           _p(y_amax), _stream()))
         return y
     check(lib().rw_conv_transpose3x3s2_blur_wino4_f32(_p(x), _p(uf), _p(y), b, i, out_ch, h, w, float(w_scale),
                                                       ctypes.byref(ep), _p(post_scale), _stream()))
@@ -627,7 +649,8 @@ def pack_conv_weight_direct16(weight):
     if n <= 0:
         raise ValueError('no direct-16 packing for a %d x %d weight' % (o, i))
     wp = torch.empty(n, device=weight.device, dtype=torch.float32)
-    check(lib().rw_pack_dconv_weight_f32(_p(weight), _p(wp), o, i, _stream()))
+    u_scale, wp.rw_u_inv = _split_scale(lib().rw_dconv_weight_absmax_f32, weight, o, i)
+    check(lib().rw_pack_dconv_weight_f32(_p(weight), _p(wp), o, i, u_scale, _stream()))
     return wp
 
 
@@ -641,14 +664,14 @@ def conv3x3_direct16(x, wp, out_ch, w_scale, style=None, demod=None, noise=None,
     """Stride-1 3x3 convolution as a direct sum on the 16-bit matrix pipe (exact f16 operand split, fp32 accumulation:
     rw_dconv3x3_f32); arguments, epilogue, x_amax and y_amax as conv3x3_wino4 with split weights."""
     x = _dev(x, 'fmap')
-    wp = _dev(wp, 'packed weight')
+    packed, wp = wp, _dev(wp, 'packed weight')
     b, i, h, w = x.shape
     _direct16_check(wp, lib().rw_packed_dconv_weight_elems(out_ch, i), 'pack_conv_weight_direct16(%d x %d)' % (out_ch, i))
     y = torch.empty(b, out_ch, h, w, device=x.device, dtype=x.dtype)
     ep, keep = _epilogue(style, demod, noise, noise_w, bias, act)
-    x_amax, y_amax = _amax_in(x, x_amax), _amax_out(y_amax)
+    x_amax, y_amax = _amax_in(x, x_amax), _amax_out(y_amax, y.numel())
     check(lib().rw_dconv3x3_f32(_p(x), _p(wp), _p(y), b, i, out_ch, h, w, float(w_scale), ctypes.byref(ep),
-                                _p(x_amax), _p(y_amax), _stream()))
+                                _u_inv(packed), _p(x_amax), _p(y_amax), _stream()))
     return y
 
 
@@ -656,7 +679,7 @@ def conv3x3_direct16_to_rgb(x, wp, out_ch, w_scale, rgb_weight, rgb_style, rgb_b
                             demod=None, noise=None, noise_w=None, bias=None, act=False, x_amax=None):
     """conv3x3_direct16 with ToRGB in the epilogue (out_ch == 32): returns (None, rgb image)."""
     x = _dev(x, 'fmap')
-    wp = _dev(wp, 'packed weight')
+    packed, wp = wp, _dev(wp, 'packed weight')
     rgb_weight = _dev(rgb_weight, 'rgb weight').contiguous()
     rgb_style = _dev(rgb_style, 'rgb style').contiguous()
     rgb_bias = _opt(rgb_bias, 'rgb bias')
@@ -674,7 +697,7 @@ def conv3x3_direct16_to_rgb(x, wp, out_ch, w_scale, rgb_weight, rgb_style, rgb_b
                      _p(rgb).value, float(rgb_scale))
     x_amax = _amax_in(x, x_amax)
     check(lib().rw_dconv3x3_to_rgb_f32(_p(x), _p(wp), b, i, out_ch, h, w, float(w_scale), ctypes.byref(ep),
-                                       ctypes.byref(re), _p(x_amax), _stream()))
+                                       ctypes.byref(re), _u_inv(packed), _p(x_amax), _stream()))
     return None, rgb
 
 
@@ -690,7 +713,8 @@ def pack_conv_transpose_blur_weight_direct16(weight, k4):
     if n <= 0:
         raise ValueError('no direct-16 phase packing for a %d x %d transposed-conv weight' % (o, i))
     wp = torch.empty(n, device=weight.device, dtype=torch.float32)
-    check(lib().rw_pack_dconv_transpose_blur_weight_f32(_p(weight), _p(k4), _p(wp), o, i, _stream()))
+    u_scale, wp.rw_u_inv = _split_scale(lib().rw_dconv_transpose_blur_weight_absmax_f32, weight, k4, o, i)
+    check(lib().rw_pack_dconv_transpose_blur_weight_f32(_p(weight), _p(k4), _p(wp), o, i, u_scale, _stream()))
     return wp
 
 
@@ -699,7 +723,7 @@ def conv_transpose3x3s2_blur_direct16(x, wp, out_ch, w_scale, style=None, demod=
     """conv_transpose3x3s2 -> blur(pad 1,1) -> noise -> bias + leaky ReLU in one pass as a direct sum on the 16-bit matrix
     pipe: (B,Cin,H,W) -> (B,Cout,2H,2W); arguments as conv_transpose3x3s2_blur_wino4 with split weights."""
     x = _dev(x, 'fmap')
-    wp = _dev(wp, 'packed weight')
+    packed, wp = wp, _dev(wp, 'packed weight')
     b, i, h, w = x.shape
     _direct16_check(wp, lib().rw_packed_dconv_transpose_blur_weight_elems(out_ch, i),
                     'pack_conv_transpose_blur_weight_direct16(%d x %d)' % (out_ch, i))
@@ -708,9 +732,10 @@ def conv_transpose3x3s2_blur_direct16(x, wp, out_ch, w_scale, style=None, demod=
     post_scale = _opt(post_scale, 'post scale')
     if post_scale is not None and tuple(post_scale.shape) != (b, out_ch):
         raise ValueError('post_scale must be batch x out_ch')
-    x_amax, y_amax = _amax_in(x, x_amax), _amax_out(y_amax)
+    x_amax, y_amax = _amax_in(x, x_amax), _amax_out(y_amax, y.numel())
     check(lib().rw_dconv_transpose3x3s2_blur_f32(_p(x), _p(wp), _p(y), b, i, out_ch, h, w, float(w_scale),
-                                                 ctypes.byref(ep), _p(post_scale), _p(x_amax), _p(y_amax), _stream()))
+                                                 ctypes.byref(ep), _p(post_scale), _u_inv(packed), _p(x_amax), _p(y_amax),
+                                                 _stream()))
     return y
 
 
@@ -726,8 +751,8 @@ def noise_add(x, noise, noise_w):
 
 def blur_noise_act(x, k4, noise, noise_w, bias, post_scale=None, y_amax=None):
     """Blur(pad 1,1) + noise + bias + leaky ReLU of an upsampling layer in one pass; post_scale (B x C, optional):
-    a factor on the result -- the style of the convolution that consumes it; y_amax (one-element tensor, optional)
-    receives max |result|."""
+    a factor on the result -- the style of the convolution that consumes it; y_amax (hip.new_bound(result elements),
+    optional) receives the bound of the result."""
     x = _dev(x, 'fmap')
     k4 = _dev(k4, 'blur kernel')
     noise = _opt(noise, 'noise')
@@ -738,7 +763,7 @@ def blur_noise_act(x, k4, noise, noise_w, bias, post_scale=None, y_amax=None):
     post_scale = _opt(post_scale, 'post scale')
     if post_scale is not None and tuple(post_scale.shape) != (b, c):
         raise ValueError('post_scale must be batch x channels')
-    y_amax = _amax_out(y_amax)
+    y_amax = _amax_out(y_amax, y.numel())
     check(lib().rw_blur_noise_act_amax_f32(_p(x), _p(k4), _p(noise), _p(noise_w), _p(bias), _p(post_scale), _p(y),
                                            b, c, ih - 1, iw - 1, _p(y_amax), _stream()))
     return y

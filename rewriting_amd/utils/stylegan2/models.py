@@ -253,11 +253,16 @@ def _direct16(dconv, h, w, kind):
     return hip.dconv_supported(dconv.out_channel, dconv.in_channel, h, w)
 
 
-def _amax_of(d, fmap):
-    """The bound max |fmap| its producer left in the bag (key 'amax': (one-element tensor, data_ptr of the map it
-    describes)), or None -- the kernels then measure the map themselves (hip.absmax)."""
-    entry = d.get('amax')
-    if entry is not None and fmap is not None and entry[1] == fmap.data_ptr():
+def _amax_of(fmap):
+    """The bound of |fmap| that its producer -- a fused layer of the running un-hooked forward -- left ON the tensor
+    (attribute rw_amax: (bound, the tensor's version counter when it was written)), or None: the kernels then measure
+    the map themselves (hip.absmax).  It travels with the tensor object, not with an address or a bag key: a slice, a
+    copy or a map that was edited in place since (hooks) carries no usable bound.  Trusted only inside the un-hooked
+    forward of a whole generator, where producer and consumer are both ours."""
+    if fmap is None or not _rgb_branch.image_path:
+        return None
+    entry = getattr(fmap, 'rw_amax', None)
+    if entry is not None and entry[1] == fmap._version:
         return entry[0]
     return None
 
@@ -526,9 +531,9 @@ class DemodulatedConv2dF(nn.Module):
         return hip.demod(self.squared_sums(), style) if self.demodulate else None
 
     def run(self, fmap, style, style_on_load, demod=None, x_amax=None, y_amax=None, **epilogue):
-        """x_amax: a one-element tensor >= max |fmap| if the producer of fmap left one (split-operand kernels; they
-        measure the map themselves otherwise); y_amax: a one-element tensor that receives max |result| where the
-        split-operand F(4x4,3x3) kernel runs (`runs_split_wino4` says whether it will)."""
+        """x_amax: the bound of |fmap| if the producer of fmap left one (hip.new_bound; split-operand kernels -- they
+        measure the map themselves otherwise); y_amax: a hip.new_bound buffer that receives the bound of the result
+        where the split-operand F(4x4,3x3) kernel runs (`runs_split_wino4` says whether it will)."""
         if demod is None:
             demod = self.demod_factors(style)
         load_style = style if style_on_load else None
@@ -882,17 +887,20 @@ class StyledConvSeq(nn.Sequential):
                 raise RuntimeError('a pre-scaled feature map reached a layer that runs module by module')
             return super().forward(d)
         d_in = d                    # as received (with the hand-over key, if any): what a re-entry must see
-        x_amax = _amax_of(d, fmap)  # the producer's bound on |fmap| (split-operand kernels), else None
+        x_amax = _amax_of(fmap)     # the producer's bound on |fmap| (split-operand kernels), else None
         if os.environ.get('RW_MM_NO_HANDOVER') == '1':
             x_amax = None
-        if pre is not None or 'amax' in d:
+        if pre is not None:
             d = DataBag(d)
             d.pop('prescaled', None)
-            d.pop('amax', None)
         split = matrix_mode() == 'split'
-        # ... and this layer's bound for the next one, inside the un-hooked forward only (bags that callers or hooks see
-        # never carry the key; a hooked model under RW_MM=split lets the kernels measure their inputs)
-        y_amax = hip.bound_scalar(fmap.device) if split and _rgb_branch.image_path else None
+        # ... and this layer's bound for the next one, inside the un-hooked forward only (a hooked model under RW_MM=split
+        # lets the kernels measure their inputs)
+        want_amax = split and _rgb_branch.image_path
+
+        def y_bound(height, width):
+            return hip.new_bound(b * dconv.out_channel * height * width, fmap.device) if want_amax else None
+        y_amax = None
         y_amax_set = False
         post = None
         if mconv.upsample and pre is not None:
@@ -908,6 +916,7 @@ class StyledConvSeq(nn.Sequential):
                     nxt[0].mconv.modulation(DataBag(style=d.latent[:, nxt[1]])).style
             h, w = 2 * fmap.shape[2], 2 * fmap.shape[3]
             noise = self.noise.noise_for(d, b, h, w, fmap.device)
+            y_amax = y_bound(h, w)
             if dconv.one_pass_upsample(fmap, mconv.blur):
                 split1 = _split_part('up1')
                 mm = dict(x_amax=x_amax, y_amax=y_amax) if split1 else {}
@@ -963,14 +972,15 @@ class StyledConvSeq(nn.Sequential):
                     demod=demod if demod is not None else dconv.demod_factors(style), noise=noise,
                     noise_w=self.noise.weight, bias=act.bias, act=True, **mm)
                 return DataBag(d, style=style, fmap=None, fused_rgb=rgb)
-            y_amax_set = y_amax is not None and dconv.runs_split_wino4(h, w)
+            y_amax_set = want_amax and dconv.runs_split_wino4(h, w)
+            y_amax = y_bound(h, w) if y_amax_set else None
             out = dconv.run(fmap, style, style_on_load=on_load, demod=demod, x_amax=x_amax,
                             y_amax=y_amax if y_amax_set else None, noise=noise,
                             noise_w=self.noise.weight, bias=act.bias, act=True)
-        # hand-over keys, only inside the un-hooked forward
+        # hand-overs, only inside the un-hooked forward: the bound rides on the tensor itself (_amax_of)
         extra = {}
         if y_amax_set:
-            extra['amax'] = (y_amax, out.data_ptr())
+            out.rw_amax = (y_amax, out._version)
         if post is not None:        # bags that callers see never carry the key
             extra['prescaled'] = post
         return DataBag(d, style=style, fmap=out, **extra)
@@ -1044,14 +1054,6 @@ class SeqStyleGAN2(nn.Sequential):
             return self._forward(input)
         _rgb_branch.image_path = True
         _rgb_branch.successor = self._successors()
-        if (input.is_cuda and matrix_mode() == 'split' and os.environ.get('RW_FORWARD_DRAIN', '1') != '0'
-                and not torch.cuda.is_current_stream_capturing()):
-            # WORKAROUND for an open issue of round 4: a forward that starts while the
-            # previous one is still running on the device occasionally multiplies some tiles with a stale bound (images
-            # 0.01 - 0.05 off, 1 sequence in 3 before rw_publish_scalar_f32, 1 in ~40 after; never once the previous
-            # forward has drained).  The trunk's stream is drained before the first launch -- the host no longer runs a
-            # forward ahead, which costs the launch-bound first millisecond of each forward.  RW_FORWARD_DRAIN=0 removes it.
-            torch.cuda.current_stream().synchronize()
         try:
             return self._forward(input)
         finally:

@@ -143,8 +143,41 @@ def _f16_pair(t, scale_exp):
     return (h + (ts - h).half().float()) * (2.0 ** -scale_exp)
 
 
+BOUND_LANES = 64
+
+
+def bound_floats(n_elems):
+    return BOUND_LANES + 2048 + int(n_elems) // 1024 + 1     # rw_bound_floats
+
+
+def new_bound(n_elems, device):
+    """hip.new_bound: BOUND_LANES floats whose maximum is the bound + the producer's slots (garbage here, as on the
+    device: nothing may read them)."""
+    return torch.full((bound_floats(n_elems),), float('nan'))
+
+
+def bound_value(bound):
+    return float(bound[:BOUND_LANES].max())
+
+
+def _bound_of(x_amax, x):
+    """what a kernel's prologue reduces: the lanes of the bound (never its slots)"""
+    return (x_amax.detach()[:BOUND_LANES] if x_amax is not None else absmax(x)[:BOUND_LANES]).max().reshape(1)
+
+
+def _fill_bound(y_amax, y, measured=False):
+    """a producer's report: lanes whose maximum is max |y| (the device spreads its slots' maxima over them)"""
+    if y_amax is not None:
+        assert y_amax.numel() >= bound_floats(0 if measured else y.numel())        # rw_absmax_f32: at most 2048 slots
+        lanes = torch.zeros(BOUND_LANES)
+        lanes[int(y.numel()) % BOUND_LANES] = y.detach().abs().max()
+        y_amax[:BOUND_LANES] = lanes
+
+
 def absmax(x):
-    return x.detach().abs().max().reshape(1)
+    out = new_bound(0, 'cpu')
+    _fill_bound(out, x, measured=True)
+    return out
 
 
 def conv_transpose_wino_split_supported(out_ch, in_ch, height, width):
@@ -166,7 +199,7 @@ def conv_transpose3x3s2_wino(x, uf, out_ch, w_scale, style=None, demod=None, out
         # |T| <= 4 max |x style| < 2^(e + 2): the kernel scales by 2^(12 - e); the weights by 2^(15 - eu), eu from the
         # largest of the 25 points (at most 4 max |w|: the exact bound is taken here, one binade cannot matter)
         smax = 1.0 if style is None else float(style.detach().abs().max())
-        ev = 12 - _pow2_above((x_amax.detach() if x_amax is not None else absmax(x)) * smax)
+        ev = 12 - _pow2_above(_bound_of(x_amax, x) * smax)
         uf = uf.handle
     if style is not None:
         x = x * style.detach()[:, :, None, None]
@@ -221,8 +254,7 @@ def blur_noise_act(x, k4, noise, noise_w, bias, post_scale=None, y_amax=None):
         y = F.leaky_relu(y + bias.detach().view(1, -1, 1, 1), 0.2) * SQRT2
     if post_scale is not None:
         y = y * post_scale.detach()[:, :, None, None]
-    if y_amax is not None:
-        y_amax.copy_(absmax(y))
+    _fill_bound(y_amax, y)
     return y
 
 
@@ -388,7 +420,7 @@ def conv3x3_wino4(x, uf, out_ch, w_scale, style=None, demod=None, noise=None, no
     split = isinstance(uf, _Split)
     if split:
         smax = 1.0 if style is None else float(style.detach().abs().max())
-        ev = 8 - _pow2_above((x_amax.detach() if x_amax is not None else absmax(x)) * smax)     # |B^T d B| <= 100 max < 2^(e + 7)
+        ev = 8 - _pow2_above(_bound_of(x_amax, x) * smax)     # |B^T d B| <= 100 max < 2^(e + 7)
         uf = uf.handle
     if style is not None:
         x = x * style.detach()[:, :, None, None]
@@ -408,8 +440,7 @@ def conv3x3_wino4(x, uf, out_ch, w_scale, style=None, demod=None, noise=None, no
         y = y + noise_w.detach().reshape(1) * noise.reshape(b, 1, h, w)
     if act:
         y = F.leaky_relu(y + bias.detach().view(1, -1, 1, 1), 0.2) * SQRT2
-    if y_amax is not None:
-        y_amax.copy_(absmax(y))
+    _fill_bound(y_amax, y)
     return y
 
 
@@ -448,8 +479,7 @@ def conv_transpose3x3s2_blur_wino4(x, uf, out_ch, w_scale, style=None, demod=Non
         y = F.leaky_relu(y + bias.detach().view(1, -1, 1, 1), 0.2) * SQRT2
     if post_scale is not None:
         y = y * post_scale.detach()[:, :, None, None]
-    if y_amax is not None:
-        y_amax.copy_(absmax(y))
+    _fill_bound(y_amax, y)
     return y
 
 
@@ -468,7 +498,7 @@ def conv3x3_direct16(x, wp, out_ch, w_scale, style=None, demod=None, noise=None,
                      x_amax=None, y_amax=None):
     x = x.detach()
     smax = 1.0 if style is None else float(style.detach().abs().max())
-    ev = 14 - _pow2_above((x_amax.detach() if x_amax is not None else absmax(x)) * smax)
+    ev = 14 - _pow2_above(_bound_of(x_amax, x) * smax)
     if style is not None:
         x = x * style.detach()[:, :, None, None]
     wt = _unpack(wp.handle, 0)
@@ -480,8 +510,7 @@ def conv3x3_direct16(x, wp, out_ch, w_scale, style=None, demod=None, noise=None,
         y = y + noise_w.detach().reshape(1) * noise.reshape(b, 1, h, w)
     if act:
         y = F.leaky_relu(y + bias.detach().view(1, -1, 1, 1), 0.2) * SQRT2
-    if y_amax is not None:
-        y_amax.copy_(absmax(y))
+    _fill_bound(y_amax, y)
     return y
 
 
@@ -524,8 +553,7 @@ def conv_transpose3x3s2_blur_direct16(x, wp, out_ch, w_scale, style=None, demod=
         y = F.leaky_relu(y + bias.detach().view(1, -1, 1, 1), 0.2) * SQRT2
     if post_scale is not None:
         y = y * post_scale.detach()[:, :, None, None]
-    if y_amax is not None:
-        y_amax.copy_(absmax(y))
+    _fill_bound(y_amax, y)
     return y
 
 
@@ -558,7 +586,8 @@ def install(monkeypatch):
              'adjust_latent', 'style_mul', 'weight_sqsum', 'demod', 'pack_conv_weight', 'conv3x3',
              'conv_transpose3x3s2', 'noise_add', 'blur_noise_act', 'to_rgb', 'pack_conv_weight_bf16x3',
              'conv3x3_bf16x6', 'pack_conv_weight_wino', 'conv3x3_wino', 'pack_conv_weight_wino4', 'conv3x3_wino4', 'pack_conv_transpose_weight_wino', 'conv_transpose3x3s2_wino',
-             'pack_conv_transpose_blur_weight_wino4', 'conv_transpose3x3s2_blur_wino4', 'absmax',
+             'pack_conv_transpose_blur_weight_wino4', 'conv_transpose3x3s2_blur_wino4', 'absmax', 'new_bound',
+             'bound_value', 'bound_floats',
              'pack_conv_weight_direct16', 'conv3x3_direct16', 'conv3x3_direct16_to_rgb',
              'pack_conv_transpose_blur_weight_direct16', 'conv_transpose3x3s2_blur_direct16',
              'conv_transpose_wino_split_supported',

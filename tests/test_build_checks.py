@@ -22,20 +22,57 @@ def test_asm_lds_reads_reach_their_consumers_only_through_their_waits():
     assert '16 asm LDS reads checked, 0 violations' in r.stdout
 
 
-def test_bound_scalars_come_from_a_ring_of_separate_cache_lines():
-    """hip.bound_scalar: one-element float32 views of one persistent tensor, 128 bytes apart, a slot reused only after the
-    whole ring -- never the allocator's freshly recycled address."""
+SPLIT_PATH_SOURCES = ['rw_common.h', 'rw_bound.hip', 'rw_wino4.hip', 'rw_upwino.hip', 'rw_dconv.hip', 'rw_ops.hip']
+
+
+def test_no_launch_hands_a_device_scalar_to_the_next_one():
+    """Round 4's split-operand path carried max |x| bounds and the packed weights' 2^-eU from launch to launch in 4-byte
+    device scalars (memset + filtered system-scope atomics + system-scope loads); a consumer occasionally read a stale one
+    (GPUTEST_r04: 0.0415 on the image).  Round 5 removed the mechanism: per-wave slots stored plainly, one reduction
+    launch, per-lane vector loads, weight scales by value.  Nothing of the old machinery may creep back into the sources
+    of that path."""
+    banned = ['__hip_atomic', 'atomicMax', 'atomicAdd', 'atomicCAS', 'hipMemsetAsync', 'hipMemset(']
+    for name in SPLIT_PATH_SOURCES:
+        text = open(os.path.join(ROOT, 'rewriting_amd', 'csrc', name)).read()
+        for word in banned:
+            assert word not in text, (name, word)
+    header = open(os.path.join(ROOT, 'include', 'rewriting_hip.h')).read()
+    assert 'rw_publish_scalar_f32(' not in header
+
+
+def test_bound_sizes_and_weight_scales_on_the_host():
+    """rw_bound_floats and rw_split_weight_scale are host functions of the library (no launch): the buffer a producer
+    needs, and the power of two u_scale = 2^(15 - e), max |U| < 2^e, that is passed BY VALUE to the pack kernels and
+    (inverted) to every convolution launch."""
+    from rewriting_amd import _lib
+    lib = _lib.load()
+    assert lib.rw_bound_floats(0) == 64 + 2048 + 1
+    assert lib.rw_bound_floats(64 * 32 * 1024 * 1024) == 64 + 2048 + 64 * 32 * 1024 + 1
+    assert lib.rw_bound_floats(-1) == -1
+    for amax, want in [(1.0, 2.0 ** 14), (0.999, 2.0 ** 15), (3.7, 2.0 ** 13), (2.0 ** -3, 2.0 ** 17), (0.0, 1.0),
+                       (65504.0, 2.0 ** -1)]:
+        su = lib.rw_split_weight_scale(amax)
+        assert su == want, (amax, su)
+        assert amax * su < 2.0 ** 15
+        if amax:
+            assert amax * su >= 2.0 ** 14
+
+
+def test_a_bound_travels_on_its_tensor_and_only_inside_the_unhooked_forward():
+    """models._amax_of: the producer's bound is an attribute of the feature-map TENSOR (not a bag key, not an address):
+    ignored outside the un-hooked forward, ignored once the tensor was written in place, absent from slices."""
     import torch
-    from rewriting_amd import hip
-    a = hip.bound_scalar('cpu')
-    b = hip.bound_scalar(torch.device('cpu'))
-    assert a.shape == b.shape == (1,) and a.dtype == torch.float32
-    assert b.data_ptr() - a.data_ptr() == 128
-    a.fill_(3.0)
-    b.zero_()
-    assert a.item() == 3.0                                  # separate storage locations of the same buffer
-    seen = {a.data_ptr(), b.data_ptr()}
-    for _ in range(hip._BOUND_SLOTS - 2):
-        seen.add(hip.bound_scalar('cpu').data_ptr())
-    assert len(seen) == hip._BOUND_SLOTS                    # every slot once ...
-    assert hip.bound_scalar('cpu').data_ptr() == a.data_ptr()          # ... then round again
+    from rewriting_amd.utils.stylegan2 import models
+    t = torch.zeros(2, 4, 8, 8)
+    bound = torch.ones(64)
+    t.rw_amax = (bound, t._version)
+    assert models._amax_of(t) is None                       # not inside SeqStyleGAN2.forward
+    models._rgb_branch.image_path = True
+    try:
+        assert models._amax_of(t) is bound
+        assert models._amax_of(t[:1]) is None               # a slice is another tensor
+        assert models._amax_of(None) is None
+        t.add_(1.0)                                         # edited in place (a hook): the bound no longer describes it
+        assert models._amax_of(t) is None
+    finally:
+        models._rgb_branch.image_path = False

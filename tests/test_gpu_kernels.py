@@ -374,10 +374,11 @@ def test_winograd_f4_conv_matches_oracle_within_its_error_class(case, mm, monkey
     scale = direct.abs().max().item()
     if split:
         # the bound on the input may be loose, and the kernel reports the maximum of what it wrote
-        amax, ymax = hip.absmax(x.to(DEV)), torch.zeros(1, device=DEV)
-        assert amax.item() == x.abs().max().item()
+        # (the buffer is poisoned first: every slot the reduction reads must have been written by the launch itself)
+        amax, ymax = hip.absmax(x.to(DEV)), hip.new_bound(b * o * h * w, DEV).fill_(3e38)
+        assert hip.bound_value(amax) == x.abs().max().item()
         loose = hip.conv3x3_wino4(x.to(DEV), uf, o, s, style=style.to(DEV), demod=dm, x_amax=amax * 37.0, y_amax=ymax)
-        assert ymax.item() == loose.abs().max().item()
+        assert hip.bound_value(ymax) == loose.abs().max().item()
         assert rel(loose, plain) < 2e-6, rel(loose, plain)
     assert (plain - direct).abs().max().item() < 1e-4 * scale, (plain - direct).abs().max().item() / scale
     assert rel(plain, direct) < 2e-5, rel(plain, direct)
@@ -537,11 +538,11 @@ def test_one_pass_upsampling_conv_matches_conv_then_blur(case, mm, monkeypatch):
     results = []
     for kw in (dict(noise=noise, noise_w=nw, bias=bias, act=True), dict()):
         want = hip.blur_noise_act(wide, k4, kw.get('noise'), kw.get('noise_w'), kw.get('bias'))
-        ymax = torch.zeros(1, device=DEV)
+        ymax = hip.new_bound(b * o * 4 * h * w, DEV).fill_(3e38)
         got = hip.conv_transpose3x3s2_blur_wino4(x.to(DEV), uf, o, s, style=style.to(DEV), demod=dm,
                                                  **(dict(kw, y_amax=ymax) if split else kw))
         assert got.shape == want.shape == (b, o, 2 * h, 2 * w)
-        assert not split or ymax.item() == got.abs().max().item()
+        assert not split or hip.bound_value(ymax) == got.abs().max().item()
         scale = want.abs().max().item()
         assert (got - want).abs().max().item() < 1e-4 * scale, (got - want).abs().max().item() / scale
         assert rel(got, want) < 3e-5, rel(got, want)
@@ -891,9 +892,9 @@ def test_direct16_conv_matches_direct_fp32_kernel_and_oracle(case, wm, ver, monk
     dm = hip.demod(hip.weight_sqsum(wt.to(DEV), s), style.to(DEV))
     pk = hip.pack_conv_weight_direct16(wt.to(DEV))
     wp = hip.pack_conv_weight(wt.to(DEV), 0)
-    ymax = torch.zeros(1, device=DEV)
+    ymax = hip.new_bound(b * o * h * w, DEV).fill_(3e38)
     plain = hip.conv3x3_direct16(x.to(DEV), pk, o, s, style=style.to(DEV), demod=dm, y_amax=ymax)
-    assert ymax.item() == plain.abs().max().item()
+    assert hip.bound_value(ymax) == plain.abs().max().item()
     direct = hip.conv3x3(x.to(DEV), wp, o, s, style=style.to(DEV), demod=dm, impl=0)
     scale = direct.abs().max().item()
     assert (plain - direct).abs().max().item() < 2e-5 * scale, (plain - direct).abs().max().item() / scale
@@ -961,10 +962,10 @@ def test_direct16_one_pass_upsampling_conv_matches_conv_then_blur(case, ver, mon
     results = []
     for kw in (dict(noise=noise, noise_w=nw, bias=bias, act=True), dict(), dict(post_scale=post)):
         want = hip.blur_noise_act(wide, k4, kw.get('noise'), kw.get('noise_w'), kw.get('bias'), kw.get('post_scale'))
-        ymax = torch.zeros(1, device=DEV)
+        ymax = hip.new_bound(b * o * 4 * h * w, DEV).fill_(3e38)
         got = hip.conv_transpose3x3s2_blur_direct16(x.to(DEV), pk, o, s, style=style.to(DEV), demod=dm, y_amax=ymax, **kw)
         assert got.shape == want.shape == (b, o, 2 * h, 2 * w)
-        assert ymax.item() == got.abs().max().item()
+        assert hip.bound_value(ymax) == got.abs().max().item()
         scale = want.abs().max().item()
         assert (got - want).abs().max().item() < 2e-5 * scale, (got - want).abs().max().item() / scale
         assert rel(got, want) < 3e-6, rel(got, want)
@@ -976,3 +977,84 @@ def test_direct16_one_pass_upsampling_conv_matches_conv_then_blur(case, ver, mon
         ref = R.fused_leaky_relu(blur + nw.cpu() * noise.cpu(), bias.cpu()) if kw else blur
         assert rel(got, ref) < 5e-6, rel(got, ref)
         assert (got - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
+# ---------------------------------------------------------------------------------------
+# Bounds and weight scales of the split-operand kernels (round 5): per-wave slots stored plainly + one reduction launch,
+# per-lane vector loads in the consumers, weight scales by value.
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize('n', [1, 3, 4, 5, 1023, 4096, 65537, 2 ** 20 + 7, 3 * 2 ** 22])
+def test_absmax_bound_is_exact_for_any_length(n):
+    from rewriting_amd import hip
+    x = torch.randn(n, generator=torch.Generator().manual_seed(n)) * 3
+    if n > 2:
+        x[n // 3] = -17.5
+    b = hip.absmax(x.to(DEV))
+    assert b.numel() == hip.bound_floats(0)
+    lanes = b[:hip.BOUND_LANES].cpu()
+    assert torch.isfinite(lanes).all() and (lanes >= 0).all()
+    assert hip.bound_value(b) == x.abs().max().item()
+
+
+@pytest.mark.parametrize('b,c,out', [(2, 32, 64), (3, 8, 128), (1, 16, 40), (2, 4, 96), (5, 64, 16), (2, 512, 8), (1, 8, 4)])
+def test_blur_noise_act_reports_the_bound_of_what_it_wrote(b, c, out):
+    """The generic kernel (a slot per workgroup), the small-map kernels (a measuring pass) and tiles too small for a slot
+    each (the same): the bound equals max |result|, post_scale included, from a POISONED buffer."""
+    from rewriting_amd import hip
+    rs = numpy.random.RandomState(out + c)
+    wide = torch.from_numpy(rs.randn(b, c, out + 1, out + 1).astype('float32')).to(DEV)
+    k1 = torch.tensor([1., 3., 3., 1.])
+    k4 = k1[:, None] * k1[None, :]
+    k4 = (k4 / k4.sum() * 4).to(DEV)
+    noise = torch.from_numpy(rs.randn(b, out * out).astype('float32')).to(DEV)
+    nw = torch.tensor([0.3], device=DEV)
+    bias = torch.from_numpy(rs.randn(c).astype('float32')).to(DEV)
+    post = torch.from_numpy((1 + 0.5 * rs.randn(b, c)).astype('float32')).to(DEV)
+    for ps in (None, post):
+        ymax = hip.new_bound(b * c * out * out, DEV).fill_(3e38)
+        got = hip.blur_noise_act(wide, k4, noise, nw, bias, post_scale=ps, y_amax=ymax)
+        same = hip.blur_noise_act(wide, k4, noise, nw, bias, post_scale=ps)
+        assert torch.equal(got, same)
+        assert hip.bound_value(ymax) == got.abs().max().item()
+    with pytest.raises(ValueError, match='new_bound'):
+        hip.blur_noise_act(wide, k4, noise, nw, bias, y_amax=torch.zeros(1, device=DEV))
+
+
+@pytest.mark.parametrize('o,i', [(32, 8), (64, 64), (512, 512)])
+def test_split_weight_scales_travel_by_value(o, i):
+    """Every split packing: u_scale = rw_split_weight_scale(max |U|) with max |U| measured on the device and read back
+    ONCE; it rides on the packed tensor (rw_u_inv) and in the trailer no kernel reads; a copy of the tensor is refused."""
+    from rewriting_amd import hip
+    rs = numpy.random.RandomState(o + i)
+    wt = torch.from_numpy(rs.randn(1, o, i, 3, 3).astype('float32') * 2.5)
+    k1 = torch.tensor([1., 3., 3., 1.])
+    k4 = k1[:, None] * k1[None, :]
+    k4 = (k4 / k4.sum() * 4).to(DEV)
+    G = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6],
+                      [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], dtype=torch.float64)
+    U = torch.einsum('ab,oibc,dc->oiad', G, wt[0].double(), G)
+    scale_of = lambda m: float(hip.lib().rw_split_weight_scale(float(m)))
+    uf = hip.pack_conv_weight_wino4(wt.to(DEV), split=True)
+    su = 1.0 / uf.rw_u_inv
+    assert su in (scale_of(U.abs().max()), scale_of(U.abs().max() * (1 + 1e-6)), scale_of(U.abs().max() * (1 - 1e-6)))
+    assert uf[-4:].cpu().tolist() == [1.0 / su, su, 0.0, 0.0]
+    # the words are the f16 pairs of U su: none overflows, the largest uses the top binade
+    words = uf[:-4].view(torch.int32).cpu()
+    hi = (words & 0xffff).to(torch.int16).view(torch.float16).float()
+    assert torch.isfinite(hi).all() and 2.0 ** 14 <= hi.abs().max().item() < 2.0 ** 15
+    packs = [uf]
+    if i % 8 == 0 and o % 16 == 0:
+        packs.append(hip.pack_conv_transpose_weight_wino(wt.to(DEV), split=True))
+    packs.append(hip.pack_conv_transpose_blur_weight_wino4(wt.to(DEV), k4, split=True))
+    if i % 16 == 0:
+        d16 = hip.pack_conv_weight_direct16(wt.to(DEV))
+        assert 1.0 / d16.rw_u_inv == scale_of(wt.abs().max())
+        packs += [d16, hip.pack_conv_transpose_blur_weight_direct16(wt.to(DEV), k4)]
+    for pk in packs:
+        s_ = 1.0 / pk.rw_u_inv
+        assert s_ == 2.0 ** round(math.log2(s_))
+        assert pk[-4:].cpu().tolist() == [pk.rw_u_inv, s_, 0.0, 0.0]
+    x = torch.randn(1, i, 8, 64).to(DEV)
+    if hip.wino4_supported(o, i, 8, 64):
+        with pytest.raises(ValueError, match='rw_u_inv'):
+            hip.conv3x3_wino4(x, uf.clone(), o, 1.0)

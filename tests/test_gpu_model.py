@@ -476,7 +476,7 @@ def test_micro_batched_forward_equals_one_launch(monkeypatch):
     z = torch.randn(12, 512, generator=torch.Generator().manual_seed(5)).to(DEV)
     with torch.no_grad():
         want = model(z)
-        torch.cuda.synchronize()          # (forwards issued back to back: test_forwards_issued_back_to_back_...)
+        torch.cuda.synchronize()          # (forwards issued back to back: tests/test_gpu_zz_sequences.py)
         with noise_batch_period(3):
             want_p = model(z)
     for spec in ('2:64', '4:128', '1:256', '5:32'):
@@ -503,7 +503,7 @@ def test_premultiplied_style_and_one_pass_layers_on_the_image_path(monkeypatch):
     z = torch.randn(4, 512, generator=torch.Generator().manual_seed(9)).to(DEV)
     with torch.no_grad():
         got = model(z)
-        torch.cuda.synchronize()          # (forwards issued back to back: test_forwards_issued_back_to_back_...)
+        torch.cuda.synchronize()          # (forwards issued back to back: tests/test_gpu_zz_sequences.py)
         monkeypatch.setenv('RW_PRESCALE', '0')
         same = model(z)
         assert (got - same).abs().max().item() < 5e-5
@@ -515,47 +515,6 @@ def test_premultiplied_style_and_one_pass_layers_on_the_image_path(monkeypatch):
         exact = model(z)
     assert (got - base).abs().max().item() < 5e-5
     assert (got - exact).abs().max().item() < 1e-4
-
-
-@pytest.mark.parametrize('drain', [pytest.param('1', id='product'),
-                                   pytest.param('0', id='without-the-drain', marks=pytest.mark.xfail(
-                                       strict=False, reason='OPEN ISSUE of round 4 (DESIGN.md section 9, item 0): intermittent, '
-                                       'about one sequence in forty after rw_publish_scalar_f32 (one in three before)'))])
-def test_forwards_issued_back_to_back_equal_their_synced_twins(monkeypatch, drain):
-    """Round 4: a forward that another forward followed WITHOUT a host sync is occasionally 0.01 - 0.05 off (split-operand
-    kernels with the bound hand-over, beside the RGB branch's second stream; every single forward, and the last one of a
-    sequence, is right, so no other test sees it; never with RW_MM_NO_HANDOVER=1, RW_RGB_STREAM=0, RW_MM=f32 or a host
-    sync).  Publishing the bounds by one thread before a consumer reads them (hip._amax_in, rw_publish_scalar_f32)
-    took it from 5 of 12 sequences to 1 of 44, not to zero -- the producers' side of the hand-over (memset + filtered
-    memory-side atomics on a recycled address) is the remaining suspect.  Twelve sequences of four differently configured
-    forwards, unsynced, against the same four with a sync after each: bit-identical when the issue does not strike
-    (scripts/forward_repro.py is the stand-alone form).  The PRODUCT drains the trunk's stream at the start of every
-    un-hooked forward in split mode until the cause is removed (models.SeqStyleGAN2.forward, RW_FORWARD_DRAIN): with it
-    the sequences must be identical, without it the case documents the open issue."""
-    monkeypatch.setenv('RW_FORWARD_DRAIN', drain)
-    model = build_stylegan(256, 0.7, device=DEV)
-    z = torch.randn(4, 512, generator=torch.Generator().manual_seed(9)).to(DEV)
-    configs = [{}, {'RW_PRESCALE': '0'}, {'RW_PRESCALE': '0', 'RW_UP_FUSED': '0', 'RW_RGB_F4': '0'},
-               {'RW_PRESCALE': '0', 'RW_UP_FUSED': '0', 'RW_RGB_F4': '0', 'RW_CONV_ALGO': 'winograd'}]
-
-    def run(sync):
-        outs = []
-        with torch.no_grad():
-            for env in configs:
-                for k, v in env.items():
-                    monkeypatch.setenv(k, v)
-                outs.append(model(z))
-                if sync:
-                    torch.cuda.synchronize()
-                for k in env:
-                    monkeypatch.delenv(k)
-        torch.cuda.synchronize()
-        return outs
-    ref = run(True)
-    for rep in range(12):
-        got = run(False)
-        for i, (a, b) in enumerate(zip(got, ref)):
-            assert torch.equal(a, b), (rep, i, (a - b).abs().max().item())
 
 
 @pytest.mark.parametrize('hook', [False, True])
