@@ -530,7 +530,7 @@ def run_forward(args, rank, world, device, size, batch, name, cpu=True):
                            weights='synthetic seed 0', parallelism='seeds partitioned per rank, no collective',
                            conv_gflop_per_image=round(conv_flops(size) / 1e9, 2),
                            matrix_mode='split' if split else 'f32',
-                           direct_sums=os.environ.get('RW_MM_DIRECT16', '0') if split else None))
+                           direct_sums=os.environ.get('RW_MM_DIRECT16', 'auto') if split else None))
     # second pass, NOT the headline: HIP events around every convolution call (on torch's current stream, the one the
     # kernels are launched on) -> the per-kernel table and the dominant kernel's roofline
     timer = ConvTimer()
@@ -800,8 +800,8 @@ def extras(args, rank, world, device):
             with torch.no_grad():
                 g(z)
         rates = {}
-        modes = {'f32': ('f32', '0'), 'split': ('split', '0'),
-                 'split, direct sums on layers 10-17': ('split', 'auto'),
+        modes = {'f32': ('f32', '0'), 'split, F(4x4,3x3) on layers 10-18': ('split', '0'),
+                 'split, direct sums on layers 10-17 (the default)': ('split', 'auto'),
                  'split, direct sums on layers 10-18': ('split', '1')}
         saved = {k: os.environ.get(k) for k in ('RW_MM', 'RW_MM_DIRECT16')}
         for mm, (pipe, d16) in modes.items():
@@ -815,11 +815,12 @@ def extras(args, rank, world, device):
                 os.environ[key] = val
         out['forward_ffhq1024_by_matrix_mode'] = dict(
             images_per_s=rates, batch=64, steps=5,
-            note='f32 = every product on fp32 MFMAs (round 3\'s kernels); split = the default of the un-hooked forward: '
-                 'f16 operand pairs on the 16-bit pipe in the F(4x4,3x3) and F(2,2) kernels; the other two rows (opt-in, '
-                 'RW_MM_DIRECT16=auto / 1) replace the F(4x4,3x3) kernels of the stride-1 layers from 64^2 up and of the '
-                 'one-pass upsampling layer / also of the last layer by DIRECT sums on the 16-bit pipe (csrc/rw_dconv.hip). '
-                 'No forward drains a stream: round 4\'s RW_FORWARD_DRAIN workaround is gone with the device scalars it covered')
+            note='f32 = every product on fp32 MFMAs (round 3\'s kernels); split = f16 operand pairs on the 16-bit pipe (four piece '
+                 'products per multiply, fp32 accumulate) in the F(2,2) kernels of the transposed convolutions and, by row: the '
+                 'F(4x4,3x3) kernels on every stride-1 layer from 64^2 up and the one-pass upsampling layer (RW_MM_DIRECT16=0) / '
+                 'DIRECT sums (csrc/rw_dconv.hip) on layers 10-17 with F(4x4,3x3) + ToRGB on the last one (auto: the default) / '
+                 'direct sums on the last layer too (1).  No forward drains a stream: round 4\'s RW_FORWARD_DRAIN workaround is '
+                 'gone with the device scalars it covered')
         del z
     del g
     if world == 1:

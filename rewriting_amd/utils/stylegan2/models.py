@@ -141,6 +141,7 @@ class _RgbBranch(threading.local):      # per thread: two threads may run genera
         self.final = None        # (last StyledConvSeq, its ToRGBF, latent index of the ToRGB) of the running forward
         self.image_path = False  # inside the un-hooked forward of a whole generator (see conv_algo)
         self.successor = {}      # id(upsampling StyledConvSeq) -> (the StyledConvSeq that reads its result, latent index)
+        self.reader = {}         # id(StyledConvSeq) -> the StyledConvSeq that reads its feature map (any kind), if any
         self.pre = {}            # id(StyledConvSeq) -> (style, demod factors), id(ToRGBF) -> style: computed up front
         self.pre_join = None     # the stream they were computed on, until the trunk has waited for it
 
@@ -234,15 +235,15 @@ def _split_part(kind):
 
 
 def _direct16(dconv, h, w, kind):
-    """Opt-in inside the split form: the DIRECT sums on the 16-bit matrix pipe (csrc/rw_dconv.hip) in place of the
-    split-operand F(4x4,3x3) kernels, kind 'conv' / 'up' / 'rgb'.  RW_MM_DIRECT16=1 turns all three on, a comma-separated
-    list of kinds selects, 'auto' = 'conv,up': the two that measured faster INSIDE the forward of the 1024 generator
-    (profiles/r04v, ms per launch at batch 64: the stride-1 layers 3.2 - 3.6 / 4.3 against 3.7 - 4.7, the one-pass upsampling
-    layer 9.6 - 10.0 against 10.4; +4.7 % on the forward; the last layer + ToRGB is slower: 7.0 against 5.8).  NOT the
-    default: with the one-pass direct kernel in the forward, repeated forwards of the 1024 generator were not
-    reproducible (rows differing by up to 0.5 with identical inputs and bounds; every kernel-level and full-size parity
-    case passes) -- an interaction that is not understood yet."""
-    mode = os.environ.get('RW_MM_DIRECT16', '0')
+    """Inside the split form: the DIRECT sums on the 16-bit matrix pipe (csrc/rw_dconv.hip) in place of the
+    split-operand F(4x4,3x3) kernels, kind 'conv' / 'up' / 'rgb'.  RW_MM_DIRECT16: 'auto' (the default) = 'conv,up', the
+    two that measure faster INSIDE the forward of the 1024 generator (same box, batch 64, profiles/r05c_ab.jsonl: 1262
+    against 1221 img/s; per launch the stride-1 layers 3.4 / 4.3 ms against 3.7 - 4.7, the one-pass upsampling layer 10.2
+    against 10.4; the last layer + ToRGB is slower as a direct sum: 7.0 against 5.8); '1' = all three, '0' = none, or a
+    comma-separated list of kinds.  (Round 4 left them opt-in because sequences of un-synced forwards were occasionally
+    wrong with them -- the device scalars of that round's bound hand-over; tests/test_gpu_zz_sequences.py holds both
+    selections to bit-identical sequences now.)"""
+    mode = os.environ.get('RW_MM_DIRECT16', 'auto')
     kinds = ('conv', 'up') if mode == 'auto' else ('conv', 'up', 'rgb') if mode == '1' else mode.split(',')
     if dconv.in_channel < 32 or kind not in kinds:
         return False
@@ -855,6 +856,21 @@ class StyledConvSeq(nn.Sequential):
             return False
         return _unhooked(mconv, self.noise, self.activate, *mconv._modules.values())
 
+    def _reads_bound(self, h, w):
+        """Would this layer, fed a map of h x w inside the un-hooked forward, run a split-operand kernel -- i.e. use a
+        bound on its input if the producer left one?  A wrong 'yes' costs the producer one small reduction launch, a wrong
+        'no' makes this layer measure its input itself (hip.absmax): neither changes a result."""
+        if not self._fusable() or matrix_mode() != 'split' or conv_impl() != 0 or conv_precision() != 'f32':
+            return False
+        dconv = self.mconv.dconv
+        if not self.mconv.upsample:
+            return dconv.runs_split_wino4(h, w)
+        if _split_part('up1') and dconv.one_pass_upsample(torch.empty(0, dconv.in_channel, h, w, device='meta'), self.mconv.blur):
+            return True
+        return (_split_part('up') and up_conv_algo() == 'winograd' and hip.up_strips_applicable(dconv.out_channel, dconv.in_channel)
+                and hip.conv_transpose_wino_supported(dconv.out_channel, dconv.in_channel, h, w)
+                and hip.conv_transpose_wino_split_supported(dconv.out_channel, dconv.in_channel, h, w))
+
     def _hands_over_prescaled(self, h, w):
         """Would this (stride-1) layer, fed a map of h x w, run an F(4x4,3x3) kernel with the style applied on load?
         Then the layer in front may multiply the style into its own result (see forward)."""
@@ -896,10 +912,13 @@ class StyledConvSeq(nn.Sequential):
         split = matrix_mode() == 'split'
         # ... and this layer's bound for the next one, inside the un-hooked forward only (a hooked model under RW_MM=split
         # lets the kernels measure their inputs)
-        want_amax = split and _rgb_branch.image_path
+        reader = _rgb_branch.reader.get(id(self)) if _rgb_branch.image_path else None
+        want_amax = split and reader is not None
 
         def y_bound(height, width):
-            return hip.new_bound(b * dconv.out_channel * height * width, fmap.device) if want_amax else None
+            if not want_amax or not reader._reads_bound(height, width):
+                return None
+            return hip.new_bound(b * dconv.out_channel * height * width, fmap.device)
         y_amax = None
         y_amax_set = False
         post = None
@@ -972,8 +991,8 @@ class StyledConvSeq(nn.Sequential):
                     demod=demod if demod is not None else dconv.demod_factors(style), noise=noise,
                     noise_w=self.noise.weight, bias=act.bias, act=True, **mm)
                 return DataBag(d, style=style, fmap=None, fused_rgb=rgb)
-            y_amax_set = want_amax and dconv.runs_split_wino4(h, w)
-            y_amax = y_bound(h, w) if y_amax_set else None
+            y_amax = y_bound(h, w) if want_amax and dconv.runs_split_wino4(h, w) else None
+            y_amax_set = y_amax is not None
             out = dconv.run(fmap, style, style_on_load=on_load, demod=demod, x_amax=x_amax,
                             y_amax=y_amax if y_amax_set else None, noise=noise,
                             noise_w=self.noise.weight, bias=act.bias, act=True)
@@ -1054,11 +1073,13 @@ class SeqStyleGAN2(nn.Sequential):
             return self._forward(input)
         _rgb_branch.image_path = True
         _rgb_branch.successor = self._successors()
+        _rgb_branch.reader = self._readers()
         try:
             return self._forward(input)
         finally:
             _rgb_branch.image_path = False
             _rgb_branch.successor = {}
+            _rgb_branch.reader = {}
 
     def _forward(self, input):
         mb, from_res = micro_batch()
@@ -1182,6 +1203,18 @@ class SeqStyleGAN2(nn.Sequential):
             picks = [m for m in mb.children() if isinstance(m, PickLatent)]
             if len(picks) == 1 and list(mb.children())[0] is picks[0]:
                 out[id(sa)] = (sb, picks[0].index)
+        return out
+
+    def _readers(self):
+        """{id(StyledConvSeq): the next StyledConvSeq of this sequence} -- the layer that reads its feature map (the ToRGB
+        / up_rgb steps in between pass it on untouched)."""
+        out, prev = {}, None
+        for mod in self._modules.values():
+            conv = getattr(mod, 'sconv', None) or getattr(mod, 'conv', None)
+            if isinstance(conv, StyledConvSeq):
+                if prev is not None:
+                    out[id(prev)] = conv
+                prev = conv
         return out
 
     def _final_pair(self):

@@ -276,7 +276,7 @@ def test_generator_with_f4_winograd_is_inside_the_image_tolerance(emulated_hip, 
     assert (base - want).abs().max().item() < 1e-4 and not torch.equal(base, got)
 
 
-@pytest.mark.parametrize('direct16', ['0', 'auto'])       # the default / the opt-in direct sums
+@pytest.mark.parametrize('direct16', ['0', 'auto'])       # F(4x4,3x3) everywhere / the default: direct sums where they are faster
 def test_one_pass_upsampling_layers_stay_inside_the_image_tolerance(emulated_hip, monkeypatch, direct16):
     """RW_UP_ALGO=winograd4: the upsampling StyledConvs as ONE pass (transposed conv (*) blur as four phase convolutions
     -- F(4x4,3x3), or, with RW_MM_DIRECT16, direct sums on the 16-bit pipe where the shape allows --, noise + bias + activation in
@@ -440,3 +440,48 @@ def test_styled_conv_modules_are_differentiable(emulated_hip):
     (y * gy).sum().backward()
     noise = models.reference_noise(2, 15, x.device).reshape(2, 1, 3, 5)
     assert torch.equal(x.grad, gy) and torch.allclose(inj.weight.grad, (gy * noise).sum().reshape(1), atol=1e-5)
+
+
+def test_bounds_are_produced_only_where_the_next_layer_reads_them(emulated_hip, monkeypatch):
+    """Round 5: a fused layer asks its kernel for the bound of its result (hip.new_bound + one reduction launch on the
+    device) only when the layer that reads the map runs a split-operand kernel; the bound rides on the tensor, never in
+    the bag; nobody measures a map (hip.absmax) whose producer already described it; a hooked model produces none."""
+    from rewriting_amd import hip
+    from rewriting_amd.utils import nethook
+    from rewriting_amd.utils.stylegan2 import models
+    g = load_golden('gen_s64_cm1')
+    meta = golden_meta(g)
+    model = build_stylegan(meta['size'], meta['truncation'], meta['channel_multiplier'])
+    z = torch.from_numpy(g['z'])
+    made, measured = [], []
+    real_new, real_abs = hip.new_bound, hip.absmax
+    monkeypatch.setattr(hip, 'new_bound', lambda n, dev: (made.append(n), real_new(n, dev))[1])
+    monkeypatch.setattr(hip, 'absmax', lambda x: (measured.append(tuple(x.shape)), real_abs(x))[1])
+    readers = model._readers()
+    names = {id(getattr(m, 'sconv', None) or getattr(m, 'conv', None)): n for n, m in model.named_children()}
+    chain = [(names[k], names[id(v)]) for k, v in readers.items()]
+    assert chain[0] == ('layer2', 'layer3') and chain[-1] == ('layer9', 'layer10') and len(chain) == 8
+    bags = []
+    hook = model.layer9.register_forward_hook(lambda m, i, o: bags.append(o))      # a torch hook: the model stays "un-hooked"
+    with torch.no_grad():
+        img = model(z)
+    hook.remove()
+    b = z.shape[0]
+    # 64-model: layer 10 (64^2, F(4x4,3x3) + ToRGB) reads the bound of layer 9's result (the blur pass reports it); layer 9
+    # (32^2 -> 64^2, F(2,2) split) measures its input itself, because layer 8 runs an fp32 kernel that reports nothing; the
+    # layers in front ask for none; the last layer has no reader
+    assert made == [b * model.channels[64] * 64 * 64], made
+    assert measured == [(b, model.channels[32], 32, 32)], measured
+    assert all('amax' not in bag for bag in bags)
+    fm = bags[0].fmap
+    assert isinstance(getattr(fm, 'rw_amax', None), tuple) and fm.rw_amax[0].numel() >= hip.bound_floats(fm.numel())
+    assert hip.bound_value(fm.rw_amax[0]) == fm.abs().max().item()
+    want = torch.from_numpy(g['image'])
+    assert (img - want).abs().max().item() < 1e-3
+    del made[:], measured[:]
+    with nethook.InstrumentedModel(model) as inst:
+        inst.retain_layer('layer7', detach=False)
+        with torch.no_grad():
+            inst(z)
+    assert not made and not measured                    # hooked: fp32 kernels, no bounds anywhere
+    assert not models._rgb_branch.reader and not models._rgb_branch.image_path
