@@ -93,6 +93,25 @@ __device__ __forceinline__ dc_f16x8 dc_expand(dc_f32x2 w) {
   const dc_f32x4 d = {w[0], w[1], w[0], w[1]};
   return __builtin_bit_cast(dc_f16x8, d);
 }
+// ---- THREE piece products per multiply where four were issued (round 5).  Vl Ul is <= 2^-22 of a product whose other
+// pieces are already rounded at 2^-22: it buys nothing.  A pixel word is [Vh c0..3 | Vl c0..3]; against [Uh | Uh] one MFMA
+// gives Vh Uh + Vl Uh, and the Vh Ul of TWO taps share a second one: the rows r and r + 1 of a window column meet the taps
+// ky = 0 and ky = 1 of the SAME output block, so [Vh(row r) | Vh(row r + 1)] x [Ul(ky 0) | Ul(ky 1)] is both taps' third
+// product (two register moves build the pixel operand, the weight operand is two 8-byte loads side by side).  Tap ky = 2
+// has no partner in its column and keeps its fourth product ([Ul | Ul]): 5 MFMAs per kernel column and output block
+// where 6 were issued, 240 per 16-channel chunk instead of 288 -- the kernels are paced by MFMA issue (profiles/r04s).
+// DC_PRODUCTS=4 (compile time) keeps the old form for comparison.
+#ifndef DC_PRODUCTS
+#define DC_PRODUCTS 3
+#endif
+// [a0 a1 a2 a3 b0 b1 b2 b3]: the first four halves of two operands (their Vh parts) / two 4-half weight pieces
+__device__ __forceinline__ dc_f16x8 dc_pair(dc_f16x8 a, dc_f16x8 b) {
+  return dc_f16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+__device__ __forceinline__ dc_f16x8 dc_pair(dc_f32x2 a, dc_f32x2 b) {
+  const dc_f32x4 d = {a[0], a[1], b[0], b[1]};
+  return __builtin_bit_cast(dc_f16x8, d);
+}
 
 // LDS-direct load: lane L's 16 bytes at sbase + voffset land at LDS byte address lds_addr + 16 L
 __device__ __forceinline__ void dc_dma_global_b128(unsigned lds_addr, int voffset, const void* sbase) {
@@ -235,11 +254,15 @@ __device__ __forceinline__ void dconv_body(const DconvProblem& p) {
         else Wc[ky][ob][part] = *reinterpret_cast<const dc_f32x2*>(wbase + ((int64_t)ob * T + t) * 1024 + part * 512);
       }
   };
+  // W[ky][ob][0] = [Uh | Uh] of tap ky; DC_PRODUCTS == 3: W[0][ob][1] = [Ul(ky 0) | Ul(ky 1)], W[2][ob][1] = [Ul | Ul] of
+  // tap 2 (W[1][ob][1] unused); == 4: W[ky][ob][1] = [Ul | Ul] of tap ky
   auto wexpand = [&](int ky) __attribute__((always_inline)) {
 #pragma unroll
-    for (int ob = 0; ob < 2; ++ob)
-#pragma unroll
-      for (int part = 0; part < 2; ++part) W[ky][ob][part] = dc_expand(Wc[ky][ob][part]);
+    for (int ob = 0; ob < 2; ++ob) {
+      W[ky][ob][0] = dc_expand(Wc[ky][ob][0]);
+      if (DC_PRODUCTS == 4 || ky == 2) W[ky][ob][1] = dc_expand(Wc[ky][ob][1]);
+      else if (ky == 1) W[0][ob][1] = dc_pair(Wc[0][ob][1], Wc[1][ob][1]);       // first used in row 1
+    }
   };
 
   dc_f32x4 acc[2][8];
@@ -269,6 +292,7 @@ __device__ __forceinline__ void dconv_body(const DconvProblem& p) {
     const unsigned char* lb = Ls + buf * BUFB;
     if (!LAST) stage_load(c + 1, rw_int<0>());
     dc_f16x8 bcur = bread(lb, 0, 0);
+    dc_f16x8 bprev[2] = {bcur, bcur};               // the operand one row up, per half (DC_PRODUCTS == 3)
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
       const bool more = !LAST || kx < 2;            // is there a next column
@@ -288,9 +312,18 @@ __device__ __forceinline__ void dconv_body(const DconvProblem& p) {
           if (DC_ABL & 2) { asm volatile("" :: "v"(bcur), "v"(W[ky][0][0]), "v"(W[ky][0][1]), "v"(W[ky][1][0]), "v"(W[ky][1][1])); continue; }
           acc[0][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bcur, W[ky][0][0], acc[0][pb], 0, 0, 0);
           acc[1][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bcur, W[ky][1][0], acc[1][pb], 0, 0, 0);
-          acc[0][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bcur, W[ky][0][1], acc[0][pb], 0, 0, 0);
-          acc[1][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bcur, W[ky][1][1], acc[1][pb], 0, 0, 0);
+          if (DC_PRODUCTS == 4 || ky == 2) {
+            acc[0][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bcur, W[ky][0][1], acc[0][pb], 0, 0, 0);
+            acc[1][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bcur, W[ky][1][1], acc[1][pb], 0, 0, 0);
+          }
         }
+        if (DC_PRODUCTS == 3 && r >= 1 && r <= 4 && !(DC_ABL & 2)) {      // Vh Ul of the taps (0, kx) on row r - 1 and (1, kx) on row r
+          const int pb = 2 * (r - 1) + half;
+          const dc_f16x8 hh = dc_pair(bprev[half], bcur);
+          acc[0][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hh, W[0][0][1], acc[0][pb], 0, 0, 0);
+          acc[1][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hh, W[0][1][1], acc[1][pb], 0, 0, 0);
+        }
+        bprev[half] = bcur;
         __builtin_amdgcn_sched_barrier(0);
         if (more && half == 1 && r >= 3) wload(r - 3, tn + 3 * (r - 3));
         bcur = bnext;
@@ -748,13 +781,22 @@ __device__ __forceinline__ void dconv_ws_body(const DconvProblem& p) {
     wread(wb, 0, 0);
     bq[0] = bread(lb, 0, 0);
     bq[1] = bread(lb, 0, 1);
+    dc_f16x8 bprev[2] = {bq[0], bq[1]};             // the operand one row up, per half (DC_PRODUCTS == 3, part 1)
 #pragma unroll
     for (int hs = 0; hs < 6; ++hs) {
       const int kx = hs >> 1, part = hs & 1;
+      // part 0: W[ky][ob] = [Uh | Uh] of tap ky.  Part 1, DC_PRODUCTS == 3: W[0][ob] = [Ul(ky 0) | Ul(ky 1)] (meets
+      // [Vh(row r - 1) | Vh(row r)]), W[2][ob] = [Ul | Ul] of tap 2; DC_PRODUCTS == 4: [Ul | Ul] of every tap
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
+      for (int ob = 0; ob < 2; ++ob) {
+        if (DC_PRODUCTS == 4 || part == 0) {
 #pragma unroll
-        for (int ob = 0; ob < 2; ++ob) W[ky][ob] = dc_expand(Wc[ky][ob]);
+          for (int ky = 0; ky < 3; ++ky) W[ky][ob] = dc_expand(Wc[ky][ob]);
+        } else {
+          W[0][ob] = dc_pair(Wc[0][ob], Wc[1][ob]);
+          W[2][ob] = dc_expand(Wc[2][ob]);
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
       if (hs + 1 < 6) wread(wb, (hs + 1) >> 1, (hs + 1) & 1);
       __builtin_amdgcn_sched_barrier(0);
@@ -764,14 +806,31 @@ __device__ __forceinline__ void dconv_ws_body(const DconvProblem& p) {
         const dc_f16x8 b = bq[idx % 3];
         if (idx + 2 < 12) bq[(idx + 2) % 3] = bread(lb, kx, idx + 2);
         else if (hs < 5) bq[(idx + 2) % 3] = bread(lb, (hs + 1) >> 1, idx + 2 - 12);
+        if (DC_PRODUCTS == 4 || part == 0) {
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-          const int pr = r - ky;
-          if (pr < 0 || pr > 3) continue;
-          const int pb = 2 * pr + half;
-          if (DC_ABL & 2) { asm volatile("" :: "v"(b), "v"(W[ky][0]), "v"(W[ky][1])); continue; }
-          acc[0][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b, W[ky][0], acc[0][pb], 0, 0, 0);
-          acc[1][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b, W[ky][1], acc[1][pb], 0, 0, 0);
+          for (int ky = 0; ky < 3; ++ky) {
+            const int pr = r - ky;
+            if (pr < 0 || pr > 3) continue;
+            const int pb = 2 * pr + half;
+            if (DC_ABL & 2) { asm volatile("" :: "v"(b), "v"(W[ky][0]), "v"(W[ky][1])); continue; }
+            acc[0][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b, W[ky][0], acc[0][pb], 0, 0, 0);
+            acc[1][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b, W[ky][1], acc[1][pb], 0, 0, 0);
+          }
+        } else if (DC_ABL & 2) {
+          asm volatile("" :: "v"(b), "v"(W[0][0]), "v"(W[0][1]), "v"(W[2][0]), "v"(W[2][1]));
+        } else {
+          if (r >= 1 && r <= 4) {                   // Vh Ul of the taps (0, kx) on row r - 1 and (1, kx) on row r
+            const int pb = 2 * (r - 1) + half;
+            const dc_f16x8 hh = dc_pair(bprev[half], b);
+            acc[0][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hh, W[0][0], acc[0][pb], 0, 0, 0);
+            acc[1][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hh, W[0][1], acc[1][pb], 0, 0, 0);
+          }
+          if (r >= 2) {                             // tap (2, kx): all four products
+            const int pb = 2 * (r - 2) + half;
+            acc[0][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b, W[2][0], acc[0][pb], 0, 0, 0);
+            acc[1][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b, W[2][1], acc[1][pb], 0, 0, 0);
+          }
+          bprev[half] = b;
         }
         __builtin_amdgcn_sched_barrier(0);
       }

@@ -209,17 +209,22 @@ def up_conv_algo():
     return os.environ.get('RW_UP_ALGO', 'winograd')
 
 
-def matrix_mode():
+def matrix_mode(kind=None):
     """Which matrix pipe multiplies inside the F(4x4,3x3) and F(2,2) kernels: 'f32' (fp32 MFMAs) or 'split' -- every
-    transformed operand as an exact pair of f16 numbers, all four piece products on the 16-bit pipe, fp32 accumulation
+    transformed operand as an exact pair of f16 numbers, the piece products on the 16-bit pipe, fp32 accumulation
     (hip.pack_conv_weight_wino4(split=True) ...: per-product error <= 2^-21, the kernels pass their parity tests at the
-    fp32 bars).  Like F(4x4,3x3) itself the split form is the default inside the un-hooked forward of the whole
-    generator only (image generation); hooked / sliced models -- key statistics, goal maps, the solve -- multiply in
-    fp32.  RW_MM=f32|split forces one everywhere."""
+    fp32 bars).  Inside the un-hooked forward of the whole generator (image generation): 'split' for every kind of
+    kernel.  Hooked / sliced models -- key statistics, goal maps, the solve's context -- keep their stride-1
+    convolutions on F(2x2,3x3) in fp32 (F(4x4,3x3) never runs there: conv_algo), and run the F(2,2) transposed
+    convolutions (kind 'up') in the split form too, which holds the DIRECT kernels' bars (test_transposed_conv_f22_...:
+    3e-6 relative) and is 1.4 - 1.5 x faster on the 64^2 ... 512^2 maps of a layer-10 / layer-14 sweep; RW_MM_HOOKED=f32
+    keeps them on fp32.  RW_MM=f32|split forces one everywhere."""
     explicit = os.environ.get('RW_MM')
     if explicit:
         return explicit
-    return 'split' if _rgb_branch.image_path else 'f32'
+    if _rgb_branch.image_path:
+        return 'split'
+    return 'split' if kind == 'up' and os.environ.get('RW_MM_HOOKED', 'split') != 'f32' else 'f32'
 
 
 def matrix_mode_of_image_path():
@@ -231,7 +236,7 @@ def _split_part(kind):
     """Diagnostics: RW_MM_PARTS=w4,up,up1 restricts the split form to the stride-1 F(4x4,3x3) kernels / the F(2,2)
     transposed convolutions / the one-pass upsampling layer."""
     parts = os.environ.get('RW_MM_PARTS')
-    return matrix_mode() == 'split' and (parts is None or kind in parts.split(','))
+    return matrix_mode(kind) == 'split' and (parts is None or kind in parts.split(','))
 
 
 def _direct16(dconv, h, w, kind):

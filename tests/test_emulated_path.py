@@ -483,5 +483,14 @@ def test_bounds_are_produced_only_where_the_next_layer_reads_them(emulated_hip, 
         inst.retain_layer('layer7', detach=False)
         with torch.no_grad():
             inst(z)
-    assert not made and not measured                    # hooked: fp32 kernels, no bounds anywhere
+    # hooked: nobody hands a bound over; the F(2,2) transposed convolution of layer 9 runs in the split form there too and
+    # measures its input itself, everything else multiplies in fp32
+    assert not made and measured == [(b, model.channels[32], 32, 32)]
+    monkeypatch.setenv('RW_MM_HOOKED', 'f32')
+    del measured[:]
+    with nethook.InstrumentedModel(model) as inst:
+        inst.retain_layer('layer7', detach=False)
+        with torch.no_grad():
+            inst(z)
+    assert not made and not measured
     assert not models._rgb_branch.reader and not models._rgb_branch.image_path

@@ -80,3 +80,30 @@ def test_a_bound_that_is_too_large_costs_low_bits_only_and_one_that_is_too_small
     with numpy.errstate(over='ignore'):
         h, _ = split(v * numpy.float32(2.0 ** (14 - e + 3)))
     assert numpy.isinf(h.astype(numpy.float32)).any()
+
+
+def test_three_piece_products_are_as_good_as_four():
+    """Round 5 (csrc/rw_dconv.hip, DC_PRODUCTS == 3): Ul Vl is dropped for the taps ky = 0 / 1 of every kernel column --
+    [Vh(row r) | Vh(row r + 1)] . [Ul(ky 0) | Ul(ky 1)] gives both taps' Vh Ul in ONE instruction where two [Vh | Vl] . [Ul | Ul]
+    were issued.  |Ul| <= 2^-11 |Uh| and |Vl| <= 2^-11 |Vh|: the dropped term is <= 2^-22 of the product, beside pieces
+    that are themselves rounded at 2^-22 -- the three-product sum holds the SAME 2^-21 bar, and a 576-term dot product of
+    such sums differs from the four-product one by less than fp32 accumulation moves it."""
+    rs = numpy.random.RandomState(4)
+    u = rs.randn(100000).astype(numpy.float32)
+    v = (rs.randn(100000) * numpy.exp(rs.randn(100000))).astype(numpy.float32)
+    eu, ev = exponent_above(numpy.abs(u).max()), exponent_above(numpy.abs(v).max())
+    us, vs = u * numpy.float32(2.0 ** (15 - eu)), v * numpy.float32(2.0 ** (14 - ev))
+    uh, ul = (x.astype(numpy.float64) for x in split(us))
+    vh, vl = (x.astype(numpy.float64) for x in split(vs))
+    exact = us.astype(numpy.float64) * vs.astype(numpy.float64)
+    three = uh * vh + uh * vl + ul * vh
+    four = three + ul * vl
+    big = (numpy.abs(us) >= 2.0 ** -3) & (numpy.abs(vs) >= 2.0 ** -3)
+    assert (numpy.abs(ul * vl)[big] / numpy.abs(exact[big])).max() <= 2.0 ** -22
+    assert (numpy.abs(three[big] - exact[big]) / numpy.abs(exact[big])).max() <= 2.0 ** -21
+    # a dot product of the layer's length: the difference between the two forms against the sum's own fp32 rounding
+    n = 576
+    t3 = three[:n * 170].reshape(170, n).sum(1)
+    t4 = four[:n * 170].reshape(170, n).sum(1)
+    scale = numpy.abs(exact[:n * 170].reshape(170, n)).sum(1)
+    assert (numpy.abs(t3 - t4) / scale).max() <= 2.0 ** -24
