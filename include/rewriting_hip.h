@@ -374,6 +374,20 @@ int rw_dconv_transpose3x3s2_blur_f32(const float* x, const float* wp, float* y, 
                                      int w, float w_scale, const rw_conv_epilogue* ep, const float* post_scale,
                                      float u_inv, const float* x_amax, float* y_amax, rw_stream_t stream);
 
+/* The upsampling StyledConv in one pass at the transposed convolution's OWN multiply count (rw_tconv.hip, round 5):
+ * utils/stylegan2/models.py:313-316 F.conv_transpose2d(stride=2) as a direct sum on the 16-bit matrix pipe (exact f16 operand
+ * split, fp32 accumulation; 9 multiplies per input position and channel pair where the phase kernels above spend 36), its
+ * (2H+1) x (2W+1) result kept in LDS, the 4x4 FIR of Blur(pad 1,1) (:275-281) read from there, NoiseInjection (:539-546),
+ * FusedLeakyReLU (:232-257) and post_scale in the same epilogue: x (B, in_ch, H, W) -> y (B, out_ch, 2H, 2W).
+ *   wp: rw_packed_dconv_weight_elems floats from rw_pack_dconv_weight_f32 -- the PLAIN packing of dconv.weight (no
+ *       composition with the blur), u_inv its scale; k4: the 4x4 FIR buffer (already multiplied by 4);
+ *   shapes: in_ch % 16 == 0 (<= 512), out_ch % 16 == 0, h % 16 == 0, w % 32 == 0;
+ *   ep / post_scale / x_amax / y_amax: as in rw_dconv_transpose3x3s2_blur_f32. */
+int rw_tconv_blur_supported(int out_ch, int in_ch, int h, int w);
+int rw_tconv_blur_f32(const float* x, const float* wp, const float* k4, float* y, int batch, int in_ch, int out_ch, int h,
+                      int w, float w_scale, const rw_conv_epilogue* ep, const float* post_scale, float u_inv,
+                      const float* x_amax, float* y_amax, rw_stream_t stream);
+
 /* rw_conv_transpose3x3s2_wino_f32 (the F(2,2) quads of the stride-2 transposed convolution) with its 25 GEMMs on the
  * 16-bit matrix pipe and the exact f16 operand split of the wino4h entry points (rw_upwino.hip): one
  * v_mfma_f32_16x16x32_f16 per point takes the two k-quads of an 8-channel interval (25 MFMAs of ~17 cycles per 8

@@ -143,6 +143,9 @@ SIGNATURES = {
     'rw_dconv_transpose3x3s2_blur_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                                  c_float, POINTER(ConvEpilogue), c_void_p, c_float, c_void_p, c_void_p,
                                                  c_void_p]),
+    'rw_tconv_blur_supported': (c_int, [c_int, c_int, c_int, c_int]),
+    'rw_tconv_blur_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
+                                  POINTER(ConvEpilogue), c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
     'rw_conv_transpose_blur_wino4_supported': (c_int, [c_int, c_int, c_int, c_int]),
     'rw_packed_conv_transpose_blur_wino4_elems': (ctypes.c_longlong, [c_int, c_int]),
     'rw_pack_conv_transpose_blur_weight_wino4_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),

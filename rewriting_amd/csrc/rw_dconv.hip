@@ -189,6 +189,7 @@ __device__ __forceinline__ void dconv_body(const DconvProblem& p) {
     }
   }
   const float noise_wg = p.noise ? p.noise_w[0] * gain : 0.f;
+  __syncthreads();                                  // St / Ct / Cr are read by other threads than their writers
 
   // ---- staging: wave g = channel quad g of the chunk; lane = pixel 64 s + lane of the flattened window
   const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(

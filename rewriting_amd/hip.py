@@ -739,6 +739,36 @@ def conv_transpose3x3s2_blur_direct16(x, wp, out_ch, w_scale, style=None, demod=
     return y
 
 
+def tconv_blur_supported(out_ch, in_ch, height, width):
+    """Shapes conv_transpose3x3s2_blur_fused takes (rw_tconv_blur_supported)."""
+    return bool(lib().rw_tconv_blur_supported(int(out_ch), int(in_ch), int(height), int(width)))
+
+
+def conv_transpose3x3s2_blur_fused(x, wp, k4, out_ch, w_scale, style=None, demod=None, noise=None, noise_w=None,
+                                   bias=None, act=False, post_scale=None, x_amax=None, y_amax=None):
+    """conv_transpose3x3s2 -> blur(pad 1,1) -> noise -> bias + leaky ReLU in one pass at the transposed convolution's OWN
+    multiply count (rw_tconv_blur_f32: a direct sum on the 16-bit matrix pipe with the exact f16 operand split, the
+    (2H+1)^2 map kept in LDS, the FIR read from there): (B,Cin,H,W) -> (B,Cout,2H,2W).  wp = pack_conv_weight_direct16 of
+    the layer's weight (the plain packing: nothing is composed with the blur), k4 the 4x4 FIR; the other arguments as
+    conv_transpose3x3s2_blur_direct16."""
+    x = _dev(x, 'fmap')
+    packed, wp = wp, _dev(wp, 'packed weight')
+    k4 = _dev(k4, 'blur kernel').contiguous()
+    if tuple(k4.shape) != (4, 4):
+        raise ValueError('the blur kernel must be 4 x 4')
+    b, i, h, w = x.shape
+    _direct16_check(wp, lib().rw_packed_dconv_weight_elems(out_ch, i), 'pack_conv_weight_direct16(%d x %d)' % (out_ch, i))
+    y = torch.empty(b, out_ch, 2 * h, 2 * w, device=x.device, dtype=x.dtype)
+    ep, keep = _epilogue(style, demod, noise, noise_w, bias, act)
+    post_scale = _opt(post_scale, 'post scale')
+    if post_scale is not None and tuple(post_scale.shape) != (b, out_ch):
+        raise ValueError('post_scale must be batch x out_ch')
+    x_amax, y_amax = _amax_in(x, x_amax), _amax_out(y_amax, y.numel())
+    check(lib().rw_tconv_blur_f32(_p(x), _p(wp), _p(k4), _p(y), b, i, out_ch, h, w, float(w_scale), ctypes.byref(ep),
+                                  _p(post_scale), _u_inv(packed), _p(x_amax), _p(y_amax), _stream()))
+    return y
+
+
 def noise_add(x, noise, noise_w):
     x = _dev(x, 'fmap')
     noise = _dev(noise, 'noise')

@@ -1058,3 +1058,58 @@ def test_split_weight_scales_travel_by_value(o, i):
     if hip.wino4_supported(o, i, 8, 64):
         with pytest.raises(ValueError, match='rw_u_inv'):
             hip.conv3x3_wino4(x, uf.clone(), o, 1.0)
+
+
+TCONV_CASES = [(1, 16, 16, 16, 32), (2, 64, 32, 16, 64), (1, 32, 16, 32, 32), (1, 128, 64, 16, 32), (3, 48, 48, 32, 64),
+               (1, 512, 32, 16, 32), (2, 256, 128, 32, 32), (1, 64, 32, 512, 512)]
+
+
+@pytest.mark.parametrize('case', TCONV_CASES)
+def test_fused_transposed_conv_and_blur_matches_conv_then_blur(case):
+    """hip.conv_transpose3x3s2_blur_fused (rw_tconv.hip: the transposed convolution as a direct sum on the 16-bit matrix
+    pipe at its own multiply count, its (2H+1)^2 result in LDS, the blur from there, noise + bias + leaky ReLU + post
+    scale in the epilogue) against the two-pass route of the same library (direct fp32 transposed conv -> blur_noise_act)
+    and the oracle (utils/stylegan2/models.py:313-316,275-281 through oracle/restatement.py), at the direct kernels'
+    bars; image borders, tile borders (h, w beyond one 16 x 32 tile), 16 .. 512 input channels, a loose bound."""
+    from rewriting_amd import hip
+    from oracle import restatement as R
+    b, i, o, h, w = case
+    assert hip.tconv_blur_supported(o, i, h, w)
+    x, wt, style = _conv_inputs(*case, seed=171)
+    rs = numpy.random.RandomState(172)
+    x = x * torch.from_numpy(numpy.exp(1.0 * rs.randn(1, i, 1, 1)).astype('float32'))
+    s = 1 / math.sqrt(i * 9)
+    k1 = torch.tensor([1., 3., 3., 1.])
+    k4 = k1[:, None] * k1[None, :]
+    k4 = (k4 / k4.sum() * 4).to(DEV)
+    noise = torch.from_numpy(rs.randn(b, 1, 2 * h, 2 * w).astype('float32')).to(DEV)
+    nw = torch.tensor([0.37], device=DEV)
+    bias = torch.from_numpy(rs.randn(o).astype('float32')).to(DEV)
+    post = torch.from_numpy((1 + 0.3 * rs.randn(b, o)).astype('float32')).to(DEV)
+    dm = hip.demod(hip.weight_sqsum(wt.to(DEV), s), style.to(DEV))
+    wp = hip.pack_conv_weight(wt.to(DEV), 1)
+    wide = hip.conv_transpose3x3s2(x.to(DEV), wp, o, s, style=style.to(DEV), demod=dm,
+                                   impl=0 if i % 16 == 0 and o % 32 == 0 else 1)
+    pk = hip.pack_conv_weight_direct16(wt.to(DEV))
+    results = []
+    for kw in (dict(noise=noise, noise_w=nw, bias=bias, act=True), dict(), dict(post_scale=post)):
+        want = hip.blur_noise_act(wide, k4, kw.get('noise'), kw.get('noise_w'), kw.get('bias'), kw.get('post_scale'))
+        ymax = hip.new_bound(b * o * 4 * h * w, DEV).fill_(3e38)
+        got = hip.conv_transpose3x3s2_blur_fused(x.to(DEV), pk, k4, o, s, style=style.to(DEV), demod=dm, y_amax=ymax, **kw)
+        assert got.shape == want.shape == (b, o, 2 * h, 2 * w)
+        assert torch.isfinite(got).all()
+        assert hip.bound_value(ymax) == got.abs().max().item()
+        scale = want.abs().max().item()
+        assert (got - want).abs().max().item() < 2e-5 * scale, (got - want).abs().max().item() / scale
+        assert rel(got, want) < 3e-6, rel(got, want)
+        results.append((kw, got.cpu()))
+    loose = hip.conv_transpose3x3s2_blur_fused(x.to(DEV), pk, k4, o, s, style=style.to(DEV), demod=dm,
+                                               x_amax=hip.absmax(x.to(DEV)) * 37.0)
+    assert rel(loose, results[1][1]) < 2e-6
+    assert b * i * o * h * w <= 2 ** 29
+    key = style[:, :, None, None] * x
+    blur = R.upfirdn2d(R.demod_conv(key, style, wt, upsample=True), k4.cpu(), pad=(1, 1))
+    for kw, got in results[:2]:
+        ref = R.fused_leaky_relu(blur + nw.cpu() * noise.cpu(), bias.cpu()) if kw else blur
+        assert rel(got, ref) < 5e-6, rel(got, ref)
+        assert (got - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
