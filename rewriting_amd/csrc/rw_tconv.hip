@@ -23,13 +23,21 @@
 // output rows (one column left, two right): a workgroup computes the positions (TY + 2) x (TX + 2) around its TY x TX
 // tile (halo factor 1.2 at 16 x 32) from an x window of (TY + 3) x (TX + 3) pixels staged as in rw_dconv.hip.
 //
-// Workgroup = 8 waves, ONE per CU (LDS: two 42.5 KB window buffers + 18 KB of weights): wave v owns the position blocks
-// v, v + 8, ... (5 of 39) x 4 phases = 80 accumulator registers.  Per chunk: the chunk's 9 KB of weights and the next
-// window are requested a chunk ahead (weights through LDS: 512 threads x 16 bytes + a tail), the window converted and
-// written behind the first / last blocks' MFMAs, one barrier per chunk.  Epilogue in two halves of 8 channels (the z tile
-// of 8 channels, 36 x 72 floats each, reuses the window buffers): accumulators -> LDS, barrier, every thread blurs eight
-// groups of four outputs (16-byte LDS reads), applies demodulation, noise, bias, leaky ReLU and the post scale, tracks
-// max |y| for the bound, and stores 16 bytes.
+// Workgroup shapes (template): <TY = 8, 4 waves> two workgroups per CU (67 KB of LDS, <= 256 registers: a workgroup's
+// epilogue runs beside the other one's MFMAs) -- the default; <TY = 16, 8 waves> one per CU (106 KB; halo factor 1.2 instead
+// of 1.33).  Wave v owns the position blocks v, v + WAVES, ... x 4 phases (96 / 80 accumulator registers).  Per chunk: the
+// chunk's 9 KB of weights and the next window are requested a chunk ahead (weights through LDS), the window converted and
+// written behind the first / last blocks' MFMAs, one barrier per chunk.
+// THREE piece products (rw_dconv.hip, DC_PRODUCTS): the taps of a phase share the Vh Ul instruction in pairs --
+// [Vh(P00) | Vh(P01)] x [Ul(t0) | Ul(t2)] and so on -- 14 MFMAs per block and chunk instead of 18, issued in three tap
+// groups (the taps on x[i][j] alone, those that also need x[i][j-1], those on the row above: six operand reads per block
+// where four would do, at most five weight operands live).
+// Epilogue in two halves of 8 channels (the z tile of 8 channels, 2 (TY + 2) x 72 floats each, reuses the window buffers):
+// accumulators -> LDS, barrier, blur, demodulation, noise, bias, leaky ReLU, post scale, max |y| for the bound, 16-byte
+// stores.  The blur: when the FIR is an outer product kv x kh (the reference's always is: make_kernel([1,3,3,1])) a
+// thread walks DOWN a strip of four output columns -- every z row is read once (two 16-byte LDS reads), filtered
+// horizontally (16 multiply-adds), and the last four filtered rows give an output row (16 more): 9.5 multiply-adds per
+// output where the direct 16-tap form spends 16, and a third of its LDS reads; any other FIR takes the 16-tap form.
 #include "rw_common.h"
 #include <stdlib.h>
 typedef float tc_f32x4 __attribute__((ext_vector_type(4)));
@@ -47,27 +55,16 @@ struct TconvProblem {
   const float* x_amax; float* y_amax;
 };
 
-#define TC_TY 16
 #define TC_TX 32
-#define TC_PR (TC_TY + 2)                 // position rows
 #define TC_PC (TC_TX + 2)                 // position columns
-#define TC_NPOS (TC_PR * TC_PC)           // 612
-#define TC_NBLK ((TC_NPOS + 15) / 16)     // 39 blocks of 16 positions
-#define TC_WR (TC_TY + 3)                 // window rows: input rows I0 - 2 .. I0 + TY
 #define TC_WC (TC_TX + 3)                 // window columns: J0 - 2 .. J0 + TX
-#define TC_NPIX (TC_WR * TC_WC)           // 665
-#define TC_BUFB (TC_NPIX * 64)            // bytes of a window buffer: 16 channels x (2 + 2) bytes per pixel
-#define TC_WAVES 8
-#define TC_BPW ((TC_NBLK + TC_WAVES - 1) / TC_WAVES)      // 5 blocks per wave
 #define TC_ZP 72                          // z row pitch (floats): columns 3 .. 70 are written, 4 .. 70 read
-#define TC_ZR (2 * TC_PR)                 // z rows of the tile: 36
-#define TC_CHS (TC_ZR * TC_ZP + 4)        // z channel stride (floats)
 #define TC_WCH 9216                       // bytes of a chunk's weights of one 16-channel block: 9 taps x [Uh | Ul] x 512
 
-static_assert(8 * TC_CHS * 4 <= 2 * TC_BUFB, "the z tile of eight channels fits the window buffers");
-
 #ifndef TC_ABL
-#define TC_ABL 0          // timing ablations (results WRONG): 1 = no staging loads, 2 = no MFMAs, 8 = no epilogue
+#define TC_ABL 0          // timing ablations (results WRONG): 1 = no staging loads, 2 = no MFMAs, 8 = no epilogue,
+                          // 16 = the epilogue without its global stores, 32 = without its noise loads, 64 = without the blur
+                          // arithmetic (z written, one row read per output row)
 #endif
 
 __device__ __forceinline__ int tc_xcd_remap(int id, int total) {
@@ -81,13 +78,36 @@ __device__ __forceinline__ tc_f16x8 tc_expand(tc_f32x2 w) {
   const tc_f32x4 d = {w[0], w[1], w[0], w[1]};
   return __builtin_bit_cast(tc_f16x8, d);
 }
+__device__ __forceinline__ tc_f16x8 tc_pair(tc_f32x2 a, tc_f32x2 b) {
+  const tc_f32x4 d = {a[0], a[1], b[0], b[1]};
+  return __builtin_bit_cast(tc_f16x8, d);
+}
+// [a0 a1 a2 a3 b0 b1 b2 b3]: the Vh parts of two pixel words
+__device__ __forceinline__ tc_f16x8 tc_pair(tc_f16x8 a, tc_f16x8 b) {
+  return tc_f16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+// [h0 h1 h2 h3 q0 q1 q2 q3]: a Vh half-word and the Vh part of a pixel word
+__device__ __forceinline__ tc_f16x8 tc_pair_hq(tc_f32x2 h, tc_f16x8 q) {
+  const tc_f32x4 qq = __builtin_bit_cast(tc_f32x4, q);
+  const tc_f32x4 d = {h[0], h[1], qq[0], qq[1]};
+  return __builtin_bit_cast(tc_f16x8, d);
+}
 template <int N> struct tc_int { static constexpr int value = N; };
 
-__global__ void __launch_bounds__(512, 1) tconv_blur_kernel(const TconvProblem p) {
-  __shared__ __attribute__((aligned(16))) unsigned char Ls[2 * TC_BUFB];
+template <int TY, int WAVES>
+__device__ __forceinline__ void tconv_body(const TconvProblem& p) {
+  constexpr int THREADS = 64 * WAVES;
+  constexpr int PR = TY + 2;                        // position rows
+  constexpr int NPOS = PR * TC_PC, NBLK = (NPOS + 15) / 16, BPW = (NBLK + WAVES - 1) / WAVES;
+  constexpr int WR = TY + 3, NPIX = WR * TC_WC;    // window rows: input rows I0 - 2 .. I0 + TY
+  constexpr int BUFB = NPIX * 64;                   // bytes of a window buffer: 16 channels x (2 + 2) bytes per pixel
+  constexpr int ZR = 2 * PR, CHS = ZR * TC_ZP + 4;  // z rows of the tile; z channel stride (floats)
+  static_assert(8 * CHS * 4 <= 2 * BUFB, "the z tile of eight channels fits the window buffers");
+  static_assert(WAVES % 4 == 0 && THREADS % 128 == 0 && 2 * TY == 8 * (THREADS / 128), "eight output rows per strip segment");
+  __shared__ __attribute__((aligned(16))) unsigned char Ls[2 * BUFB];
   __shared__ __attribute__((aligned(16))) unsigned char Wl[2 * TC_WCH];
   __shared__ __attribute__((aligned(16))) float St[512];
-  __shared__ float Sc[16], Bs[16], Po[16], Kf[16], Red[TC_WAVES];
+  __shared__ float Sc[16], Bs[16], Po[16], Kf[16], Red[WAVES];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -99,7 +119,7 @@ __global__ void __launch_bounds__(512, 1) tconv_blur_kernel(const TconvProblem p
   const int tx = pg % p.tiles_x; pg /= p.tiles_x;
   const int ty = pg % p.tiles_y;
   const int ib = pg / p.tiles_y;
-  const int I0 = ty * TC_TY, J0 = tx * TC_TX;
+  const int I0 = ty * TY, J0 = tx * TC_TX;
   const int64_t hw = (int64_t)p.h * p.w;
   const int NC = p.in_ch >> 4, T = 9 * NC;
 
@@ -108,13 +128,13 @@ __global__ void __launch_bounds__(512, 1) tconv_blur_kernel(const TconvProblem p
   {
     float smax = p.style ? 0.f : 1.f;
     if (p.style)
-      for (int i = tid; i < p.in_ch; i += 512) smax = fmaxf(smax, fabsf(p.style[(int64_t)ib * p.in_ch + i]));
+      for (int i = tid; i < p.in_ch; i += THREADS) smax = fmaxf(smax, fabsf(p.style[(int64_t)ib * p.in_ch + i]));
     smax = rw_wave_max(smax);
     if (lane == 0) Red[wave] = smax;
     __syncthreads();
     smax = Red[0];
 #pragma unroll
-    for (int v = 1; v < TC_WAVES; ++v) smax = fmaxf(smax, Red[v]);
+    for (int v = 1; v < WAVES; ++v) smax = fmaxf(smax, Red[v]);
     const float am = rw_bound_load(p.x_amax) * smax;
     int e = (int)((__float_as_uint(am) >> 23) & 0xff) - 126;      // am < 2^e
     e = e < -100 ? -100 : (e > 100 ? 100 : e);
@@ -122,7 +142,7 @@ __global__ void __launch_bounds__(512, 1) tconv_blur_kernel(const TconvProblem p
     out_scale = __uint_as_float((unsigned)(127 + e - 14) << 23) * p.u_inv;
   }
   const float gain = p.act ? 1.4142135623730951f : 1.f, slope = p.act ? 0.2f : 1.f;
-  for (int i = tid; i < p.in_ch; i += 512) St[i] = (p.style ? p.style[(int64_t)ib * p.in_ch + i] : 1.0f) * in_scale;
+  for (int i = tid; i < p.in_ch; i += THREADS) St[i] = (p.style ? p.style[(int64_t)ib * p.in_ch + i] : 1.0f) * in_scale;
   if (tid < 16) {
     const int o = 16 * ot + tid;
     Sc[tid] = (p.demod ? p.demod[(int64_t)ib * p.out_ch + o] * p.w_scale : p.w_scale) * out_scale * gain;
@@ -134,21 +154,22 @@ __global__ void __launch_bounds__(512, 1) tconv_blur_kernel(const TconvProblem p
   const float noise_wg = p.noise ? p.noise_w[0] * gain : 0.f;
   __syncthreads();                                  // the tables are read by other threads than their writers
 
-  // ---- staging: wave v stages channel quad v & 3 of pixels 64 (v >> 2) + lane + 128 s of the flattened window
+  // ---- staging: wave v stages channel quad v & 3 of the pixels 64 (NSL s + (v >> 2)) + lane of the flattened window
+  constexpr int NSL = WAVES / 4;
   const int g = wave & 3, hsel = wave >> 2;
   const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(p.x + (int64_t)ib * p.in_ch * hw), 0, (int)((int64_t)p.in_ch * hw * 4), 0x00020000);
   const int hw4 = (int)hw * 4;
-  constexpr int SI = (TC_NPIX + 127) / 128, SH = (SI + 1) / 2;
+  constexpr int SI = (NPIX + 64 * NSL - 1) / (64 * NSL), SH = (SI + 1) / 2;
   int xoff[SI], loff[SI];
 #pragma unroll
   for (int s = 0; s < SI; ++s) {
-    const int pi = 128 * s + 64 * hsel + lane;
+    const int pi = 64 * (NSL * s + hsel) + lane;
     const int r = pi / TC_WC, cc = pi - r * TC_WC;
     const int iy = I0 - 2 + r, ix = J0 - 2 + cc;
-    const bool ok = pi < TC_NPIX && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
+    const bool ok = pi < NPIX && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
     xoff[s] = ok ? (iy * p.w + ix) * 4 : 0x7fffffff;
-    loff[s] = pi < TC_NPIX ? pi * 64 + ((g ^ tc_swz(cc)) << 4) : -1;
+    loff[s] = pi < NPIX ? pi * 64 + ((g ^ tc_swz(cc)) << 4) : -1;
   }
   float raw[SH][4];
   auto stage_load = [&](int c, auto half_tag) __attribute__((always_inline)) {
@@ -163,7 +184,7 @@ __global__ void __launch_bounds__(512, 1) tconv_blur_kernel(const TconvProblem p
   auto stage_store = [&](int c, int buf, auto half_tag) __attribute__((always_inline)) {
     constexpr int S0 = decltype(half_tag)::value ? SH : 0, S1 = decltype(half_tag)::value ? SI : SH;
     const tc_f32x4 sv = *reinterpret_cast<const tc_f32x4*>(&St[16 * c + 4 * g]);
-    unsigned char* dst = Ls + buf * TC_BUFB;
+    unsigned char* dst = Ls + buf * BUFB;
 #pragma unroll
     for (int s = S0; s < S1; ++s) {
       const float (&rw)[4] = raw[s - S0];
@@ -183,85 +204,126 @@ __global__ void __launch_bounds__(512, 1) tconv_blur_kernel(const TconvProblem p
   };
   // the chunk's weights of this workgroup's 16 out-channels: 9216 contiguous bytes of the packed array -> LDS
   const unsigned char* wsrc = p.wp + (int64_t)ot * T * 1024;
-  tc_f32x4 wraw0, wraw1;
+  constexpr int NWP = (TC_WCH / 16 + THREADS - 1) / THREADS;       // 16-byte pieces per thread
+  tc_f32x4 wraw[NWP];
   auto wstage_load = [&](int c) __attribute__((always_inline)) {
     const unsigned char* src = wsrc + (int64_t)c * TC_WCH;
-    wraw0 = *reinterpret_cast<const tc_f32x4*>(src + tid * 16);
-    if (tid < (TC_WCH - 512 * 16) / 16) wraw1 = *reinterpret_cast<const tc_f32x4*>(src + 512 * 16 + tid * 16);
+#pragma unroll
+    for (int k = 0; k < NWP; ++k)
+      if ((k + 1) * THREADS <= TC_WCH / 16 || tid + k * THREADS < TC_WCH / 16)
+        wraw[k] = *reinterpret_cast<const tc_f32x4*>(src + (tid + k * THREADS) * 16);
   };
   auto wstage_store = [&](int buf) __attribute__((always_inline)) {
     unsigned char* dst = Wl + buf * TC_WCH;
-    *reinterpret_cast<tc_f32x4*>(dst + tid * 16) = wraw0;
-    if (tid < (TC_WCH - 512 * 16) / 16) *reinterpret_cast<tc_f32x4*>(dst + 512 * 16 + tid * 16) = wraw1;
+#pragma unroll
+    for (int k = 0; k < NWP; ++k)
+      if ((k + 1) * THREADS <= TC_WCH / 16 || tid + k * THREADS < TC_WCH / 16)
+        *reinterpret_cast<tc_f32x4*>(dst + (tid + k * THREADS) * 16) = wraw[k];
   };
 
   // ---- this wave's position blocks: operand addresses of the lane's position q = 16 blk + lt (clamped), pixel offsets
   // (a, b) = x[i - a][j - b] at window pixel (r + 1 - a, c + 1 - b)
-  unsigned pb0[TC_BPW], pb1[TC_BPW];               // column offset b = 0 / 1 at row offset a = 0 (a = 1: - TC_WC * 64)
+  unsigned pb0[BPW], pb1[BPW];                     // column offset b = 0 / 1 at row offset a = 0 (a = 1: - TC_WC * 64)
 #pragma unroll
-  for (int b = 0; b < TC_BPW; ++b) {
-    int q = 16 * (wave + TC_WAVES * b) + lt;
-    q = q < TC_NPOS ? q : TC_NPOS - 1;
+  for (int b = 0; b < BPW; ++b) {
+    int q = 16 * (wave + WAVES * b) + lt;
+    q = q < NPOS ? q : NPOS - 1;
     const int r = q / TC_PC, c = q - r * TC_PC;
     pb0[b] = (unsigned)(((r + 1) * TC_WC + c + 1) * 64 + ((lk ^ tc_swz(c + 1)) << 4));
     pb1[b] = (unsigned)(((r + 1) * TC_WC + c) * 64 + ((lk ^ tc_swz(c)) << 4));
   }
 
-  tc_f32x4 acc[TC_BPW][4];
+  tc_f32x4 acc[BPW][4];
 #pragma unroll
-  for (int b = 0; b < TC_BPW; ++b)
+  for (int b = 0; b < BPW; ++b)
 #pragma unroll
     for (int ph = 0; ph < 4; ++ph) acc[b][ph] = tc_f32x4{0.f, 0.f, 0.f, 0.f};
 
-  tc_f16x8 W[9][2];                                // [tap 3 ky + kx][Uh | Ul], each doubled into the operand
-  auto wread = [&](int buf) __attribute__((always_inline)) {
-    const unsigned char* wb = Wl + buf * TC_WCH + lane * 8;
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-      for (int part = 0; part < 2; ++part)
-        W[t][part] = tc_expand(*reinterpret_cast<const tc_f32x2*>(wb + t * 1024 + part * 512));
-  };
+  // One chunk in THREE tap groups, so that at most five weight operands (20 registers) are live beside the 80 - 96
+  // accumulators: G0 = the taps on x[i][j] alone, G1 = those that also need x[i][j-1], G2 = those on the row above.
+  // Tap t = 3 ky + kx of phase ph = 2 py + px sits on the operand (a, b) = x[i-a][j-b] with ky = py + 2a, kx = px + 2b.
+  // Three piece products (rw_dconv.hip): Vh Uh + Vl Uh by [Vh | Vl] x [Uh | Uh]; the Vh Ul of two taps of one phase share an
+  // instruction, [Vh(P) | Vh(Q)] x [Ul(tP) | Ul(tQ)]; tap (1, 1), alone in its phase, keeps all four ([Ul | Ul]).
+#define TC_MFMA(PH, A, B) acc[b][PH] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, acc[b][PH], 0, 0, 0)
+#define TC_UH(T_) tc_expand(*reinterpret_cast<const tc_f32x2*>(wb + (T_) * 1024))
+#define TC_UL(T_) (*reinterpret_cast<const tc_f32x2*>(wb + (T_) * 1024 + 512))
+#define TC_PIX(OFF) (*reinterpret_cast<const tc_f16x8*>(lb + (OFF)))
+#define TC_VH(OFF) (*reinterpret_cast<const tc_f32x2*>(lb + (OFF)))
   auto chunk = [&](int c, auto last_tag) __attribute__((always_inline)) {
     constexpr bool LAST = decltype(last_tag)::value != 0;
     const int buf = c & 1;
-    const unsigned char* lb = Ls + buf * TC_BUFB;
+    const unsigned char* lb = Ls + buf * BUFB;
+    const unsigned char* wb = Wl + buf * TC_WCH + lane * 8;
     if (!LAST) { stage_load(c + 1, tc_int<0>()); wstage_load(c + 1); }
-    wread(buf);
+    // (operands one block ahead, the order pinned: left to itself the scheduler hoists every block's LDS reads to the top
+    // of a group and spills; only the last block of a wave can be missing: NBLK > WAVES (BPW - 1))
+    constexpr int LB = BPW - 1;
+    const bool last_ok = wave + WAVES * LB < NBLK;  // wave-uniform
+    {
+      const tc_f16x8 u0 = TC_UH(0), u1 = TC_UH(1), u3 = TC_UH(3), u4 = TC_UH(4), l4 = tc_expand(TC_UL(4));
+      tc_f16x8 pc = TC_PIX(pb0[0]);
 #pragma unroll
-    for (int b = 0; b < TC_BPW; ++b) {
-      if (wave + TC_WAVES * b < TC_NBLK) {          // wave-uniform
-        const tc_f16x8 P00 = *reinterpret_cast<const tc_f16x8*>(lb + pb0[b]);
-        const tc_f16x8 P01 = *reinterpret_cast<const tc_f16x8*>(lb + pb1[b]);
-        const tc_f16x8 P10 = *reinterpret_cast<const tc_f16x8*>(lb + pb0[b] - TC_WC * 64);
-        const tc_f16x8 P11 = *reinterpret_cast<const tc_f16x8*>(lb + pb1[b] - TC_WC * 64);
-        if (TC_ABL & 2) {
-          asm volatile("" :: "v"(P00), "v"(P01), "v"(P10), "v"(P11));
-        } else {
-          // phase ph = 2 py + px; tap (py + 2a, px + 2b) on the operand (a, b)
-          acc[b][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(P00, W[0][0], acc[b][0], 0, 0, 0);
-          acc[b][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(P00, W[1][0], acc[b][1], 0, 0, 0);
-          acc[b][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(P00, W[3][0], acc[b][2], 0, 0, 0);
-          acc[b][3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(P00, W[4][0], acc[b][3], 0, 0, 0);
-          acc[b][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(P00, W[0][1], acc[b][0], 0, 0, 0);
-          acc[b][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(P00, W[1][1], acc[b][1], 0, 0, 0);
-          acc[b][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(P00, W[3][1], acc[b][2], 0, 0, 0);
-          acc[b][3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(P00, W[4][1], acc[b][3], 0, 0, 0);
-          acc[b][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(P01, W[2][0], acc[b][0], 0, 0, 0);       // (0, 0): tap (0, 2)
-          acc[b][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(P01, W[5][0], acc[b][2], 0, 0, 0);       // (1, 0): tap (1, 2)
-          acc[b][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(P01, W[2][1], acc[b][0], 0, 0, 0);
-          acc[b][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(P01, W[5][1], acc[b][2], 0, 0, 0);
-          acc[b][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(P10, W[6][0], acc[b][0], 0, 0, 0);       // (0, 0): tap (2, 0)
-          acc[b][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(P10, W[7][0], acc[b][1], 0, 0, 0);       // (0, 1): tap (2, 1)
-          acc[b][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(P10, W[6][1], acc[b][0], 0, 0, 0);
-          acc[b][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(P10, W[7][1], acc[b][1], 0, 0, 0);
-          acc[b][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(P11, W[8][0], acc[b][0], 0, 0, 0);       // (0, 0): tap (2, 2)
-          acc[b][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(P11, W[8][1], acc[b][0], 0, 0, 0);
+      for (int b = 0; b < BPW; ++b) {
+        tc_f16x8 pn = pc;
+        if (b + 1 < BPW) pn = TC_PIX(pb0[b + 1]);
+        if (b < LB || last_ok) {
+          if (TC_ABL & 2) { asm volatile("" :: "v"(pc), "v"(u0), "v"(u1), "v"(u3), "v"(u4), "v"(l4)); }
+          else {
+            TC_MFMA(0, pc, u0); TC_MFMA(1, pc, u1); TC_MFMA(2, pc, u3); TC_MFMA(3, pc, u4);
+            TC_MFMA(3, pc, l4);
+          }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        pc = pn;
       }
-      if (!LAST && b == 1) {                        // the first half of the next window: converted behind two blocks' MFMAs
-        stage_store(c + 1, buf ^ 1, tc_int<0>());
-        stage_load(c + 1, tc_int<1>());
+    }
+    if (!LAST) {                                    // the first half of the next window: converted behind a group's MFMAs
+      stage_store(c + 1, buf ^ 1, tc_int<0>());
+      stage_load(c + 1, tc_int<1>());
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const tc_f16x8 u2 = TC_UH(2), u5 = TC_UH(5), m02 = tc_pair(TC_UL(0), TC_UL(2)), m35 = tc_pair(TC_UL(3), TC_UL(5));
+      tc_f32x2 hc = TC_VH(pb0[0]);                  // Vh of x[i][j]: the first half of its word
+      tc_f16x8 qc = TC_PIX(pb1[0]);
+#pragma unroll
+      for (int b = 0; b < BPW; ++b) {
+        tc_f32x2 hn = hc;
+        tc_f16x8 qn = qc;
+        if (b + 1 < BPW) { hn = TC_VH(pb0[b + 1]); qn = TC_PIX(pb1[b + 1]); }
+        if (b < LB || last_ok) {
+          if (TC_ABL & 2) { asm volatile("" :: "v"(hc), "v"(qc), "v"(u2), "v"(u5), "v"(m02), "v"(m35)); }
+          else {
+            const tc_f16x8 M = tc_pair_hq(hc, qc);
+            TC_MFMA(0, qc, u2); TC_MFMA(2, qc, u5);                               // taps (0, 2), (1, 2)
+            TC_MFMA(0, M, m02); TC_MFMA(2, M, m35);                               // Vh Ul of (0, 0) + (0, 2); (1, 0) + (1, 2)
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        hc = hn; qc = qn;
+      }
+    }
+    {
+      const tc_f16x8 u6 = TC_UH(6), u7 = TC_UH(7), u8 = TC_UH(8), m17 = tc_pair(TC_UL(1), TC_UL(7)),
+                     m68 = tc_pair(TC_UL(6), TC_UL(8));
+      tc_f32x2 hc = TC_VH(pb0[0]);
+      tc_f16x8 qc = TC_PIX(pb0[0] - TC_WC * 64), rc = TC_PIX(pb1[0] - TC_WC * 64);
+#pragma unroll
+      for (int b = 0; b < BPW; ++b) {
+        tc_f32x2 hn = hc;
+        tc_f16x8 qn = qc, rn = rc;
+        if (b + 1 < BPW) { hn = TC_VH(pb0[b + 1]); qn = TC_PIX(pb0[b + 1] - TC_WC * 64); rn = TC_PIX(pb1[b + 1] - TC_WC * 64); }
+        if (b < LB || last_ok) {
+          if (TC_ABL & 2) { asm volatile("" :: "v"(hc), "v"(qc), "v"(rc), "v"(u6), "v"(u7), "v"(u8), "v"(m17), "v"(m68)); }
+          else {
+            const tc_f16x8 M02 = tc_pair_hq(hc, qc), M23 = tc_pair(qc, rc);
+            TC_MFMA(0, qc, u6); TC_MFMA(1, qc, u7);                               // taps (2, 0), (2, 1)
+            TC_MFMA(0, rc, u8); TC_MFMA(1, M02, m17);                             // tap (2, 2); Vh Ul of (0, 1) + (2, 1)
+            TC_MFMA(0, M23, m68);                                                 // Vh Ul of (2, 0) + (2, 2)
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        hc = hn; qc = qn; rc = rn;
       }
     }
     if (!LAST) {
@@ -291,19 +353,41 @@ __global__ void __launch_bounds__(512, 1) tconv_blur_kernel(const TconvProblem p
   float kf[16];
 #pragma unroll
   for (int t = 0; t < 16; ++t) kf[t] = Kf[t];
+  // is the FIR an outer product kv x kh?  (kh = its first row, kv = its first column / its corner)
+  bool sep = kf[0] != 0.f;
+  float kv[4], kmax = 0.f;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) kmax = fmaxf(kmax, fabsf(kf[t]));
+#pragma unroll
+  for (int a = 0; a < 4; ++a) kv[a] = sep ? kf[4 * a] / kf[0] : 0.f;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) sep = sep && fabsf(kf[t] - kv[t >> 2] * kf[t & 3]) <= 1e-6f * kmax;
   const int W2 = 2 * p.w;
   const int64_t hw2 = 4 * hw;
+  // strip of this thread (separable FIR): four output columns, eight output rows, one channel per pass.  Its eight noise
+  // vectors are the same in both passes: requested here, ahead of the z writes and their barrier (one L2 round trip
+  // instead of one per output row)
+  const int strip = tid & 127, seg = tid >> 7;
+  const int s_og = strip & 15, s_ch = strip >> 4, s_oy0 = 8 * seg;
+  const int64_t s_pix = (int64_t)(2 * I0 + s_oy0) * W2 + 2 * J0 + 4 * s_og;
+  tc_f32x4 nzr[8];
+#pragma unroll
+  for (int oy = 0; oy < 8; ++oy) {
+    nzr[oy] = tc_f32x4{0.f, 0.f, 0.f, 0.f};
+    if (sep && p.noise && !(TC_ABL & 32))
+      nzr[oy] = *reinterpret_cast<const tc_f32x4*>(p.noise + (int64_t)ib * hw2 + s_pix + (int64_t)oy * W2);
+  }
 #pragma unroll 1
   for (int pass = 0; pass < 2; ++pass) {
     if ((lt >> 3) == pass) {
-      float* zc = Z + (lt & 7) * TC_CHS;
+      float* zc = Z + (lt & 7) * CHS;
 #pragma unroll
-      for (int b = 0; b < TC_BPW; ++b) {
-        if (wave + TC_WAVES * b >= TC_NBLK) continue;
+      for (int b = 0; b < BPW; ++b) {
+        if (wave + WAVES * b >= NBLK) continue;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int q = 16 * (wave + TC_WAVES * b) + 4 * lk + j;
-          if (q < TC_NPOS) {
+          const int q = 16 * (wave + WAVES * b) + 4 * lk + j;
+          if (q < NPOS) {
             const int r = q / TC_PC, c = q - r * TC_PC;
             float* zp = zc + (2 * r) * TC_ZP + 2 * c + 3;
             zp[0] = acc[b][0][j];
@@ -315,43 +399,91 @@ __global__ void __launch_bounds__(512, 1) tconv_blur_kernel(const TconvProblem p
       }
     }
     __syncthreads();
-#pragma unroll 2
-    for (int k = 0; k < 8; ++k) {
-      const int gid = tid + 512 * k;                // 8 channels x 32 rows x 16 groups of four outputs
-      const int og = gid & 15, oy = (gid >> 4) & 31, ch = gid >> 9;
-      const float* zb = Z + ch * TC_CHS + (oy + 1) * TC_ZP + 4 * og + 4;
-      float res[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        const tc_f32x4 lo = *reinterpret_cast<const tc_f32x4*>(zb + a * TC_ZP);
-        const tc_f32x4 hi = *reinterpret_cast<const tc_f32x4*>(zb + a * TC_ZP + 4);
-        const float rowv[7] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2]};
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int cc = 0; cc < 4; ++cc) res[q] += rowv[q + cc] * kf[a * 4 + cc];
-      }
-      const int cl = 8 * pass + ch;                 // channel within the workgroup's 16
-      const int64_t pix = (int64_t)(2 * I0 + oy) * W2 + 2 * J0 + 4 * og;
-      tc_f32x4 nz = {0.f, 0.f, 0.f, 0.f};
-      if (p.noise) nz = *reinterpret_cast<const tc_f32x4*>(p.noise + (int64_t)ib * hw2 + pix) * noise_wg;
+    if (sep) {
+      // strip of four output columns, eight output rows: z rows oy0 + 1 .. oy0 + 11, each read once
+      const float* zb = Z + s_ch * CHS + (s_oy0 + 1) * TC_ZP + 4 * s_og + 4;
+      const int cl = 8 * pass + s_ch;               // channel within the workgroup's 16
       const float sc = Sc[cl], bs = Bs[cl], post = Po[cl];
-      tc_f32x4 v;
+      float* yb = p.y + ((int64_t)ib * p.out_ch + 16 * ot + cl) * hw2 + s_pix;
+      tc_f32x4 hrow[4];                             // the last four horizontally filtered rows
+      tc_f32x4 lo = *reinterpret_cast<const tc_f32x4*>(zb), hi = *reinterpret_cast<const tc_f32x4*>(zb + 4);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float u = res[q] * sc + nz[q] + bs;
-        v[q] = fmaxf(u, u * slope) * post;
-        ymax = fmaxf(ymax, fabsf(v[q]));
+      for (int zr = 0; zr < 11; ++zr) {
+        tc_f32x4 lon = lo, hin = hi;                // the next z row, requested before this one is filtered
+        if (zr + 1 < 11) {
+          lon = *reinterpret_cast<const tc_f32x4*>(zb + (zr + 1) * TC_ZP);
+          hin = *reinterpret_cast<const tc_f32x4*>(zb + (zr + 1) * TC_ZP + 4);
+        }
+        tc_f32x4 hsum = lo * kf[0];
+        if (!(TC_ABL & 64)) {
+          hsum += tc_f32x4{lo[1], lo[2], lo[3], hi[0]} * kf[1];
+          hsum += tc_f32x4{lo[2], lo[3], hi[0], hi[1]} * kf[2];
+          hsum += tc_f32x4{lo[3], hi[0], hi[1], hi[2]} * kf[3];
+        }
+        hrow[zr & 3] = hsum;
+        if (zr >= 3) {
+          const int oy = zr - 3;                    // output row oy0 + oy: filtered rows zr - 3 .. zr
+          tc_f32x4 res = hrow[(zr - 3) & 3] * kv[0];
+          if (!(TC_ABL & 64)) {
+            res += hrow[(zr - 2) & 3] * kv[1];
+            res += hrow[(zr - 1) & 3] * kv[2];
+            res += hrow[zr & 3] * kv[3];
+          }
+          const tc_f32x4 nz = nzr[oy] * noise_wg;
+          tc_f32x4 v;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float u = res[q] * sc + nz[q] + bs;
+            v[q] = fmaxf(u, u * slope) * post;
+            ymax = fmaxf(ymax, fabsf(v[q]));
+          }
+          if (!(TC_ABL & 16)) *reinterpret_cast<tc_f32x4*>(yb + (int64_t)oy * W2) = v;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        lo = lon; hi = hin;
       }
-      *reinterpret_cast<tc_f32x4*>(p.y + ((int64_t)ib * p.out_ch + 16 * ot + cl) * hw2 + pix) = v;
+    } else {
+#pragma unroll 1
+      for (int k = 0; k < 8 * 2 * TY * 16 / THREADS; ++k) {
+        const int gid = tid + THREADS * k;          // 8 channels x 2 TY rows x 16 groups of four outputs
+        const int og = gid & 15, oy = (gid >> 4) % (2 * TY), ch = gid / (32 * TY);
+        const float* zb = Z + ch * CHS + (oy + 1) * TC_ZP + 4 * og + 4;
+        float res[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const tc_f32x4 lo = *reinterpret_cast<const tc_f32x4*>(zb + a * TC_ZP);
+          const tc_f32x4 hi = *reinterpret_cast<const tc_f32x4*>(zb + a * TC_ZP + 4);
+          const float rowv[7] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2]};
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) res[q] += rowv[q + cc] * kf[a * 4 + cc];
+        }
+        const int cl = 8 * pass + ch;
+        const int64_t pix = (int64_t)(2 * I0 + oy) * W2 + 2 * J0 + 4 * og;
+        tc_f32x4 nz = {0.f, 0.f, 0.f, 0.f};
+        if (p.noise) nz = *reinterpret_cast<const tc_f32x4*>(p.noise + (int64_t)ib * hw2 + pix) * noise_wg;
+        const float sc = Sc[cl], bs = Bs[cl], post = Po[cl];
+        tc_f32x4 v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float u = res[q] * sc + nz[q] + bs;
+          v[q] = fmaxf(u, u * slope) * post;
+          ymax = fmaxf(ymax, fabsf(v[q]));
+        }
+        *reinterpret_cast<tc_f32x4*>(p.y + ((int64_t)ib * p.out_ch + 16 * ot + cl) * hw2 + pix) = v;
+      }
     }
     __syncthreads();
   }
   if (p.y_amax) rw_bound_store_wave(p.y_amax, rw_wave_max(ymax));
 }
 
+__global__ void __launch_bounds__(256, 2) tconv_blur_t8_kernel(const TconvProblem p) { tconv_body<8, 4>(p); }
+__global__ void __launch_bounds__(512, 1) tconv_blur_t16_kernel(const TconvProblem p) { tconv_body<16, 8>(p); }
+
 static bool tconv_shape_ok(int out_ch, int in_ch, int h, int w) {
-  return out_ch > 0 && out_ch % 16 == 0 && in_ch >= 16 && in_ch % 16 == 0 && in_ch <= 512 && w % TC_TX == 0 && h % TC_TY == 0;
+  return out_ch > 0 && out_ch % 16 == 0 && in_ch >= 16 && in_ch % 16 == 0 && in_ch <= 512 && w % TC_TX == 0 && h % 16 == 0;
 }
 
 extern "C" int rw_tconv_blur_supported(int out_ch, int in_ch, int h, int w) { return tconv_shape_ok(out_ch, in_ch, h, w) ? 1 : 0; }
@@ -371,12 +503,16 @@ extern "C" int rw_tconv_blur_f32(const float* x, const float* wp, const float* k
   p.post = post_scale;
   p.batch = batch; p.in_ch = in_ch; p.out_ch = out_ch; p.h = h; p.w = w; p.w_scale = w_scale; p.u_inv = u_inv;
   p.x_amax = x_amax; p.y_amax = y_amax;
-  p.tiles_x = w / TC_TX; p.tiles_y = h / TC_TY; p.o_tiles = out_ch / 16;
+  const char* e = getenv("RW_TCONV_TY");            // 8 (default): two 4-wave workgroups per CU; 16: one 8-wave workgroup
+  const int ty = e && atoi(e) == 16 ? 16 : 8;
+  const int waves = ty == 16 ? 8 : 4;
+  p.tiles_x = w / TC_TX; p.tiles_y = h / ty; p.o_tiles = out_ch / 16;
   const int64_t work = (int64_t)batch * p.tiles_y * p.tiles_x * p.o_tiles;
   if (work <= 0 || work > 0x7fffffff) return RW_ERR_UNSUPPORTED;
-  if (y_amax && TC_WAVES * work > rw_bound_slot_capacity((int64_t)batch * out_ch * 4 * h * w)) return RW_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(tconv_blur_kernel, dim3((unsigned)work), dim3(512), 0, rw_s(stream), p);
+  if (y_amax && waves * work > rw_bound_slot_capacity((int64_t)batch * out_ch * 4 * h * w)) return RW_ERR_UNSUPPORTED;
+  if (ty == 16) hipLaunchKernelGGL(tconv_blur_t16_kernel, dim3((unsigned)work), dim3(512), 0, rw_s(stream), p);
+  else hipLaunchKernelGGL(tconv_blur_t8_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
   const int rc = RW_LAUNCH_RESULT();
   if (rc || !y_amax) return rc;
-  return rw_bound_finish(y_amax, TC_WAVES * work, rw_s(stream));
+  return rw_bound_finish(y_amax, waves * work, rw_s(stream));
 }

@@ -279,6 +279,7 @@ def _amax_of(fmap):
 _DEFAULT_CONV_ALGO = 'winograd'
 _IMAGE_CONV_ALGO = 'winograd4'
 _ONE_PASS_UP_MAX_IN = 64       # see DemodulatedConv2dF.one_pass_upsample
+_FUSED_UP_MAX_IN = 128         # see DemodulatedConv2dF.fused_upsample
 
 
 def micro_batch():
@@ -511,6 +512,26 @@ class DemodulatedConv2dF(nn.Module):
         if algo == 'winograd4':
             return True
         return conv_algo() == 'winograd4' and self.in_channel <= _ONE_PASS_UP_MAX_IN
+
+    def fused_upsample(self, fmap, blur):
+        """Transposed conv + blur + noise + activation in one pass at the transposed convolution's OWN multiply count
+        (hip.conv_transpose3x3s2_blur_fused, csrc/rw_tconv.hip: a direct sum on the 16-bit matrix pipe, the (2H+1)^2 map
+        kept in LDS).  OPT-IN (RW_UP_FUSED2=1; layers of at most RW_UP_FUSED2_MAX_IN input channels, default
+        _FUSED_UP_MAX_IN), inside the un-hooked whole-generator forward in split mode.  Why not the default (round 5,
+        DESIGN.md section 4.5): the kernel holds its parity bars (8 kernel-level cases, and inside the forward its own
+        output is bit-identical from run to run), it is 0.6 - 2.3 ms faster per launch than what it replaces -- but while it
+        runs, workgroups of the RGB branch that share its CUs (to_rgb_kernel on the second stream) come back with wrong
+        values in lanes 48 - 63 of some waves (profiles/r05i: the image 0.3 - 0.8 off; never when the trunk waits for that
+        stream first, RW_UP_FUSED2_JOIN=1, and never without this kernel's MFMAs).  Cause not found inside the round."""
+        if not self.upsample or conv_impl() != 0 or conv_precision() != 'f32' or up_conv_algo() == 'direct':
+            return False
+        if os.environ.get('RW_UP_FUSED2', '0') != '1' or not _rgb_branch.image_path or not _split_part('up1'):
+            return False
+        if tuple(blur.pad) != (1, 1) or tuple(blur.kernel.shape) != (4, 4):
+            return False
+        if self.in_channel > int(os.environ.get('RW_UP_FUSED2_MAX_IN', _FUSED_UP_MAX_IN)):
+            return False
+        return hip.tconv_blur_supported(self.out_channel, self.in_channel, fmap.shape[-2], fmap.shape[-1])
 
     def direct16_weight(self):
         return self._derived.get('direct16', self.weight, lambda: hip.pack_conv_weight_direct16(self.weight))
@@ -870,7 +891,10 @@ class StyledConvSeq(nn.Sequential):
         dconv = self.mconv.dconv
         if not self.mconv.upsample:
             return dconv.runs_split_wino4(h, w)
-        if _split_part('up1') and dconv.one_pass_upsample(torch.empty(0, dconv.in_channel, h, w, device='meta'), self.mconv.blur):
+        probe = torch.empty(0, dconv.in_channel, h, w, device='meta')
+        if dconv.fused_upsample(probe, self.mconv.blur):
+            return True
+        if _split_part('up1') and dconv.one_pass_upsample(probe, self.mconv.blur):
             return True
         return (_split_part('up') and up_conv_algo() == 'winograd' and hip.up_strips_applicable(dconv.out_channel, dconv.in_channel)
                 and hip.conv_transpose_wino_supported(dconv.out_channel, dconv.in_channel, h, w)
@@ -941,7 +965,16 @@ class StyledConvSeq(nn.Sequential):
             h, w = 2 * fmap.shape[2], 2 * fmap.shape[3]
             noise = self.noise.noise_for(d, b, h, w, fmap.device)
             y_amax = y_bound(h, w)
-            if dconv.one_pass_upsample(fmap, mconv.blur):
+            if dconv.fused_upsample(fmap, mconv.blur):
+                mm = dict(y_amax=y_amax) if y_amax is not None else {}
+                if os.environ.get('RW_UP_FUSED2_JOIN') == '1' and _rgb_branch.stream is not None:
+                    torch.cuda.current_stream().wait_stream(_rgb_branch.stream)      # see fused_upsample
+                out = hip.conv_transpose3x3s2_blur_fused(
+                    fmap, dconv.direct16_weight(), mconv.blur.kernel, dconv.out_channel, dconv.scale,
+                    style=style, demod=demod if demod is not None else dconv.demod_factors(style), noise=noise,
+                    noise_w=self.noise.weight, bias=act.bias, act=True, post_scale=post, x_amax=x_amax, **mm)
+                y_amax_set = y_amax is not None
+            elif dconv.one_pass_upsample(fmap, mconv.blur):
                 split1 = _split_part('up1')
                 mm = dict(x_amax=x_amax, y_amax=y_amax) if split1 else {}
                 if split1 and _direct16(dconv, fmap.shape[2], fmap.shape[3], 'up'):

@@ -52,6 +52,12 @@ def main():
         pk = hip.pack_conv_weight_direct16(wt)
         ymax = hip.new_bound(batch * cout * 4 * res * res, DEV)
         a = hip.conv_transpose3x3s2_blur_fused(x, pk, k4, cout, s, y_amax=ymax, **args)
+        if os.environ.get('RW_TCONV_ONLY'):           # ablation builds: the fused kernel's time alone
+            row['fused_ms'] = timed(lambda: hip.conv_transpose3x3s2_blur_fused(x, pk, k4, cout, s, y_amax=ymax, **args))
+            print(json.dumps({k: (float('%.4g' % v) if isinstance(v, float) else v) for k, v in row.items()}), flush=True)
+            del a, x, noise
+            torch.cuda.empty_cache()
+            continue
         # the two-pass route of the forward: F(2,2) split quads + strips + blur pass
         uf = hip.pack_conv_transpose_weight_wino(wt, split=True)
         wp = hip.pack_conv_weight(wt, 1)

@@ -557,6 +557,35 @@ def conv_transpose3x3s2_blur_direct16(x, wp, out_ch, w_scale, style=None, demod=
     return y
 
 
+def tconv_blur_supported(out_ch, in_ch, height, width):
+    return out_ch % 16 == 0 and in_ch % 16 == 0 and 16 <= in_ch <= 512 and width % 32 == 0 and height % 16 == 0
+
+
+def conv_transpose3x3s2_blur_fused(x, wp, k4, out_ch, w_scale, style=None, demod=None, noise=None, noise_w=None,
+                                   bias=None, act=False, post_scale=None, x_amax=None, y_amax=None):
+    """rw_tconv.hip: the transposed convolution itself as a direct sum with the operands rounded to f16 pairs, then the blur,
+    noise, bias + leaky ReLU and the post scale."""
+    x = x.detach()
+    smax = 1.0 if style is None else float(style.detach().abs().max())
+    ev = 14 - _pow2_above(_bound_of(x_amax, x) * smax)
+    if style is not None:
+        x = x * style.detach()[:, :, None, None]
+    wt = _unpack(wp.handle, 0)                           # [o][i][3][3]
+    z = F.conv_transpose2d(_f16_pair(x, ev), _f16_pair(wt, 15 - _pow2_above(wt)).transpose(0, 1), stride=2) * w_scale
+    if demod is not None:
+        z = z * demod[:, :, None, None]
+    y = R.upfirdn2d(z, k4.detach(), pad=(1, 1))
+    n, _, h2, w2 = y.shape
+    if noise is not None:
+        y = y + noise_w.detach().reshape(1) * noise.reshape(n, 1, h2, w2)
+    if act:
+        y = F.leaky_relu(y + bias.detach().view(1, -1, 1, 1), 0.2) * SQRT2
+    if post_scale is not None:
+        y = y * post_scale.detach()[:, :, None, None]
+    _fill_bound(y_amax, y)
+    return y
+
+
 def conv_wgrad(g, x, upsample, scale=1.0, gscale=None, xscale=None):
     """d W of conv2d(x, W, pad 1) / conv_transpose2d(x, W^T, stride 2) given g = d L / d y, through torch's own
     autograd of the same op (rw_conv_wgrad_f32's definition)."""
@@ -590,7 +619,7 @@ def install(monkeypatch):
              'bound_value', 'bound_floats',
              'pack_conv_weight_direct16', 'conv3x3_direct16', 'conv3x3_direct16_to_rgb',
              'pack_conv_transpose_blur_weight_direct16', 'conv_transpose3x3s2_blur_direct16',
-             'conv_transpose_wino_split_supported',
+             'conv_transpose_wino_split_supported', 'tconv_blur_supported', 'conv_transpose3x3s2_blur_fused',
              'second_moment_accumulate', 'channel_sums', 'project_weight', 'solve_ksplit',
              'solve_step', 'solve_run', 'conv_wgrad', 'rowdot']
     for n in names:

@@ -494,3 +494,41 @@ def test_bounds_are_produced_only_where_the_next_layer_reads_them(emulated_hip, 
             inst(z)
     assert not made and not measured
     assert not models._rgb_branch.reader and not models._rgb_branch.image_path
+
+
+def test_fused_transposed_conv_and_blur_layer_stays_inside_the_image_tolerance(emulated_hip, monkeypatch):
+    """DemodulatedConv2dF.fused_upsample: inside the un-hooked forward an upsampling StyledConv whose shape
+    hip.tconv_blur_supported takes runs as ONE launch of hip.conv_transpose3x3s2_blur_fused (the transposed convolution at
+    its own multiply count, the blur from LDS) with the layer's plain direct-16 packing; same generator, reference
+    golden, image tolerance; RW_UP_FUSED2=0 and hooked models never take it."""
+    from rewriting_amd import hip
+    from rewriting_amd.utils import nethook
+    g = load_golden('gen_s64_cm1')
+    meta = golden_meta(g)
+    model = build_stylegan(meta['size'], meta['truncation'], meta['channel_multiplier'])
+    z = torch.from_numpy(g['z'])
+    want = torch.from_numpy(g['image'])
+    calls = []
+    real = hip.conv_transpose3x3s2_blur_fused
+    monkeypatch.setattr(hip, 'conv_transpose3x3s2_blur_fused', lambda *a, **k: (calls.append((a[0].shape, sorted(k))), real(*a, **k))[1])
+    with torch.no_grad():
+        model(z)
+    assert not calls                                                    # opt-in (models.DemodulatedConv2dF.fused_upsample)
+    monkeypatch.setenv('RW_UP_FUSED2', '1')
+    monkeypatch.setenv('RW_UP_FUSED2_MAX_IN', '512')
+    with torch.no_grad():
+        got = model(z)
+    assert [tuple(sh[2:]) for sh, _ in calls] == [(32, 32)]             # layer 9: 32^2 -> 64^2 (h % 16 == 0, w % 32 == 0)
+    assert 'y_amax' in calls[0][1] and 'post_scale' in calls[0][1]      # its reader (layer 10, F(4x4,3x3)) takes bound and style
+    assert (got - want).abs().max().item() < 1e-3
+    del calls[:]
+    monkeypatch.setenv('RW_UP_FUSED2', '0')
+    with torch.no_grad():
+        base = model(z)
+    assert not calls and (got - base).abs().max().item() < 1e-4
+    monkeypatch.setenv('RW_UP_FUSED2', '1')
+    with nethook.InstrumentedModel(model) as inst:
+        inst.retain_layer('layer9', detach=False)
+        with torch.no_grad():
+            hooked = inst(z)
+    assert not calls and (hooked - got).abs().max().item() < 1e-4
