@@ -64,7 +64,7 @@ struct TconvProblem {
 #ifndef TC_ABL
 #define TC_ABL 0          // timing ablations (results WRONG): 1 = no staging loads, 2 = no MFMAs, 8 = no epilogue,
                           // 16 = the epilogue without its global stores, 32 = without its noise loads, 64 = without the blur
-                          // arithmetic (z written, one row read per output row)
+                          // arithmetic (z written, one row read per output row), 128 = three position blocks per wave only
 #endif
 
 __device__ __forceinline__ int tc_xcd_remap(int id, int total) {
@@ -98,7 +98,11 @@ template <int TY, int WAVES>
 __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
   constexpr int THREADS = 64 * WAVES;
   constexpr int PR = TY + 2;                        // position rows
+#if TC_ABL & 128
+  constexpr int NPOS = PR * TC_PC, NBLK = 3 * WAVES, BPW = 3;       // (ablation: three blocks per wave -> fewer registers; results wrong)
+#else
   constexpr int NPOS = PR * TC_PC, NBLK = (NPOS + 15) / 16, BPW = (NBLK + WAVES - 1) / WAVES;
+#endif
   constexpr int WR = TY + 3, NPIX = WR * TC_WC;    // window rows: input rows I0 - 2 .. I0 + TY
   constexpr int BUFB = NPIX * 64;                   // bytes of a window buffer: 16 channels x (2 + 2) bytes per pixel
   constexpr int ZR = 2 * PR, CHS = ZR * TC_ZP + 4;  // z rows of the tile; z channel stride (floats)
@@ -269,8 +273,8 @@ __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
         if (b < LB || last_ok) {
           if (TC_ABL & 2) { asm volatile("" :: "v"(pc), "v"(u0), "v"(u1), "v"(u3), "v"(u4), "v"(l4)); }
           else {
-            TC_MFMA(0, pc, u0); TC_MFMA(1, pc, u1); TC_MFMA(2, pc, u3); TC_MFMA(3, pc, u4);
-            TC_MFMA(3, pc, l4);
+            TC_MFMA(3, pc, u4); TC_MFMA(0, pc, u0); TC_MFMA(1, pc, u1); TC_MFMA(2, pc, u3);
+            TC_MFMA(3, pc, l4);                     // (never two dependent MFMAs back to back)
           }
         }
         __builtin_amdgcn_sched_barrier(0);
