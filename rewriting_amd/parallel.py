@@ -172,17 +172,20 @@ def gather_images(local_images, seeds_total):
     """all_gather of per-rank image batches produced with seed i -> rank i mod world (this rank holds seeds
     rank, rank + world, ... in that order); returns all seeds_total images in seed order on every rank (optional:
     ranks normally write their own files).  The collective wants equal shapes: ranks are padded to
-    ceil(seeds_total / world) images -- the last seeds_total % world ranks hold one image less when the division leaves
-    a remainder."""
+    ceil(seeds_total / world) images -- when the division leaves a remainder r = seeds_total % world, the LAST
+    world - r ranks hold one image less.  A rank whose batch has the wrong length does not raise on its own (the others
+    would wait in the collective for ever): the verdict is agreed on by all ranks first, then every rank raises."""
     if shard() is None:
         if local_images.shape[0] != seeds_total:
             raise ValueError('one process holds all %d images, got %d' % (seeds_total, local_images.shape[0]))
         return local_images
     rank, world = shard()
     mine = len(range(rank, seeds_total, world))
-    if local_images.shape[0] != mine:
-        raise ValueError('rank %d of %d holds %d of %d images, got %d' % (rank, world, mine, seeds_total,
-                                                                        local_images.shape[0]))
+    bad = torch.tensor([0 if local_images.shape[0] == mine else 1], dtype=torch.int32, device=collective_device())
+    dist.all_reduce(bad, op=dist.ReduceOp.SUM)
+    if int(bad.item()):
+        raise ValueError('gather_images: %d rank(s) hold the wrong number of images (rank %d of %d: %d, expected %d of %d)'
+                         % (int(bad.item()), rank, world, local_images.shape[0], mine, seeds_total))
     per_rank = -(-seeds_total // world)
     padded = local_images.contiguous()
     if mine < per_rank:

@@ -75,7 +75,7 @@ def _uneven_worker(rank, world, port, out):
     everything = parallel.gather_images(local, total)
     ok_order = all(torch.equal(everything[s], torch.full((3, 2, 2), float(s))) for s in range(total))
     try:
-        parallel.gather_images(local[:-1], total)
+        parallel.gather_images(local[:-1] if rank == 0 else local, total)     # ONE rank is wrong: every rank raises, none hangs
         refused = False
     except ValueError:
         refused = True
