@@ -255,11 +255,18 @@ def issued_fraction(kernel):
     (rw_wino.hip, rw_wino4.hip, rw_upwino.hip headers)."""
     f32 = ('fp32 MFMA', FP32_MFMA_PEAK_TFLOPS)
     f16 = ('f16 MFMA, 4 piece products per multiply (exact operand split), fp32 accumulate', F16_MFMA_PEAK_TFLOPS)
+    # rw_dconv.hip, round 5 (DC_PRODUCTS == 3): 5 MFMAs per kernel column and output block where 6 carried four piece
+    # products -- the matrix FLOPs ISSUED are 4 x 5/6 = 3.33 per multiply
+    f16d = ('f16 MFMA, 3 piece products for the taps ky = 0 / 1 and 4 for ky = 2 (exact operand split, 10 MFMA-halves per 3 '
+            'taps), fp32 accumulate', F16_MFMA_PEAK_TFLOPS)
     if kernel.startswith('dconv') and '_up_' in kernel:
-        return (16.0, 'transposed conv (*) blur as four DIRECT 3x3 phase convolutions: 4x the transposed conv\'s direct-sum '
-                'multiplies, each as 4 f16 piece products') + f16
+        return (16.0 * 5 / 6, 'transposed conv (*) blur as four DIRECT 3x3 phase convolutions: 4x the transposed conv\'s '
+                'direct-sum multiplies, 3.33 f16 piece products issued per multiply') + f16d
     if kernel.startswith('dconv'):
-        return (4.0, 'direct sum, each multiply as 4 f16 piece products') + f16
+        return (4.0 * 5 / 6, 'direct sum, 3.33 f16 piece products issued per multiply') + f16d
+    if kernel.startswith('tconv_blur'):
+        return (14.0 / 18.0 * 4 * 1.2, 'transposed conv as a direct sum at its own multiply count (14 of 18 MFMA-halves: three '
+                'piece products, x 1.2 halo positions), blur from LDS') + f16d
     if kernel.startswith('conv_up_wino36h'):
         return (4.0, 'transposed conv (*) blur as four F(4x4,3x3) phase convolutions: the transposed conv\'s direct-sum '
                 'multiply count, each as 4 f16 piece products') + f16
