@@ -61,6 +61,9 @@ struct TconvProblem {
 #define TC_ZP 72                          // z row pitch (floats): columns 3 .. 70 are written, 4 .. 70 read
 #define TC_WCH 9216                       // bytes of a chunk's weights of one 16-channel block: 9 taps x [Uh | Ul] x 512
 
+#ifndef TC_LDS_PAD
+#define TC_LDS_PAD 0
+#endif
 #ifndef TC_ABL
 #define TC_ABL 0          // timing ablations (results WRONG): 1 = no staging loads, 2 = no MFMAs, 8 = no epilogue,
                           // 16 = the epilogue without its global stores, 32 = without its noise loads, 64 = without the blur
@@ -112,6 +115,13 @@ __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
   __shared__ __attribute__((aligned(16))) unsigned char Wl[2 * TC_WCH];
   __shared__ __attribute__((aligned(16))) float St[512];
   __shared__ float Sc[16], Bs[16], Po[16], Kf[16], Red[WAVES];
+#if TC_LDS_PAD
+  // (experiment / workaround, TY == 16 only: claim the rest of the CU's 160 KB of LDS so that no workgroup that uses LDS --
+  // to_rgb_kernel -- can share the CU: profiles/r05i)
+  constexpr int PADB = TY == 16 ? 163840 - 2 * BUFB - 2 * TC_WCH - 2048 - 4 * 64 - 4 * WAVES - 64 : 16;
+  __shared__ unsigned char Pad[PADB];
+  if (p.batch < 0) Pad[threadIdx.x] = 1;           // never true: keeps the array allocated
+#endif
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

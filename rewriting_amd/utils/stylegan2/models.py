@@ -518,11 +518,12 @@ class DemodulatedConv2dF(nn.Module):
         (hip.conv_transpose3x3s2_blur_fused, csrc/rw_tconv.hip: a direct sum on the 16-bit matrix pipe, the (2H+1)^2 map
         kept in LDS).  OPT-IN (RW_UP_FUSED2=1; layers of at most RW_UP_FUSED2_MAX_IN input channels, default
         _FUSED_UP_MAX_IN), inside the un-hooked whole-generator forward in split mode.  Why not the default (round 5,
-        DESIGN.md section 4.5): the kernel holds its parity bars (8 kernel-level cases, and inside the forward its own
-        output is bit-identical from run to run), it is 0.6 - 2.3 ms faster per launch than what it replaces -- but while it
-        runs, workgroups of the RGB branch that share its CUs (to_rgb_kernel on the second stream) come back with wrong
-        values in lanes 48 - 63 of some waves (profiles/r05i: the image 0.3 - 0.8 off; never when the trunk waits for that
-        stream first, RW_UP_FUSED2_JOIN=1, and never without this kernel's MFMAs).  Cause not found inside the round."""
+        DESIGN.md section 4.5): it holds its parity bars and is 0.2 - 1.7 ms faster per launch than what it replaces
+        stand-alone, +1.6 % on the forward when every upsampling layer takes it -- but while it ran, to_rgb_kernel on the
+        second stream came back with wrong values (its PACKED fp32 FMAs, low half, lanes 48 - 63: profiles/r05i).  The
+        streaming kernels are compiled without packed fp32 math since (csrc/rw_ops.hip, first line; the forward is then
+        bit-reproducible with this kernel too: profiles/r05l), but what exactly in this kernel disturbs another wave's
+        v_pk_fma_f32 is not understood, and a kernel that can disturb its neighbours is not made a default for 1.6 %."""
         if not self.upsample or conv_impl() != 0 or conv_precision() != 'f32' or up_conv_algo() == 'direct':
             return False
         if os.environ.get('RW_UP_FUSED2', '0') != '1' or not _rgb_branch.image_path or not _split_part('up1'):

@@ -76,3 +76,26 @@ def test_a_bound_travels_on_its_tensor_and_only_inside_the_unhooked_forward():
         assert models._amax_of(t) is None
     finally:
         models._rgb_branch.image_path = False
+
+
+@pytest.mark.skipif(shutil.which('hipcc') is None and not os.path.exists('/opt/rocm/bin/hipcc'), reason='no hipcc')
+def test_side_stream_kernels_are_compiled_without_packed_fp32_fma():
+    """rw_ops.hip carries `// hipcc-flags: -fno-slp-vectorize`: its kernels run on the side streams beside the convolutions'
+    MFMAs, and to_rgb_kernel's v_pk_fma_f32 came back wrong (low half, lanes 48..63) while rw_tconv.hip's kernel ran on
+    another stream (round 5: scripts/interference_repro.py, profiles/r05i / r05l).  The generated code of the RGB branch's
+    kernels must not contain a packed fp32 FMA."""
+    src = os.path.join(ROOT, 'rewriting_amd', 'csrc', 'rw_ops.hip')
+    first = open(src).readline()
+    assert first.startswith('// hipcc-flags:') and '-fno-slp-vectorize' in first
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    out = os.path.join('/tmp', 'rw_ops_check_%d.s' % os.getpid())
+    flags = first[len('// hipcc-flags:'):].split()
+    r = subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-S', '--cuda-device-only'] + flags +
+                       ['-o', out, src], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = open(out).read()
+    os.remove(out)
+    for kernel in ('to_rgb_kernel', 'upfirdn2d_up2k4_kernel', 'to_rgb_scalar_kernel'):
+        start = text.index(kernel)
+        body = text[start:text.index('s_endpgm', start)]
+        assert 'v_pk_fma_f32' not in body, kernel
