@@ -110,7 +110,9 @@ __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
   constexpr int BUFB = NPIX * 64;                   // bytes of a window buffer: 16 channels x (2 + 2) bytes per pixel
   constexpr int ZR = 2 * PR, CHS = ZR * TC_ZP + 4;  // z rows of the tile; z channel stride (floats)
   static_assert(8 * CHS * 4 <= 2 * BUFB, "the z tile of eight channels fits the window buffers");
-  static_assert(WAVES % 4 == 0 && THREADS % 128 == 0 && 2 * TY == 8 * (THREADS / 128), "eight output rows per strip segment");
+  constexpr int SR = 2 * TY * 128 / THREADS;        // output rows of a thread's strip in the epilogue
+  static_assert(WAVES % 4 == 0 && THREADS % 128 == 0 && SR * (THREADS / 128) == 2 * TY && (SR == 4 || SR == 8),
+                "four or eight output rows per strip segment");
   __shared__ __attribute__((aligned(16))) unsigned char Ls[2 * BUFB];
   __shared__ __attribute__((aligned(16))) unsigned char Wl[2 * TC_WCH];
   __shared__ __attribute__((aligned(16))) float St[512];
@@ -378,15 +380,15 @@ __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
   for (int t = 0; t < 16; ++t) sep = sep && fabsf(kf[t] - kv[t >> 2] * kf[t & 3]) <= 1e-6f * kmax;
   const int W2 = 2 * p.w;
   const int64_t hw2 = 4 * hw;
-  // strip of this thread (separable FIR): four output columns, eight output rows, one channel per pass.  Its eight noise
+  // strip of this thread (separable FIR): four output columns, SR output rows, one channel per pass.  Its SR noise
   // vectors are the same in both passes: requested here, ahead of the z writes and their barrier (one L2 round trip
   // instead of one per output row)
   const int strip = tid & 127, seg = tid >> 7;
-  const int s_og = strip & 15, s_ch = strip >> 4, s_oy0 = 8 * seg;
+  const int s_og = strip & 15, s_ch = strip >> 4, s_oy0 = SR * seg;
   const int64_t s_pix = (int64_t)(2 * I0 + s_oy0) * W2 + 2 * J0 + 4 * s_og;
-  tc_f32x4 nzr[8];
+  tc_f32x4 nzr[SR];
 #pragma unroll
-  for (int oy = 0; oy < 8; ++oy) {
+  for (int oy = 0; oy < SR; ++oy) {
     nzr[oy] = tc_f32x4{0.f, 0.f, 0.f, 0.f};
     if (sep && p.noise && !(TC_ABL & 32))
       nzr[oy] = *reinterpret_cast<const tc_f32x4*>(p.noise + (int64_t)ib * hw2 + s_pix + (int64_t)oy * W2);
@@ -414,7 +416,7 @@ __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
     }
     __syncthreads();
     if (sep) {
-      // strip of four output columns, eight output rows: z rows oy0 + 1 .. oy0 + 11, each read once
+      // strip of four output columns, SR output rows: z rows oy0 + 1 .. oy0 + SR + 3, each read once
       const float* zb = Z + s_ch * CHS + (s_oy0 + 1) * TC_ZP + 4 * s_og + 4;
       const int cl = 8 * pass + s_ch;               // channel within the workgroup's 16
       const float sc = Sc[cl], bs = Bs[cl], post = Po[cl];
@@ -422,9 +424,9 @@ __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
       tc_f32x4 hrow[4];                             // the last four horizontally filtered rows
       tc_f32x4 lo = *reinterpret_cast<const tc_f32x4*>(zb), hi = *reinterpret_cast<const tc_f32x4*>(zb + 4);
 #pragma unroll
-      for (int zr = 0; zr < 11; ++zr) {
+      for (int zr = 0; zr < SR + 3; ++zr) {
         tc_f32x4 lon = lo, hin = hi;                // the next z row, requested before this one is filtered
-        if (zr + 1 < 11) {
+        if (zr + 1 < SR + 3) {
           lon = *reinterpret_cast<const tc_f32x4*>(zb + (zr + 1) * TC_ZP);
           hin = *reinterpret_cast<const tc_f32x4*>(zb + (zr + 1) * TC_ZP + 4);
         }
@@ -495,6 +497,509 @@ __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
 
 __global__ void __launch_bounds__(256, 2) tconv_blur_t8_kernel(const TconvProblem p) { tconv_body<8, 4>(p); }
 __global__ void __launch_bounds__(512, 1) tconv_blur_t16_kernel(const TconvProblem p) { tconv_body<16, 8>(p); }
+// four waves per SIMD (128 registers, three position blocks per wave, strips of four output rows): two 8-wave workgroups
+// of the small tile per CU / one 16-wave workgroup of the large one
+__global__ void __launch_bounds__(512, 4) tconv_blur_t8w8_kernel(const TconvProblem p) { tconv_body<8, 8>(p); }
+__global__ void __launch_bounds__(1024, 4) tconv_blur_t16w16_kernel(const TconvProblem p) { tconv_body<16, 16>(p); }
+
+// ---------------------------------------------------------------------------------------
+// Third form: the waves of a workgroup SPECIALISE and the workgroup is PERSISTENT (rw_dconv.hip's dconv_ws_body, applied to
+// the kernel above).  Measured on the forms above (profiles/r05g, layer 17): the window loads cost 2.2 ms of 7.8 (every
+// half-chunk's HBM latency is exposed: four chunks, nothing else to run), the epilogue 3.9 (its noise loads alone 1.0), and
+// nothing overlaps -- one wave does every job in turn.  Here ONE workgroup of eight waves owns a CU and walks every
+// (grid)th tile:
+//   waves 4..7 (one per SIMD) stage: one channel quad each, a lane's item = a 16-byte aligned run of four window columns x
+//     four channels; piece s of chunk n + 1 is converted and written, then piece s of chunk n + 2 requested into the same
+//     registers -- across tile boundaries and through the epilogue: loads are in flight all the time.  They carry the
+//     chunk's 9 KB of weights (three 1-KB tap pieces per wave at most) and the tile's tables too;
+//   waves 0..3 (one per SIMD) multiply: six position blocks each (96 accumulator registers), the tap groups of the kernel
+//     above, pixel AND weight operands from LDS, and write the z tile (its own 46 KB of LDS: the window buffers belong to
+//     the staging waves);
+//   ALL eight run the blur: 512 strips of four output columns x four rows per pass of eight channels (noise requested a
+//     chunk of MFMAs earlier), 16-byte stores.
+// One raw s_barrier per chunk and two more per tile (z written -> blurred | the other eight channels written -> blurred).
+// Tile: 8 x 32 positions (16 x 64 outputs) x 16 out-channels; in_ch >= 32 (the tables are double-buffered by tile parity).
+// ---------------------------------------------------------------------------------------
+#ifndef TC_PROF
+#define TC_PROF 0         // 1: workgroups 0 and 100 leave cycle counts of wave 0 (multiplying) and wave 4 (staging) in tc_prof
+#endif
+#if TC_PROF
+__device__ unsigned long long tc_prof[32];
+extern "C" int rw_tconv_prof(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tc_prof), sizeof(unsigned long long) * 32);
+}
+#define TP_DECL(...) unsigned long long __VA_ARGS__
+#define TP_NOW(t) t = (unsigned long long)clock64()
+#define TP_ADD(var, t) { const unsigned long long tp_n = (unsigned long long)clock64(); var += tp_n - t; t = tp_n; }
+#else
+#define TP_DECL(...)
+#define TP_NOW(t)
+#define TP_ADD(var, t)
+#endif
+
+__global__ void __launch_bounds__(512, 2) tconv_blur_ws_kernel(const TconvProblem p) {
+  constexpr int TY = 8, MW = 4;
+  constexpr int PR = TY + 2, NPOS = PR * TC_PC, NBLK = (NPOS + 15) / 16, BPW = (NBLK + MW - 1) / MW;
+  constexpr int WR = TY + 3, NPIX = WR * TC_WC, BUFB = NPIX * 64;
+  constexpr int IPR = TC_TX / 4 + 2, NITEM = WR * IPR, SI = (NITEM + 63) / 64;   // items: window columns 4 j - 2 .. 4 j + 1
+  constexpr int ZR = 2 * PR, CHS = ZR * TC_ZP + 4;
+  constexpr int SR = 4, CT = 512;                   // output rows of a strip; threads of the blur (all)
+  static_assert(SI == 2 && BPW == 6 && SR * (CT / 128) == 2 * TY, "piece / block / strip counts the code below is written for");
+  __shared__ __attribute__((aligned(16))) unsigned char Ls[2 * BUFB];
+  __shared__ __attribute__((aligned(16))) unsigned char Wl[2 * TC_WCH];
+  __shared__ __attribute__((aligned(16))) float Zs[8 * CHS];
+  __shared__ float Sc[2][16], Bs[2][16], Po[2][16], Kf[16];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t hw = (int64_t)p.h * p.w;
+  const int NC = p.in_ch >> 4, T = 9 * NC;
+  const float gain = p.act ? 1.4142135623730951f : 1.f, slope = p.act ? 0.2f : 1.f;
+
+  // this workgroup's run: tile k * grid + bx (ot fastest, then x, y, image); those running at the same time are neighbours
+  const int64_t total = (int64_t)p.batch * p.tiles_y * p.tiles_x * p.o_tiles;
+  const int bx = tc_xcd_remap(blockIdx.x, gridDim.x);
+  const int count = (int)((total - bx + gridDim.x - 1) / gridDim.x);
+  if (count <= 0) {                                 // (every wave of the launch owns a slot of the bound: rw_common.h)
+    if (p.y_amax) rw_bound_store_wave(p.y_amax, 0.f);
+    return;
+  }
+  const int N = count * NC;                         // chunks of the run
+  auto decode = [&](int pos, int& ot, int& tx, int& ty, int& ib) __attribute__((always_inline)) {
+    const int64_t tile = (int64_t)pos * gridDim.x + bx;
+    ot = (int)(tile % p.o_tiles);
+    int64_t pg = tile / p.o_tiles;
+    tx = (int)(pg % p.tiles_x); pg /= p.tiles_x;
+    ty = (int)(pg % p.tiles_y);
+    ib = (int)(pg / p.tiles_y);
+  };
+  auto lds_barrier = [&]() __attribute__((always_inline)) {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);             // lgkmcnt(0): vector loads and stores stay in flight across the barrier
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  if (tid < 16) {
+    const int a = tid >> 2, c = tid & 3;
+    Kf[tid] = p.k4[(3 - a) * 4 + (3 - c)];          // flipped, as upfirdn2d applies it (read after the first barrier)
+  }
+
+  // ---- the blur of one pass (every thread): strip = four output columns x SR rows of one channel
+  const float noise_wg = p.noise ? p.noise_w[0] * gain : 0.f;
+  const int W2 = 2 * p.w;
+  const int64_t hw2 = 4 * hw;
+  const int strip = tid & 127, seg = tid >> 7;
+  const int s_og = strip & 15, s_ch = strip >> 4, s_oy0 = SR * seg;
+  float kh[4] = {0.f, 0.f, 0.f, 0.f}, kv[4] = {0.f, 0.f, 0.f, 0.f};
+  bool sep = false;
+  tc_f32x4 nzr[SR];
+#pragma unroll
+  for (int oy = 0; oy < SR; ++oy) nzr[oy] = tc_f32x4{0.f, 0.f, 0.f, 0.f};
+  float ymax = 0.f;
+  // is the FIR an outer product kv x kh?  (tconv_body; only kh and kv stay in registers, the 16-tap form reads Kf)
+  auto fir_setup = [&]() __attribute__((always_inline)) {
+    float kf[16], kmax = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { kf[t] = Kf[t]; kmax = fmaxf(kmax, fabsf(kf[t])); }
+    sep = kf[0] != 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) { kv[a] = sep ? kf[4 * a] / kf[0] : 0.f; kh[a] = kf[a]; }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) sep = sep && fabsf(kf[t] - kv[t >> 2] * kf[t & 3]) <= 1e-6f * kmax;
+  };
+  // the strip's noise (the same in both passes), requested a chunk of MFMAs before the epilogue
+  auto noise_request = [&](int ty, int tx, int ib) __attribute__((always_inline)) {
+    if (sep && p.noise) {
+      const int64_t s_pix = (int64_t)(2 * ty * TY + s_oy0) * W2 + 2 * tx * TC_TX + 4 * s_og;
+#pragma unroll
+      for (int oy = 0; oy < SR; ++oy)
+        nzr[oy] = *reinterpret_cast<const tc_f32x4*>(p.noise + (int64_t)ib * hw2 + s_pix + (int64_t)oy * W2);
+    }
+  };
+  auto blur = [&](int pass, int par, int ot, int tx, int ty, int ib) __attribute__((always_inline)) {
+    if (sep) {
+      const int cl = 8 * pass + s_ch;               // channel within the workgroup's 16
+      const int64_t s_pix = (int64_t)(2 * ty * TY + s_oy0) * W2 + 2 * tx * TC_TX + 4 * s_og;
+      const float* zb = Zs + s_ch * CHS + (s_oy0 + 1) * TC_ZP + 4 * s_og + 4;
+      const float sc = Sc[par][cl], bs = Bs[par][cl], post = Po[par][cl];
+      float* yb = p.y + ((int64_t)ib * p.out_ch + 16 * ot + cl) * hw2 + s_pix;
+      tc_f32x4 hrow[4];                             // the last four horizontally filtered rows
+      tc_f32x4 lo = *reinterpret_cast<const tc_f32x4*>(zb), hi = *reinterpret_cast<const tc_f32x4*>(zb + 4);
+#pragma unroll
+      for (int zr = 0; zr < SR + 3; ++zr) {
+        tc_f32x4 lon = lo, hin = hi;                // the next z row, requested before this one is filtered
+        if (zr + 1 < SR + 3) {
+          lon = *reinterpret_cast<const tc_f32x4*>(zb + (zr + 1) * TC_ZP);
+          hin = *reinterpret_cast<const tc_f32x4*>(zb + (zr + 1) * TC_ZP + 4);
+        }
+        tc_f32x4 hsum = lo * kh[0];
+        hsum += tc_f32x4{lo[1], lo[2], lo[3], hi[0]} * kh[1];
+        hsum += tc_f32x4{lo[2], lo[3], hi[0], hi[1]} * kh[2];
+        hsum += tc_f32x4{lo[3], hi[0], hi[1], hi[2]} * kh[3];
+        hrow[zr & 3] = hsum;
+        if (zr >= 3) {
+          const int oy = zr - 3;                    // output row oy0 + oy: filtered rows zr - 3 .. zr
+          tc_f32x4 res = hrow[(zr - 3) & 3] * kv[0];
+          res += hrow[(zr - 2) & 3] * kv[1];
+          res += hrow[(zr - 1) & 3] * kv[2];
+          res += hrow[zr & 3] * kv[3];
+          const tc_f32x4 nz = nzr[oy] * noise_wg;
+          tc_f32x4 v;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float u = res[q] * sc + nz[q] + bs;
+            v[q] = fmaxf(u, u * slope) * post;
+            ymax = fmaxf(ymax, fabsf(v[q]));
+          }
+          *reinterpret_cast<tc_f32x4*>(yb + (int64_t)oy * W2) = v;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        lo = lon; hi = hin;
+      }
+    } else {
+#pragma unroll 1
+      for (int k = 0; k < 8 * 2 * TY * 16 / CT; ++k) {
+        const int gid = tid + CT * k;               // 8 channels x 2 TY rows x 16 groups of four outputs
+        const int og = gid & 15, oy = (gid >> 4) % (2 * TY), ch = gid / (32 * TY);
+        const float* zb = Zs + ch * CHS + (oy + 1) * TC_ZP + 4 * og + 4;
+        float res[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const tc_f32x4 lo = *reinterpret_cast<const tc_f32x4*>(zb + a * TC_ZP);
+          const tc_f32x4 hi = *reinterpret_cast<const tc_f32x4*>(zb + a * TC_ZP + 4);
+          const float rowv[7] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2]};
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) res[q] += rowv[q + cc] * Kf[a * 4 + cc];
+        }
+        const int cg = 8 * pass + ch;
+        const int64_t pix = (int64_t)(2 * ty * TY + oy) * W2 + 2 * tx * TC_TX + 4 * og;
+        tc_f32x4 nz = {0.f, 0.f, 0.f, 0.f};
+        if (p.noise) nz = *reinterpret_cast<const tc_f32x4*>(p.noise + (int64_t)ib * hw2 + pix) * noise_wg;
+        const float sc = Sc[par][cg], bs = Bs[par][cg], post = Po[par][cg];
+        tc_f32x4 v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float u = res[q] * sc + nz[q] + bs;
+          v[q] = fmaxf(u, u * slope) * post;
+          ymax = fmaxf(ymax, fabsf(v[q]));
+        }
+        *reinterpret_cast<tc_f32x4*>(p.y + ((int64_t)ib * p.out_ch + 16 * ot + cg) * hw2 + pix) = v;
+      }
+    }
+  };
+
+  if (wave >= MW) {
+    // =========================== staging waves: channel quad g of every chunk ===========================
+    const int g = wave - MW, lid = g * 64 + lane;
+    const float xam = rw_bound_load(p.x_amax);
+    const int hw4 = (int)hw * 4;
+    int l_pos = 0, l_c = 0, l_ib = -1, l_ot = 0;
+    float in_scale = 1.f, out_scale = 1.f;
+    int xoff[SI];
+    __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, 0, 0x00020000);
+    tc_f32x4 raw[SI][4];                            // [piece][channel]: four pixels
+    tc_f32x4 wraw[3];                               // tap pieces g, g + 4 and (g == 0) 8 of the chunk's weights
+    float psv[4], sv[4];
+    float a_demod = 1.f, a_bias = 0.f, a_post = 1.f, a_oscale = 1.f, a_iscale = 1.f;
+    bool a_first = false;
+    int a_par = 0, l_s0 = 0;
+    const unsigned char* l_wsrc = p.wp;
+    auto setup = [&]() __attribute__((always_inline)) {            // the chunk to REQUEST: (l_pos, l_c); loads only, none used here
+      if (l_pos >= count) { l_pos = count - 1; l_c = NC - 1; }     // past the run: the last chunk again (never read)
+      a_first = l_c == 0;
+      if (l_c == 0) {
+        int tx, ty, ib;
+        decode(l_pos, l_ot, tx, ty, ib);
+        const int i0 = ty * TY, j0 = tx * TC_TX;
+        if (ib != l_ib) {
+          l_ib = ib;
+          float smax = p.style ? 0.f : 1.f;
+          if (p.style)
+            for (int i = lane; i < p.in_ch; i += 64) smax = fmaxf(smax, fabsf(p.style[(int64_t)ib * p.in_ch + i]));
+          smax = rw_wave_max(smax);
+          const float am = xam * smax;
+          int e = (int)((__float_as_uint(am) >> 23) & 0xff) - 126;      // am < 2^e
+          e = e < -100 ? -100 : (e > 100 ? 100 : e);
+          in_scale = __uint_as_float((unsigned)(127 + 14 - e) << 23);
+          out_scale = __uint_as_float((unsigned)(127 + e - 14) << 23) * p.u_inv;
+          xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (int64_t)ib * p.in_ch * hw), 0,
+                                                   (int)((int64_t)p.in_ch * hw * 4), 0x00020000);
+        }
+#pragma unroll
+        for (int s = 0; s < SI; ++s) {
+          const int it = 64 * s + lane;
+          const int r = it / IPR, j = it - r * IPR;
+          const int iy = i0 - 2 + r, ix = j0 - 4 + 4 * j;            // the item lies inside the row or outside it as a whole
+          const bool ok = it < NITEM && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
+          xoff[s] = ok ? (iy * p.w + ix) * 4 : 0x7ffffff0;
+        }
+        a_par = l_pos & 1;
+        a_oscale = out_scale;
+        if (lid < 16) {
+          const int o = 16 * l_ot + lid;
+          a_demod = p.demod ? p.demod[(int64_t)l_ib * p.out_ch + o] : 1.f;
+          a_bias = p.act ? p.bias[o] : 0.f;
+          a_post = p.post ? p.post[(int64_t)l_ib * p.out_ch + o] : 1.f;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) psv[k] = p.style ? p.style[(int64_t)l_ib * p.in_ch + 16 * l_c + 4 * g + k] : 1.f;
+      a_iscale = in_scale;
+      l_s0 = (16 * l_c + 4 * g) * hw4;
+      l_wsrc = p.wp + ((int64_t)l_ot * T + 9 * l_c) * 1024 + lane * 16;
+      if (++l_c == NC) { l_c = 0; ++l_pos; }
+    };
+    auto request_s = [&](int s) __attribute__((always_inline)) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        raw[s][k] = __builtin_bit_cast(tc_f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, xoff[s], l_s0 + k * hw4, 0));
+      if (s == 0) wraw[0] = *reinterpret_cast<const tc_f32x4*>(l_wsrc + g * 1024);
+      else {
+        wraw[1] = *reinterpret_cast<const tc_f32x4*>(l_wsrc + (g + 4) * 1024);
+        if (g == 0) wraw[2] = *reinterpret_cast<const tc_f32x4*>(l_wsrc + 8 * 1024);
+      }
+    };
+    // what setup() requested beside the pixels -> registers / LDS (the first wait of an interval)
+    auto tables = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) sv[k] = psv[k] * a_iscale;
+      if (a_first && lid < 16) {
+        Sc[a_par][lid] = a_demod * p.w_scale * a_oscale * gain;
+        Bs[a_par][lid] = a_bias * gain;
+        Po[a_par][lid] = a_post;
+      }
+    };
+    auto deliver_s = [&](int buf, int s) __attribute__((always_inline)) {
+      unsigned char* dst = Ls + buf * BUFB;
+      unsigned char* wdst = Wl + buf * TC_WCH + lane * 16;
+      if (s == 0) *reinterpret_cast<tc_f32x4*>(wdst + g * 1024) = wraw[0];
+      else {
+        *reinterpret_cast<tc_f32x4*>(wdst + (g + 4) * 1024) = wraw[1];
+        if (g == 0) *reinterpret_cast<tc_f32x4*>(wdst + 8 * 1024) = wraw[2];
+      }
+      const int it = 64 * s + lane;
+      const int r = it / IPR, j = it - r * IPR;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v0 = raw[s][0][e] * sv[0], v1 = raw[s][1][e] * sv[1], v2 = raw[s][2][e] * sv[2], v3 = raw[s][3][e] * sv[3];
+        const tc_f16x2 h01 = __builtin_convertvector(tc_f32x2{v0, v1}, tc_f16x2);
+        const tc_f16x2 h23 = __builtin_convertvector(tc_f32x2{v2, v3}, tc_f16x2);
+        float r0, r1, r2, r3;                        // v - (float)h, exact
+        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h01), "v"(v0));
+        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h01), "v"(v1));
+        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r2) : "v"(h23), "v"(v2));
+        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r3) : "v"(h23), "v"(v3));
+        const tc_f16x2 l01 = __builtin_convertvector(tc_f32x2{r0, r1}, tc_f16x2);
+        const tc_f16x2 l23 = __builtin_convertvector(tc_f32x2{r2, r3}, tc_f16x2);
+        const tc_f16x8 word = {h01[0], h01[1], h23[0], h23[1], l01[0], l01[1], l23[0], l23[1]};
+        const int cc = 4 * j - 2 + e;                // window column of this pixel
+        if (it < NITEM && cc >= 0 && cc < TC_WC)
+          *reinterpret_cast<tc_f16x8*>(dst + (r * TC_WC + cc) * 64 + ((g ^ tc_swz(cc)) << 4)) = word;
+      }
+    };
+
+    // chunk 0: requested and delivered; chunk 1: requested
+    setup();
+#pragma unroll
+    for (int s = 0; s < SI; ++s) request_s(s);
+    tables();
+    __builtin_amdgcn_sched_barrier(0);
+    setup();
+#pragma unroll
+    for (int s = 0; s < SI; ++s) { deliver_s(0, s); __builtin_amdgcn_sched_barrier(0); request_s(s); __builtin_amdgcn_sched_barrier(0); }
+    lds_barrier();
+    fir_setup();
+    int cn = 0, e_pos = 0;                          // the tile the multiplying waves are on (its epilogue is shared)
+    int e_ot, e_tx, e_ty, e_ib;
+    decode(e_pos, e_ot, e_tx, e_ty, e_ib);
+    TP_DECL(tp = 0, tp_all = 0, tp_setup = 0, tp_del = 0, tp_bar = 0, tp_blur = 0, tp_ebar = 0);
+    TP_NOW(tp); TP_NOW(tp_all);
+    for (int n = 0; n < N; ++n) {
+      // chunk n + 1 (in flight) -> LDS piece by piece, chunk n + 2 requested behind it (past the run: harmless repeats)
+      tables();
+      __builtin_amdgcn_sched_barrier(0);
+      // (the strip's noise BEFORE this interval's window requests: loads return in order, and the wait for the noise at the
+      // blur must leave the younger window loads in flight)
+      if (cn == NC - 1) noise_request(e_ty, e_tx, e_ib);
+      __builtin_amdgcn_sched_barrier(0);
+      setup();
+      TP_ADD(tp_setup, tp);
+#pragma unroll
+      for (int s = 0; s < SI; ++s) { deliver_s((n + 1) & 1, s); __builtin_amdgcn_sched_barrier(0); request_s(s); __builtin_amdgcn_sched_barrier(0); }
+      TP_ADD(tp_del, tp);
+      lds_barrier();
+      TP_ADD(tp_bar, tp);
+      if (++cn == NC) {                             // the tile's epilogue (the loads stay in flight)
+        cn = 0;
+        const int par = e_pos & 1;
+        blur(0, par, e_ot, e_tx, e_ty, e_ib);
+        TP_ADD(tp_blur, tp);
+        lds_barrier();                              // z is free: the multiplying waves write the other eight channels
+        lds_barrier();
+        TP_ADD(tp_ebar, tp);
+        blur(1, par, e_ot, e_tx, e_ty, e_ib);
+        TP_ADD(tp_blur, tp);
+        if (++e_pos < count) decode(e_pos, e_ot, e_tx, e_ty, e_ib);
+      }
+    }
+#if TC_PROF
+    if (wave == MW && lane == 0 && (blockIdx.x == 0 || blockIdx.x == 100)) {
+      unsigned long long* o = tc_prof + (blockIdx.x == 0 ? 0 : 16);
+      o[8] = (unsigned long long)clock64() - tp_all; o[9] = tp_setup; o[10] = tp_del; o[11] = tp_bar; o[12] = tp_blur; o[13] = tp_ebar; o[14] = N;
+    }
+#endif
+    if (p.y_amax) rw_bound_store_wave(p.y_amax, rw_wave_max(ymax));
+    return;
+  }
+
+  // =========================== multiplying waves ===========================
+  const int lk = lane >> 4, lt = lane & 15;
+  unsigned pb0[BPW], pb1[BPW];                     // operand addresses as in tconv_body
+#pragma unroll
+  for (int b = 0; b < BPW; ++b) {
+    int q = 16 * (wave + MW * b) + lt;
+    q = q < NPOS ? q : NPOS - 1;
+    const int r = q / TC_PC, c = q - r * TC_PC;
+    pb0[b] = (unsigned)(((r + 1) * TC_WC + c + 1) * 64 + ((lk ^ tc_swz(c + 1)) << 4));
+    pb1[b] = (unsigned)(((r + 1) * TC_WC + c) * 64 + ((lk ^ tc_swz(c)) << 4));
+  }
+  tc_f32x4 acc[BPW][4];
+#pragma unroll
+  for (int b = 0; b < BPW; ++b)
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) acc[b][ph] = tc_f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int LB = BPW - 1;
+  const bool last_ok = wave + MW * LB < NBLK;       // wave-uniform: only the last block of a wave can be missing
+  // one chunk: the three tap groups of tconv_body's chunk()
+  auto mma = [&](const unsigned char* lb, const unsigned char* wb) __attribute__((always_inline)) {
+    {
+      const tc_f16x8 u0 = TC_UH(0), u1 = TC_UH(1), u3 = TC_UH(3), u4 = TC_UH(4), l4 = tc_expand(TC_UL(4));
+      tc_f16x8 pc = TC_PIX(pb0[0]);
+#pragma unroll
+      for (int b = 0; b < BPW; ++b) {
+        tc_f16x8 pn = pc;
+        if (b + 1 < BPW) pn = TC_PIX(pb0[b + 1]);
+        if (b < LB || last_ok) {
+          TC_MFMA(3, pc, u4); TC_MFMA(0, pc, u0); TC_MFMA(1, pc, u1); TC_MFMA(2, pc, u3);
+          TC_MFMA(3, pc, l4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        pc = pn;
+      }
+    }
+    {
+      const tc_f16x8 u2 = TC_UH(2), u5 = TC_UH(5), m02 = tc_pair(TC_UL(0), TC_UL(2)), m35 = tc_pair(TC_UL(3), TC_UL(5));
+      tc_f32x2 hc = TC_VH(pb0[0]);
+      tc_f16x8 qc = TC_PIX(pb1[0]);
+#pragma unroll
+      for (int b = 0; b < BPW; ++b) {
+        tc_f32x2 hn = hc;
+        tc_f16x8 qn = qc;
+        if (b + 1 < BPW) { hn = TC_VH(pb0[b + 1]); qn = TC_PIX(pb1[b + 1]); }
+        if (b < LB || last_ok) {
+          const tc_f16x8 M = tc_pair_hq(hc, qc);
+          TC_MFMA(0, qc, u2); TC_MFMA(2, qc, u5);
+          TC_MFMA(0, M, m02); TC_MFMA(2, M, m35);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        hc = hn; qc = qn;
+      }
+    }
+    {
+      const tc_f16x8 u6 = TC_UH(6), u7 = TC_UH(7), u8 = TC_UH(8), m17 = tc_pair(TC_UL(1), TC_UL(7)),
+                     m68 = tc_pair(TC_UL(6), TC_UL(8));
+      tc_f32x2 hc = TC_VH(pb0[0]);
+      tc_f16x8 qc = TC_PIX(pb0[0] - TC_WC * 64), rc = TC_PIX(pb1[0] - TC_WC * 64);
+#pragma unroll
+      for (int b = 0; b < BPW; ++b) {
+        tc_f32x2 hn = hc;
+        tc_f16x8 qn = qc, rn = rc;
+        if (b + 1 < BPW) { hn = TC_VH(pb0[b + 1]); qn = TC_PIX(pb0[b + 1] - TC_WC * 64); rn = TC_PIX(pb1[b + 1] - TC_WC * 64); }
+        if (b < LB || last_ok) {
+          const tc_f16x8 M02 = tc_pair_hq(hc, qc), M23 = tc_pair(qc, rc);
+          TC_MFMA(0, qc, u6); TC_MFMA(1, qc, u7);
+          TC_MFMA(0, rc, u8); TC_MFMA(1, M02, m17);
+          TC_MFMA(0, M23, m68);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        hc = hn; qc = qn; rc = rn;
+      }
+    }
+  };
+  // eight of the sixteen channels -> the z tile (lanes lt >> 3 == pass hold them)
+  auto zwrite = [&](int pass) __attribute__((always_inline)) {
+    if ((lt >> 3) == pass) {
+      // (the addresses are loop invariants: left to itself the compiler keeps all of them in registers for the whole run;
+      // an opaque zero keeps their three instructions each inside the loop)
+      int opaque;
+      asm volatile("v_mov_b32 %0, 0" : "=v"(opaque));
+      float* zc = Zs + (lt & 7) * CHS;
+#pragma unroll
+      for (int b = 0; b < BPW; ++b) {
+        if (wave + MW * b >= NBLK) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int q = 16 * (wave + MW * b) + 4 * lk + j + opaque;
+          if (q < NPOS) {
+            const int r = (q * 1928) >> 16, cq = q - r * TC_PC;        // q / 34 for q < 340
+            float* zp = zc + (2 * r) * TC_ZP + 2 * cq + 3;
+            zp[0] = acc[b][0][j];
+            zp[1] = acc[b][1][j];
+            zp[TC_ZP] = acc[b][2][j];
+            zp[TC_ZP + 1] = acc[b][3][j];
+          }
+        }
+      }
+    }
+  };
+
+  int pos = 0, c = 0;
+  int ot, tx, ty, ib;
+  decode(pos, ot, tx, ty, ib);
+  lds_barrier();                                    // chunk 0 and the FIR are in LDS
+  fir_setup();
+  TP_DECL(tp = 0, tp_all = 0, tp_mma = 0, tp_bar = 0, tp_zw = 0, tp_blur = 0, tp_ebar = 0);
+  TP_NOW(tp); TP_NOW(tp_all);
+  for (int n = 0; n < N; ++n) {
+    const unsigned char* lb = Ls + (n & 1) * BUFB;
+    const unsigned char* wb = Wl + (n & 1) * TC_WCH + lane * 8;
+    if (c == NC - 1) noise_request(ty, tx, ib);
+    mma(lb, wb);
+    TP_ADD(tp_mma, tp);
+    if (c + 1 < NC) { ++c; lds_barrier(); TP_ADD(tp_bar, tp); continue; }
+    // ---- epilogue of the tile, eight channels at a time
+    c = 0;
+    const int par = pos & 1;
+    zwrite(0);
+    TP_ADD(tp_zw, tp);
+    lds_barrier();                                  // (the barrier of the tile's last chunk)
+    TP_ADD(tp_bar, tp);
+    blur(0, par, ot, tx, ty, ib);
+    TP_ADD(tp_blur, tp);
+    lds_barrier();                                  // every strip of the first eight channels is read: z is free again
+    TP_ADD(tp_ebar, tp);
+    zwrite(1);
+    TP_ADD(tp_zw, tp);
+    lds_barrier();
+    TP_ADD(tp_ebar, tp);
+    blur(1, par, ot, tx, ty, ib);
+    TP_ADD(tp_blur, tp);
+#pragma unroll
+    for (int b = 0; b < BPW; ++b)
+#pragma unroll
+      for (int ph = 0; ph < 4; ++ph) acc[b][ph] = tc_f32x4{0.f, 0.f, 0.f, 0.f};
+    if (++pos < count) decode(pos, ot, tx, ty, ib);
+  }
+#if TC_PROF
+  if (wave == 0 && lane == 0 && (blockIdx.x == 0 || blockIdx.x == 100)) {
+    unsigned long long* o = tc_prof + (blockIdx.x == 0 ? 0 : 16);
+    o[0] = (unsigned long long)clock64() - tp_all; o[1] = tp_mma; o[2] = tp_bar; o[3] = tp_zw; o[4] = tp_blur; o[5] = tp_ebar; o[6] = N;
+  }
+#endif
+  if (p.y_amax) rw_bound_store_wave(p.y_amax, rw_wave_max(ymax));
+}
 
 static bool tconv_shape_ok(int out_ch, int in_ch, int h, int w) {
   return out_ch > 0 && out_ch % 16 == 0 && in_ch >= 16 && in_ch % 16 == 0 && in_ch <= 512 && w % TC_TX == 0 && h % 16 == 0;
@@ -517,14 +1022,32 @@ extern "C" int rw_tconv_blur_f32(const float* x, const float* wp, const float* k
   p.post = post_scale;
   p.batch = batch; p.in_ch = in_ch; p.out_ch = out_ch; p.h = h; p.w = w; p.w_scale = w_scale; p.u_inv = u_inv;
   p.x_amax = x_amax; p.y_amax = y_amax;
-  const char* e = getenv("RW_TCONV_TY");            // 8 (default): two 4-wave workgroups per CU; 16: one 8-wave workgroup
-  const int ty = e && atoi(e) == 16 ? 16 : 8;
-  const int waves = ty == 16 ? 8 : 4;
+  // RW_TCONV_TY = 8 (default): two 4-wave workgroups per CU; 16: one 8-wave workgroup; 88 / 1616: the 8- / 16-wave forms
+  // of the two tiles (four waves per SIMD)
+  const char* e = getenv("RW_TCONV_TY");
+  const int sel = e ? atoi(e) : 8;
+  if (sel == 0 && in_ch >= 32) {                    // 0: the specialised persistent kernel (one workgroup of eight waves per CU)
+    p.tiles_x = w / TC_TX; p.tiles_y = h / 8; p.o_tiles = out_ch / 16;
+    const int64_t tiles = (int64_t)batch * p.tiles_y * p.tiles_x * p.o_tiles;
+    if (tiles <= 0 || tiles > 0x7fffffff) return RW_ERR_UNSUPPORTED;
+    const char* ge = getenv("RW_TCONV_GRID");
+    int64_t grid = ge ? atoi(ge) : 256;
+    grid = grid < 1 ? 1 : (grid > tiles ? tiles : grid);
+    if (y_amax && 8 * grid > rw_bound_slot_capacity((int64_t)batch * out_ch * 4 * h * w)) return RW_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(tconv_blur_ws_kernel, dim3((unsigned)grid), dim3(512), 0, rw_s(stream), p);
+    const int rc = RW_LAUNCH_RESULT();
+    if (rc || !y_amax) return rc;
+    return rw_bound_finish(y_amax, 8 * grid, rw_s(stream));
+  }
+  const int ty = (sel == 16 || sel == 1616) ? 16 : 8;
+  const int waves = sel == 1616 ? 16 : (sel == 16 || sel == 88) ? 8 : 4;
   p.tiles_x = w / TC_TX; p.tiles_y = h / ty; p.o_tiles = out_ch / 16;
   const int64_t work = (int64_t)batch * p.tiles_y * p.tiles_x * p.o_tiles;
   if (work <= 0 || work > 0x7fffffff) return RW_ERR_UNSUPPORTED;
   if (y_amax && waves * work > rw_bound_slot_capacity((int64_t)batch * out_ch * 4 * h * w)) return RW_ERR_UNSUPPORTED;
-  if (ty == 16) hipLaunchKernelGGL(tconv_blur_t16_kernel, dim3((unsigned)work), dim3(512), 0, rw_s(stream), p);
+  if (sel == 1616) hipLaunchKernelGGL(tconv_blur_t16w16_kernel, dim3((unsigned)work), dim3(1024), 0, rw_s(stream), p);
+  else if (sel == 88) hipLaunchKernelGGL(tconv_blur_t8w8_kernel, dim3((unsigned)work), dim3(512), 0, rw_s(stream), p);
+  else if (ty == 16) hipLaunchKernelGGL(tconv_blur_t16_kernel, dim3((unsigned)work), dim3(512), 0, rw_s(stream), p);
   else hipLaunchKernelGGL(tconv_blur_t8_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
   const int rc = RW_LAUNCH_RESULT();
   if (rc || !y_amax) return rc;

@@ -1,0 +1,51 @@
+"""Cycle counts from inside the specialised persistent kernel of rw_tconv.hip (library built with -DTC_PROF=1, RW_HIP_LIB):
+where the multiplying wave 0 and the staging wave 4 of workgroups 0 and 100 spend their time.  RW_LAYERS picks the layers."""
+import ctypes, json, math, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ['RW_TCONV_TY'] = '0'
+from rewriting_amd import hip, _lib  # noqa: E402
+DEV = 'cuda:0'
+batch = int(os.environ.get('RW_BATCH', '64'))
+layers = dict(layer9=(512, 512, 32), layer11=(512, 256, 64), layer13=(256, 128, 128), layer15=(128, 64, 256), layer17=(64, 32, 512))
+lib = _lib.load()
+lib.rw_tconv_prof.argtypes = [ctypes.c_void_p]
+lib.rw_tconv_prof.restype = ctypes.c_int
+for name in os.environ.get('RW_LAYERS', 'layer17,layer13').split(','):
+    cin, cout, res = layers[name]
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(batch, cin, res, res, device=DEV)
+    wt = torch.randn(1, cout, cin, 3, 3, generator=g).to(DEV)
+    style = (1 + 0.3 * torch.randn(batch, cin, generator=g)).to(DEV)
+    s = 1 / math.sqrt(cin * 9)
+    dm = hip.demod(hip.weight_sqsum(wt, s), style)
+    bias = torch.randn(cout, generator=g).to(DEV)
+    noise = torch.randn(batch, 1, 2 * res, 2 * res, device=DEV)
+    nw = torch.tensor([0.1], device=DEV)
+    k1 = torch.tensor([1., 3., 3., 1.])
+    k4 = (k1[:, None] * k1[None, :])
+    k4 = (k4 / k4.sum() * 4).to(DEV)
+    pk = hip.pack_conv_weight_direct16(wt)
+    amax = hip.absmax(x)
+    ymax = hip.new_bound(batch * cout * 4 * res * res, DEV)
+    args = dict(style=style, demod=dm, noise=noise, noise_w=nw, bias=bias, act=True, x_amax=amax, y_amax=ymax)
+    for _ in range(3):
+        hip.conv_transpose3x3s2_blur_fused(x, pk, k4, cout, s, **args)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(5):
+        hip.conv_transpose3x3s2_blur_fused(x, pk, k4, cout, s, **args)
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / 5
+    buf = (ctypes.c_ulonglong * 32)()
+    assert lib.rw_tconv_prof(buf) == 0
+    for wg, o in ((0, 0), (100, 16)):
+        v = list(buf[o:o + 16])
+        print(json.dumps(dict(layer=name, ms=round(ms, 3), wg=wg,
+                              mfma_wave=dict(total=v[0], mma=v[1], chunk_barrier=v[2], zwrite=v[3], blur=v[4], epilogue_barriers=v[5], chunks=v[6]),
+                              staging_wave=dict(total=v[8], setup=v[9], deliver_request=v[10], barrier=v[11], blur=v[12], epilogue_barriers=v[13], chunks=v[14]))),
+              flush=True)
+    del x, noise
+    torch.cuda.empty_cache()

@@ -969,6 +969,11 @@ def test_direct16_one_pass_upsampling_conv_matches_conv_then_blur(case, ver, mon
         scale = want.abs().max().item()
         assert (got - want).abs().max().item() < 2e-5 * scale, (got - want).abs().max().item() / scale
         assert rel(got, want) < 3e-6, rel(got, want)
+        if form == 'specialised-persistent':
+            monkeypatch.setenv('RW_TCONV_GRID', '5')
+            again = hip.conv_transpose3x3s2_blur_fused(x.to(DEV), pk, k4, o, s, style=style.to(DEV), demod=dm, **kw)
+            monkeypatch.delenv('RW_TCONV_GRID')
+            assert torch.equal(again, got)
         results.append((kw, got.cpu()))
     assert b * i * o * h * w <= 2 ** 29
     key = style[:, :, None, None] * x
@@ -1064,16 +1069,23 @@ TCONV_CASES = [(1, 16, 16, 16, 32), (2, 64, 32, 16, 64), (1, 32, 16, 32, 32), (1
                (1, 512, 32, 16, 32), (2, 256, 128, 32, 32), (1, 64, 32, 512, 512)]
 
 
+TCONV_FORMS = {'two-workgroups-per-cu': '8', 'one-workgroup-per-cu': '16', 'specialised-persistent': '0'}
+
+
+@pytest.mark.parametrize('form', sorted(TCONV_FORMS))
 @pytest.mark.parametrize('case', TCONV_CASES)
-def test_fused_transposed_conv_and_blur_matches_conv_then_blur(case):
+def test_fused_transposed_conv_and_blur_matches_conv_then_blur(case, form, monkeypatch):
     """hip.conv_transpose3x3s2_blur_fused (rw_tconv.hip: the transposed convolution as a direct sum on the 16-bit matrix
     pipe at its own multiply count, its (2H+1)^2 result in LDS, the blur from there, noise + bias + leaky ReLU + post
     scale in the epilogue) against the two-pass route of the same library (direct fp32 transposed conv -> blur_noise_act)
     and the oracle (utils/stylegan2/models.py:313-316,275-281 through oracle/restatement.py), at the direct kernels'
-    bars; image borders, tile borders (h, w beyond one 16 x 32 tile), 16 .. 512 input channels, a loose bound."""
+    bars; image borders, tile borders (h, w beyond one 16 x 32 tile), 16 .. 512 input channels, a loose bound -- in the
+    kernel's three forms (RW_TCONV_TY: two 4-wave workgroups per CU, one 8-wave workgroup, the specialised persistent one;
+    that one also with a grid of five workgroups: runs of many tiles that cross images, bit-identical to the full grid)."""
     from rewriting_amd import hip
     from oracle import restatement as R
     b, i, o, h, w = case
+    monkeypatch.setenv('RW_TCONV_TY', TCONV_FORMS[form])
     assert hip.tconv_blur_supported(o, i, h, w)
     x, wt, style = _conv_inputs(*case, seed=171)
     rs = numpy.random.RandomState(172)
@@ -1102,6 +1114,11 @@ def test_fused_transposed_conv_and_blur_matches_conv_then_blur(case):
         scale = want.abs().max().item()
         assert (got - want).abs().max().item() < 2e-5 * scale, (got - want).abs().max().item() / scale
         assert rel(got, want) < 3e-6, rel(got, want)
+        if form == 'specialised-persistent':
+            monkeypatch.setenv('RW_TCONV_GRID', '5')
+            again = hip.conv_transpose3x3s2_blur_fused(x.to(DEV), pk, k4, o, s, style=style.to(DEV), demod=dm, **kw)
+            monkeypatch.delenv('RW_TCONV_GRID')
+            assert torch.equal(again, got)
         results.append((kw, got.cpu()))
     loose = hip.conv_transpose3x3s2_blur_fused(x.to(DEV), pk, k4, o, s, style=style.to(DEV), demod=dm,
                                                x_amax=hip.absmax(x.to(DEV)) * 37.0)
@@ -1113,3 +1130,30 @@ def test_fused_transposed_conv_and_blur_matches_conv_then_blur(case):
         ref = R.fused_leaky_relu(blur + nw.cpu() * noise.cpu(), bias.cpu()) if kw else blur
         assert rel(got, ref) < 5e-6, rel(got, ref)
         assert (got - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize('form', sorted(TCONV_FORMS))
+def test_fused_transposed_conv_and_blur_with_a_fir_that_is_no_outer_product(form, monkeypatch):
+    """The reference's FIR is always make_kernel([1, 3, 3, 1]) (an outer product: the strip walk); any other 4 x 4 kernel
+    takes the 16-tap form of the epilogue.  Against blur_noise_act on the direct fp32 transposed convolution."""
+    from rewriting_amd import hip
+    monkeypatch.setenv('RW_TCONV_TY', TCONV_FORMS[form])
+    b, i, o, h, w = 2, 64, 32, 16, 64
+    x, wt, style = _conv_inputs(b, i, o, h, w, seed=181)
+    rs = numpy.random.RandomState(182)
+    s = 1 / math.sqrt(i * 9)
+    k4 = torch.from_numpy((0.25 + 0.1 * rs.randn(4, 4)).astype('float32')).to(DEV)
+    noise = torch.from_numpy(rs.randn(b, 1, 2 * h, 2 * w).astype('float32')).to(DEV)
+    nw = torch.tensor([0.21], device=DEV)
+    bias = torch.from_numpy(rs.randn(o).astype('float32')).to(DEV)
+    dm = hip.demod(hip.weight_sqsum(wt.to(DEV), s), style.to(DEV))
+    wide = hip.conv_transpose3x3s2(x.to(DEV), hip.pack_conv_weight(wt.to(DEV), 1), o, s, style=style.to(DEV), demod=dm, impl=0)
+    want = hip.blur_noise_act(wide, k4, noise, nw, bias)
+    got = hip.conv_transpose3x3s2_blur_fused(x.to(DEV), hip.pack_conv_weight_direct16(wt.to(DEV)), k4, o, s,
+                                             style=style.to(DEV), demod=dm, noise=noise, noise_w=nw, bias=bias, act=True)
+    assert (got - want).abs().max().item() < 2e-5 * want.abs().max().item()
+    assert rel(got, want) < 3e-6, rel(got, want)
+    from oracle import restatement as R
+    ref = R.upfirdn2d(R.demod_conv(style[:, :, None, None] * x, style, wt, upsample=True), k4.cpu(), pad=(1, 1))
+    ref = R.fused_leaky_relu(ref + nw.cpu() * noise.cpu(), bias.cpu())
+    assert rel(got.cpu(), ref) < 5e-6, rel(got.cpu(), ref)
