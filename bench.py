@@ -104,7 +104,22 @@ class ConvTimer:
                       hip.conv3x3_wino, hip.conv3x3_wino_to_rgb, hip.conv3x3_wino4, hip.conv_transpose3x3s2_wino,
                       hip.conv_transpose3x3s2_blur_wino4, hip.conv3x3_wino4_to_rgb,
                       hip.conv3x3_direct16, hip.conv_transpose3x3s2_blur_direct16, hip.conv3x3_direct16_to_rgb)
+        self._orig_fused = hip.conv_transpose3x3s2_blur_fused
         timer = self
+
+        def fused(x, wp, k4, out_ch, w_scale, *a, **k):
+            # csrc/rw_tconv.hip: the launcher's form by input channels (RW_TCONV_TY overrides)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            y = timer._orig_fused(x, wp, k4, out_ch, w_scale, *a, **k)
+            e.record()
+            b, i, h, w = x.shape
+            form = os.environ.get('RW_TCONV_TY') or ('0' if 32 <= i <= 128 else '16')
+            name = {'0': 'tconv_blur_ws_kernel' if i >= 32 else 'tconv_blur_t8_kernel',
+                    '16': 'tconv_blur_t16_kernel'}.get(form, 'tconv_blur_t8_kernel')
+            timer.calls.append((name, s, e, 2.0 * 9 * i * out_ch * h * w * b, 4.0 * (b * i * h * w + b * out_ch * 4 * h * w)))
+            return y
+        hip.conv_transpose3x3s2_blur_fused = fused
 
         def wrap(fn, upsample, split=False, wino=None):
             def inner(x, wp, out_ch, w_scale, *a, **k):
@@ -191,6 +206,7 @@ class ConvTimer:
          hip.conv3x3_wino_to_rgb, hip.conv3x3_wino4, hip.conv_transpose3x3s2_wino,
          hip.conv_transpose3x3s2_blur_wino4, hip.conv3x3_wino4_to_rgb, hip.conv3x3_direct16,
          hip.conv_transpose3x3s2_blur_direct16, hip.conv3x3_direct16_to_rgb) = self._orig
+        hip.conv_transpose3x3s2_blur_fused = self._orig_fused
 
     def result(self):
         per = {}
@@ -265,8 +281,10 @@ def issued_fraction(kernel):
     if kernel.startswith('dconv'):
         return (4.0 * 5 / 6, 'direct sum, 3.33 f16 piece products issued per multiply') + f16d
     if kernel.startswith('tconv_blur'):
-        return (14.0 / 18.0 * 4 * 1.2, 'transposed conv as a direct sum at its own multiply count (14 of 18 MFMA-halves: three '
-                'piece products, x 1.2 halo positions), blur from LDS') + f16d
+        halo = 18.0 * 34 / (16 * 32) if 't16' in kernel else 10.0 * 34 / (8 * 32)     # positions computed / positions kept
+        return (14.0 / 18.0 * 4 * halo, 'transposed conv as a direct sum at its own multiply count (14 MFMAs per block and '
+                'chunk where four piece products take 18; x %.2f halo positions), its (2H+1)^2 map in LDS, blur from there'
+                % halo) + f16d
     if kernel.startswith('conv_up_wino36h'):
         return (4.0, 'transposed conv (*) blur as four F(4x4,3x3) phase convolutions: the transposed conv\'s direct-sum '
                 'multiply count, each as 4 f16 piece products') + f16

@@ -497,10 +497,8 @@ __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
 
 __global__ void __launch_bounds__(256, 2) tconv_blur_t8_kernel(const TconvProblem p) { tconv_body<8, 4>(p); }
 __global__ void __launch_bounds__(512, 1) tconv_blur_t16_kernel(const TconvProblem p) { tconv_body<16, 8>(p); }
-// four waves per SIMD (128 registers, three position blocks per wave, strips of four output rows): two 8-wave workgroups
-// of the small tile per CU / one 16-wave workgroup of the large one
-__global__ void __launch_bounds__(512, 4) tconv_blur_t8w8_kernel(const TconvProblem p) { tconv_body<8, 8>(p); }
-__global__ void __launch_bounds__(1024, 4) tconv_blur_t16w16_kernel(const TconvProblem p) { tconv_body<16, 16>(p); }
+// (four waves per SIMD -- <8, 8> twice per CU, <16, 16> once -- do not fit: 128 registers against 48 accumulators + ~125
+// for the operands and the epilogue, 120 - 150 spilled)
 
 // ---------------------------------------------------------------------------------------
 // Third form: the waves of a workgroup SPECIALISE and the workgroup is PERSISTENT (rw_dconv.hip's dconv_ws_body, applied to
@@ -542,13 +540,16 @@ __global__ void __launch_bounds__(512, 2) tconv_blur_ws_kernel(const TconvProble
   constexpr int PR = TY + 2, NPOS = PR * TC_PC, NBLK = (NPOS + 15) / 16, BPW = (NBLK + MW - 1) / MW;
   constexpr int WR = TY + 3, NPIX = WR * TC_WC, BUFB = NPIX * 64;
   constexpr int IPR = TC_TX / 4 + 2, NITEM = WR * IPR, SI = (NITEM + 63) / 64;   // items: window columns 4 j - 2 .. 4 j + 1
-  constexpr int ZR = 2 * PR, CHS = ZR * TC_ZP + 4;
+  // z tile: rows 0 .. 2 PR - 1 + two spare rows (the last position block runs 12 positions past the window: written, never
+  // read -- no per-position test in the write loop); position column c owns z columns 2 c + 4, 2 c + 5 (8-byte aligned
+  // pairs; the blur reads the aligned 16-byte pieces 4 og + 4 .. 4 og + 11 and uses seven of them)
+  constexpr int ZR = 2 * PR + 2, CHS = ZR * TC_ZP + 4;
   constexpr int SR = 4, CT = 512;                   // output rows of a strip; threads of the blur (all)
   static_assert(SI == 2 && BPW == 6 && SR * (CT / 128) == 2 * TY, "piece / block / strip counts the code below is written for");
   __shared__ __attribute__((aligned(16))) unsigned char Ls[2 * BUFB];
   __shared__ __attribute__((aligned(16))) unsigned char Wl[2 * TC_WCH];
   __shared__ __attribute__((aligned(16))) float Zs[8 * CHS];
-  __shared__ float Sc[2][16], Bs[2][16], Po[2][16], Kf[16];
+  __shared__ float Sc[2][16], Bs[2][16], Po[2][16], Kf[16], Ks[12];   // Ks: kh[4], kv[4], [8] = 1 when the FIR is kv x kh
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -565,13 +566,28 @@ __global__ void __launch_bounds__(512, 2) tconv_blur_ws_kernel(const TconvProble
     return;
   }
   const int N = count * NC;                         // chunks of the run
-  auto decode = [&](int pos, int& ot, int& tx, int& ty, int& ib) __attribute__((always_inline)) {
-    const int64_t tile = (int64_t)pos * gridDim.x + bx;
-    ot = (int)(tile % p.o_tiles);
-    int64_t pg = tile / p.o_tiles;
-    tx = (int)(pg % p.tiles_x); pg /= p.tiles_x;
-    ty = (int)(pg % p.tiles_y);
-    ib = (int)(pg / p.tiles_y);
+  // tile coordinates: (ot, tx, ty, ib) of tile bx once, then + the grid's digits per step (64-bit divisions per tile cost the
+  // staging waves 1.7 k cycles per chunk on layer 17: profiles/r05p)
+  auto digits = [&](unsigned tile, int& ot, int& tx, int& ty, int& ib) __attribute__((always_inline)) {
+    ot = (int)(tile % (unsigned)p.o_tiles);
+    unsigned pg = tile / (unsigned)p.o_tiles;
+    tx = (int)(pg % (unsigned)p.tiles_x); pg /= (unsigned)p.tiles_x;
+    ty = (int)(pg % (unsigned)p.tiles_y);
+    ib = (int)(pg / (unsigned)p.tiles_y);
+  };
+  int g_ot, g_tx, g_ty, g_ib;
+  digits(gridDim.x, g_ot, g_tx, g_ty, g_ib);
+  auto advance = [&](int& ot, int& tx, int& ty, int& ib) __attribute__((always_inline)) {
+    ot += g_ot;
+    int carry = ot >= p.o_tiles ? 1 : 0;
+    ot -= carry ? p.o_tiles : 0;
+    tx += g_tx + carry;
+    carry = tx >= p.tiles_x ? 1 : 0;
+    tx -= carry ? p.tiles_x : 0;
+    ty += g_ty + carry;
+    carry = ty >= p.tiles_y ? 1 : 0;
+    ty -= carry ? p.tiles_y : 0;
+    ib += g_ib + carry;
   };
   auto lds_barrier = [&]() __attribute__((always_inline)) {
     asm volatile("" ::: "memory");
@@ -590,26 +606,29 @@ __global__ void __launch_bounds__(512, 2) tconv_blur_ws_kernel(const TconvProble
   const int64_t hw2 = 4 * hw;
   const int strip = tid & 127, seg = tid >> 7;
   const int s_og = strip & 15, s_ch = strip >> 4, s_oy0 = SR * seg;
-  float kh[4] = {0.f, 0.f, 0.f, 0.f}, kv[4] = {0.f, 0.f, 0.f, 0.f};
-  bool sep = false;
   tc_f32x4 nzr[SR];
 #pragma unroll
   for (int oy = 0; oy < SR; ++oy) nzr[oy] = tc_f32x4{0.f, 0.f, 0.f, 0.f};
   float ymax = 0.f;
-  // is the FIR an outer product kv x kh?  (tconv_body; only kh and kv stay in registers, the 16-tap form reads Kf)
+  // is the FIR an outer product kv x kh?  (tconv_body; kh, kv and the answer live in LDS: every register counts beside the
+  // multiplying waves' accumulators and operands.)  Thread 0 decides, before the first barrier.
   auto fir_setup = [&]() __attribute__((always_inline)) {
-    float kf[16], kmax = 0.f;
+    if (tid == 0) {
+      float kf[16], kvv[4], kmax = 0.f;
 #pragma unroll
-    for (int t = 0; t < 16; ++t) { kf[t] = Kf[t]; kmax = fmaxf(kmax, fabsf(kf[t])); }
-    sep = kf[0] != 0.f;
+      for (int t = 0; t < 16; ++t) { kf[t] = p.k4[(3 - (t >> 2)) * 4 + (3 - (t & 3))]; kmax = fmaxf(kmax, fabsf(kf[t])); }
+      bool ok = kf[0] != 0.f;
 #pragma unroll
-    for (int a = 0; a < 4; ++a) { kv[a] = sep ? kf[4 * a] / kf[0] : 0.f; kh[a] = kf[a]; }
+      for (int a = 0; a < 4; ++a) { kvv[a] = ok ? kf[4 * a] / kf[0] : 0.f; Ks[a] = kf[a]; Ks[4 + a] = kvv[a]; }
 #pragma unroll
-    for (int t = 0; t < 16; ++t) sep = sep && fabsf(kf[t] - kv[t >> 2] * kf[t & 3]) <= 1e-6f * kmax;
+      for (int t = 0; t < 16; ++t) ok = ok && fabsf(kf[t] - kvv[t >> 2] * kf[t & 3]) <= 1e-6f * kmax;
+      Ks[8] = ok ? 1.f : 0.f;
+    }
   };
+  fir_setup();
   // the strip's noise (the same in both passes), requested a chunk of MFMAs before the epilogue
   auto noise_request = [&](int ty, int tx, int ib) __attribute__((always_inline)) {
-    if (sep && p.noise) {
+    if (Ks[8] != 0.f && p.noise) {
       const int64_t s_pix = (int64_t)(2 * ty * TY + s_oy0) * W2 + 2 * tx * TC_TX + 4 * s_og;
 #pragma unroll
       for (int oy = 0; oy < SR; ++oy)
@@ -617,7 +636,8 @@ __global__ void __launch_bounds__(512, 2) tconv_blur_ws_kernel(const TconvProble
     }
   };
   auto blur = [&](int pass, int par, int ot, int tx, int ty, int ib) __attribute__((always_inline)) {
-    if (sep) {
+    if (Ks[8] != 0.f) {
+      const float kh[4] = {Ks[0], Ks[1], Ks[2], Ks[3]}, kv[4] = {Ks[4], Ks[5], Ks[6], Ks[7]};
       const int cl = 8 * pass + s_ch;               // channel within the workgroup's 16
       const int64_t s_pix = (int64_t)(2 * ty * TY + s_oy0) * W2 + 2 * tx * TC_TX + 4 * s_og;
       const float* zb = Zs + s_ch * CHS + (s_oy0 + 1) * TC_ZP + 4 * s_og + 4;
@@ -632,10 +652,10 @@ __global__ void __launch_bounds__(512, 2) tconv_blur_ws_kernel(const TconvProble
           lon = *reinterpret_cast<const tc_f32x4*>(zb + (zr + 1) * TC_ZP);
           hin = *reinterpret_cast<const tc_f32x4*>(zb + (zr + 1) * TC_ZP + 4);
         }
-        tc_f32x4 hsum = lo * kh[0];
-        hsum += tc_f32x4{lo[1], lo[2], lo[3], hi[0]} * kh[1];
-        hsum += tc_f32x4{lo[2], lo[3], hi[0], hi[1]} * kh[2];
-        hsum += tc_f32x4{lo[3], hi[0], hi[1], hi[2]} * kh[3];
+        tc_f32x4 hsum = tc_f32x4{lo[1], lo[2], lo[3], hi[0]} * kh[0];
+        hsum += tc_f32x4{lo[2], lo[3], hi[0], hi[1]} * kh[1];
+        hsum += tc_f32x4{lo[3], hi[0], hi[1], hi[2]} * kh[2];
+        hsum += hi * kh[3];
         hrow[zr & 3] = hsum;
         if (zr >= 3) {
           const int oy = zr - 3;                    // output row oy0 + oy: filtered rows zr - 3 .. zr
@@ -667,7 +687,7 @@ __global__ void __launch_bounds__(512, 2) tconv_blur_ws_kernel(const TconvProble
         for (int a = 0; a < 4; ++a) {
           const tc_f32x4 lo = *reinterpret_cast<const tc_f32x4*>(zb + a * TC_ZP);
           const tc_f32x4 hi = *reinterpret_cast<const tc_f32x4*>(zb + a * TC_ZP + 4);
-          const float rowv[7] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2]};
+          const float rowv[7] = {lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
           for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -695,7 +715,9 @@ __global__ void __launch_bounds__(512, 2) tconv_blur_ws_kernel(const TconvProble
     const int g = wave - MW, lid = g * 64 + lane;
     const float xam = rw_bound_load(p.x_amax);
     const int hw4 = (int)hw * 4;
-    int l_pos = 0, l_c = 0, l_ib = -1, l_ot = 0;
+    int l_pos = 0, l_c = 0, l_ib = -1, l_ot, l_tx, l_ty, l_ibn;       // (l_ot, l_tx, l_ty, l_ibn): the tile being requested
+    bool l_past = false;
+    digits((unsigned)bx, l_ot, l_tx, l_ty, l_ibn);
     float in_scale = 1.f, out_scale = 1.f;
     int xoff[SI];
     __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, 0, 0x00020000);
@@ -707,12 +729,10 @@ __global__ void __launch_bounds__(512, 2) tconv_blur_ws_kernel(const TconvProble
     int a_par = 0, l_s0 = 0;
     const unsigned char* l_wsrc = p.wp;
     auto setup = [&]() __attribute__((always_inline)) {            // the chunk to REQUEST: (l_pos, l_c); loads only, none used here
-      if (l_pos >= count) { l_pos = count - 1; l_c = NC - 1; }     // past the run: the last chunk again (never read)
-      a_first = l_c == 0;
-      if (l_c == 0) {
-        int tx, ty, ib;
-        decode(l_pos, l_ot, tx, ty, ib);
-        const int i0 = ty * TY, j0 = tx * TC_TX;
+      a_first = l_c == 0 && !l_past;                              // (past the run: the last chunk again, never read)
+      if (a_first) {
+        const int ib = l_ibn;
+        const int i0 = l_ty * TY, j0 = l_tx * TC_TX;
         if (ib != l_ib) {
           l_ib = ib;
           float smax = p.style ? 0.f : 1.f;
@@ -749,7 +769,10 @@ __global__ void __launch_bounds__(512, 2) tconv_blur_ws_kernel(const TconvProble
       a_iscale = in_scale;
       l_s0 = (16 * l_c + 4 * g) * hw4;
       l_wsrc = p.wp + ((int64_t)l_ot * T + 9 * l_c) * 1024 + lane * 16;
-      if (++l_c == NC) { l_c = 0; ++l_pos; }
+      if (++l_c == NC) {
+        if (l_pos + 1 < count) { l_c = 0; ++l_pos; advance(l_ot, l_tx, l_ty, l_ibn); }
+        else { l_c = NC - 1; l_past = true; }
+      }
     };
     auto request_s = [&](int s) __attribute__((always_inline)) {
 #pragma unroll
@@ -810,10 +833,9 @@ __global__ void __launch_bounds__(512, 2) tconv_blur_ws_kernel(const TconvProble
 #pragma unroll
     for (int s = 0; s < SI; ++s) { deliver_s(0, s); __builtin_amdgcn_sched_barrier(0); request_s(s); __builtin_amdgcn_sched_barrier(0); }
     lds_barrier();
-    fir_setup();
     int cn = 0, e_pos = 0;                          // the tile the multiplying waves are on (its epilogue is shared)
     int e_ot, e_tx, e_ty, e_ib;
-    decode(e_pos, e_ot, e_tx, e_ty, e_ib);
+    digits((unsigned)bx, e_ot, e_tx, e_ty, e_ib);
     TP_DECL(tp = 0, tp_all = 0, tp_setup = 0, tp_del = 0, tp_bar = 0, tp_blur = 0, tp_ebar = 0);
     TP_NOW(tp); TP_NOW(tp_all);
     for (int n = 0; n < N; ++n) {
@@ -841,7 +863,8 @@ __global__ void __launch_bounds__(512, 2) tconv_blur_ws_kernel(const TconvProble
         TP_ADD(tp_ebar, tp);
         blur(1, par, e_ot, e_tx, e_ty, e_ib);
         TP_ADD(tp_blur, tp);
-        if (++e_pos < count) decode(e_pos, e_ot, e_tx, e_ty, e_ib);
+        ++e_pos;
+        advance(e_ot, e_tx, e_ty, e_ib);
       }
     }
 #if TC_PROF
@@ -872,51 +895,56 @@ __global__ void __launch_bounds__(512, 2) tconv_blur_ws_kernel(const TconvProble
     for (int ph = 0; ph < 4; ++ph) acc[b][ph] = tc_f32x4{0.f, 0.f, 0.f, 0.f};
   constexpr int LB = BPW - 1;
   const bool last_ok = wave + MW * LB < NBLK;       // wave-uniform: only the last block of a wave can be missing
-  // one chunk: the three tap groups of tconv_body's chunk()
+  // One chunk: the three tap groups of tconv_body's chunk() (at most five weight operands live), the pixel operands of a
+  // block requested TWO blocks ahead -- a group gives a block four or five MFMAs (90 - 110 cycles with one multiplying
+  // wave per SIMD), less than an LDS round trip beside the staging waves' traffic: 36 cycles per MFMA with the operands one
+  // block ahead (profiles/r05p).  (All fourteen weight operands live and fourteen MFMAs per block would cover it too: 35
+  // registers more than there are.)
   auto mma = [&](const unsigned char* lb, const unsigned char* wb) __attribute__((always_inline)) {
     {
       const tc_f16x8 u0 = TC_UH(0), u1 = TC_UH(1), u3 = TC_UH(3), u4 = TC_UH(4), l4 = tc_expand(TC_UL(4));
-      tc_f16x8 pc = TC_PIX(pb0[0]);
+      tc_f16x8 pc = TC_PIX(pb0[0]), pd = TC_PIX(pb0[1]);
 #pragma unroll
       for (int b = 0; b < BPW; ++b) {
-        tc_f16x8 pn = pc;
-        if (b + 1 < BPW) pn = TC_PIX(pb0[b + 1]);
+        tc_f16x8 pn = pd;
+        if (b + 2 < BPW) pn = TC_PIX(pb0[b + 2]);
         if (b < LB || last_ok) {
           TC_MFMA(3, pc, u4); TC_MFMA(0, pc, u0); TC_MFMA(1, pc, u1); TC_MFMA(2, pc, u3);
           TC_MFMA(3, pc, l4);
         }
         __builtin_amdgcn_sched_barrier(0);
-        pc = pn;
+        pc = pd; pd = pn;
       }
     }
     {
       const tc_f16x8 u2 = TC_UH(2), u5 = TC_UH(5), m02 = tc_pair(TC_UL(0), TC_UL(2)), m35 = tc_pair(TC_UL(3), TC_UL(5));
-      tc_f32x2 hc = TC_VH(pb0[0]);
-      tc_f16x8 qc = TC_PIX(pb1[0]);
+      tc_f32x2 hc = TC_VH(pb0[0]), hd = TC_VH(pb0[1]);
+      tc_f16x8 qc = TC_PIX(pb1[0]), qd = TC_PIX(pb1[1]);
 #pragma unroll
       for (int b = 0; b < BPW; ++b) {
-        tc_f32x2 hn = hc;
-        tc_f16x8 qn = qc;
-        if (b + 1 < BPW) { hn = TC_VH(pb0[b + 1]); qn = TC_PIX(pb1[b + 1]); }
+        tc_f32x2 hn = hd;
+        tc_f16x8 qn = qd;
+        if (b + 2 < BPW) { hn = TC_VH(pb0[b + 2]); qn = TC_PIX(pb1[b + 2]); }
         if (b < LB || last_ok) {
           const tc_f16x8 M = tc_pair_hq(hc, qc);
           TC_MFMA(0, qc, u2); TC_MFMA(2, qc, u5);
           TC_MFMA(0, M, m02); TC_MFMA(2, M, m35);
         }
         __builtin_amdgcn_sched_barrier(0);
-        hc = hn; qc = qn;
+        hc = hd; qc = qd; hd = hn; qd = qn;
       }
     }
     {
       const tc_f16x8 u6 = TC_UH(6), u7 = TC_UH(7), u8 = TC_UH(8), m17 = tc_pair(TC_UL(1), TC_UL(7)),
                      m68 = tc_pair(TC_UL(6), TC_UL(8));
-      tc_f32x2 hc = TC_VH(pb0[0]);
+      tc_f32x2 hc = TC_VH(pb0[0]), hd = TC_VH(pb0[1]);
       tc_f16x8 qc = TC_PIX(pb0[0] - TC_WC * 64), rc = TC_PIX(pb1[0] - TC_WC * 64);
+      tc_f16x8 qd = TC_PIX(pb0[1] - TC_WC * 64), rd = TC_PIX(pb1[1] - TC_WC * 64);
 #pragma unroll
       for (int b = 0; b < BPW; ++b) {
-        tc_f32x2 hn = hc;
-        tc_f16x8 qn = qc, rn = rc;
-        if (b + 1 < BPW) { hn = TC_VH(pb0[b + 1]); qn = TC_PIX(pb0[b + 1] - TC_WC * 64); rn = TC_PIX(pb1[b + 1] - TC_WC * 64); }
+        tc_f32x2 hn = hd;
+        tc_f16x8 qn = qd, rn = rd;
+        if (b + 2 < BPW) { hn = TC_VH(pb0[b + 2]); qn = TC_PIX(pb0[b + 2] - TC_WC * 64); rn = TC_PIX(pb1[b + 2] - TC_WC * 64); }
         if (b < LB || last_ok) {
           const tc_f16x8 M02 = tc_pair_hq(hc, qc), M23 = tc_pair(qc, rc);
           TC_MFMA(0, qc, u6); TC_MFMA(1, qc, u7);
@@ -924,7 +952,7 @@ __global__ void __launch_bounds__(512, 2) tconv_blur_ws_kernel(const TconvProble
           TC_MFMA(0, M23, m68);
         }
         __builtin_amdgcn_sched_barrier(0);
-        hc = hn; qc = qn; rc = rn;
+        hc = hd; qc = qd; rc = rd; hd = hn; qd = qn; rd = rn;
       }
     }
   };
@@ -941,15 +969,11 @@ __global__ void __launch_bounds__(512, 2) tconv_blur_ws_kernel(const TconvProble
         if (wave + MW * b >= NBLK) continue;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int q = 16 * (wave + MW * b) + 4 * lk + j + opaque;
-          if (q < NPOS) {
-            const int r = (q * 1928) >> 16, cq = q - r * TC_PC;        // q / 34 for q < 340
-            float* zp = zc + (2 * r) * TC_ZP + 2 * cq + 3;
-            zp[0] = acc[b][0][j];
-            zp[1] = acc[b][1][j];
-            zp[TC_ZP] = acc[b][2][j];
-            zp[TC_ZP + 1] = acc[b][3][j];
-          }
+          const int q = 16 * (wave + MW * b) + 4 * lk + j + opaque;     // < 352: the spare rows take what lies past the window
+          const int r = (q * 1928) >> 16, cq = q - r * TC_PC;          // q / 34 for q < 400
+          float* zp = zc + (2 * r) * TC_ZP + 2 * cq + 4;
+          *reinterpret_cast<tc_f32x2*>(zp) = tc_f32x2{acc[b][0][j], acc[b][1][j]};
+          *reinterpret_cast<tc_f32x2*>(zp + TC_ZP) = tc_f32x2{acc[b][2][j], acc[b][3][j]};
         }
       }
     }
@@ -957,21 +981,20 @@ __global__ void __launch_bounds__(512, 2) tconv_blur_ws_kernel(const TconvProble
 
   int pos = 0, c = 0;
   int ot, tx, ty, ib;
-  decode(pos, ot, tx, ty, ib);
+  digits((unsigned)bx, ot, tx, ty, ib);
   lds_barrier();                                    // chunk 0 and the FIR are in LDS
-  fir_setup();
   TP_DECL(tp = 0, tp_all = 0, tp_mma = 0, tp_bar = 0, tp_zw = 0, tp_blur = 0, tp_ebar = 0);
   TP_NOW(tp); TP_NOW(tp_all);
   for (int n = 0; n < N; ++n) {
     const unsigned char* lb = Ls + (n & 1) * BUFB;
     const unsigned char* wb = Wl + (n & 1) * TC_WCH + lane * 8;
-    if (c == NC - 1) noise_request(ty, tx, ib);
     mma(lb, wb);
     TP_ADD(tp_mma, tp);
     if (c + 1 < NC) { ++c; lds_barrier(); TP_ADD(tp_bar, tp); continue; }
     // ---- epilogue of the tile, eight channels at a time
     c = 0;
     const int par = pos & 1;
+    noise_request(ty, tx, ib);                      // (behind the MFMAs: sixteen registers they need; the z write and a barrier cover it)
     zwrite(0);
     TP_ADD(tp_zw, tp);
     lds_barrier();                                  // (the barrier of the tile's last chunk)
@@ -990,7 +1013,8 @@ __global__ void __launch_bounds__(512, 2) tconv_blur_ws_kernel(const TconvProble
     for (int b = 0; b < BPW; ++b)
 #pragma unroll
       for (int ph = 0; ph < 4; ++ph) acc[b][ph] = tc_f32x4{0.f, 0.f, 0.f, 0.f};
-    if (++pos < count) decode(pos, ot, tx, ty, ib);
+    ++pos;
+    advance(ot, tx, ty, ib);
   }
 #if TC_PROF
   if (wave == 0 && lane == 0 && (blockIdx.x == 0 || blockIdx.x == 100)) {
@@ -1022,10 +1046,11 @@ extern "C" int rw_tconv_blur_f32(const float* x, const float* wp, const float* k
   p.post = post_scale;
   p.batch = batch; p.in_ch = in_ch; p.out_ch = out_ch; p.h = h; p.w = w; p.w_scale = w_scale; p.u_inv = u_inv;
   p.x_amax = x_amax; p.y_amax = y_amax;
-  // RW_TCONV_TY = 8 (default): two 4-wave workgroups per CU; 16: one 8-wave workgroup; 88 / 1616: the 8- / 16-wave forms
-  // of the two tiles (four waves per SIMD)
+  // the form: RW_TCONV_TY = 0 the specialised persistent kernel, 8 / 16 the two shapes of tconv_body; unset: by input channels -- the persistent kernel where a tile has few chunks (<= 128
+  // channels: its staging waves run ahead through the epilogue), the one-workgroup-per-CU shape where the MFMAs dominate
+  // (profiles/r05q: layer 17 6.4 against 7.1 ms, layer 15 4.6 / 4.9, layer 13 3.7 / 3.7, layer 11 3.3 / 3.2, layer 9 1.9 / 1.7)
   const char* e = getenv("RW_TCONV_TY");
-  const int sel = e ? atoi(e) : 8;
+  const int sel = e ? atoi(e) : (in_ch >= 32 && in_ch <= 128 ? 0 : 16);
   if (sel == 0 && in_ch >= 32) {                    // 0: the specialised persistent kernel (one workgroup of eight waves per CU)
     p.tiles_x = w / TC_TX; p.tiles_y = h / 8; p.o_tiles = out_ch / 16;
     const int64_t tiles = (int64_t)batch * p.tiles_y * p.tiles_x * p.o_tiles;
@@ -1039,15 +1064,13 @@ extern "C" int rw_tconv_blur_f32(const float* x, const float* wp, const float* k
     if (rc || !y_amax) return rc;
     return rw_bound_finish(y_amax, 8 * grid, rw_s(stream));
   }
-  const int ty = (sel == 16 || sel == 1616) ? 16 : 8;
-  const int waves = sel == 1616 ? 16 : (sel == 16 || sel == 88) ? 8 : 4;
+  const int ty = sel == 16 ? 16 : 8;
+  const int waves = ty == 16 ? 8 : 4;
   p.tiles_x = w / TC_TX; p.tiles_y = h / ty; p.o_tiles = out_ch / 16;
   const int64_t work = (int64_t)batch * p.tiles_y * p.tiles_x * p.o_tiles;
   if (work <= 0 || work > 0x7fffffff) return RW_ERR_UNSUPPORTED;
   if (y_amax && waves * work > rw_bound_slot_capacity((int64_t)batch * out_ch * 4 * h * w)) return RW_ERR_UNSUPPORTED;
-  if (sel == 1616) hipLaunchKernelGGL(tconv_blur_t16w16_kernel, dim3((unsigned)work), dim3(1024), 0, rw_s(stream), p);
-  else if (sel == 88) hipLaunchKernelGGL(tconv_blur_t8w8_kernel, dim3((unsigned)work), dim3(512), 0, rw_s(stream), p);
-  else if (ty == 16) hipLaunchKernelGGL(tconv_blur_t16_kernel, dim3((unsigned)work), dim3(512), 0, rw_s(stream), p);
+  if (ty == 16) hipLaunchKernelGGL(tconv_blur_t16_kernel, dim3((unsigned)work), dim3(512), 0, rw_s(stream), p);
   else hipLaunchKernelGGL(tconv_blur_t8_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
   const int rc = RW_LAUNCH_RESULT();
   if (rc || !y_amax) return rc;

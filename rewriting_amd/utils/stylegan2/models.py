@@ -279,7 +279,7 @@ def _amax_of(fmap):
 _DEFAULT_CONV_ALGO = 'winograd'
 _IMAGE_CONV_ALGO = 'winograd4'
 _ONE_PASS_UP_MAX_IN = 64       # see DemodulatedConv2dF.one_pass_upsample
-_FUSED_UP_MAX_IN = 128         # see DemodulatedConv2dF.fused_upsample
+_FUSED_UP_MAX_IN = 512         # see DemodulatedConv2dF.fused_upsample
 
 
 def micro_batch():
@@ -516,17 +516,17 @@ class DemodulatedConv2dF(nn.Module):
     def fused_upsample(self, fmap, blur):
         """Transposed conv + blur + noise + activation in one pass at the transposed convolution's OWN multiply count
         (hip.conv_transpose3x3s2_blur_fused, csrc/rw_tconv.hip: a direct sum on the 16-bit matrix pipe, the (2H+1)^2 map
-        kept in LDS).  OPT-IN (RW_UP_FUSED2=1; layers of at most RW_UP_FUSED2_MAX_IN input channels, default
-        _FUSED_UP_MAX_IN), inside the un-hooked whole-generator forward in split mode.  Why not the default (round 5,
-        DESIGN.md section 4.5): it holds its parity bars and is 0.2 - 1.7 ms faster per launch than what it replaces
-        stand-alone, +1.6 % on the forward when every upsampling layer takes it -- but while it ran, to_rgb_kernel on the
-        second stream came back with wrong values (its PACKED fp32 FMAs, low half, lanes 48 - 63: profiles/r05i).  The
-        streaming kernels are compiled without packed fp32 math since (csrc/rw_ops.hip, first line; the forward is then
-        bit-reproducible with this kernel too: profiles/r05l), but what exactly in this kernel disturbs another wave's
-        v_pk_fma_f32 is not understood, and a kernel that can disturb its neighbours is not made a default for 1.6 %."""
+        kept in LDS) -- the default for every upsampling layer it takes (w % 32 == 0, h % 16 == 0: 32^2 maps and up; at most
+        RW_UP_FUSED2_MAX_IN input channels) inside the un-hooked whole-generator forward in split mode; RW_UP_FUSED2=0
+        brings back the two-pass / phase-kernel routes.  History (round 5): the first forms were
+        +1.6 % on the forward and stayed opt-in because to_rgb_kernel on the second stream came back wrong beside them (its
+        packed fp32 FMAs; the streaming kernels are compiled without packed fp32 math since: csrc/rw_ops.hip, first line);
+        the persistent form with specialised waves on the layers of few channels and the one-workgroup-per-CU form on the
+        others (both fill a CU's register file: nothing else runs beside them) are +7 % (profiles/r05r), and the sequence /
+        stress / parity tests of the forward run with them."""
         if not self.upsample or conv_impl() != 0 or conv_precision() != 'f32' or up_conv_algo() == 'direct':
             return False
-        if os.environ.get('RW_UP_FUSED2', '0') != '1' or not _rgb_branch.image_path or not _split_part('up1'):
+        if os.environ.get('RW_UP_FUSED2', '1') != '1' or not _rgb_branch.image_path or not _split_part('up1'):
             return False
         if tuple(blur.pad) != (1, 1) or tuple(blur.kernel.shape) != (4, 4):
             return False

@@ -297,6 +297,7 @@ def test_one_pass_upsampling_layers_stay_inside_the_image_tolerance(emulated_hip
                         lambda *a, **k: (calls.append(a[0].shape), direct.append(a[0].shape), real16(*a, **k))[2])
     monkeypatch.setenv('RW_UP_ALGO', 'winograd4')
     monkeypatch.setenv('RW_MM_DIRECT16', direct16)
+    monkeypatch.setenv('RW_UP_FUSED2', '0')             # (the default takes the 32^2 layer in rw_tconv.hip's kernel instead)
     with torch.no_grad():
         got = model(z)
     assert len(calls) == 4                              # 4 -> 8 -> 16 -> 32 -> 64
@@ -500,7 +501,7 @@ def test_fused_transposed_conv_and_blur_layer_stays_inside_the_image_tolerance(e
     """DemodulatedConv2dF.fused_upsample: inside the un-hooked forward an upsampling StyledConv whose shape
     hip.tconv_blur_supported takes runs as ONE launch of hip.conv_transpose3x3s2_blur_fused (the transposed convolution at
     its own multiply count, the blur from LDS) with the layer's plain direct-16 packing; same generator, reference
-    golden, image tolerance; RW_UP_FUSED2=0 and hooked models never take it."""
+    golden, image tolerance; RW_UP_FUSED2=0, a layer above RW_UP_FUSED2_MAX_IN channels and hooked models never take it."""
     from rewriting_amd import hip
     from rewriting_amd.utils import nethook
     g = load_golden('gen_s64_cm1')
@@ -511,13 +512,13 @@ def test_fused_transposed_conv_and_blur_layer_stays_inside_the_image_tolerance(e
     calls = []
     real = hip.conv_transpose3x3s2_blur_fused
     monkeypatch.setattr(hip, 'conv_transpose3x3s2_blur_fused', lambda *a, **k: (calls.append((a[0].shape, sorted(k))), real(*a, **k))[1])
+    monkeypatch.setenv('RW_UP_FUSED2_MAX_IN', '256')
     with torch.no_grad():
         model(z)
-    assert not calls                                                    # opt-in (models.DemodulatedConv2dF.fused_upsample)
-    monkeypatch.setenv('RW_UP_FUSED2', '1')
-    monkeypatch.setenv('RW_UP_FUSED2_MAX_IN', '512')
+    assert not calls                                                    # layer 9 has 512 input channels
+    monkeypatch.delenv('RW_UP_FUSED2_MAX_IN')
     with torch.no_grad():
-        got = model(z)
+        got = model(z)                                                  # the default (models.DemodulatedConv2dF.fused_upsample)
     assert [tuple(sh[2:]) for sh, _ in calls] == [(32, 32)]             # layer 9: 32^2 -> 64^2 (h % 16 == 0, w % 32 == 0)
     assert 'y_amax' in calls[0][1] and 'post_scale' in calls[0][1]      # its reader (layer 10, F(4x4,3x3)) takes bound and style
     assert (got - want).abs().max().item() < 1e-3
@@ -526,7 +527,7 @@ def test_fused_transposed_conv_and_blur_layer_stays_inside_the_image_tolerance(e
     with torch.no_grad():
         base = model(z)
     assert not calls and (got - base).abs().max().item() < 1e-4
-    monkeypatch.setenv('RW_UP_FUSED2', '1')
+    monkeypatch.delenv('RW_UP_FUSED2')
     with nethook.InstrumentedModel(model) as inst:
         inst.retain_layer('layer9', detach=False)
         with torch.no_grad():

@@ -1069,7 +1069,7 @@ TCONV_CASES = [(1, 16, 16, 16, 32), (2, 64, 32, 16, 64), (1, 32, 16, 32, 32), (1
                (1, 512, 32, 16, 32), (2, 256, 128, 32, 32), (1, 64, 32, 512, 512)]
 
 
-TCONV_FORMS = {'two-workgroups-per-cu': '8', 'one-workgroup-per-cu': '16', 'specialised-persistent': '0'}
+TCONV_FORMS = {'two-workgroups-per-cu': '8', 'one-workgroup-per-cu': '16', 'specialised-persistent': '0', 'automatic': None}
 
 
 @pytest.mark.parametrize('form', sorted(TCONV_FORMS))
@@ -1085,7 +1085,10 @@ def test_fused_transposed_conv_and_blur_matches_conv_then_blur(case, form, monke
     from rewriting_amd import hip
     from oracle import restatement as R
     b, i, o, h, w = case
-    monkeypatch.setenv('RW_TCONV_TY', TCONV_FORMS[form])
+    if TCONV_FORMS[form] is None:
+        monkeypatch.delenv('RW_TCONV_TY', raising=False)
+    else:
+        monkeypatch.setenv('RW_TCONV_TY', TCONV_FORMS[form])
     assert hip.tconv_blur_supported(o, i, h, w)
     x, wt, style = _conv_inputs(*case, seed=171)
     rs = numpy.random.RandomState(172)
@@ -1137,7 +1140,10 @@ def test_fused_transposed_conv_and_blur_with_a_fir_that_is_no_outer_product(form
     """The reference's FIR is always make_kernel([1, 3, 3, 1]) (an outer product: the strip walk); any other 4 x 4 kernel
     takes the 16-tap form of the epilogue.  Against blur_noise_act on the direct fp32 transposed convolution."""
     from rewriting_amd import hip
-    monkeypatch.setenv('RW_TCONV_TY', TCONV_FORMS[form])
+    if TCONV_FORMS[form] is None:
+        monkeypatch.delenv('RW_TCONV_TY', raising=False)
+    else:
+        monkeypatch.setenv('RW_TCONV_TY', TCONV_FORMS[form])
     b, i, o, h, w = 2, 64, 32, 16, 64
     x, wt, style = _conv_inputs(b, i, o, h, w, seed=181)
     rs = numpy.random.RandomState(182)

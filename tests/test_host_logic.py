@@ -289,6 +289,7 @@ def test_split_precision_switch_only_takes_eligible_stride1_layers(emulated_hip,
         seen.append((x.shape[1], out_ch, x.shape[-1]))
         return orig(x, wb, out_ch, *a, **k)
     monkeypatch.setattr(hip, 'conv3x3_bf16x6', spy)
+    monkeypatch.setenv('RW_UP_FUSED2', '0')        # (the fused upsampling kernel is an fp32-precision route: the switch turns it off)
     with torch.no_grad():
         default = model(z)
         monkeypatch.setenv('RW_CONV_ALGO', 'direct')               # the direct sum, which the split path restates
