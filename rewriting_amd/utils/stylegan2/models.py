@@ -150,6 +150,12 @@ _rgb_branch = _RgbBranch()
 _rgb_side_streams = {}          # one per device, module-level: models are deep-copied by the rewriters
 
 
+def _side_stream(device):
+    """A stream for the work beside the trunk (RGB branch, border strips, prefetch).  RW_SIDE_PRIORITY (default 0): the
+    priority torch gives it (positive = below the trunk's stream; clamped to the device's range)."""
+    return torch.cuda.Stream(device=device, priority=int(os.environ.get('RW_SIDE_PRIORITY', '0')))
+
+
 def _rgb_stream():
     return _rgb_branch.stream
 
@@ -575,7 +581,7 @@ class DemodulatedConv2dF(nn.Module):
                     and not torch.cuda.is_current_stream_capturing()):
                 aux = _rgb_side_streams.get((fmap.device, 'aux'))
                 if aux is None:
-                    aux = _rgb_side_streams[(fmap.device, 'aux')] = torch.cuda.Stream(device=fmap.device)
+                    aux = _rgb_side_streams[(fmap.device, 'aux')] = _side_stream(fmap.device)
             b, _, h, w = fmap.shape
             f22 = (up_conv_algo() == 'winograd' and conv_impl() == 0
                    and hip.up_strips_applicable(self.out_channel, self.in_channel)
@@ -1135,10 +1141,10 @@ class SeqStyleGAN2(nn.Sequential):
         main = torch.cuda.current_stream()
         side = _rgb_side_streams.get(input.device)
         if side is None:
-            side = _rgb_side_streams[input.device] = torch.cuda.Stream(device=input.device)
+            side = _rgb_side_streams[input.device] = _side_stream(input.device)
         aux = _rgb_side_streams.get((input.device, 'aux'))
         if aux is None:
-            aux = _rgb_side_streams[(input.device, 'aux')] = torch.cuda.Stream(device=input.device)
+            aux = _rgb_side_streams[(input.device, 'aux')] = _side_stream(input.device)
         _rgb_branch.stream = side
         _rgb_branch.aux = aux
         _rgb_branch.final = self._final_pair()
