@@ -258,6 +258,17 @@ class ConvTimer:
                                          effective_over_fp32_direct_roof=round(
                                              tot_fl / (tot_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
                                          ms_per_step=None))
+        # the roof the dominant kernel is NEARER to is the one `bound` / `achieved` / `peak` / `frac` name (the fused upsampling
+        # kernels of the layers with few channels move more bytes per FLOP than they issue MFMAs); the other stays beside it
+        if out['hbm']['frac'] > out['frac']:
+            out['mfma'] = dict(achieved_tflops=out['achieved'], peak_tflops=out['peak'], frac=out['frac'])
+            out.update(bound='hbm', achieved=out['hbm']['achieved_gbs'], peak=HBM_PEAK_GBS, unit='GB/s', frac=out['hbm']['frac'])
+            out['note'] = ('`achieved` = the launch\'s ALGORITHMIC bytes (input map once + result once, SURVEY 8d) per second of its '
+                           'average duration against the HBM roof -- the nearer of this kernel\'s two roofs; `mfma` = the matrix '
+                           'FLOPs it ISSUES per second (direct-sum FLOPs x the algorithm\'s multiply count / the direct sum\'s, x '
+                           'the f16 piece products per multiply) against the 16-bit pipe\'s dense peak; `effective_tflops` = the '
+                           'direct sum\'s FLOPs per second.  Neither roof binds it: DESIGN.md section 4.5 (cycle counters, '
+                           'ablations)')
         out['per_kernel'] = {n: rec(n, v) for n, v in sorted(per.items(), key=lambda kv: -kv[1]['ms'])}
         out['_tot_ms'] = tot_ms
         out['_pipe_s'] = pipe_s

@@ -522,9 +522,9 @@ __global__ void __launch_bounds__(512, 1) tconv_blur_t16_kernel(const TconvProbl
 #define TC_PROF 0         // 1: workgroups 0 and 100 leave cycle counts of wave 0 (multiplying) and wave 4 (staging) in tc_prof
 #endif
 #if TC_PROF
-__device__ unsigned long long tc_prof[32];
+__device__ unsigned long long tc_prof[64];
 extern "C" int rw_tconv_prof(unsigned long long* out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tc_prof), sizeof(unsigned long long) * 32);
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tc_prof), sizeof(unsigned long long) * 64);
 }
 #define TP_DECL(...) unsigned long long __VA_ARGS__
 #define TP_NOW(t) t = (unsigned long long)clock64()
@@ -721,16 +721,28 @@ __global__ void __launch_bounds__(512, 2) tconv_blur_ws_kernel(const TconvProble
     float in_scale = 1.f, out_scale = 1.f;
     int xoff[SI];
     __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, 0, 0x00020000);
-    tc_f32x4 raw[SI][4];                            // [piece][channel]: four pixels
-    tc_f32x4 wraw[3];                               // tap pieces g, g + 4 and (g == 0) 8 of the chunk's weights
-    float psv[4], sv[4];
-    float a_demod = 1.f, a_bias = 0.f, a_post = 1.f, a_oscale = 1.f, a_iscale = 1.f;
-    bool a_first = false;
-    int a_par = 0, l_s0 = 0;
+    // Two chunks are in flight at any time (registers: slot n & 1 holds chunk n's window pieces, weight pieces and
+    // scalars): chunk n + 3 is requested when chunk n + 1 has been written -- two intervals between a request and its use
+    // (one left layer 17 waiting: 1.3 of 6.5 ms disappeared with the window loads, profiles/r05u)
+    struct Flight {
+      tc_f32x4 raw[SI][4];                          // [piece][channel]: four pixels
+      float psv[4];
+      float demod, bias, post, oscale, iscale;
+      bool first;
+      int par;
+    };
+    Flight fl[2];
+    // (the weights come from the L2 and stay ONE interval ahead: tap pieces g, g + 4 and (g == 0) 8 of the chunk after the
+    // one being written; w_next = where the chunk requested last finds its weights)
+    tc_f32x4 wraw[3];
+    float sv[4];
+    int l_s0 = 0;
     const unsigned char* l_wsrc = p.wp;
-    auto setup = [&]() __attribute__((always_inline)) {            // the chunk to REQUEST: (l_pos, l_c); loads only, none used here
-      a_first = l_c == 0 && !l_past;                              // (past the run: the last chunk again, never read)
-      if (a_first) {
+    const unsigned char* w_next = p.wp;
+    auto setup = [&](auto tag) __attribute__((always_inline)) {   // the chunk to REQUEST: (l_pos, l_c); loads only, none used here
+      Flight& F = fl[decltype(tag)::value];
+      F.first = l_c == 0 && !l_past;                              // (past the run: the last chunk again, never read)
+      if (F.first) {
         const int ib = l_ibn;
         const int i0 = l_ty * TY, j0 = l_tx * TC_TX;
         if (ib != l_ib) {
@@ -755,50 +767,58 @@ __global__ void __launch_bounds__(512, 2) tconv_blur_ws_kernel(const TconvProble
           const bool ok = it < NITEM && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
           xoff[s] = ok ? (iy * p.w + ix) * 4 : 0x7ffffff0;
         }
-        a_par = l_pos & 1;
-        a_oscale = out_scale;
+        F.par = l_pos & 1;
+        F.oscale = out_scale;
         if (lid < 16) {
           const int o = 16 * l_ot + lid;
-          a_demod = p.demod ? p.demod[(int64_t)l_ib * p.out_ch + o] : 1.f;
-          a_bias = p.act ? p.bias[o] : 0.f;
-          a_post = p.post ? p.post[(int64_t)l_ib * p.out_ch + o] : 1.f;
+          F.demod = p.demod ? p.demod[(int64_t)l_ib * p.out_ch + o] : 1.f;
+          F.bias = p.act ? p.bias[o] : 0.f;
+          F.post = p.post ? p.post[(int64_t)l_ib * p.out_ch + o] : 1.f;
         }
       }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) psv[k] = p.style ? p.style[(int64_t)l_ib * p.in_ch + 16 * l_c + 4 * g + k] : 1.f;
-      a_iscale = in_scale;
+      for (int k = 0; k < 4; ++k) F.psv[k] = p.style ? p.style[(int64_t)l_ib * p.in_ch + 16 * l_c + 4 * g + k] : 1.f;
+      F.iscale = in_scale;
       l_s0 = (16 * l_c + 4 * g) * hw4;
-      l_wsrc = p.wp + ((int64_t)l_ot * T + 9 * l_c) * 1024 + lane * 16;
+      l_wsrc = w_next;                              // the weights of the chunk set up ONE call ago
+      w_next = p.wp + ((int64_t)l_ot * T + 9 * l_c) * 1024 + lane * 16;
       if (++l_c == NC) {
         if (l_pos + 1 < count) { l_c = 0; ++l_pos; advance(l_ot, l_tx, l_ty, l_ibn); }
         else { l_c = NC - 1; l_past = true; }
       }
     };
-    auto request_s = [&](int s) __attribute__((always_inline)) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        raw[s][k] = __builtin_bit_cast(tc_f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, xoff[s], l_s0 + k * hw4, 0));
-      if (s == 0) wraw[0] = *reinterpret_cast<const tc_f32x4*>(l_wsrc + g * 1024);
-      else {
+    auto request_s = [&](auto tag, int s, bool with_w = true) __attribute__((always_inline)) {
+      Flight& F = fl[decltype(tag)::value];
+      // (the weights FIRST, all with piece 0: loads return in order -- the wait for them, an interval later, must not reach
+      // past this interval's window requests)
+      if (with_w && s == 0) {
+        wraw[0] = *reinterpret_cast<const tc_f32x4*>(l_wsrc + g * 1024);
         wraw[1] = *reinterpret_cast<const tc_f32x4*>(l_wsrc + (g + 4) * 1024);
         if (g == 0) wraw[2] = *reinterpret_cast<const tc_f32x4*>(l_wsrc + 8 * 1024);
       }
-    };
-    // what setup() requested beside the pixels -> registers / LDS (the first wait of an interval)
-    auto tables = [&]() __attribute__((always_inline)) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) sv[k] = psv[k] * a_iscale;
-      if (a_first && lid < 16) {
-        Sc[a_par][lid] = a_demod * p.w_scale * a_oscale * gain;
-        Bs[a_par][lid] = a_bias * gain;
-        Po[a_par][lid] = a_post;
+      for (int k = 0; k < 4; ++k) {
+        if (TC_ABL & 1) F.raw[s][k] = tc_f32x4{1.f, 1.f, 1.f, 1.f};     // (timing ablation: no window loads; results wrong)
+        else F.raw[s][k] = __builtin_bit_cast(tc_f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, xoff[s], l_s0 + k * hw4, 0));
       }
     };
-    auto deliver_s = [&](int buf, int s) __attribute__((always_inline)) {
+    // what setup() requested beside the pixels -> registers / LDS (the first wait of an interval)
+    auto tables = [&](auto tag) __attribute__((always_inline)) {
+      Flight& F = fl[decltype(tag)::value];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) sv[k] = F.psv[k] * F.iscale;
+      if (F.first && lid < 16) {
+        Sc[F.par][lid] = F.demod * p.w_scale * F.oscale * gain;
+        Bs[F.par][lid] = F.bias * gain;
+        Po[F.par][lid] = F.post;
+      }
+    };
+    auto deliver_s = [&](auto tag, int buf, int s) __attribute__((always_inline)) {
+      Flight& F = fl[decltype(tag)::value];
       unsigned char* dst = Ls + buf * BUFB;
       unsigned char* wdst = Wl + buf * TC_WCH + lane * 16;
-      if (s == 0) *reinterpret_cast<tc_f32x4*>(wdst + g * 1024) = wraw[0];
-      else {
+      if (s == 0) {
+        *reinterpret_cast<tc_f32x4*>(wdst + g * 1024) = wraw[0];
         *reinterpret_cast<tc_f32x4*>(wdst + (g + 4) * 1024) = wraw[1];
         if (g == 0) *reinterpret_cast<tc_f32x4*>(wdst + 8 * 1024) = wraw[2];
       }
@@ -806,7 +826,8 @@ __global__ void __launch_bounds__(512, 2) tconv_blur_ws_kernel(const TconvProble
       const int r = it / IPR, j = it - r * IPR;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float v0 = raw[s][0][e] * sv[0], v1 = raw[s][1][e] * sv[1], v2 = raw[s][2][e] * sv[2], v3 = raw[s][3][e] * sv[3];
+        const float v0 = F.raw[s][0][e] * sv[0], v1 = F.raw[s][1][e] * sv[1], v2 = F.raw[s][2][e] * sv[2],
+                    v3 = F.raw[s][3][e] * sv[3];
         const tc_f16x2 h01 = __builtin_convertvector(tc_f32x2{v0, v1}, tc_f16x2);
         const tc_f16x2 h23 = __builtin_convertvector(tc_f32x2{v2, v3}, tc_f16x2);
         float r0, r1, r2, r3;                        // v - (float)h, exact
@@ -823,33 +844,45 @@ __global__ void __launch_bounds__(512, 2) tconv_blur_ws_kernel(const TconvProble
       }
     };
 
-    // chunk 0: requested and delivered; chunk 1: requested
-    setup();
+    // chunks 0 and 1 requested (chunk 0's weights with chunk 1's window); chunk 0 written; chunk 2 requested
+    setup(tc_int<0>());
 #pragma unroll
-    for (int s = 0; s < SI; ++s) request_s(s);
-    tables();
+    for (int s = 0; s < SI; ++s) request_s(tc_int<0>(), s, false);
+    setup(tc_int<1>());
+#pragma unroll
+    for (int s = 0; s < SI; ++s) request_s(tc_int<1>(), s);
+    tables(tc_int<0>());
     __builtin_amdgcn_sched_barrier(0);
-    setup();
+    setup(tc_int<0>());
 #pragma unroll
-    for (int s = 0; s < SI; ++s) { deliver_s(0, s); __builtin_amdgcn_sched_barrier(0); request_s(s); __builtin_amdgcn_sched_barrier(0); }
+    for (int s = 0; s < SI; ++s) {
+      deliver_s(tc_int<0>(), 0, s); __builtin_amdgcn_sched_barrier(0);
+      request_s(tc_int<0>(), s); __builtin_amdgcn_sched_barrier(0);
+    }
     lds_barrier();
     int cn = 0, e_pos = 0;                          // the tile the multiplying waves are on (its epilogue is shared)
     int e_ot, e_tx, e_ty, e_ib;
     digits((unsigned)bx, e_ot, e_tx, e_ty, e_ib);
-    TP_DECL(tp = 0, tp_all = 0, tp_setup = 0, tp_del = 0, tp_bar = 0, tp_blur = 0, tp_ebar = 0);
+    TP_DECL(tp = 0, tp_all = 0, tp_setup = 0, tp_del = 0, tp_bar = 0, tp_blur = 0, tp_ebar = 0, tp_tab = 0);
     TP_NOW(tp); TP_NOW(tp_all);
-    for (int n = 0; n < N; ++n) {
-      // chunk n + 1 (in flight) -> LDS piece by piece, chunk n + 2 requested behind it (past the run: harmless repeats)
-      tables();
+    // interval n: chunk n + 1 (slot (n + 1) & 1, in flight for two intervals; its weights for one) -> LDS piece by piece, the
+    // window of chunk n + 3 and the weights of chunk n + 2 requested behind it into the same registers (past the run:
+    // harmless repeats)
+    auto interval = [&](int n, auto tag) __attribute__((always_inline)) {
+      tables(tag);
+      TP_ADD(tp_tab, tp);
       __builtin_amdgcn_sched_barrier(0);
       // (the strip's noise BEFORE this interval's window requests: loads return in order, and the wait for the noise at the
       // blur must leave the younger window loads in flight)
       if (cn == NC - 1) noise_request(e_ty, e_tx, e_ib);
       __builtin_amdgcn_sched_barrier(0);
-      setup();
+      setup(tag);
       TP_ADD(tp_setup, tp);
 #pragma unroll
-      for (int s = 0; s < SI; ++s) { deliver_s((n + 1) & 1, s); __builtin_amdgcn_sched_barrier(0); request_s(s); __builtin_amdgcn_sched_barrier(0); }
+      for (int s = 0; s < SI; ++s) {
+        deliver_s(tag, (n + 1) & 1, s); __builtin_amdgcn_sched_barrier(0);
+        request_s(tag, s); __builtin_amdgcn_sched_barrier(0);
+      }
       TP_ADD(tp_del, tp);
       lds_barrier();
       TP_ADD(tp_bar, tp);
@@ -866,11 +899,15 @@ __global__ void __launch_bounds__(512, 2) tconv_blur_ws_kernel(const TconvProble
         ++e_pos;
         advance(e_ot, e_tx, e_ty, e_ib);
       }
-    }
+    };
+    int n = 0;
+    for (; n + 1 < N; n += 2) { interval(n, tc_int<1>()); interval(n + 1, tc_int<0>()); }
+    if (n < N) interval(n, tc_int<1>());
 #if TC_PROF
     if (wave == MW && lane == 0 && (blockIdx.x == 0 || blockIdx.x == 100)) {
-      unsigned long long* o = tc_prof + (blockIdx.x == 0 ? 0 : 16);
+      unsigned long long* o = tc_prof + (blockIdx.x == 0 ? 0 : 32);
       o[8] = (unsigned long long)clock64() - tp_all; o[9] = tp_setup; o[10] = tp_del; o[11] = tp_bar; o[12] = tp_blur; o[13] = tp_ebar; o[14] = N;
+      o[16] = tp_tab;
     }
 #endif
     if (p.y_amax) rw_bound_store_wave(p.y_amax, rw_wave_max(ymax));
@@ -956,22 +993,25 @@ __global__ void __launch_bounds__(512, 2) tconv_blur_ws_kernel(const TconvProble
       }
     }
   };
-  // eight of the sixteen channels -> the z tile (lanes lt >> 3 == pass hold them)
+  // eight of the sixteen channels -> the z tile (lanes lt >> 3 == pass hold them).  A lane's four positions of a block are
+  // consecutive: one division per block, then + 2 floats per position and + 76 (a z row pair is 144, a position row 68)
+  // where the run crosses the end of a position row
   auto zwrite = [&](int pass) __attribute__((always_inline)) {
     if ((lt >> 3) == pass) {
       // (the addresses are loop invariants: left to itself the compiler keeps all of them in registers for the whole run;
-      // an opaque zero keeps their three instructions each inside the loop)
+      // an opaque zero keeps their few instructions inside the loop)
       int opaque;
       asm volatile("v_mov_b32 %0, 0" : "=v"(opaque));
-      float* zc = Zs + (lt & 7) * CHS;
+      float* zc = Zs + (lt & 7) * CHS + 4;
 #pragma unroll
       for (int b = 0; b < BPW; ++b) {
         if (wave + MW * b >= NBLK) continue;
+        const int q0 = 16 * (wave + MW * b) + 4 * lk + opaque;         // < 352: the spare rows take what lies past the window
+        const int r0 = (q0 * 1928) >> 16, c0 = q0 - r0 * TC_PC;        // q0 / 34 for q0 < 400
+        float* z0 = zc + (2 * r0) * TC_ZP + 2 * c0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int q = 16 * (wave + MW * b) + 4 * lk + j + opaque;     // < 352: the spare rows take what lies past the window
-          const int r = (q * 1928) >> 16, cq = q - r * TC_PC;          // q / 34 for q < 400
-          float* zp = zc + (2 * r) * TC_ZP + 2 * cq + 4;
+          float* zp = z0 + 2 * j + (c0 + j >= TC_PC ? 2 * TC_ZP - 2 * TC_PC : 0);
           *reinterpret_cast<tc_f32x2*>(zp) = tc_f32x2{acc[b][0][j], acc[b][1][j]};
           *reinterpret_cast<tc_f32x2*>(zp + TC_ZP) = tc_f32x2{acc[b][2][j], acc[b][3][j]};
         }
@@ -1018,7 +1058,7 @@ __global__ void __launch_bounds__(512, 2) tconv_blur_ws_kernel(const TconvProble
   }
 #if TC_PROF
   if (wave == 0 && lane == 0 && (blockIdx.x == 0 || blockIdx.x == 100)) {
-    unsigned long long* o = tc_prof + (blockIdx.x == 0 ? 0 : 16);
+    unsigned long long* o = tc_prof + (blockIdx.x == 0 ? 0 : 32);
     o[0] = (unsigned long long)clock64() - tp_all; o[1] = tp_mma; o[2] = tp_bar; o[3] = tp_zw; o[4] = tp_blur; o[5] = tp_ebar; o[6] = N;
   }
 #endif

@@ -39,13 +39,14 @@ for name in os.environ.get('RW_LAYERS', 'layer17,layer13').split(','):
     b.record()
     torch.cuda.synchronize()
     ms = a.elapsed_time(b) / 5
-    buf = (ctypes.c_ulonglong * 32)()
+    buf = (ctypes.c_ulonglong * 64)()
     assert lib.rw_tconv_prof(buf) == 0
-    for wg, o in ((0, 0), (100, 16)):
-        v = list(buf[o:o + 16])
+    for wg, o in ((0, 0), (100, 32)):
+        v = list(buf[o:o + 32])
         print(json.dumps(dict(layer=name, ms=round(ms, 3), wg=wg,
                               mfma_wave=dict(total=v[0], mma=v[1], chunk_barrier=v[2], zwrite=v[3], blur=v[4], epilogue_barriers=v[5], chunks=v[6]),
-                              staging_wave=dict(total=v[8], setup=v[9], deliver_request=v[10], barrier=v[11], blur=v[12], epilogue_barriers=v[13], chunks=v[14]))),
+                              staging_wave=dict(total=v[8], setup=v[9], deliver_request=v[10], barrier=v[11], blur=v[12], epilogue_barriers=v[13], chunks=v[14],
+                                                tables=v[16]))),
               flush=True)
     del x, noise
     torch.cuda.empty_cache()
