@@ -382,7 +382,10 @@ int rw_dconv_transpose3x3s2_blur_f32(const float* x, const float* wp, float* y, 
  *   wp: rw_packed_dconv_weight_elems floats from rw_pack_dconv_weight_f32 -- the PLAIN packing of dconv.weight (no
  *       composition with the blur), u_inv its scale; k4: the 4x4 FIR buffer (already multiplied by 4);
  *   shapes: in_ch % 16 == 0 (<= 512), out_ch % 16 == 0, h % 16 == 0, w % 32 == 0;
- *   ep / post_scale / x_amax / y_amax: as in rw_dconv_transpose3x3s2_blur_f32. */
+ *   ep / post_scale / x_amax / y_amax: as in rw_dconv_transpose3x3s2_blur_f32;
+ *   the kernel's form is picked by in_ch (32 .. 128: one persistent workgroup per CU with specialised waves; otherwise one
+ *   8-wave workgroup per CU and tile); environment RW_TCONV_TY = 0 / 16 / 8 forces a form, RW_TCONV_GRID the persistent
+ *   form's workgroup count (diagnostics). */
 int rw_tconv_blur_supported(int out_ch, int in_ch, int h, int w);
 int rw_tconv_blur_f32(const float* x, const float* wp, const float* k4, float* y, int batch, int in_ch, int out_ch, int h,
                       int w, float w_scale, const rw_conv_epilogue* ep, const float* post_scale, float u_inv,

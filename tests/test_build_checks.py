@@ -22,7 +22,7 @@ def test_asm_lds_reads_reach_their_consumers_only_through_their_waits():
     assert '16 asm LDS reads checked, 0 violations' in r.stdout
 
 
-SPLIT_PATH_SOURCES = ['rw_common.h', 'rw_bound.hip', 'rw_wino4.hip', 'rw_upwino.hip', 'rw_dconv.hip', 'rw_ops.hip']
+SPLIT_PATH_SOURCES = ['rw_common.h', 'rw_bound.hip', 'rw_wino4.hip', 'rw_upwino.hip', 'rw_dconv.hip', 'rw_tconv.hip', 'rw_ops.hip']
 
 
 def test_no_launch_hands_a_device_scalar_to_the_next_one():

@@ -37,18 +37,18 @@ def _run(model, z, monkeypatch, sync, configs=CONFIGS):
 
 @pytest.mark.parametrize('direct16', [pytest.param(None, id='default'), pytest.param('0', id='f4x4-everywhere'),
                                       pytest.param('1', id='direct16-all'),
-                                      pytest.param('fused-up', id='fused-upsampling')])
+                                      pytest.param('unfused-up', id='two-pass-upsampling')])
 @pytest.mark.parametrize('size,batch,reps', [(256, 4, 200), (1024, 2, 200)])
 def test_forwards_issued_back_to_back_equal_their_synced_twins(monkeypatch, size, batch, reps, direct16):
     """200 sequences of four differently configured forwards, issued WITHOUT a host sync in between (a forward starts
     while the previous one still runs, the RGB branch on its second stream), against the same four with a sync after
     each: bit-identical, at 256^2 and 1024^2, for the default kernel selection (direct sums on layers 10 - 17), with the
-    split F(4x4,3x3) kernels everywhere (RW_MM_DIRECT16=0), with direct sums also on the last layer (=1), and with the opt-in
-    fused upsampling kernel (RW_UP_FUSED2=1) -- the one whose neighbours on the RGB stream came back wrong until the streaming
-    kernels lost their packed fp32 FMAs: its sequences are held to the same bit-identity."""
-    if direct16 == 'fused-up':        # the opt-in one-pass upsampling kernel of csrc/rw_tconv.hip on every layer that takes it
-        monkeypatch.setenv('RW_UP_FUSED2', '1')
-        monkeypatch.setenv('RW_UP_FUSED2_MAX_IN', '512')
+    split F(4x4,3x3) kernels everywhere (RW_MM_DIRECT16=0), with direct sums also on the last layer (=1), and without the
+    fused upsampling kernel (RW_UP_FUSED2=0: the routes that were the default before it).  The default INCLUDES that kernel --
+    the one whose first forms' neighbours on the RGB stream came back wrong until the streaming kernels lost their packed
+    fp32 FMAs: its sequences are held to the same bit-identity."""
+    if direct16 == 'unfused-up':      # without csrc/rw_tconv.hip's kernel: F(2,2) transposed convolutions + blur passes, phase kernels
+        monkeypatch.setenv('RW_UP_FUSED2', '0')
     elif direct16:
         monkeypatch.setenv('RW_MM_DIRECT16', direct16)
     assert 'RW_FORWARD_DRAIN' not in os.environ          # the round-4 workaround is gone, not switched off
