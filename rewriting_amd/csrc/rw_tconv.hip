@@ -1012,8 +1012,12 @@ __global__ void __launch_bounds__(512, 2) tconv_blur_ws_kernel(const TconvProble
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float* zp = z0 + 2 * j + (c0 + j >= TC_PC ? 2 * TC_ZP - 2 * TC_PC : 0);
-          *reinterpret_cast<tc_f32x2*>(zp) = tc_f32x2{acc[b][0][j], acc[b][1][j]};
-          *reinterpret_cast<tc_f32x2*>(zp + TC_ZP) = tc_f32x2{acc[b][2][j], acc[b][3][j]};
+          // (four dword stores: the compiler pairs them into ds_write2_b32 -- two separate source registers each; as 8-byte
+          // vectors every pair cost two moves to bring accumulators of different blocks side by side)
+          zp[0] = acc[b][0][j];
+          zp[1] = acc[b][1][j];
+          zp[TC_ZP] = acc[b][2][j];
+          zp[TC_ZP + 1] = acc[b][3][j];
         }
       }
     }
