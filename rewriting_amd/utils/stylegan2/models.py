@@ -224,7 +224,8 @@ def matrix_mode(kind=None):
     convolutions on F(2x2,3x3) in fp32 (F(4x4,3x3) never runs there: conv_algo), and run the F(2,2) transposed
     convolutions (kind 'up') in the split form too, which holds the DIRECT kernels' bars (test_transposed_conv_f22_...:
     3e-6 relative) and is 1.4 - 1.5 x faster on the 64^2 ... 512^2 maps of a layer-10 / layer-14 sweep; RW_MM_HOOKED=f32
-    keeps them on fp32.  RW_MM=f32|split forces one everywhere."""
+    keeps them on fp32.  Where that split form applies, an upsampling layer without a hook inside runs as ONE launch of the
+    fused kernel (DemodulatedConv2dF.fused_upsample; +13 - 16 % on those sweeps).  RW_MM=f32|split forces one everywhere."""
     explicit = os.environ.get('RW_MM')
     if explicit:
         return explicit
@@ -523,8 +524,9 @@ class DemodulatedConv2dF(nn.Module):
         """Transposed conv + blur + noise + activation in one pass at the transposed convolution's OWN multiply count
         (hip.conv_transpose3x3s2_blur_fused, csrc/rw_tconv.hip: a direct sum on the 16-bit matrix pipe, the (2H+1)^2 map
         kept in LDS) -- the default for every upsampling layer it takes (w % 32 == 0, h % 16 == 0: 32^2 maps and up; at most
-        RW_UP_FUSED2_MAX_IN input channels) inside the un-hooked whole-generator forward in split mode; RW_UP_FUSED2=0
-        brings back the two-pass / phase-kernel routes.  History (round 5): the first forms were
+        RW_UP_FUSED2_MAX_IN input channels) inside the un-hooked whole-generator forward in split mode, and of hooked / sliced
+        models too (the statistics sweeps; RW_UP_FUSED2_HOOKED=0: not there); RW_UP_FUSED2=0 brings back the two-pass /
+        phase-kernel routes.  History (round 5): the first forms were
         +1.6 % on the forward and stayed opt-in because to_rgb_kernel on the second stream came back wrong beside them (its
         packed fp32 FMAs; the streaming kernels are compiled without packed fp32 math since: csrc/rw_ops.hip, first line);
         the persistent form with specialised waves on the layers of few channels and the one-workgroup-per-CU form on the
@@ -532,7 +534,13 @@ class DemodulatedConv2dF(nn.Module):
         stress / parity tests of the forward run with them."""
         if not self.upsample or conv_impl() != 0 or conv_precision() != 'f32' or up_conv_algo() == 'direct':
             return False
-        if os.environ.get('RW_UP_FUSED2', '1') != '1' or not _rgb_branch.image_path or not _split_part('up1'):
+        if os.environ.get('RW_UP_FUSED2', '1') != '1':
+            return False
+        # the un-hooked forward: with the one-pass kinds of the split form; a hooked / sliced model (the statistics sweeps,
+        # the rewriter's sub-models: no hook INSIDE this layer, or StyledConvSeq would not be on its fused path): where
+        # the F(2,2) transposed convolutions run in the split form (matrix_mode('up')), unless RW_UP_FUSED2_HOOKED=0
+        if not (_split_part('up1') if _rgb_branch.image_path
+                else _split_part('up') and os.environ.get('RW_UP_FUSED2_HOOKED', '1') == '1'):
             return False
         if tuple(blur.pad) != (1, 1) or tuple(blur.kernel.shape) != (4, 4):
             return False

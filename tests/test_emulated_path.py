@@ -501,7 +501,8 @@ def test_fused_transposed_conv_and_blur_layer_stays_inside_the_image_tolerance(e
     """DemodulatedConv2dF.fused_upsample: inside the un-hooked forward an upsampling StyledConv whose shape
     hip.tconv_blur_supported takes runs as ONE launch of hip.conv_transpose3x3s2_blur_fused (the transposed convolution at
     its own multiply count, the blur from LDS) with the layer's plain direct-16 packing; same generator, reference
-    golden, image tolerance; RW_UP_FUSED2=0, a layer above RW_UP_FUSED2_MAX_IN channels and hooked models never take it."""
+    golden, image tolerance; RW_UP_FUSED2=0 and a layer above RW_UP_FUSED2_MAX_IN channels never take it; hooked models do
+    unless a hook sits inside the layer."""
     from rewriting_amd import hip
     from rewriting_amd.utils import nethook
     g = load_golden('gen_s64_cm1')
@@ -528,8 +529,24 @@ def test_fused_transposed_conv_and_blur_layer_stays_inside_the_image_tolerance(e
         base = model(z)
     assert not calls and (got - base).abs().max().item() < 1e-4
     monkeypatch.delenv('RW_UP_FUSED2')
+    # a hooked model (a hook on the layer's OUTPUT, as the sweeps and the rewriters set them) takes it too, where its F(2,2)
+    # transposed convolutions run in the split form; not with RW_UP_FUSED2_HOOKED=0, not with RW_MM_HOOKED=f32, and not a
+    # layer with a hook INSIDE it (that one runs child by child)
     with nethook.InstrumentedModel(model) as inst:
         inst.retain_layer('layer9', detach=False)
         with torch.no_grad():
             hooked = inst(z)
-    assert not calls and (hooked - got).abs().max().item() < 1e-4
+        assert [tuple(sh[2:]) for sh, _ in calls] == [(32, 32)] and 'y_amax' not in calls[0][1]
+        assert (hooked - got).abs().max().item() < 1e-4
+        del calls[:]
+        for name in ('RW_UP_FUSED2_HOOKED', 'RW_MM_HOOKED'):
+            monkeypatch.setenv(name, '0' if name == 'RW_UP_FUSED2_HOOKED' else 'f32')
+            with torch.no_grad():
+                other = inst(z)
+            monkeypatch.delenv(name)
+            assert not calls and (other - got).abs().max().item() < 1e-4
+    with nethook.InstrumentedModel(model) as inst:
+        inst.retain_layer('layer9.sconv.mconv.blur', detach=False)
+        with torch.no_grad():
+            inside = inst(z)
+    assert not calls and (inside - got).abs().max().item() < 1e-4
