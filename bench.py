@@ -789,9 +789,11 @@ def measure_sweep(device, size, layer, nseeds, steps, warmup, world, g=None):
                               peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=issued_frac, traffic=None,
                               effective_tflops=round(effective, 2),
                               effective_over_fp32_direct_roof=round(effective / FP32_MFMA_PEAK_TFLOPS, 4),
-                              note='per GPU.  `frac` = the headline\'s definition: matrix FLOPs the context forward\'s '
-                                   'convolution kernels ISSUE / the fp32 MFMA peak over their own time (one launch under '
-                                   'HIP events; null when not measured: N > 1).  `effective_*` = direct-sum conv FLOPs of '
+                              note='per GPU.  `frac` = the time the matrix pipes would need AT THEIR DENSE PEAKS (fp32 MFMAs for '
+                                   'the layers below 32^2, the 16-bit pipe for the split-operand kernels from 32^2 up) for '
+                                   'what the context forward\'s convolution kernels issue / those kernels\' own time (one '
+                                   'launch under HIP events; null when not measured: N > 1); `achieved` = that fraction of '
+                                   'the fp32 MFMA peak.  `effective_*` = direct-sum conv FLOPs of '
                                    'layers 2..%d + 2 H W C^2 of a^T a per seed (SURVEY.md 8d) / wall time -- the minimal-'
                                    'filtering kernels issue fewer; the key map itself (%.1f MB per seed) is read once'
                                    % (layer - 1, per_seed_bytes / 1e6)))
@@ -802,7 +804,9 @@ def run_sweep(args, rank, world, device):
     return dict(metric='key-statistics sweep seeds/sec (layer %d of stylegan2-%d)' % (args.layer, args.size),
                 value=m['seeds_per_s'], unit='seeds/sec', n_gpus=world, steps=args.steps,
                 warmup=args.warmup, ms_per_step=m['ms_per_sweep'], higher_is_better=True,
-                scaling='strong', vs_baseline=None, dtype='f32', data='synthetic',
+                scaling='strong', vs_baseline=None,
+                dtype='f32 (exact f16 operand split inside the convolution kernels from 32 x 32 maps up, f32 accumulate)',
+                data='synthetic',
                 config=dict(workload='%d-seed second-moment sweep, launches of %d seeds (reference batches of 10 '
                                      'inside) dealt round-robin, one all-reduce' % (args.seeds, m['launch']),
                             key_map=m['key_map'], gflop_per_seed=m['gflop_per_seed'],

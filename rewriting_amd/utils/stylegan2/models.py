@@ -220,8 +220,9 @@ def matrix_mode(kind=None):
     transformed operand as an exact pair of f16 numbers, the piece products on the 16-bit pipe, fp32 accumulation
     (hip.pack_conv_weight_wino4(split=True) ...: per-product error <= 2^-21, the kernels pass their parity tests at the
     fp32 bars).  Inside the un-hooked forward of the whole generator (image generation): 'split' for every kind of
-    kernel.  Hooked / sliced models -- key statistics, goal maps, the solve's context -- keep their stride-1
-    convolutions on F(2x2,3x3) in fp32 (F(4x4,3x3) never runs there: conv_algo), and run the F(2,2) transposed
+    kernel.  Hooked / sliced models -- key statistics, goal maps, the solve's context -- run their stride-1
+    convolutions on F(2x2,3x3) in fp32 below 32^2 and as direct sums on the 16-bit pipe from there up (F(4x4,3x3) never
+    runs there: conv_algo; DemodulatedConv2dF.hooked_direct16), and run the F(2,2) transposed
     convolutions (kind 'up') in the split form too, which holds the DIRECT kernels' bars (test_transposed_conv_f22_...:
     3e-6 relative) and is 1.4 - 1.5 x faster on the 64^2 ... 512^2 maps of a layer-10 / layer-14 sweep; RW_MM_HOOKED=f32
     keeps them on fp32.  Where that split form applies, an upsampling layer without a hook inside runs as ONE launch of the
@@ -566,6 +567,16 @@ class DemodulatedConv2dF(nn.Module):
         return (not self.upsample and _split_part('w4') and conv_algo() == 'winograd4' and conv_impl() == 0
                 and conv_precision() == 'f32' and hip.wino4_supported(self.out_channel, self.in_channel, h, w))
 
+    def hooked_direct16(self, h, w):
+        """A hooked / sliced model (statistics sweeps, goal maps, the solve's context): the stride-1 convolutions of maps from
+        32^2 up as DIRECT sums on the 16-bit matrix pipe (exact f16 operand pairs, fp32 accumulation: 4e-7 from the fp32
+        direct sum, the error class these models are held to) in place of the fp32 F(2x2,3x3) kernel -- where their F(2,2)
+        transposed convolutions run in the split form too (matrix_mode('up')).  The kernel measures its input itself: nobody
+        hands a bound over outside the un-hooked forward.  RW_DIRECT16_HOOKED=0: off."""
+        return (not self.upsample and not _rgb_branch.image_path and os.environ.get('RW_DIRECT16_HOOKED', '1') == '1'
+                and os.environ.get('RW_CONV_ALGO') is None and matrix_mode('up') == 'split' and conv_impl() == 0
+                and conv_precision() == 'f32' and _direct16(self, h, w, 'conv'))
+
     def squared_sums(self):
         return self._derived.get('wsq', self.weight, lambda: hip.weight_sqsum(self.weight, self.scale))
 
@@ -638,6 +649,9 @@ class DemodulatedConv2dF(nn.Module):
                                          demod=demod, x_amax=x_amax, y_amax=y_amax, **epilogue)
             return hip.conv3x3_wino4(fmap, self.wino4_weight(), self.out_channel, self.scale, style=load_style,
                                      demod=demod, **epilogue)
+        if self.hooked_direct16(fmap.shape[-2], fmap.shape[-1]):
+            return hip.conv3x3_direct16(fmap, self.direct16_weight(), self.out_channel, self.scale, style=load_style,
+                                        demod=demod, x_amax=x_amax, **epilogue)
         if (conv_algo() in ('winograd', 'winograd4') and conv_impl() == 0 and conv_precision() == 'f32'
                 and hip.wino_supported(self.out_channel, self.in_channel, fmap.shape[-2], fmap.shape[-1])):
             return hip.conv3x3_wino(fmap, self.wino_weight(), self.out_channel, self.scale, style=load_style,

@@ -484,9 +484,18 @@ def test_bounds_are_produced_only_where_the_next_layer_reads_them(emulated_hip, 
         inst.retain_layer('layer7', detach=False)
         with torch.no_grad():
             inst(z)
-    # hooked: nobody hands a bound over; the F(2,2) transposed convolution of layer 9 runs in the split form there too and
-    # measures its input itself, everything else multiplies in fp32
-    assert not made and measured == [(b, model.channels[32], 32, 32)]
+    # hooked: nobody hands a bound over; from 32^2 up the convolutions run on the 16-bit pipe there too (layer 8: direct sums,
+    # layer 9: the fused upsampling kernel, layer 10: direct sums) and each measures its input itself, everything below
+    # multiplies in fp32
+    assert not made and measured == [(b, model.channels[32], 32, 32)] * 2 + [(b, model.channels[64], 64, 64)], measured
+    monkeypatch.setenv('RW_DIRECT16_HOOKED', '0')
+    del measured[:]
+    with nethook.InstrumentedModel(model) as inst:
+        inst.retain_layer('layer7', detach=False)
+        with torch.no_grad():
+            inst(z)
+    assert not made and measured == [(b, model.channels[32], 32, 32)]         # layer 9 alone
+    monkeypatch.delenv('RW_DIRECT16_HOOKED')
     monkeypatch.setenv('RW_MM_HOOKED', 'f32')
     del measured[:]
     with nethook.InstrumentedModel(model) as inst:
