@@ -557,8 +557,9 @@ def run_forward(args, rank, world, device, size, batch, name, cpu=True):
     out = dict(metric='images/sec StyleGANv2-%d fwd' % size, value=round(images / dt, 2), unit='images/sec',
                n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3),
                higher_is_better=True, scaling='weak', vs_baseline=None,
-               dtype=('f32 (exact f16 operand split inside the F(4x4,3x3) / F(2,2) kernels: four piece products per '
-                      'multiply on the 16-bit matrix pipe, f32 accumulate; f32 everywhere else)' if split and
+               dtype=('f32 (exact f16 operand split inside the convolution kernels of the maps from 32 x 32 up -- direct '
+                      'sums, fused transposed conv + blur, F(4x4,3x3): three or four piece products per multiply on the '
+                      '16-bit matrix pipe, f32 accumulate; f32 everywhere else)' if split and
                       args.precision == 'f32' else
                       'f32' if args.precision == 'f32' else 'f32 via bf16x6 split (stride-1 convs), f32 elsewhere'),
                data='synthetic',
