@@ -446,6 +446,7 @@ def cpu_baseline_forward(size, images=8):
     finally:
         torch.set_num_threads(saved)
     return dict(value=round(n / dt, 4), unit='images/sec', cores=best, threads=best, host_cores=ncpu, kind=kind,
+                sample_short='%d images, batches of %d, %.1f s at %d of %d threads' % (n, batch, dt, best, ncpu),
                 sample='%d images of the stylegan2-%d forward in batches of %d through %s (torch %s CPU kernels), '
                        '%.1f s at %d threads; probe img/s by (threads, batch): %s; host has %d logical cpus'
                        % (n, size, batch, "the reference's own utils/stylegan2/models.py (oracle/reference_shim.py)"
@@ -557,9 +558,7 @@ def run_forward(args, rank, world, device, size, batch, name, cpu=True):
     out = dict(metric='images/sec StyleGANv2-%d fwd' % size, value=round(images / dt, 2), unit='images/sec',
                n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3),
                higher_is_better=True, scaling='weak', vs_baseline=None,
-               dtype=('f32 (exact f16 operand split inside the convolution kernels of the maps from 32 x 32 up -- direct '
-                      'sums, fused transposed conv + blur, F(4x4,3x3): three or four piece products per multiply on the '
-                      '16-bit matrix pipe, f32 accumulate; f32 everywhere else)' if split and
+               dtype=('f32 (conv operands split into exact f16 pairs from 32x32 up, f32 accumulate)' if split and
                       args.precision == 'f32' else
                       'f32' if args.precision == 'f32' else 'f32 via bf16x6 split (stride-1 convs), f32 elsewhere'),
                data='synthetic',
@@ -806,7 +805,7 @@ def run_sweep(args, rank, world, device):
                 value=m['seeds_per_s'], unit='seeds/sec', n_gpus=world, steps=args.steps,
                 warmup=args.warmup, ms_per_step=m['ms_per_sweep'], higher_is_better=True,
                 scaling='strong', vs_baseline=None,
-                dtype='f32 (exact f16 operand split inside the convolution kernels from 32 x 32 maps up, f32 accumulate)',
+                dtype='f32 (conv operands split into exact f16 pairs from 32x32 up, f32 accumulate)',
                 data='synthetic',
                 config=dict(workload='%d-seed second-moment sweep, launches of %d seeds (reference batches of 10 '
                                      'inside) dealt round-robin, one all-reduce' % (args.seeds, m['launch']),
@@ -906,6 +905,108 @@ def extras(args, rank, world, device):
     return out
 
 
+def _num(v, nd=4):
+    """Numbers only (rounded); anything else becomes None."""
+    if isinstance(v, bool) or v is None:
+        return v
+    if isinstance(v, (int, float)):
+        return v if isinstance(v, int) else (round(v, nd) if math.isfinite(v) else None)
+    return None
+
+
+def compact_line(out):
+    """The ONE line the driver parses: the contract keys only, numbers and short names, < 4 KB.  Everything else the
+    run measured (per-kernel tables, notes, samples, sources) is in bench_detail.json (write_detail)."""
+    short = lambda v, n=80: v if not isinstance(v, str) or len(v) <= n else v[:n - 1].rstrip() + '~'
+    c = {k: out.get(k) for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better',
+                                 'scaling', 'vs_baseline', 'dtype', 'data')}
+    c['dtype'] = short(c['dtype'])
+    c['config'] = {k: short(v, 64) for k, v in (out.get('config') or {}).items()
+                   if isinstance(v, (str, int, float, bool)) or v is None}
+    r = out.get('roofline')
+    c['roofline'] = None                 # always present; null = this workload is a job time, no single kernel priced
+    if r:
+        c['roofline'] = {k: (short(r.get(k), 48) if k in ('bound', 'kernel', 'unit') else _num(r.get(k)))
+                         for k in ('bound', 'kernel', 'launches', 'avg_launch_us', 'achieved', 'peak', 'unit', 'frac',
+                                   'traffic')}
+        alg = r.get('algorithmic_bytes_per_launch') or (r.get('hbm') or {}).get('algorithmic_bytes_per_launch')
+        if alg:
+            c['roofline']['algorithmic_bytes_per_launch'] = alg
+        if isinstance(r.get('mfma'), dict):
+            c['roofline']['mfma_frac'] = _num(r['mfma'].get('frac'))
+    b = out.get('cpu_baseline')
+    if b:
+        c['cpu_baseline'] = dict(value=_num(b.get('value')), unit=short(b.get('unit'), 24), cores=b.get('cores'),
+                                 kind=b.get('kind'), sample=short(b.get('sample_short') or b.get('sample'), 96))
+    st = out.get('step')
+    if st:
+        c['step'] = {k: _num(st.get(k)) for k in ('hbm_frac', 'hbm_bytes_algorithmic', 'hbm_bytes_pmc',
+                                                   'matrix_pipe_time_frac')}
+    pa = out.get('parity')
+    if pa:
+        c['parity'] = dict(linf=_num(pa.get('linf'), 9), ok=pa.get('ok'), bar=pa.get('bar_linf'))
+    if out.get('rccl'):
+        c['rccl'] = {k: out['rccl'].get(k) for k in ('backend', 'world_size')}
+    ex = out.get('extra')
+    if ex:
+        e = {}
+        for k, v in ex.items():
+            if k.startswith('sweep_') and isinstance(v, dict):
+                e[k + '_seeds_per_s'] = _num(v.get('seeds_per_s'))
+                if v.get('allreduce_ms') is not None:
+                    e[k + '_allreduce_ms'] = _num(v.get('allreduce_ms'))
+                    e[k + '_launches_this_rank'] = v.get('launches_this_rank')
+        ed = ex.get('edit_horse256_layer8')
+        if ed:
+            e['edit_s'] = _num(ed.get('seconds_per_edit'))
+            e['edit_key_collect_s'] = _num(ed.get('key_collect_s'))
+            e['edit_apply_s'] = _num(ed.get('apply_edit_s'))
+            e['edit_solve_s'] = _num(ed.get('solve_s'))
+            cb = ed.get('apply_edit_with_update_callback_s') or {}
+            e['edit_apply_reference_callback_s'] = _num(cb.get('reference_contract'))
+            if ed.get('cpu_baseline'):
+                e['edit_cpu_s'] = _num(ed['cpu_baseline'].get('value'))
+                e['edit_cpu_cores'] = ed['cpu_baseline'].get('cores')
+        f = ex.get('forward_ffhq256_b64')
+        if f:
+            e['ffhq256_b64_images_per_s'] = _num(f.get('images_per_s'))
+            e['ffhq256_parity_linf'] = _num((f.get('parity') or {}).get('linf'), 9)
+            e['ffhq256_hbm_frac'] = _num((f.get('step') or {}).get('hbm_frac'))
+        m = ex.get('forward_ffhq1024_by_matrix_mode')
+        if m:
+            e['ffhq1024_f32_pipe_images_per_s'] = _num((m.get('images_per_s') or {}).get('f32'))
+        w = ex.get('watermark_church256')
+        if w:
+            e['watermark_job_s'] = _num(w.get('seconds_per_job'))
+            e['watermark_images_per_s'] = _num(w.get('images_per_s'))
+        rc = ex.get('rccl_one_rank')
+        if rc:
+            e['rccl_one_rank_ok'] = bool(rc.get('ok'))
+            e['rccl_one_rank_allreduce_us'] = _num(rc.get('allreduce_us'))
+        c['extra'] = e
+    c['detail'] = out.get('detail')
+    return c
+
+
+def write_detail(out):
+    """The long form (per-kernel tables, notes, samples, counter sources): bench_detail.json next to this file and,
+    when the directory exists (a gpurun call), under gpurun_out/ so that it travels back; RW_BENCH_DETAIL=<path> names
+    the one file to write instead.  Returns the path written first, relative to the repository."""
+    text = json.dumps(out, indent=1)
+    written = None
+    where = ([os.environ['RW_BENCH_DETAIL']] if os.environ.get('RW_BENCH_DETAIL') else
+             [os.path.join(d, 'bench_detail.json') for d in (ROOT, os.path.join(ROOT, 'gpurun_out'))])
+    for path in where:
+        if os.path.isdir(os.path.dirname(os.path.abspath(path))):
+            try:
+                with open(path, 'w') as f:
+                    f.write(text)
+                written = written or os.path.relpath(path, ROOT)
+            except OSError:
+                pass
+    return written
+
+
 def rccl_selfcheck():
     """scripts/rccl_selfcheck.py in a child process (its own process group, bounded by a timeout): RCCL initialises a
     one-rank communicator on this box's GPU and runs the sweep's all-reduce.  A failure is reported, never raised."""
@@ -996,7 +1097,12 @@ def main():
                                 'the sweeps\' all-reduce of (mom2, count) (extra.sweep_*: allreduce_ms, launches, '
                                 'launches_this_rank = rank 0\'s share)')
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        # stdout: a pointer to the long form, then THE line (compact, contract keys, < 4 KB) as the last line
+        out['detail'] = write_detail(out)
+        print('# bench detail (per-kernel tables, notes, sources): %s' % out['detail'], flush=True)
+        line = json.dumps(compact_line(out), allow_nan=False, separators=(',', ':'))
+        assert len(line) < 4096, len(line)
+        print(line, flush=True)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

@@ -19,7 +19,7 @@
 #include <stdlib.h>
 #include <stdint.h>
 
-extern "C" int rw_abi_version(void) { return 7; }
+extern "C" int rw_abi_version(void) { return 8; }
 
 extern "C" const char* rw_error_string(int code) {
   if (code == 0) return "success";
