@@ -1,3 +1,5 @@
+// hipcc-flags: -fno-slp-vectorize -fno-vectorize
+// (no packed fp32 math beside the convolutions: rw_ops.hip header, tests/test_build_checks.py)
 // Bounds handed from launch to launch (rw_common.h, "a BOUND on a map" in include/rewriting_hip.h): the reduction of a
 // producer's slots, the stand-alone measurement of a map, and the host-side helpers of the by-value weight scale.
 #include "rw_common.h"

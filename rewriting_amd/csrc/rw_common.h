@@ -13,6 +13,19 @@ static inline hipStream_t rw_s(rw_stream_t s) { return (hipStream_t)s; }
 
 static inline int64_t rw_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Compute units of the CURRENT device (queried once per device; 256 on a whole MI355X, fewer on a partitioned one): the
+// workgroup count of the persistent kernels, which own a CU each.
+static inline int rw_cu_count(void) {
+  static int cached[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cached[dev] == 0) {
+    int n = 0;
+    cached[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+  }
+  return cached[dev];
+}
+
 // Grid for a memory-bound grid-stride kernel: enough blocks to fill 256 CUs x 8, no more.
 static inline int rw_stream_grid(int64_t work_items, int block) {
   int64_t g = rw_cdiv(work_items, block);

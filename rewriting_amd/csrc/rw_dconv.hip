@@ -1032,7 +1032,7 @@ static bool dconv_specialised(int in_ch, const rw_conv_epilogue* ep) {
 // as many workgroups as fit the chip at once, each taking every (grid)th tile
 static unsigned dconv_ws_grid(int64_t tiles, int per_cu = 1) {
   const char* e = getenv("RW_DCONV_GRID");
-  int64_t g = e ? atoi(e) : 256 * per_cu;
+  int64_t g = e ? atoi(e) : (int64_t)rw_cu_count() * per_cu;
   if (g < 1) g = 1;
   return (unsigned)(tiles < g ? tiles : g);
 }

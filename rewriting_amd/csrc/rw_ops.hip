@@ -1,4 +1,4 @@
-// hipcc-flags: -fno-slp-vectorize
+// hipcc-flags: -fno-slp-vectorize -fno-vectorize
 // (no PACKED fp32 math -- v_pk_fma_f32 / v_pk_mul_f32 -- in this file's kernels: they are the streaming kernels that run on the
 // side streams BESIDE the convolutions' MFMAs.  Round 5 found (scripts/interference_repro.py, profiles/r05i, r05l): with
 // rw_tconv.hip's kernel running on another stream, to_rgb_kernel's v_pk_fma_f32 results came back wrong in the low half of
@@ -622,9 +622,9 @@ __global__ void __launch_bounds__(64) demod_mfma_kernel(const float* __restrict_
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
       if (c0 + d < blocks) {
-        const rw_lin_f32x4 a2 = a[d] * a[d];
+        // (component by component: a vector multiply would be two v_pk_mul_f32 -- no packed fp32 math in this file)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[j], b[d][j], acc, 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[d][j] * a[d][j], b[d][j], acc, 0, 0, 0);
       }
     }
   }

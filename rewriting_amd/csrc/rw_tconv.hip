@@ -1100,7 +1100,7 @@ extern "C" int rw_tconv_blur_f32(const float* x, const float* wp, const float* k
     const int64_t tiles = (int64_t)batch * p.tiles_y * p.tiles_x * p.o_tiles;
     if (tiles <= 0 || tiles > 0x7fffffff) return RW_ERR_UNSUPPORTED;
     const char* ge = getenv("RW_TCONV_GRID");
-    int64_t grid = ge ? atoi(ge) : 256;
+    int64_t grid = ge ? atoi(ge) : rw_cu_count();       // one persistent workgroup per compute unit
     grid = grid < 1 ? 1 : (grid > tiles ? tiles : grid);
     if (y_amax && 8 * grid > rw_bound_slot_capacity((int64_t)batch * out_ch * 4 * h * w)) return RW_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(tconv_blur_ws_kernel, dim3((unsigned)grid), dim3(512), 0, rw_s(stream), p);

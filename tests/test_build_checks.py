@@ -84,18 +84,25 @@ def test_side_stream_kernels_are_compiled_without_packed_fp32_fma():
     MFMAs, and to_rgb_kernel's v_pk_fma_f32 came back wrong (low half, lanes 48..63) while rw_tconv.hip's kernel ran on
     another stream (round 5: scripts/interference_repro.py, profiles/r05i / r05l).  The generated code of the RGB branch's
     kernels must not contain a packed fp32 FMA."""
-    src = os.path.join(ROOT, 'rewriting_amd', 'csrc', 'rw_ops.hip')
-    first = open(src).readline()
-    assert first.startswith('// hipcc-flags:') and '-fno-slp-vectorize' in first
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
-    out = os.path.join('/tmp', 'rw_ops_check_%d.s' % os.getpid())
-    flags = first[len('// hipcc-flags:'):].split()
-    r = subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-S', '--cuda-device-only'] + flags +
-                       ['-o', out, src], capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr[-2000:]
-    text = open(out).read()
-    os.remove(out)
-    for kernel in ('to_rgb_kernel', 'upfirdn2d_up2k4_kernel', 'to_rgb_scalar_kernel'):
-        start = text.index(kernel)
-        body = text[start:text.index('s_endpgm', start)]
-        assert 'v_pk_fma_f32' not in body, kernel
+    # rw_ops.hip: every streaming kernel (ToRGB, upfirdn2d, equalised linear / modulation, demodulation factors, noise,
+    # bias + activation ...) -- whatever the forward puts on the RGB / prefetch streams comes from this file;
+    # rw_bound.hip: the bound reduction that follows every split-operand launch
+    for name in ('rw_ops.hip', 'rw_bound.hip'):
+        src = os.path.join(ROOT, 'rewriting_amd', 'csrc', name)
+        first = open(src).readline()
+        assert first.startswith('// hipcc-flags:') and '-fno-slp-vectorize' in first, name
+        out = os.path.join('/tmp', '%s_check_%d.s' % (name, os.getpid()))
+        flags = first[len('// hipcc-flags:'):].split()
+        r = subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-S', '--cuda-device-only'] + flags +
+                           ['-o', out, src], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        text = open(out).read()
+        os.remove(out)
+        if name == 'rw_ops.hip':
+            for kernel in ('to_rgb_kernel', 'upfirdn2d_up2k4_kernel', 'to_rgb_scalar_kernel', 'equal_linear_mfma_kernel'):
+                assert kernel in text, kernel
+        # no packed fp32 arithmetic in ANY kernel of the file (the FMA is what was seen to fail; the others share its pipe)
+        for insn in ('v_pk_fma_f32', 'v_pk_mul_f32', 'v_pk_add_f32'):
+            lines = [l for l in text.splitlines() if insn in l and not l.lstrip().startswith(';')]
+            assert not lines, (name, insn, len(lines))

@@ -314,3 +314,33 @@ def test_quantile_cache_interoperates_with_the_reference(tmp_path):
     numpy.savez(str(tmp_path / 'small.npz'), **small.state_dict())
     theirs_small = ref.runningstats.RunningQuantile(state=str(tmp_path / 'small.npz'))
     assert close(theirs_small.quantiles(qs), want)
+
+
+def test_exact_trajectory_fixture_of_the_full_size_edit_is_consistent_with_the_reference_runs():
+    """rw_s256_l8_horsehat_1000_exact.npz (oracle/make_golden.py golden_edit_full_exact): the float64 trajectory of
+    configs[2]'s solve.  Checked here: the oracle's float32 arithmetic re-run on the fixture's goal reproduces its
+    recorded distance from the exact update at 11 steps; the REFERENCE's own weights (rw_s256_l8_horsehat_1000.npz) are
+    within 1e-5 of the exact update through 101 steps and 2.3e-3 / 2.6e-3 away at 2001 (the horizon at which its 8-thread
+    and 1-thread runs differ by 2.2e-3 from each other): the bar of the GPU test is 1.5 x that."""
+    g, ge = load_golden('rw_s256_l8_horsehat_1000'), load_golden('rw_s256_l8_horsehat_1000_exact')
+    sd = oracle_state_dict(build_stylegan(256, 0.5))
+    W0 = sd['layer8.sconv.mconv.dconv.weight'].clone()
+    mkey = torch.from_numpy(g['mkey'])
+    _, _, snaps = R.insert_explicit(W0, torch.from_numpy(g['goal_in_fmap']), torch.from_numpy(g['goal_in_style']),
+                                    torch.from_numpy(g['goal_out_fmap']), sd['layer8.sconv.activate.bias'],
+                                    sd['layer8.sconv.noise.weight'], mkey, niter=11, piter=10, snapshots=(1, 10, 11))
+    for n in (1, 10, 11):
+        cos = torch.einsum('oiyx,di->odyx', (snaps[n] - W0)[0].double(), mkey.double())
+        d = ((cos - torch.from_numpy(ge['exact_dW_%d_cos' % n])).norm() / float(ge['exact_dW_%d_norm' % n])).item()
+        # (the recorded figure is the distance of the WHOLE tensor; its component along the direction cannot be larger)
+        assert d < 1e-4 and d <= float(ge['restatement_f32_vs_exact_%d' % n]) + 1e-7, (n, d)
+        if n % 10 == 1:                      # a projection step (it % piter == 0): the update lies along the direction
+            assert float(ge['exact_off_direction_%d' % n]) < 1e-6      # (the direction is unit in float32 only)
+    for tag in ('1', '10', '11', '100', '101'):
+        ref_cos = torch.from_numpy(g['dW_%s_cos' % tag]).double()
+        d = ((ref_cos - torch.from_numpy(ge['exact_dW_%s_cos' % tag])).norm() / float(ge['exact_dW_%s_norm' % tag])).item()
+        assert d < 1e-5 and abs(d - float(ge['reference_vs_exact_%s' % tag])) < 1e-9, (tag, d)
+    d8, d1 = float(ge['reference_vs_exact_2001_t8']), float(ge['reference_vs_exact_2001_t1'])
+    assert 1e-3 < d8 < 5e-3 and 1e-3 < d1 < 5e-3
+    # the two reference runs are as far from each other as each is from the exact update: float32's chaos, not a bug
+    assert abs(float(g['self_scatter_2001']) - 2.2e-3) < 1e-3
