@@ -4,7 +4,7 @@
 //
 // Stand-alone: HIP runtime + the library's C ABI only (no torch, no Python).  Two streams; per (aggressor, victim) pair the
 // victim runs alone once (its reference), then REPS times beside the aggressor (aggressor launched first on stream A, the
-// victim right behind it on stream B, both drained), and every overlapped result is compared with the reference BIT FOR BIT.
+// victim right behind it on stream B, the aggressor once more behind that on stream A, both drained), and every overlapped result is compared with the reference BIT FOR BIT.
 // One JSON line per pair: overlapped launches whose result differs, differing elements, the largest deviation, and where
 // the differing elements sit (lane of the wave that wrote them, component of the lane's four pixels, output colour).
 //
@@ -35,15 +35,18 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
 // ------------------------------------------------------------------ victims
-enum { V_PKFMA = 0, V_PKMULADD = 1, V_FMA = 2, V_COUNT = 3 };
-static const char* const victim_name[V_COUNT] = {"v_pk_fma_f32", "v_pk_mul_f32+v_pk_add_f32", "v_fma_f32"};
+enum { V_PKFMA = 0, V_PKMULADD = 1, V_FMA = 2, V_COMPILER = 3, V_COMPILER_DUP = 4, V_COUNT = 5 };
+static const char* const victim_name[V_COUNT] = {"v_pk_fma_f32", "v_pk_mul_f32+v_pk_add_f32", "v_fma_f32",
+                                                  "compiler-written (float4 accumulate; the SLP vectoriser packs it: v_pk_fma_f32 with op_sel)",
+                                                  "compiler-written, weights stored as {w, w} pairs (v_pk_fma_f32 without op_sel)"};
 
 template <int KIND>
 __global__ void __launch_bounds__(256) victim_kernel(const float* __restrict__ x, const float* __restrict__ w3,
                                                       float* __restrict__ y, int in_ch, long long hw) {
   __shared__ float wm[3 * 64];
+  __shared__ f2 wm2[3 * 64];
   const int b = blockIdx.y;
-  for (int t = threadIdx.x; t < 3 * in_ch; t += 256) wm[t] = w3[t] * (1.0f + 0.01f * b);
+  for (int t = threadIdx.x; t < 3 * in_ch; t += 256) { wm[t] = w3[t] * (1.0f + 0.01f * b); wm2[t] = f2{wm[t], wm[t]}; }
   __syncthreads();
   const long long hw4 = hw >> 2;
   const float* xb = x + (long long)b * in_ch * hw;
@@ -59,7 +62,13 @@ __global__ void __launch_bounds__(256) victim_kernel(const float* __restrict__ x
       for (int c = 0; c < 3; ++c) {
         const float w = wm[c * in_ch + i];
         const f2 ww = {w, w};
-        if (KIND == V_PKFMA) {
+        if (KIND == V_COMPILER_DUP) {              // the same arithmetic on ready {w, w} operands
+          const f2 w2 = wm2[c * in_ch + i];
+          a[c][0] = __builtin_elementwise_fma(lo, w2, a[c][0]);
+          a[c][1] = __builtin_elementwise_fma(hi, w2, a[c][1]);
+        } else if (KIND == V_COMPILER) {           // to_rgb_kernel's own statements (round 5's victim)
+          a[c][0][0] += w * v[0]; a[c][0][1] += w * v[1]; a[c][1][0] += w * v[2]; a[c][1][1] += w * v[3];
+        } else if (KIND == V_PKFMA) {
           asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(a[c][0]) : "v"(lo), "v"(ww));
           asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(a[c][1]) : "v"(hi), "v"(ww));
         } else if (KIND == V_PKMULADD) {
@@ -83,9 +92,10 @@ __global__ void __launch_bounds__(256) victim_kernel(const float* __restrict__ x
 }
 
 // ------------------------------------------------------------------ synthetic aggressors
-enum { S_MFMA = 0, S_MFMA_PRIO = 1, S_MFMA_LDS = 2, S_MFMA_GLOBAL = 3, S_VALU = 4, S_COUNT = 5 };
+enum { S_MFMA = 0, S_MFMA_PRIO = 1, S_MFMA_LDS = 2, S_MFMA_GLOBAL = 3, S_VALU = 4, S_LDS_ONLY = 5, S_GLOBAL_ONLY = 6, S_COUNT = 7 };
 static const char* const synth_name[S_COUNT] = {"synthetic: MFMA loop", "synthetic: MFMA loop + s_setprio 3", "synthetic: MFMA + LDS reads",
-                                                "synthetic: MFMA + global loads", "synthetic: v_pk_fma_f32 loop, no MFMA"};
+                                                "synthetic: MFMA + global loads", "synthetic: v_pk_fma_f32 loop, no MFMA",
+                                                "synthetic: LDS reads, no MFMA", "synthetic: global loads, no MFMA"};
 
 template <int KIND>
 __global__ void __launch_bounds__(512, 2) synth_kernel(float* out, const float* src, long long src_elems, int iters, float a, float b) {
@@ -113,13 +123,14 @@ __global__ void __launch_bounds__(512, 2) synth_kernel(float* out, const float* 
     } else {
 #pragma unroll
       for (int m = 0; m < 40; ++m) {
-        acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha, hb, acc[m], 0, 0, 0);
-        if (KIND == S_MFMA_LDS && (m & 3) == 0) {
+        if (KIND != S_LDS_ONLY && KIND != S_GLOBAL_ONLY) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha, hb, acc[m], 0, 0, 0);
+        else asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(acc[m][0]) : "v"(a));
+        if ((KIND == S_MFMA_LDS || KIND == S_LDS_ONLY) && (m & 3) == 0) {
           const f4 l = *reinterpret_cast<const f4*>(&lds[((threadIdx.x * 4 + 64 * m + 16 * it) & 16380)]);
           ha[0] += (_Float16)(l[0] * 1e-9f);
         }
       }
-      if (KIND == S_MFMA_GLOBAL) {
+      if (KIND == S_MFMA_GLOBAL || KIND == S_GLOBAL_ONLY) {
         g += *reinterpret_cast<const f4*>(src + (gi % (src_elems - 4)));
         gi += (long long)gridDim.x * 512 * 4;
       }
@@ -162,6 +173,8 @@ int main(int argc, char** argv) {
     if (kind == V_PKFMA) hipLaunchKernelGGL(victim_kernel<V_PKFMA>, grid, dim3(256), 0, s, vx, vw, vy, vc, vhw);
     if (kind == V_PKMULADD) hipLaunchKernelGGL(victim_kernel<V_PKMULADD>, grid, dim3(256), 0, s, vx, vw, vy, vc, vhw);
     if (kind == V_FMA) hipLaunchKernelGGL(victim_kernel<V_FMA>, grid, dim3(256), 0, s, vx, vw, vy, vc, vhw);
+    if (kind == V_COMPILER) hipLaunchKernelGGL(victim_kernel<V_COMPILER>, grid, dim3(256), 0, s, vx, vw, vy, vc, vhw);
+    if (kind == V_COMPILER_DUP) hipLaunchKernelGGL(victim_kernel<V_COMPILER_DUP>, grid, dim3(256), 0, s, vx, vw, vy, vc, vhw);
     CK(hipGetLastError());
   };
 
@@ -217,7 +230,7 @@ int main(int argc, char** argv) {
     }
   };
   // length of the synthetic loops: ~ the library kernel's duration at this batch
-  int synth_iters = 3000 * B;
+  int synth_iters = 1000 * B;
   auto launch_aggressor = [&](int a, hipStream_t s) {
     if (a == A_NONE) return;
     if (a == A_TCONV_WS || a == A_TCONV_T16) {
@@ -233,6 +246,8 @@ int main(int argc, char** argv) {
     if (k == S_MFMA_LDS) hipLaunchKernelGGL(synth_kernel<S_MFMA_LDS>, dim3(256), dim3(512), 0, s, synth_out, x, src_elems, it, 0.5f, 0.25f);
     if (k == S_MFMA_GLOBAL) hipLaunchKernelGGL(synth_kernel<S_MFMA_GLOBAL>, dim3(256), dim3(512), 0, s, synth_out, x, src_elems, it, 0.5f, 0.25f);
     if (k == S_VALU) hipLaunchKernelGGL(synth_kernel<S_VALU>, dim3(256), dim3(512), 0, s, synth_out, x, src_elems, it, 0.5f, 0.25f);
+    if (k == S_LDS_ONLY) hipLaunchKernelGGL(synth_kernel<S_LDS_ONLY>, dim3(256), dim3(512), 0, s, synth_out, x, src_elems, it, 0.5f, 0.25f);
+    if (k == S_GLOBAL_ONLY) hipLaunchKernelGGL(synth_kernel<S_GLOBAL_ONLY>, dim3(256), dim3(512), 0, s, synth_out, x, src_elems, it, 0.5f, 0.25f);
     CK(hipGetLastError());
   };
 
@@ -256,8 +271,11 @@ int main(int argc, char** argv) {
       for (int r = 0; r < REPS; ++r) {
         CK(hipMemsetAsync(vy, 0, vout * 4, sb));
         CK(hipStreamSynchronize(sb));
+        // the order of round 5's reproducer: aggressor, victim, aggressor -- the victim's workgroups take the compute
+        // units the first launch's tail frees and give them to the second launch's workgroups
         launch_aggressor(a, sa);
         CK(hipEventRecord(v0, sb)); launch_victim(v, sb); CK(hipEventRecord(v1, sb));
+        launch_aggressor(a, sa);
         CK(hipStreamSynchronize(sa)); CK(hipStreamSynchronize(sb));
         float v_ms = 0.f; CK(hipEventElapsedTime(&v_ms, v0, v1)); v_ms_sum += v_ms;
         CK(hipMemcpy(got.data(), vy, vout * 4, hipMemcpyDeviceToHost));
