@@ -362,6 +362,20 @@ int rw_pack_dconv_weight_f32(const float* w, float* wp, int out_ch, int in_ch, f
 int rw_dconv3x3_f32(const float* x, const float* wp, float* y, int batch, int in_ch, int out_ch, int h, int w,
                     float w_scale, const rw_conv_epilogue* ep, float u_inv, const float* x_amax, float* y_amax,
                     rw_stream_t stream);
+/* rw_dconv3x3_f32 that ALSO leaves the channel sums of the ToRGB which reads its result (ToRGBF.forward, models.py:639-655;
+ * the reference's generator applies it to the output of every second styled convolution, :126-131): rgb->out receives
+ * rw_dconv3x3_rgb_partials(out_ch) = out_ch / 32 partial images, layout (partial, batch, 3, h, w) -- one per wave's 32
+ * out-channels, summed while the activated values are in registers; rgb->weight (3, out_ch), rgb->style (batch, out_ch),
+ * rgb->scale as in rw_rgb_epilogue, rgb->bias / rgb->skip are NOT used here.  rw_rgb_combine_f32 finishes the ToRGB:
+ *   out[b][c][p] = sum_k partial[k][b][c][p] + bias[c] + skip[b][c][p]      (bias, skip nullable; hw % 4 == 0).
+ * The feature map y is written as by rw_dconv3x3_f32 (the next layer reads it); the second pass over it (rw_to_rgb_f32)
+ * disappears.  Same shapes as rw_dconv3x3_f32. */
+int rw_dconv3x3_rgb_partials(int out_ch);
+int rw_dconv3x3_rgb_partial_f32(const float* x, const float* wp, float* y, int batch, int in_ch, int out_ch, int h, int w,
+                                float w_scale, const rw_conv_epilogue* ep, const rw_rgb_epilogue* rgb, float u_inv,
+                                const float* x_amax, float* y_amax, rw_stream_t stream);
+int rw_rgb_combine_f32(const float* partials, int n_part, const float* bias, const float* skip, float* y, int batch,
+                       int64_t hw, rw_stream_t stream);
 int rw_dconv3x3_to_rgb_supported(int out_ch, int in_ch, int h, int w);
 int rw_dconv3x3_to_rgb_f32(const float* x, const float* wp, int batch, int in_ch, int out_ch, int h, int w,
                            float w_scale, const rw_conv_epilogue* ep, const rw_rgb_epilogue* rgb, float u_inv,

@@ -14,7 +14,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('RW_HIP_LIB') or os.path.join(_HERE, 'librewriting_hip.so')    # RW_HIP_LIB: tuning builds
 
-ABI_VERSION = 8        # 8: rw_tconv_blur_* (fused transposed conv + blur); 7: bounds as RW_BOUND_LANES-float vectors written by plain stores, weight scales by value (rw_split_weight_scale, rw_*_absmax_f32), no rw_publish_scalar_f32; 6: rw_publish_scalar_f32; 5: rw_dconv* (direct sums on the 16-bit pipe); 4: rw_*_wino4h_* (operands split into f16 pairs), rw_absmax_f32; 3: rw_solve_run_*, the 8x8 / 4x4 shapes (style == NULL), packed F(4x4,3x3) point order w4_nat; 2: rw_solve_supported 1/0, sizes[6]
+ABI_VERSION = 9        # 9: rw_dconv3x3_rgb_partial_f32 / rw_rgb_combine_f32 (ToRGB sums left by the producing convolution); 8: rw_tconv_blur_* (fused transposed conv + blur); 7: bounds as RW_BOUND_LANES-float vectors written by plain stores, weight scales by value (rw_split_weight_scale, rw_*_absmax_f32), no rw_publish_scalar_f32; 6: rw_publish_scalar_f32; 5: rw_dconv* (direct sums on the 16-bit pipe); 4: rw_*_wino4h_* (operands split into f16 pairs), rw_absmax_f32; 3: rw_solve_run_*, the 8x8 / 4x4 shapes (style == NULL), packed F(4x4,3x3) point order w4_nat; 2: rw_solve_supported 1/0, sizes[6]
 
 
 class ConvEpilogue(Structure):
@@ -134,6 +134,11 @@ SIGNATURES = {
     'rw_pack_dconv_weight_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     'rw_dconv3x3_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                 POINTER(ConvEpilogue), c_float, c_void_p, c_void_p, c_void_p]),
+    'rw_dconv3x3_rgb_partials': (c_int, [c_int]),
+    'rw_dconv3x3_rgb_partial_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
+                                            POINTER(ConvEpilogue), POINTER(RgbEpilogue), c_float, c_void_p, c_void_p,
+                                            c_void_p]),
+    'rw_rgb_combine_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]),
     'rw_dconv3x3_to_rgb_supported': (c_int, [c_int, c_int, c_int, c_int]),
     'rw_dconv3x3_to_rgb_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                        POINTER(ConvEpilogue), POINTER(RgbEpilogue), c_float, c_void_p, c_void_p]),

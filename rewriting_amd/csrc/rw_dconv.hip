@@ -130,7 +130,7 @@ __device__ __forceinline__ float dc_row_sum(float v) {
 
 template <int MODE, int WM>
 __device__ __forceinline__ void dconv_body(const DconvProblem& p) {
-  constexpr bool UP = MODE == 1, RGB = MODE == 2;
+  constexpr bool UP = MODE == 1, RGB = MODE == 2, RGBP = MODE == 3;
   static_assert(!RGB || WM == 1, "ToRGB: one wave holds all out-channels of its pixels");
   static_assert(!UP || WM == 2, "UP: the wave pairs are the two row phases");
   constexpr int WN = 4 / WM, TR = 4 * WN, PR = TR + 2;
@@ -141,7 +141,7 @@ __device__ __forceinline__ void dconv_body(const DconvProblem& p) {
   __shared__ __attribute__((aligned(16))) unsigned char Ls[2 * BUFB];
   __shared__ __attribute__((aligned(16))) float St[512];
   __shared__ float Ct[2][VCH];
-  __shared__ float Cr[3][32];
+  __shared__ float Cr[3][(RGB || RGBP) ? 32 * WM : 1];
   __shared__ float Red[4];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -182,7 +182,7 @@ __device__ __forceinline__ void dconv_body(const DconvProblem& p) {
     const int o = UP ? 16 * ot + (tid & 15) : ot * VCH + tid;
     Ct[0][tid] = (p.demod ? p.demod[(int64_t)ib * real_ch + o] * p.w_scale : p.w_scale) * out_scale * gain;
     Ct[1][tid] = p.act ? p.bias[o] * gain : 0.f;
-    if (RGB) {
+    if (RGB || RGBP) {
       const float sr = p.rgb_scale * p.rgb_style[(int64_t)ib * p.out_ch + o];
 #pragma unroll
       for (int cc = 0; cc < 3; ++cc) Cr[cc][tid] = sr * p.rgb_weight[cc * p.out_ch + o];
@@ -357,25 +357,45 @@ __device__ __forceinline__ void dconv_body(const DconvProblem& p) {
 
   // ---- epilogue: lane (lk, lt) holds out-channel lt of block ob, pixels 4 lk .. 4 lk + 3 of pixel block pb
   float ymax = 0.f;
-  if (MODE == 0) {
+  if (MODE == 0 || RGBP) {
     const int oc = 16 * (2 * wm) + lt;              // + 16 ob
     const float sc[2] = {Ct[0][oc], Ct[0][oc + 16]}, bs[2] = {Ct[1][oc], Ct[1][oc + 16]};
     float* yb = p.y + ((int64_t)ib * p.out_ch + ot * VCH + oc) * hw;
+    // RGBP: this wave's share of the ToRGB that reads the result (models.py:639-655) -- the sum over ITS 32 channels of
+    // rgb weight x rgb style x activated value, per colour: partial (ot WM + wm) of out_ch / 32, planes [partial][image][colour]
+    float cr[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    float* rb = nullptr;
+    if (RGBP) {
+#pragma unroll
+      for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) cr[ob][cc] = Cr[cc][oc + 16 * ob];
+      rb = p.rgb_out + (((int64_t)(ot * WM + wm) * p.batch + ib) * 3 + (lt < 3 ? lt : 0)) * hw;
+    }
 #pragma unroll
     for (int pb = 0; pb < 8; ++pb) {
       const int64_t pix = (int64_t)(y0 + 4 * wn + (pb >> 1)) * p.w + x0 + 16 * (pb & 1) + 4 * lk;
       dc_f32x4 nz = {0.f, 0.f, 0.f, 0.f};
       if (p.noise) nz = *reinterpret_cast<const dc_f32x4*>(p.noise + (int64_t)ib * hw + pix) * noise_wg;
+      dc_f32x4 v[2];
 #pragma unroll
       for (int ob = 0; ob < 2; ++ob) {
-        dc_f32x4 v;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float u = acc[ob][pb][j] * sc[ob] + nz[j] + bs[ob];
-          v[j] = fmaxf(u, u * slope);
-          ymax = fmaxf(ymax, fabsf(v[j]));
+          v[ob][j] = fmaxf(u, u * slope);
+          ymax = fmaxf(ymax, fabsf(v[ob][j]));
         }
-        *reinterpret_cast<dc_f32x4*>(yb + (int64_t)(16 * ob) * hw + pix) = v;
+        *reinterpret_cast<dc_f32x4*>(yb + (int64_t)(16 * ob) * hw + pix) = v[ob];
+      }
+      if (RGBP) {
+        dc_f32x4 sum[3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int cc = 0; cc < 3; ++cc) sum[cc][j] = dc_row_sum(v[0][j] * cr[0][cc] + v[1][j] * cr[1][cc]);
+        // every lane of the row holds the sums: lane lt == cc stores colour cc
+        if (lt < 3) *reinterpret_cast<dc_f32x4*>(rb + pix) = lt == 0 ? sum[0] : (lt == 1 ? sum[1] : sum[2]);
       }
     }
   } else if (UP) {
@@ -953,12 +973,19 @@ __device__ __forceinline__ void dconv_ws_body(const DconvProblem& p) {
 // tiles 64 columns wide: 16 rows (32 out-channels), 8 rows (64), 4 rows (128)
 __global__ void __launch_bounds__(768, 3) dconv_ws_w2_kernel(const DconvProblem p) { dconv_ws_body<0, 2, 8, 4, 2>(p); }
 __global__ void __launch_bounds__(768, 3) dconv_ws_up_kernel(const DconvProblem p) { dconv_ws_body<1, 2, 8, 4, 2>(p); }
+// ToRGB in the epilogue (out_ch == 32: a wave holds every out-channel of its pixels): four multiplying waves (one per SIMD,
+// 8 rows x 64 columns per tile) + two staging waves (two channel quads and one weight block each); 120 KB of LDS
+__global__ void __launch_bounds__(384, 2) dconv_ws_rgb_kernel(const DconvProblem p) { dconv_ws_body<2, 1, 4, 2, 2>(p); }
 
 __global__ void __launch_bounds__(256, 2) dconv_w1_kernel(const DconvProblem p) { dconv_body<0, 1>(p); }
 __global__ void __launch_bounds__(256, 2) dconv_w2_kernel(const DconvProblem p) { dconv_body<0, 2>(p); }
 __global__ void __launch_bounds__(256, 2) dconv_w4_kernel(const DconvProblem p) { dconv_body<0, 4>(p); }
 __global__ void __launch_bounds__(256, 2) dconv_up_kernel(const DconvProblem p) { dconv_body<1, 2>(p); }
 __global__ void __launch_bounds__(256, 2) dconv_rgb_kernel(const DconvProblem p) { dconv_body<2, 1>(p); }
+// MODE 3: the stride-1 convolution that ALSO leaves the partial sums of the ToRGB that reads its result (one per 32 channels)
+__global__ void __launch_bounds__(256, 2) dconv_w1_rgbp_kernel(const DconvProblem p) { dconv_body<3, 1>(p); }
+__global__ void __launch_bounds__(256, 2) dconv_w2_rgbp_kernel(const DconvProblem p) { dconv_body<3, 2>(p); }
+__global__ void __launch_bounds__(256, 2) dconv_w4_rgbp_kernel(const DconvProblem p) { dconv_body<3, 4>(p); }
 
 // ---------------------------------------------------------------------------------------
 // Packing.  PASS 1 (rw_dconv_*_absmax_f32): max |U| as a bound; PASS 2: the f16 pieces of U su in operand order, su BY VALUE
@@ -1136,6 +1163,39 @@ extern "C" int rw_dconv3x3_f32(const float* x, const float* wp, float* y, int ba
   return dconv_finish(y_amax, 4 * work, stream);
 }
 
+// ---- the same convolution + the partial sums of the ToRGB that consumes its result (ToRGBF.forward, models.py:639-655: a 1x1
+// modulated convolution to three colours, no demodulation): every wave adds up ITS 32 out-channels' contributions while the
+// activated values are in registers -- rgb->out receives out_ch / 32 partial images (partial, image, colour, pixel), which
+// rw_rgb_combine_f32 sums with the bias and the upsampled running image.  The feature map is written as usual (the next
+// layer reads it); what disappears is the second pass over it.  rgb->bias / rgb->skip are not used here.
+extern "C" int rw_dconv3x3_rgb_partials(int out_ch) { return out_ch > 0 && out_ch % 32 == 0 ? out_ch / 32 : -1; }
+extern "C" int rw_dconv3x3_rgb_partial_f32(const float* x, const float* wp, float* y, int batch, int in_ch, int out_ch, int h,
+                                           int w, float w_scale, const rw_conv_epilogue* ep, const rw_rgb_epilogue* rgb,
+                                           float u_inv, const float* x_amax, float* y_amax, rw_stream_t stream) {
+  RW_CHECK_ARG(x && wp && y && x_amax && u_inv > 0.f && batch > 0 && in_ch > 0 && out_ch > 0 && h > 0 && w > 0);
+  RW_CHECK_ARG(rgb && rgb->weight && rgb->style && rgb->out);
+  RW_CHECK_ARG(!ep || ((!ep->noise || ep->noise_w) && (!ep->act || ep->bias)));
+  if (!dconv_shape_ok(out_ch, in_ch, h, w)) return RW_ERR_UNSUPPORTED;
+  if ((int64_t)in_ch * h * w * 4 > 0x7fffffffLL) return RW_ERR_UNSUPPORTED;
+  DconvProblem p = {};
+  dconv_fill(p, x, wp, batch, in_ch, out_ch, h, w, w_scale, ep, u_inv, x_amax, y_amax);
+  p.y = y;
+  p.rgb_weight = rgb->weight; p.rgb_style = rgb->style; p.rgb_out = rgb->out; p.rgb_scale = rgb->scale;
+  const int64_t cap = rw_bound_slot_capacity((int64_t)batch * out_ch * h * w);
+  const char* e = getenv("RW_DCONV_WM");
+  int wm = out_ch % 128 == 0 ? 4 : (out_ch % 64 == 0 ? 2 : 1);
+  if (e && (atoi(e) == 1 || atoi(e) == 2 || atoi(e) == 4) && out_ch % (32 * atoi(e)) == 0) wm = atoi(e);
+  p.o_tiles = out_ch / (32 * wm);
+  p.tiles_y = h / (16 / wm);
+  const int64_t work = (int64_t)batch * p.tiles_y * p.tiles_x * p.o_tiles;
+  if (work <= 0 || work > 0x7fffffff) return RW_ERR_UNSUPPORTED;
+  if (y_amax && 4 * work > cap) return RW_ERR_UNSUPPORTED;
+  if (wm == 4) hipLaunchKernelGGL(dconv_w4_rgbp_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
+  else if (wm == 2) hipLaunchKernelGGL(dconv_w2_rgbp_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
+  else hipLaunchKernelGGL(dconv_w1_rgbp_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
+  return dconv_finish(y_amax, 4 * work, stream);
+}
+
 // ---- conv_transpose(stride 2) + blur + noise + bias + leaky ReLU in one pass (rw_conv_transpose3x3s2_blur_wino4_f32's operation)
 static bool dconv_up_shape_ok(int out_ch, int in_ch, int h, int w) {
   return out_ch > 0 && out_ch % 16 == 0 && in_ch >= 16 && in_ch % 16 == 0 && in_ch <= 512 && w % 32 == 0 && h % 8 == 0;
@@ -1206,6 +1266,16 @@ extern "C" int rw_dconv3x3_to_rgb_f32(const float* x, const float* wp, int batch
   p.tiles_y = h / 16;
   const int64_t work = (int64_t)batch * p.tiles_y * p.tiles_x;
   if (work <= 0 || work > 0x7fffffff) return RW_ERR_UNSUPPORTED;
+  // RW_DCONV_V=2 (opt-in: at layer 18's shape it takes 7.4 ms where the kernel below takes 6.7 and the F(4x4) kernel 5.8 --
+  // four multiplying waves per CU issue half the matrix rate of eight, profiles/r06l), a style on load, maps 64 columns wide:
+  // the persistent workgroup with specialised waves
+  const char* ve = getenv("RW_DCONV_V");
+  if (ve && ve[0] == '2' && dconv_specialised(in_ch, ep) && h % 8 == 0 && w % 64 == 0) {
+    p.tiles_y = h / 8; p.tiles_x = w / 64;
+    const unsigned grid = dconv_ws_grid((int64_t)batch * p.tiles_y * p.tiles_x);
+    hipLaunchKernelGGL(dconv_ws_rgb_kernel, dim3(grid), dim3(384), 0, rw_s(stream), p);
+    return RW_LAUNCH_RESULT();
+  }
   hipLaunchKernelGGL(dconv_rgb_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
   return RW_LAUNCH_RESULT();
 }

@@ -19,7 +19,7 @@
 #include <stdlib.h>
 #include <stdint.h>
 
-extern "C" int rw_abi_version(void) { return 8; }
+extern "C" int rw_abi_version(void) { return 9; }
 
 extern "C" const char* rw_error_string(int code) {
   if (code == 0) return "success";
@@ -1046,6 +1046,39 @@ __global__ void __launch_bounds__(256) to_rgb_kernel(const float* __restrict__ x
 #endif
     }
   }
+}
+
+// ToRGB whose channel sums were left behind by the convolution that produced the feature map (rw_dconv3x3_rgb_partial_f32):
+// out[b][c][p] = sum_k partial[k][b][c][p] + bias[c] + skip[b][c][p] -- n_part small images instead of a pass over the map.
+__global__ void __launch_bounds__(256) rgb_combine_kernel(const float* __restrict__ part, int n_part,
+                                                          const float* __restrict__ bias, const float* __restrict__ skip,
+                                                          float* __restrict__ y, int64_t n4, int64_t hw4, int64_t stride4) {
+  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n4; q += (int64_t)gridDim.x * 256) {
+    float4 a = reinterpret_cast<const float4*>(part)[q];
+    for (int k = 1; k < n_part; ++k) {
+      const float4 v = reinterpret_cast<const float4*>(part)[q + k * stride4];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    if (bias) {
+      const float bv = bias[(q / hw4) % 3];
+      a.x += bv; a.y += bv; a.z += bv; a.w += bv;
+    }
+    if (skip) {
+      const float4 s = reinterpret_cast<const float4*>(skip)[q];
+      a.x += s.x; a.y += s.y; a.z += s.z; a.w += s.w;
+    }
+    reinterpret_cast<float4*>(y)[q] = a;
+  }
+}
+
+extern "C" int rw_rgb_combine_f32(const float* partials, int n_part, const float* bias, const float* skip, float* y,
+                                  int batch, int64_t hw, rw_stream_t stream) {
+  RW_CHECK_ARG(partials && y && n_part > 0 && batch > 0 && hw > 0);
+  if (hw % 4) return RW_ERR_UNSUPPORTED;
+  const int64_t n4 = (int64_t)batch * 3 * hw / 4;
+  hipLaunchKernelGGL(rgb_combine_kernel, dim3(rw_stream_grid(n4, 256)), dim3(256), 0, rw_s(stream), partials, n_part, bias,
+                     skip, y, n4, hw / 4, n4);
+  return RW_LAUNCH_RESULT();
 }
 
 // The same for maps whose pixel count is not a multiple of four (the cropped goal maps of a rewriter whose target

@@ -518,6 +518,12 @@ __global__ void __launch_bounds__(512, 1) tconv_blur_t16_kernel(const TconvProbl
 // One raw s_barrier per chunk and two more per tile (z written -> blurred | the other eight channels written -> blurred).
 // Tile: 8 x 32 positions (16 x 64 outputs) x 16 out-channels; in_ch >= 32 (the tables are double-buffered by tile parity).
 // ---------------------------------------------------------------------------------------
+#ifndef TC_NT
+#define TC_NT 0           // pipelined form: 1 = the result leaves with non-temporal stores
+#endif
+#ifndef TC_PP_MQ
+#define TC_PP_MQ 2        // pipelined form: of a tile's four blur passes, how many the multiplying waves take (0 .. 4)
+#endif
 #ifndef TC_PROF
 #define TC_PROF 0         // 1: workgroups 0 and 100 leave cycle counts of wave 0 (multiplying) and wave 4 (staging) in tc_prof
 #endif
@@ -1069,6 +1075,535 @@ __global__ void __launch_bounds__(512, 2) tconv_blur_ws_kernel(const TconvProble
   if (p.y_amax) rw_bound_store_wave(p.y_amax, rw_wave_max(ymax));
 }
 
+// ---------------------------------------------------------------------------------------
+// Fourth form (round 6): the persistent kernel above with its two halves PIPELINED across tiles.  There the phases of a
+// tile take turns -- all eight waves wait while four multiply, the matrix pipe idles while all eight blur (27 - 29 k cycles
+// per tile on layer 17: multiplies 10 k, z write 4 k in two half-lane passes, blur 8 k of vector issue per SIMD, waits).
+// Here the z tile holds all SIXTEEN channels (20 rows: the last position block tests its positions instead of writing
+// into spare rows -- 92 KB, 161 KB of LDS with the windows and the weights) and
+//   waves 0..3 multiply tile t, then write ITS z tile in one pass with every lane active (one barrier before: z is free;
+//     one behind: z is ready), and go on to tile t + 1;
+//   waves 4..7 stage as before AND blur tile t - 1 meanwhile: four passes of four channels (256 strips of four columns x
+//     four rows each), spread over the chunk intervals of tile t, the noise of the tile requested at the switch.
+// The vector work of a tile (staging conversion + blur) runs beside the matrix work of the next one; NC + 1 barriers per
+// tile.  The staging waves' LDS addresses are computed once (the window's geometry does not change from chunk to chunk).
+// Tables (demodulation x scales, bias, post scale) are kept for FOUR tiles (tile index & 3): the tile being requested is two
+// ahead of the one being blurred.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512, 2) tconv_blur_pp_kernel(const TconvProblem p) {
+  constexpr int TY = 8, MW = 4;
+  constexpr int PR = TY + 2, NPOS = PR * TC_PC, NBLK = (NPOS + 15) / 16, BPW = (NBLK + MW - 1) / MW;
+  constexpr int WR = TY + 3, NPIX = WR * TC_WC, BUFB = NPIX * 64;
+  constexpr int IPR = TC_TX / 4 + 2, NITEM = WR * IPR, SI = (NITEM + 63) / 64;   // items: window columns 4 j - 2 .. 4 j + 1
+  constexpr int ZR = 2 * PR, CHS = ZR * TC_ZP + 4;  // z rows 0 .. 2 PR - 1; position column c owns z columns 2 c + 4, 2 c + 5
+  constexpr int SR = 4;                             // output rows of a strip
+  static_assert(SI == 2 && BPW == 6 && 4 * SR == 2 * TY, "piece / block / strip counts the code below is written for");
+  static_assert(2 * BUFB + 2 * TC_WCH + 16 * CHS * 4 + 1024 <= 163840, "LDS of a compute unit");
+  __shared__ __attribute__((aligned(16))) unsigned char Ls[2 * BUFB];
+  __shared__ __attribute__((aligned(16))) unsigned char Wl[2 * TC_WCH];
+  __shared__ __attribute__((aligned(16))) float Zs[16 * CHS];
+  __shared__ float Sc[4][16], Bs[4][16], Po[4][16], Kf[16], Ks[12];   // Ks: kh[4], kv[4], [8] = 1 when the FIR is kv x kh
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t hw = (int64_t)p.h * p.w;
+  const int NC = p.in_ch >> 4, T = 9 * NC;
+  const float gain = p.act ? 1.4142135623730951f : 1.f, slope = p.act ? 0.2f : 1.f;
+
+  const int64_t total = (int64_t)p.batch * p.tiles_y * p.tiles_x * p.o_tiles;
+  const int bx = tc_xcd_remap(blockIdx.x, gridDim.x);
+  const int count = (int)((total - bx + gridDim.x - 1) / gridDim.x);
+  if (count <= 0) {                                 // (every wave of the launch owns a slot of the bound: rw_common.h)
+    if (p.y_amax) rw_bound_store_wave(p.y_amax, 0.f);
+    return;
+  }
+  const int N = count * NC;                         // chunks of the run
+  auto digits = [&](unsigned tile, int& ot, int& tx, int& ty, int& ib) __attribute__((always_inline)) {
+    ot = (int)(tile % (unsigned)p.o_tiles);
+    unsigned pg = tile / (unsigned)p.o_tiles;
+    tx = (int)(pg % (unsigned)p.tiles_x); pg /= (unsigned)p.tiles_x;
+    ty = (int)(pg % (unsigned)p.tiles_y);
+    ib = (int)(pg / (unsigned)p.tiles_y);
+  };
+  int g_ot, g_tx, g_ty, g_ib;
+  digits(gridDim.x, g_ot, g_tx, g_ty, g_ib);
+  auto advance = [&](int& ot, int& tx, int& ty, int& ib) __attribute__((always_inline)) {
+    ot += g_ot;
+    int carry = ot >= p.o_tiles ? 1 : 0;
+    ot -= carry ? p.o_tiles : 0;
+    tx += g_tx + carry;
+    carry = tx >= p.tiles_x ? 1 : 0;
+    tx -= carry ? p.tiles_x : 0;
+    ty += g_ty + carry;
+    carry = ty >= p.tiles_y ? 1 : 0;
+    ty -= carry ? p.tiles_y : 0;
+    ib += g_ib + carry;
+  };
+  auto lds_barrier = [&]() __attribute__((always_inline)) {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);             // lgkmcnt(0): vector loads and stores stay in flight across the barrier
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  if (tid < 16) {
+    const int a = tid >> 2, c = tid & 3;
+    Kf[tid] = p.k4[(3 - a) * 4 + (3 - c)];          // flipped, as upfirdn2d applies it (read after the first barrier)
+  }
+  if (tid == 0) {                                   // is the FIR an outer product kv x kh?  (tconv_body)
+    float kf[16], kvv[4], kmax = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { kf[t] = p.k4[(3 - (t >> 2)) * 4 + (3 - (t & 3))]; kmax = fmaxf(kmax, fabsf(kf[t])); }
+    bool ok = kf[0] != 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) { kvv[a] = ok ? kf[4 * a] / kf[0] : 0.f; Ks[a] = kf[a]; Ks[4 + a] = kvv[a]; }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) ok = ok && fabsf(kf[t] - kvv[t >> 2] * kf[t & 3]) <= 1e-6f * kmax;
+    Ks[8] = ok ? 1.f : 0.f;
+  }
+
+  // ---- the blur (both roles): strip = four output columns x SR rows of one channel; wave (w & 3) owns the rows SR (w & 3) ..,
+  // a pass covers four channels with the 256 threads of a role
+  const int bw = wave & 3, lid = bw * 64 + lane;
+  const float noise_wg = p.noise ? p.noise_w[0] * gain : 0.f;
+  const int W2 = 2 * p.w;
+  const int64_t hw2 = 4 * hw;
+  const int s_og = lane & 15, s_chl = lane >> 4, s_oy0 = SR * bw;
+  tc_f32x4 nzr[SR];
+#pragma unroll
+  for (int oy = 0; oy < SR; ++oy) nzr[oy] = tc_f32x4{0.f, 0.f, 0.f, 0.f};
+  float ymax = 0.f;
+  auto noise_request = [&](int ty, int tx, int ib) __attribute__((always_inline)) {
+    if (p.noise) {
+      const int64_t s_pix = (int64_t)(2 * ty * TY + s_oy0) * W2 + 2 * tx * TC_TX + 4 * s_og;
+#pragma unroll
+      for (int oy = 0; oy < SR; ++oy)
+        nzr[oy] = *reinterpret_cast<const tc_f32x4*>(p.noise + (int64_t)ib * hw2 + s_pix + (int64_t)oy * W2);
+    }
+  };
+  auto blur = [&](int pass, int par, int ot, int tx, int ty, int ib) __attribute__((always_inline)) {
+    if (Ks[8] != 0.f) {
+      const float kh[4] = {Ks[0], Ks[1], Ks[2], Ks[3]}, kv[4] = {Ks[4], Ks[5], Ks[6], Ks[7]};
+      const int cl = 4 * pass + s_chl;            // channel within the workgroup's 16
+      const int64_t s_pix = (int64_t)(2 * ty * TY + s_oy0) * W2 + 2 * tx * TC_TX + 4 * s_og;
+      const float* zb = Zs + cl * CHS + (s_oy0 + 1) * TC_ZP + 4 * s_og + 4;
+      const float sc = Sc[par][cl], bs = Bs[par][cl], post = Po[par][cl];
+      float* yb = p.y + ((int64_t)ib * p.out_ch + 16 * ot + cl) * hw2 + s_pix;
+      tc_f32x4 hrow[4];                           // the last four horizontally filtered rows
+      tc_f32x4 lo = *reinterpret_cast<const tc_f32x4*>(zb), hi = *reinterpret_cast<const tc_f32x4*>(zb + 4);
+#pragma unroll
+      for (int zr = 0; zr < SR + 3; ++zr) {
+        tc_f32x4 lon = lo, hin = hi;              // the next z row, requested before this one is filtered
+        if (zr + 1 < SR + 3) {
+          lon = *reinterpret_cast<const tc_f32x4*>(zb + (zr + 1) * TC_ZP);
+          hin = *reinterpret_cast<const tc_f32x4*>(zb + (zr + 1) * TC_ZP + 4);
+        }
+        tc_f32x4 hsum = tc_f32x4{lo[1], lo[2], lo[3], hi[0]} * kh[0];
+        hsum += tc_f32x4{lo[2], lo[3], hi[0], hi[1]} * kh[1];
+        hsum += tc_f32x4{lo[3], hi[0], hi[1], hi[2]} * kh[2];
+        hsum += hi * kh[3];
+        hrow[zr & 3] = hsum;
+        if (zr >= 3) {
+          const int oy = zr - 3;                  // output row oy0 + oy: filtered rows zr - 3 .. zr
+          tc_f32x4 res = hrow[(zr - 3) & 3] * kv[0];
+          res += hrow[(zr - 2) & 3] * kv[1];
+          res += hrow[(zr - 1) & 3] * kv[2];
+          res += hrow[zr & 3] * kv[3];
+          const tc_f32x4 nz = nzr[oy] * noise_wg;
+          tc_f32x4 v;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float u = res[q] * sc + nz[q] + bs;
+            v[q] = fmaxf(u, u * slope) * post;
+            ymax = fmaxf(ymax, fabsf(v[q]));
+          }
+          *reinterpret_cast<tc_f32x4*>(yb + (int64_t)oy * W2) = v;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        lo = lon; hi = hin;
+      }
+    } else {
+#pragma unroll 1
+      for (int k = 0; k < 4; ++k) {
+        const int gid = lid + 256 * k;            // 4 channels x 2 TY rows x 16 groups of four outputs
+        const int og = gid & 15, oy = (gid >> 4) & (2 * TY - 1), ch = gid >> 8;
+        const int cg = 4 * pass + ch;
+        const float* zb = Zs + cg * CHS + (oy + 1) * TC_ZP + 4 * og + 4;
+        float res[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const tc_f32x4 lo = *reinterpret_cast<const tc_f32x4*>(zb + a * TC_ZP);
+          const tc_f32x4 hi = *reinterpret_cast<const tc_f32x4*>(zb + a * TC_ZP + 4);
+          const float rowv[7] = {lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) res[q] += rowv[q + cc] * Kf[a * 4 + cc];
+        }
+        const int64_t pix = (int64_t)(2 * ty * TY + oy) * W2 + 2 * tx * TC_TX + 4 * og;
+        tc_f32x4 nz = {0.f, 0.f, 0.f, 0.f};
+        if (p.noise) nz = *reinterpret_cast<const tc_f32x4*>(p.noise + (int64_t)ib * hw2 + pix) * noise_wg;
+        const float sc = Sc[par][cg], bs = Bs[par][cg], post = Po[par][cg];
+        tc_f32x4 v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float u = res[q] * sc + nz[q] + bs;
+          v[q] = fmaxf(u, u * slope) * post;
+          ymax = fmaxf(ymax, fabsf(v[q]));
+        }
+        *reinterpret_cast<tc_f32x4*>(p.y + ((int64_t)ib * p.out_ch + 16 * ot + cg) * hw2 + pix) = v;
+      }
+    }
+  };
+
+  if (wave >= MW) {
+    // =========================== staging + blurring waves ===========================
+    const int g = wave - MW;
+    const float xam = rw_bound_load(p.x_amax);
+    const int hw4 = (int)hw * 4;
+    int l_pos = 0, l_c = 0, l_ib = -1, l_ot, l_tx, l_ty, l_ibn;       // (l_ot, l_tx, l_ty, l_ibn): the tile being requested
+    bool l_past = false;
+    digits((unsigned)bx, l_ot, l_tx, l_ty, l_ibn);
+    float in_scale = 1.f, out_scale = 1.f;
+    int xoff[SI];
+    // where a lane's pixels go in a window buffer: the same for every chunk and tile (-1: outside the window)
+    int ldst[SI][4];
+#pragma unroll
+    for (int s = 0; s < SI; ++s) {
+      const int it = 64 * s + lane;
+      const int r = it / IPR, j = it - r * IPR;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int cc = 4 * j - 2 + e;               // window column of this pixel
+        ldst[s][e] = (it < NITEM && cc >= 0 && cc < TC_WC) ? (r * TC_WC + cc) * 64 + ((g ^ tc_swz(cc)) << 4) : -1;
+      }
+    }
+    __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, 0, 0x00020000);
+    struct Flight {
+      tc_f32x4 raw[SI][4];                          // [piece][channel]: four pixels
+      float psv[4];
+      float demod, bias, post, oscale, iscale;
+      bool first;
+      int par;
+    };
+    Flight fl[2];
+    tc_f32x4 wraw[3];
+    float sv[4];
+    int l_s0 = 0;
+    const unsigned char* l_wsrc = p.wp;
+    const unsigned char* w_next = p.wp;
+    auto setup = [&](auto tag) __attribute__((always_inline)) {   // the chunk to REQUEST: (l_pos, l_c); loads only, none used here
+      Flight& F = fl[decltype(tag)::value];
+      F.first = l_c == 0 && !l_past;                              // (past the run: the last chunk again, never read)
+      if (F.first) {
+        const int ib = (TC_ABL & 1024) ? 0 : l_ibn;                   // (timing ablation 1024: every tile reads image 0's first window -- cache hits)
+        const int i0 = (TC_ABL & 1024) ? 0 : l_ty * TY, j0 = (TC_ABL & 1024) ? 0 : l_tx * TC_TX;
+        if (ib != l_ib) {
+          l_ib = ib;
+          float smax = p.style ? 0.f : 1.f;
+          if (p.style)
+            for (int i = lane; i < p.in_ch; i += 64) smax = fmaxf(smax, fabsf(p.style[(int64_t)ib * p.in_ch + i]));
+          smax = rw_wave_max(smax);
+          const float am = xam * smax;
+          int e = (int)((__float_as_uint(am) >> 23) & 0xff) - 126;      // am < 2^e
+          e = e < -100 ? -100 : (e > 100 ? 100 : e);
+          in_scale = __uint_as_float((unsigned)(127 + 14 - e) << 23);
+          out_scale = __uint_as_float((unsigned)(127 + e - 14) << 23) * p.u_inv;
+          xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (int64_t)ib * p.in_ch * hw), 0,
+                                                   (int)((int64_t)p.in_ch * hw * 4), 0x00020000);
+        }
+#pragma unroll
+        for (int s = 0; s < SI; ++s) {
+          const int it = 64 * s + lane;
+          const int r = it / IPR, j = it - r * IPR;
+          const int iy = i0 - 2 + r, ix = j0 - 4 + 4 * j;            // the item lies inside the row or outside it as a whole
+          const bool ok = it < NITEM && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
+          xoff[s] = ok ? (iy * p.w + ix) * 4 : 0x7ffffff0;
+        }
+        F.par = l_pos & 3;
+        F.oscale = out_scale;
+        if (lid < 16) {
+          const int o = 16 * l_ot + lid;
+          F.demod = p.demod ? p.demod[(int64_t)l_ib * p.out_ch + o] : 1.f;
+          F.bias = p.act ? p.bias[o] : 0.f;
+          F.post = p.post ? p.post[(int64_t)l_ib * p.out_ch + o] : 1.f;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) F.psv[k] = p.style ? p.style[(int64_t)l_ib * p.in_ch + 16 * l_c + 4 * g + k] : 1.f;
+      F.iscale = in_scale;
+      l_s0 = (16 * l_c + 4 * g) * hw4;
+      l_wsrc = w_next;                              // the weights of the chunk set up ONE call ago
+      w_next = p.wp + ((int64_t)l_ot * T + 9 * l_c) * 1024 + lane * 16;
+      if (++l_c == NC) {
+        if (l_pos + 1 < count) { l_c = 0; ++l_pos; advance(l_ot, l_tx, l_ty, l_ibn); }
+        else { l_c = NC - 1; l_past = true; }
+      }
+    };
+    auto request_s = [&](auto tag, int s, bool with_w = true) __attribute__((always_inline)) {
+      Flight& F = fl[decltype(tag)::value];
+      if (with_w && s == 0) {                       // the weights FIRST (loads return in order)
+        wraw[0] = *reinterpret_cast<const tc_f32x4*>(l_wsrc + g * 1024);
+        wraw[1] = *reinterpret_cast<const tc_f32x4*>(l_wsrc + (g + 4) * 1024);
+        if (g == 0) wraw[2] = *reinterpret_cast<const tc_f32x4*>(l_wsrc + 8 * 1024);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (TC_ABL & 1) F.raw[s][k] = tc_f32x4{1.f, 1.f, 1.f, 1.f};     // (timing ablation: no window loads; results wrong)
+        else F.raw[s][k] = __builtin_bit_cast(tc_f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, xoff[s], l_s0 + k * hw4, 0));
+      }
+    };
+    auto tables = [&](auto tag) __attribute__((always_inline)) {
+      Flight& F = fl[decltype(tag)::value];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) sv[k] = F.psv[k] * F.iscale;
+      if (F.first && lid < 16) {
+        Sc[F.par][lid] = F.demod * p.w_scale * F.oscale * gain;
+        Bs[F.par][lid] = F.bias * gain;
+        Po[F.par][lid] = F.post;
+      }
+    };
+    auto deliver_s = [&](auto tag, int buf, int s) __attribute__((always_inline)) {
+      Flight& F = fl[decltype(tag)::value];
+      unsigned char* dst = Ls + buf * BUFB;
+      unsigned char* wdst = Wl + buf * TC_WCH + lane * 16;
+      if (s == 0) {
+        *reinterpret_cast<tc_f32x4*>(wdst + g * 1024) = wraw[0];
+        *reinterpret_cast<tc_f32x4*>(wdst + (g + 4) * 1024) = wraw[1];
+        if (g == 0) *reinterpret_cast<tc_f32x4*>(wdst + 8 * 1024) = wraw[2];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v0 = F.raw[s][0][e] * sv[0], v1 = F.raw[s][1][e] * sv[1], v2 = F.raw[s][2][e] * sv[2],
+                    v3 = F.raw[s][3][e] * sv[3];
+        const tc_f16x2 h01 = __builtin_convertvector(tc_f32x2{v0, v1}, tc_f16x2);
+        const tc_f16x2 h23 = __builtin_convertvector(tc_f32x2{v2, v3}, tc_f16x2);
+        float r0, r1, r2, r3;                        // v - (float)h, exact
+        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h01), "v"(v0));
+        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h01), "v"(v1));
+        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r2) : "v"(h23), "v"(v2));
+        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r3) : "v"(h23), "v"(v3));
+        const tc_f16x2 l01 = __builtin_convertvector(tc_f32x2{r0, r1}, tc_f16x2);
+        const tc_f16x2 l23 = __builtin_convertvector(tc_f32x2{r2, r3}, tc_f16x2);
+        tc_f16x8 word = {h01[0], h01[1], h23[0], h23[1], l01[0], l01[1], l23[0], l23[1]};
+        if (TC_ABL & 256)                            // (timing ablation: no conversion arithmetic; results wrong)
+          word = __builtin_bit_cast(tc_f16x8, tc_f32x4{F.raw[s][0][e], F.raw[s][1][e], F.raw[s][2][e], F.raw[s][3][e]});
+        if (!(TC_ABL & 512) && ldst[s][e] >= 0) *reinterpret_cast<tc_f16x8*>(dst + ldst[s][e]) = word;
+        if (TC_ABL & 512) asm volatile("" :: "v"(word));
+      }
+    };
+
+    // chunks 0 and 1 requested (chunk 0's weights with chunk 1's window); chunk 0 written; chunk 2 requested
+    setup(tc_int<0>());
+#pragma unroll
+    for (int s = 0; s < SI; ++s) request_s(tc_int<0>(), s, false);
+    setup(tc_int<1>());
+#pragma unroll
+    for (int s = 0; s < SI; ++s) request_s(tc_int<1>(), s);
+    tables(tc_int<0>());
+    __builtin_amdgcn_sched_barrier(0);
+    setup(tc_int<0>());
+#pragma unroll
+    for (int s = 0; s < SI; ++s) {
+      deliver_s(tc_int<0>(), 0, s); __builtin_amdgcn_sched_barrier(0);
+      request_s(tc_int<0>(), s); __builtin_amdgcn_sched_barrier(0);
+    }
+    lds_barrier();
+    int cn = 0, e_pos = 0;                          // the tile the multiplying waves are on
+    int e_ot, e_tx, e_ty, e_ib;
+    digits((unsigned)bx, e_ot, e_tx, e_ty, e_ib);
+    bool have_prev = false;                         // the tile whose z tile is in LDS, waiting to be blurred
+    int b_ot = 0, b_tx = 0, b_ty = 0, b_ib = 0, b_par = 0;
+    TP_DECL(tp = 0, tp_all = 0, tp_setup = 0, tp_del = 0, tp_bar = 0, tp_blur = 0, tp_zbar = 0);
+    TP_NOW(tp); TP_NOW(tp_all);
+    // interval n: chunk n + 1 -> LDS piece by piece, the window of chunk n + 3 and the weights of chunk n + 2 requested behind
+    // it; then this interval's share of the previous tile's blur
+    auto interval = [&](int n, auto tag) __attribute__((always_inline)) {
+      tables(tag);
+      __builtin_amdgcn_sched_barrier(0);
+      setup(tag);
+      TP_ADD(tp_setup, tp);
+#pragma unroll
+      for (int s = 0; s < SI; ++s) {
+        deliver_s(tag, (n + 1) & 1, s); __builtin_amdgcn_sched_barrier(0);
+        request_s(tag, s); __builtin_amdgcn_sched_barrier(0);
+      }
+      TP_ADD(tp_del, tp);
+      if (have_prev) {
+        // the staging waves' passes TC_PP_MQ .. 3, spread over the tile's intervals: pass MQ + k in interval [k NC / NS]
+        constexpr int NS = 4 - TC_PP_MQ;
+        const int p_lo = TC_PP_MQ + (NS * cn + NC - 1) / NC, p_hi = TC_PP_MQ + (NS * cn + NS + NC - 1) / NC;
+#pragma unroll 1
+        for (int ps = p_lo; ps < p_hi; ++ps) blur(ps, b_par, b_ot, b_tx, b_ty, b_ib);
+      }
+      TP_ADD(tp_blur, tp);
+      lds_barrier();
+      TP_ADD(tp_bar, tp);
+      if (++cn == NC) {                             // the multiplying waves write the z tile of THEIR tile now
+        cn = 0;
+        b_ot = e_ot; b_tx = e_tx; b_ty = e_ty; b_ib = e_ib; b_par = e_pos & 3;
+        have_prev = true;
+        if (TC_PP_MQ < 4) noise_request(b_ty, b_tx, b_ib);       // (ahead of the next interval's window requests: loads return in order)
+        ++e_pos;
+        advance(e_ot, e_tx, e_ty, e_ib);
+        lds_barrier();                              // z is ready
+        TP_ADD(tp_zbar, tp);
+      }
+    };
+    int n = 0;
+    for (; n + 1 < N; n += 2) { interval(n, tc_int<1>()); interval(n + 1, tc_int<0>()); }
+    if (n < N) interval(n, tc_int<1>());
+    // the last tile's blur: nobody waits for it
+#pragma unroll 1
+    for (int ps = TC_PP_MQ; ps < 4; ++ps) blur(ps, b_par, b_ot, b_tx, b_ty, b_ib);
+#if TC_PROF
+    if (wave == MW && lane == 0 && (blockIdx.x == 0 || blockIdx.x == 100)) {
+      unsigned long long* o = tc_prof + (blockIdx.x == 0 ? 0 : 32);
+      o[8] = (unsigned long long)clock64() - tp_all; o[9] = tp_setup; o[10] = tp_del; o[11] = tp_bar; o[12] = tp_blur; o[13] = tp_zbar; o[14] = N;
+      o[16] = 0;
+    }
+#endif
+    if (p.y_amax) rw_bound_store_wave(p.y_amax, rw_wave_max(ymax));
+    return;
+  }
+
+  // =========================== multiplying waves ===========================
+  const int lk = lane >> 4, lt = lane & 15;
+  unsigned pb0[BPW], pb1[BPW];                     // operand addresses as in tconv_body
+#pragma unroll
+  for (int b = 0; b < BPW; ++b) {
+    int q = 16 * (wave + MW * b) + lt;
+    q = q < NPOS ? q : NPOS - 1;
+    const int r = q / TC_PC, c = q - r * TC_PC;
+    pb0[b] = (unsigned)(((r + 1) * TC_WC + c + 1) * 64 + ((lk ^ tc_swz(c + 1)) << 4));
+    pb1[b] = (unsigned)(((r + 1) * TC_WC + c) * 64 + ((lk ^ tc_swz(c)) << 4));
+  }
+  tc_f32x4 acc[BPW][4];
+#pragma unroll
+  for (int b = 0; b < BPW; ++b)
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) acc[b][ph] = tc_f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int LB = BPW - 1;
+  const bool last_ok = wave + MW * LB < NBLK;       // wave-uniform: only the last block of a wave can be missing
+  auto mma = [&](const unsigned char* lb, const unsigned char* wb) __attribute__((always_inline)) {
+    {
+      const tc_f16x8 u0 = TC_UH(0), u1 = TC_UH(1), u3 = TC_UH(3), u4 = TC_UH(4), l4 = tc_expand(TC_UL(4));
+      tc_f16x8 pc = TC_PIX(pb0[0]), pd = TC_PIX(pb0[1]);
+#pragma unroll
+      for (int b = 0; b < BPW; ++b) {
+        tc_f16x8 pn = pd;
+        if (b + 2 < BPW) pn = TC_PIX(pb0[b + 2]);
+        if (b < LB || last_ok) {
+          TC_MFMA(3, pc, u4); TC_MFMA(0, pc, u0); TC_MFMA(1, pc, u1); TC_MFMA(2, pc, u3);
+          TC_MFMA(3, pc, l4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        pc = pd; pd = pn;
+      }
+    }
+    {
+      const tc_f16x8 u2 = TC_UH(2), u5 = TC_UH(5), m02 = tc_pair(TC_UL(0), TC_UL(2)), m35 = tc_pair(TC_UL(3), TC_UL(5));
+      tc_f32x2 hc = TC_VH(pb0[0]), hd = TC_VH(pb0[1]);
+      tc_f16x8 qc = TC_PIX(pb1[0]), qd = TC_PIX(pb1[1]);
+#pragma unroll
+      for (int b = 0; b < BPW; ++b) {
+        tc_f32x2 hn = hd;
+        tc_f16x8 qn = qd;
+        if (b + 2 < BPW) { hn = TC_VH(pb0[b + 2]); qn = TC_PIX(pb1[b + 2]); }
+        if (b < LB || last_ok) {
+          const tc_f16x8 M = tc_pair_hq(hc, qc);
+          TC_MFMA(0, qc, u2); TC_MFMA(2, qc, u5);
+          TC_MFMA(0, M, m02); TC_MFMA(2, M, m35);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        hc = hd; qc = qd; hd = hn; qd = qn;
+      }
+    }
+    {
+      const tc_f16x8 u6 = TC_UH(6), u7 = TC_UH(7), u8 = TC_UH(8), m17 = tc_pair(TC_UL(1), TC_UL(7)),
+                     m68 = tc_pair(TC_UL(6), TC_UL(8));
+      tc_f32x2 hc = TC_VH(pb0[0]), hd = TC_VH(pb0[1]);
+      tc_f16x8 qc = TC_PIX(pb0[0] - TC_WC * 64), rc = TC_PIX(pb1[0] - TC_WC * 64);
+      tc_f16x8 qd = TC_PIX(pb0[1] - TC_WC * 64), rd = TC_PIX(pb1[1] - TC_WC * 64);
+#pragma unroll
+      for (int b = 0; b < BPW; ++b) {
+        tc_f32x2 hn = hd;
+        tc_f16x8 qn = qd, rn = rd;
+        if (b + 2 < BPW) { hn = TC_VH(pb0[b + 2]); qn = TC_PIX(pb0[b + 2] - TC_WC * 64); rn = TC_PIX(pb1[b + 2] - TC_WC * 64); }
+        if (b < LB || last_ok) {
+          const tc_f16x8 M02 = tc_pair_hq(hc, qc), M23 = tc_pair(qc, rc);
+          TC_MFMA(0, qc, u6); TC_MFMA(1, qc, u7);
+          TC_MFMA(0, rc, u8); TC_MFMA(1, M02, m17);
+          TC_MFMA(0, M23, m68);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        hc = hd; qc = qd; rc = rd; hd = hn; qd = qn; rd = rn;
+      }
+    }
+  };
+  // all sixteen channels -> the z tile: lane (lk, lt) holds channel lt of the positions 4 lk .. 4 lk + 3 of each block
+  auto zwrite = [&]() __attribute__((always_inline)) {
+    int opaque;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(opaque));          // (keeps the address arithmetic inside the loop: tconv_blur_ws_kernel)
+    float* zc = Zs + lt * CHS + 4;
+#pragma unroll
+    for (int b = 0; b < BPW; ++b) {
+      if (wave + MW * b >= NBLK) continue;
+      const int q0 = 16 * (wave + MW * b) + 4 * lk + opaque;
+      const int r0 = (q0 * 1928) >> 16, c0 = q0 - r0 * TC_PC;          // q0 / 34 for q0 < 400
+      float* z0 = zc + (2 * r0) * TC_ZP + 2 * c0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (b == BPW - 1 && q0 + j >= NPOS) continue;                  // (the last block runs past the window: no spare rows here)
+        float* zp = z0 + 2 * j + (c0 + j >= TC_PC ? 2 * TC_ZP - 2 * TC_PC : 0);
+        zp[0] = acc[b][0][j];
+        zp[1] = acc[b][1][j];
+        zp[TC_ZP] = acc[b][2][j];
+        zp[TC_ZP + 1] = acc[b][3][j];
+      }
+    }
+  };
+
+  int c = 0, pos = 0;
+  int ot, tx, ty, ib;
+  digits((unsigned)bx, ot, tx, ty, ib);
+  lds_barrier();                                    // chunk 0 and the FIR are in LDS
+  TP_DECL(tp = 0, tp_all = 0, tp_mma = 0, tp_bar = 0, tp_zw = 0, tp_zbar = 0, tp_blur = 0);
+  TP_NOW(tp); TP_NOW(tp_all);
+  for (int n = 0; n < N; ++n) {
+    const unsigned char* lb = Ls + (n & 1) * BUFB;
+    const unsigned char* wb = Wl + (n & 1) * TC_WCH + lane * 8;
+    mma(lb, wb);
+    TP_ADD(tp_mma, tp);
+    lds_barrier();                                  // the chunk is consumed; at a tile's last chunk also: the previous tile is blurred, z is free
+    TP_ADD(tp_bar, tp);
+    if (c + 1 < NC) { ++c; continue; }
+    c = 0;
+    if (TC_PP_MQ > 0) noise_request(ty, tx, ib);    // (the z write and a barrier cover it)
+    zwrite();
+    TP_ADD(tp_zw, tp);
+    lds_barrier();                                  // z is ready
+    TP_ADD(tp_zbar, tp);
+    // this role's share of the tile's blur (passes 0 .. TC_PP_MQ - 1), before the next tile's multiplies; the staging
+    // waves take the rest beside them
+#pragma unroll 1
+    for (int ps = 0; ps < TC_PP_MQ; ++ps) blur(ps, pos & 3, ot, tx, ty, ib);
+    TP_ADD(tp_blur, tp);
+    ++pos;
+    advance(ot, tx, ty, ib);
+#pragma unroll
+    for (int b = 0; b < BPW; ++b)
+#pragma unroll
+      for (int ph = 0; ph < 4; ++ph) acc[b][ph] = tc_f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#if TC_PROF
+  if (wave == 0 && lane == 0 && (blockIdx.x == 0 || blockIdx.x == 100)) {
+    unsigned long long* o = tc_prof + (blockIdx.x == 0 ? 0 : 32);
+    o[0] = (unsigned long long)clock64() - tp_all; o[1] = tp_mma; o[2] = tp_bar; o[3] = tp_zw; o[4] = tp_blur; o[5] = tp_zbar; o[6] = N;
+  }
+#endif
+  if (p.y_amax) rw_bound_store_wave(p.y_amax, rw_wave_max(ymax));
+}
+
 static bool tconv_shape_ok(int out_ch, int in_ch, int h, int w) {
   return out_ch > 0 && out_ch % 16 == 0 && in_ch >= 16 && in_ch % 16 == 0 && in_ch <= 512 && w % TC_TX == 0 && h % 16 == 0;
 }
@@ -1094,8 +1629,10 @@ extern "C" int rw_tconv_blur_f32(const float* x, const float* wp, const float* k
   // channels: its staging waves run ahead through the epilogue), the one-workgroup-per-CU shape where the MFMAs dominate
   // (profiles/r05q: layer 17 6.4 against 7.1 ms, layer 15 4.6 / 4.9, layer 13 3.7 / 3.7, layer 11 3.3 / 3.2, layer 9 1.9 / 1.7)
   const char* e = getenv("RW_TCONV_TY");
-  const int sel = e ? atoi(e) : (in_ch >= 32 && in_ch <= 128 ? 0 : 16);
-  if (sel == 0 && in_ch >= 32) {                    // 0: the specialised persistent kernel (one workgroup of eight waves per CU)
+  // (RW_TCONV_PERSISTENT = 0 / 2: which of the two persistent kernels the automatic choice means)
+  const char* pe = getenv("RW_TCONV_PERSISTENT");
+  const int sel = e ? atoi(e) : (in_ch >= 32 && in_ch <= 128 ? (pe && atoi(pe) == 2 ? 2 : 0) : 16);
+  if ((sel == 0 || sel == 2) && in_ch >= 32) {      // 0: the specialised persistent kernel (one workgroup of eight waves per CU); 2: its pipelined form
     p.tiles_x = w / TC_TX; p.tiles_y = h / 8; p.o_tiles = out_ch / 16;
     const int64_t tiles = (int64_t)batch * p.tiles_y * p.tiles_x * p.o_tiles;
     if (tiles <= 0 || tiles > 0x7fffffff) return RW_ERR_UNSUPPORTED;
@@ -1103,7 +1640,8 @@ extern "C" int rw_tconv_blur_f32(const float* x, const float* wp, const float* k
     int64_t grid = ge ? atoi(ge) : rw_cu_count();       // one persistent workgroup per compute unit
     grid = grid < 1 ? 1 : (grid > tiles ? tiles : grid);
     if (y_amax && 8 * grid > rw_bound_slot_capacity((int64_t)batch * out_ch * 4 * h * w)) return RW_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(tconv_blur_ws_kernel, dim3((unsigned)grid), dim3(512), 0, rw_s(stream), p);
+    if (sel == 2) hipLaunchKernelGGL(tconv_blur_pp_kernel, dim3((unsigned)grid), dim3(512), 0, rw_s(stream), p);
+    else hipLaunchKernelGGL(tconv_blur_ws_kernel, dim3((unsigned)grid), dim3(512), 0, rw_s(stream), p);
     const int rc = RW_LAUNCH_RESULT();
     if (rc || !y_amax) return rc;
     return rw_bound_finish(y_amax, 8 * grid, rw_s(stream));

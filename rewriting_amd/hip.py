@@ -675,6 +675,45 @@ def conv3x3_direct16(x, wp, out_ch, w_scale, style=None, demod=None, noise=None,
     return y
 
 
+def conv3x3_direct16_rgb_partial(x, wp, out_ch, w_scale, rgb_weight, rgb_style, rgb_scale, style=None, demod=None, noise=None,
+                                 noise_w=None, bias=None, act=False, x_amax=None, y_amax=None):
+    """conv3x3_direct16 that also leaves the channel sums of the ToRGB which reads its result (rw_dconv3x3_rgb_partial_f32):
+    returns (feature map, partial images (out_ch / 32, B, 3, H, W)); rgb_combine() turns the partials into the image."""
+    x = _dev(x, 'fmap')
+    packed, wp = wp, _dev(wp, 'packed weight')
+    rgb_weight = _dev(rgb_weight, 'rgb weight').contiguous()
+    rgb_style = _dev(rgb_style, 'rgb style').contiguous()
+    b, i, h, w = x.shape
+    if tuple(rgb_weight.shape) != (3, out_ch) or tuple(rgb_style.shape) != (b, out_ch):
+        raise ValueError('rgb weight / style shapes')
+    _direct16_check(wp, lib().rw_packed_dconv_weight_elems(out_ch, i), 'pack_conv_weight_direct16(%d x %d)' % (out_ch, i))
+    n_part = lib().rw_dconv3x3_rgb_partials(out_ch)
+    if n_part <= 0:
+        raise ValueError('no ToRGB partial sums for %d out-channels' % out_ch)
+    y = torch.empty(b, out_ch, h, w, device=x.device, dtype=x.dtype)
+    part = torch.empty(n_part, b, 3, h, w, device=x.device, dtype=x.dtype)
+    ep, keep = _epilogue(style, demod, noise, noise_w, bias, act)
+    from ._lib import RgbEpilogue
+    re = RgbEpilogue(_p(rgb_weight).value, _p(rgb_style).value, None, None, _p(part).value, float(rgb_scale))
+    x_amax, y_amax = _amax_in(x, x_amax), _amax_out(y_amax, y.numel())
+    check(lib().rw_dconv3x3_rgb_partial_f32(_p(x), _p(wp), _p(y), b, i, out_ch, h, w, float(w_scale), ctypes.byref(ep),
+                                            ctypes.byref(re), _u_inv(packed), _p(x_amax), _p(y_amax), _stream()))
+    return y, part
+
+
+def rgb_combine(partials, bias, skip):
+    """ToRGB from the partial sums a convolution left (conv3x3_direct16_rgb_partial): sum over partials + bias + skip."""
+    partials = _dev(partials, 'rgb partial sums')
+    bias = _opt(bias, 'rgb bias')
+    skip = _opt(skip, 'rgb skip')
+    n, b, c, h, w = partials.shape
+    if c != 3 or (skip is not None and tuple(skip.shape) != (b, 3, h, w)):
+        raise ValueError('rgb partial / skip shapes')
+    y = torch.empty(b, 3, h, w, device=partials.device, dtype=partials.dtype)
+    check(lib().rw_rgb_combine_f32(_p(partials), n, _p(bias), _p(skip), _p(y), b, h * w, _stream()))
+    return y
+
+
 def conv3x3_direct16_to_rgb(x, wp, out_ch, w_scale, rgb_weight, rgb_style, rgb_bias, rgb_skip, rgb_scale, style=None,
                             demod=None, noise=None, noise_w=None, bias=None, act=False, x_amax=None):
     """conv3x3_direct16 with ToRGB in the epilogue (out_ch == 32): returns (None, rgb image)."""

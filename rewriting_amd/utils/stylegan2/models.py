@@ -142,6 +142,7 @@ class _RgbBranch(threading.local):      # per thread: two threads may run genera
         self.image_path = False  # inside the un-hooked forward of a whole generator (see conv_algo)
         self.successor = {}      # id(upsampling StyledConvSeq) -> (the StyledConvSeq that reads its result, latent index)
         self.reader = {}         # id(StyledConvSeq) -> the StyledConvSeq that reads its feature map (any kind), if any
+        self.torgb = {}          # id(StyledConvSeq) -> (the ToRGBF that reads its feature map, its latent index), if any
         self.pre = {}            # id(StyledConvSeq) -> (style, demod factors), id(ToRGBF) -> style: computed up front
         self.pre_join = None     # the stream they were computed on, until the trunk has waited for it
 
@@ -583,10 +584,22 @@ class DemodulatedConv2dF(nn.Module):
     def demod_factors(self, style):
         return hip.demod(self.squared_sums(), style) if self.demodulate else None
 
-    def run(self, fmap, style, style_on_load, demod=None, x_amax=None, y_amax=None, **epilogue):
+    def leaves_rgb_partials(self, h, w):
+        """Will run(..., rgb=...) on a map of h x w execute the direct-sum kernel that also leaves the channel sums of the
+        ToRGB reading its result (hip.conv3x3_direct16_rgb_partial)?  Inside the un-hooked forward only; RW_RGB_PARTIAL=0:
+        off (ToRGB then re-reads the feature map on the RGB stream, as before round 6)."""
+        return (not self.upsample and _rgb_branch.image_path and os.environ.get('RW_RGB_PARTIAL', '1') != '0'
+                and _split_part('w4') and conv_algo() == 'winograd4' and conv_impl() == 0 and conv_precision() == 'f32'
+                and self.out_channel % 32 == 0
+                and hip.wino4_supported(self.out_channel, self.in_channel, h, w) and _direct16(self, h, w, 'conv'))
+
+    def run(self, fmap, style, style_on_load, demod=None, x_amax=None, y_amax=None, rgb=None, **epilogue):
         """x_amax: the bound of |fmap| if the producer of fmap left one (hip.new_bound; split-operand kernels -- they
         measure the map themselves otherwise); y_amax: a hip.new_bound buffer that receives the bound of the result
-        where the split-operand F(4x4,3x3) kernel runs (`runs_split_wino4` says whether it will)."""
+        where the split-operand F(4x4,3x3) kernel runs (`runs_split_wino4` says whether it will); rgb: only where
+        `leaves_rgb_partials` says so."""
+        if rgb is not None and not self.leaves_rgb_partials(fmap.shape[-2], fmap.shape[-1]):
+            raise RuntimeError('run(rgb=...) on a layer that does not leave ToRGB partial sums')
         if demod is None:
             demod = self.demod_factors(style)
         load_style = style if style_on_load else None
@@ -642,6 +655,10 @@ class DemodulatedConv2dF(nn.Module):
         if (conv_algo() == 'winograd4' and conv_impl() == 0 and conv_precision() == 'f32'
                 and hip.wino4_supported(self.out_channel, self.in_channel, fmap.shape[-2], fmap.shape[-1])):
             if split and _direct16(self, fmap.shape[-2], fmap.shape[-1], 'conv'):
+                if rgb is not None:             # (weight (3, out), style (B, out), scale): returns (map, partial images)
+                    return hip.conv3x3_direct16_rgb_partial(fmap, self.direct16_weight(), self.out_channel, self.scale,
+                                                            rgb[0], rgb[1], rgb[2], style=load_style, demod=demod,
+                                                            x_amax=x_amax, y_amax=y_amax, **epilogue)
                 return hip.conv3x3_direct16(fmap, self.direct16_weight(), self.out_channel, self.scale, style=load_style,
                                             demod=demod, x_amax=x_amax, y_amax=y_amax, **epilogue)
             if split:
@@ -828,6 +845,17 @@ class ToRGBF(nn.Module):
                     skip = up(skip)
         conv = self.conv
         side = _rgb_stream()
+        partials = d.get('rgb_partials')
+        if partials is not None:                    # the producing convolution left this ToRGB's channel sums
+            if side is None:
+                raise RuntimeError('ToRGB partial sums outside the forward that produces them')
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                out = hip.rgb_combine(partials, self.bias.view(3), skip)
+            _rgb_branch.keep.append((partials,))
+            nd = DataBag(d, output=out)
+            nd.pop('rgb_partials', None)        # bags that callers see never carry the key
+            return nd
         if side is None:
             style = conv.modulation(d.style)
             out = hip.to_rgb(d.fmap, conv.weight.view(3, conv.in_channel), style, self.bias.view(3), skip,
@@ -980,6 +1008,7 @@ class StyledConvSeq(nn.Sequential):
         y_amax = None
         y_amax_set = False
         post = None
+        rgb_partials = None
         if mconv.upsample and pre is not None:
             raise RuntimeError('a pre-scaled feature map reached an upsampling layer')
         if mconv.upsample:
@@ -1060,11 +1089,24 @@ class StyledConvSeq(nn.Sequential):
                 return DataBag(d, style=style, fmap=None, fused_rgb=rgb)
             y_amax = y_bound(h, w) if want_amax and dconv.runs_split_wino4(h, w) else None
             y_amax_set = y_amax is not None
+            # the ToRGB that reads this layer's result (to_rgbK follows layer 2K): its channel sums are left by the
+            # convolution itself where the direct-sum kernel runs -- the RGB stream then adds a few small images instead
+            # of re-reading the feature map (4.3 GB for layer 16 at batch 64)
+            tr = _rgb_branch.torgb.get(id(self)) if _rgb_branch.stream is not None else None
+            rgb = None
+            if tr is not None and dconv.leaves_rgb_partials(h, w):
+                rgb_ahead = _prefetched(tr[0])
+                rgb_style = rgb_ahead if rgb_ahead is not None else tr[0].conv.modulation(d.latent[:, tr[1]])
+                rgb = (tr[0].conv.weight.view(3, tr[0].conv.in_channel), rgb_style, tr[0].conv.scale)
             out = dconv.run(fmap, style, style_on_load=on_load, demod=demod, x_amax=x_amax,
-                            y_amax=y_amax if y_amax_set else None, noise=noise,
+                            y_amax=y_amax if y_amax_set else None, rgb=rgb, noise=noise,
                             noise_w=self.noise.weight, bias=act.bias, act=True)
+            if rgb is not None:
+                out, rgb_partials = out
         # hand-overs, only inside the un-hooked forward: the bound rides on the tensor itself (_amax_of)
         extra = {}
+        if rgb_partials is not None:
+            extra['rgb_partials'] = rgb_partials
         if y_amax_set:
             out.rw_amax = (y_amax, out._version)
         if post is not None:        # bags that callers see never carry the key
@@ -1141,12 +1183,14 @@ class SeqStyleGAN2(nn.Sequential):
         _rgb_branch.image_path = True
         _rgb_branch.successor = self._successors()
         _rgb_branch.reader = self._readers()
+        _rgb_branch.torgb = self._torgbs()
         try:
             return self._forward(input)
         finally:
             _rgb_branch.image_path = False
             _rgb_branch.successor = {}
             _rgb_branch.reader = {}
+            _rgb_branch.torgb = {}
 
     def _forward(self, input):
         mb, from_res = micro_batch()
@@ -1282,6 +1326,22 @@ class SeqStyleGAN2(nn.Sequential):
                 if prev is not None:
                     out[id(prev)] = conv
                 prev = conv
+        return out
+
+    def _torgbs(self):
+        """{id(StyledConvSeq): (ToRGBF, latent index)} for every 'layerN' directly followed by a 'to_rgbK' step whose first
+        child picks the latent and whose second is the ToRGB (models.py:126-131)."""
+        out = {}
+        names = list(self._modules)
+        for a, b in zip(names, names[1:]):
+            sconv = getattr(self._modules[a], 'sconv', None) or getattr(self._modules[a], 'conv', None)
+            rgbseq = self._modules[b]
+            torgb = getattr(rgbseq, 'rgb', None)
+            if not isinstance(sconv, StyledConvSeq) or not isinstance(torgb, ToRGBF):
+                continue
+            kids = list(rgbseq.children())
+            if len(kids) == 2 and isinstance(kids[0], PickLatent) and kids[1] is torgb:
+                out[id(sconv)] = (torgb, kids[0].index)
         return out
 
     def _final_pair(self):

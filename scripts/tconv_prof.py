@@ -3,7 +3,7 @@ where the multiplying wave 0 and the staging wave 4 of workgroups 0 and 100 spen
 import ctypes, json, math, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ['RW_TCONV_TY'] = '0'
+os.environ.setdefault('RW_TCONV_TY', '0')         # '2': the pipelined form (its counters: blur = the staging waves' only; epilogue_barriers = the z hand-over)
 from rewriting_amd import hip, _lib  # noqa: E402
 DEV = 'cuda:0'
 batch = int(os.environ.get('RW_BATCH', '64'))

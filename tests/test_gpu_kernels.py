@@ -1064,7 +1064,8 @@ TCONV_CASES = [(1, 16, 16, 16, 32), (2, 64, 32, 16, 64), (1, 32, 16, 32, 32), (1
                (1, 512, 32, 16, 32), (2, 256, 128, 32, 32), (1, 64, 32, 512, 512)]
 
 
-TCONV_FORMS = {'two-workgroups-per-cu': '8', 'one-workgroup-per-cu': '16', 'specialised-persistent': '0', 'automatic': None}
+TCONV_FORMS = {'two-workgroups-per-cu': '8', 'one-workgroup-per-cu': '16', 'specialised-persistent': '0',
+               'pipelined-persistent': '2', 'automatic': None}
 
 
 @pytest.mark.parametrize('form', sorted(TCONV_FORMS))
@@ -1112,7 +1113,7 @@ def test_fused_transposed_conv_and_blur_matches_conv_then_blur(case, form, monke
         scale = want.abs().max().item()
         assert (got - want).abs().max().item() < 2e-5 * scale, (got - want).abs().max().item() / scale
         assert rel(got, want) < 3e-6, rel(got, want)
-        if form == 'specialised-persistent':
+        if form in ('specialised-persistent', 'pipelined-persistent'):
             monkeypatch.setenv('RW_TCONV_GRID', '5')
             again = hip.conv_transpose3x3s2_blur_fused(x.to(DEV), pk, k4, o, s, style=style.to(DEV), demod=dm, **kw)
             monkeypatch.delenv('RW_TCONV_GRID')
@@ -1158,3 +1159,52 @@ def test_fused_transposed_conv_and_blur_with_a_fir_that_is_no_outer_product(form
     ref = R.upfirdn2d(R.demod_conv(style[:, :, None, None] * x, style, wt, upsample=True), k4.cpu(), pad=(1, 1))
     ref = R.fused_leaky_relu(ref + nw.cpu() * noise.cpu(), bias.cpu())
     assert rel(got.cpu(), ref) < 5e-6, rel(got.cpu(), ref)
+
+
+@pytest.mark.parametrize('case', [(2, 64, 32, 16, 32), (1, 64, 64, 32, 64), (2, 128, 128, 16, 64), (1, 512, 512, 16, 32),
+                                  (3, 32, 256, 32, 32), (64, 64, 64, 16, 32)])
+@pytest.mark.parametrize('on_load', [False, True])
+def test_direct_sum_conv_that_leaves_the_to_rgb_sums_matches_separate_kernels(case, on_load):
+    """rw_dconv3x3_rgb_partial_f32 (the stride-1 direct sum on the 16-bit pipe that also leaves, per 32 out-channels, the
+    channel sums of the ToRGB reading its result: ToRGBF.forward, models.py:639-655) + rw_rgb_combine_f32 against
+    rw_dconv3x3_f32 followed by rw_to_rgb_f32: the feature map bit for bit, the image at the direct kernels' bar; 32 / 64 /
+    128-channel workgroups, one and several partials, with and without the style on load, bias / skip absent."""
+    from rewriting_amd import hip
+    b, i, o, h, w = case
+    assert hip.dconv_supported(o, i, h, w)
+    x, wt, style = _conv_inputs(*case, seed=311)
+    rs = numpy.random.RandomState(312)
+    noise = torch.from_numpy(rs.randn(b, h * w).astype('float32')).to(DEV)
+    nw = torch.tensor([0.2]).to(DEV)
+    bias = torch.from_numpy(rs.randn(o).astype('float32')).to(DEV)
+    wrgb = torch.from_numpy(rs.randn(3, o).astype('float32')).to(DEV)
+    srgb = torch.from_numpy((1 + 0.3 * rs.randn(b, o)).astype('float32')).to(DEV)
+    brgb = torch.from_numpy(rs.randn(3).astype('float32')).to(DEV)
+    skip = torch.from_numpy(rs.randn(b, 3, h, w).astype('float32')).to(DEV)
+    s = 1 / math.sqrt(i * 9)
+    st = style.to(DEV)
+    dm = hip.demod(hip.weight_sqsum(wt.to(DEV), s), st)
+    xin = x.to(DEV) if on_load else (x * style[:, :, None, None]).to(DEV)
+    pk = hip.pack_conv_weight_direct16(wt.to(DEV))
+    args = dict(style=st if on_load else None, demod=dm, noise=noise, noise_w=nw, bias=bias, act=True, x_amax=hip.absmax(xin))
+    ymax_a, ymax_b = hip.new_bound(b * o * h * w, DEV), hip.new_bound(b * o * h * w, DEV)
+    fmap = hip.conv3x3_direct16(xin, pk, o, s, y_amax=ymax_a, **args)
+    want = hip.to_rgb(fmap, wrgb, srgb, brgb, skip, 1 / math.sqrt(o))
+    y, part = hip.conv3x3_direct16_rgb_partial(xin, pk, o, s, wrgb, srgb, 1 / math.sqrt(o), y_amax=ymax_b, **args)
+    assert part.shape == (o // 32, b, 3, h, w)
+    if on_load and o % 64 == 0 and w % 64 == 0:         # conv3x3_direct16 takes its specialised kernel there: another order of sums
+        assert rel(y, fmap) < 1e-6
+    else:
+        assert torch.equal(y, fmap) and hip.bound_value(ymax_a) == hip.bound_value(ymax_b)
+    fmap = y
+    want = hip.to_rgb(fmap, wrgb, srgb, brgb, skip, 1 / math.sqrt(o))
+    rgb = hip.rgb_combine(part, brgb, skip)
+    assert rgb.shape == want.shape and torch.isfinite(rgb).all()
+    assert rel(rgb, want) < 2e-6, rel(rgb, want)
+    assert (rgb - want).abs().max().item() < 1e-5 * max(1.0, want.abs().max().item())
+    bare = hip.rgb_combine(part, None, None)
+    assert rel(bare, want - skip - brgb.view(1, 3, 1, 1)) < 1e-5
+    # the einsum the reference computes (models.py:649-655), in float64
+    ref = torch.einsum('co,bo,bohw->bchw', wrgb.double().cpu(), srgb.double().cpu(), fmap.double().cpu()) / math.sqrt(o)
+    ref = ref + brgb.double().cpu().view(1, 3, 1, 1) + skip.double().cpu()
+    assert rel(rgb.double().cpu(), ref) < 2e-6
