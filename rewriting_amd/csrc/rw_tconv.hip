@@ -64,6 +64,13 @@ struct TconvProblem {
 #ifndef TC_LDS_PAD
 #define TC_LDS_PAD 0
 #endif
+#ifndef TC_FULLAHEAD
+#define TC_FULLAHEAD 3    // tconv_body, 16-byte loads: 3 = the software pipeline of `chunk` (default); 1 / 2 = both pieces of the next window
+                          // requested at the top of a chunk, written behind two / three tap groups; 0 = one piece at a time (round 5)
+#endif
+#ifndef TC_STAGE_B128
+#define TC_STAGE_B128 1   // tconv_body: 1 = the window arrives in 16-byte loads (four pixels of a channel), 0 = round 5's 4-byte loads
+#endif
 #ifndef TC_ABL
 #define TC_ABL 0          // timing ablations (results WRONG): 1 = no staging loads, 2 = no MFMAs, 8 = no epilogue,
                           // 16 = the epilogue without its global stores, 32 = without its noise loads, 64 = without the blur
@@ -95,7 +102,30 @@ __device__ __forceinline__ tc_f16x8 tc_pair_hq(tc_f32x2 h, tc_f16x8 q) {
   const tc_f32x4 d = {h[0], h[1], qq[0], qq[1]};
   return __builtin_bit_cast(tc_f16x8, d);
 }
+#ifndef TC_PROF
+#define TC_PROF 0         // 1: workgroups 0 and 100 leave cycle counts of wave 0 (multiplying) and wave 4 (staging) in tc_prof
+#endif
+#if TC_PROF
+__device__ unsigned long long tc_prof[64];
+extern "C" int rw_tconv_prof(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tc_prof), sizeof(unsigned long long) * 64);
+}
+#define TP_DECL(...) unsigned long long __VA_ARGS__
+#define TP_NOW(t) t = (unsigned long long)clock64()
+#define TP_ADD(var, t) { const unsigned long long tp_n = (unsigned long long)clock64(); var += tp_n - t; t = tp_n; }
+#else
+#define TP_DECL(...)
+#define TP_NOW(t)
+#define TP_ADD(var, t)
+#endif
 template <int N> struct tc_int { static constexpr int value = N; };
+// a * b as ONE v_mul_f32: left to the vectoriser, products of values that sit in different 16-byte load results become
+// v_pk_mul_f32 on register pairs assembled with two v_mov_b32 each
+__device__ __forceinline__ float tc_mul(float a, float b) {
+  float r;
+  asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 
 template <int TY, int WAVES>
 __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
@@ -170,12 +200,119 @@ __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
   const float noise_wg = p.noise ? p.noise_w[0] * gain : 0.f;
   __syncthreads();                                  // the tables are read by other threads than their writers
 
-  // ---- staging: wave v stages channel quad v & 3 of the pixels 64 (NSL s + (v >> 2)) + lane of the flattened window
+  // ---- staging: wave v stages channel quad g = v & 3
   constexpr int NSL = WAVES / 4;
   const int g = wave & 3, hsel = wave >> 2;
   const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(p.x + (int64_t)ib * p.in_ch * hw), 0, (int)((int64_t)p.in_ch * hw * 4), 0x00020000);
   const int hw4 = (int)hw * 4;
+#if TC_STAGE_B128
+  // A lane's ITEM is a 16-byte aligned run of four window columns (4 j - 2 .. 4 j + 1 of the window: input columns
+  // J0 - 4 + 4 j ..) of one row: four 16-byte loads -- one per channel of the quad -- bring 4 pixels x 4 channels, i.e. four
+  // LDS words.  A quarter of the load instructions of the one-pixel form below for the same bytes: there the 24 dword loads a
+  // thread issues per chunk took ~20 cycles EACH to issue (cycle counters, profiles/r06q: the vector-memory address path, not
+  // latency or bandwidth, paced the window -- requesting both halves a whole chunk ahead made it slower).  Items outside the
+  // image read 0 through the descriptor's range check; the two columns left of the window (j = 0) and the three right of it
+  // (j = IPR - 1) are loaded and dropped.  Piece s of wave v: item LPP (NSL s + (v >> 2)) + lane of the WR x IPR items, lanes
+  // < LPP -- every wave has BOTH pieces (48 of 64 lanes each at TY = 16): no wave-dependent branch around a request, which
+  // would make hipcc's vmcnt waits for the OLDER requests assume it absent (the software pipeline below keeps ten in flight).
+  constexpr int IPR = TC_TX / 4 + 2, NITEM = WR * IPR;
+  constexpr int SI = 2, SH = 1, LPP = ((NITEM + SI * NSL - 1) / (SI * NSL) + 3) & ~3;
+  static_assert(LPP <= 64 && LPP * SI * NSL >= NITEM, "two pieces per wave cover the window");
+  int xoff[SI], lofa[SI], lofb[SI], lok[SI];        // LDS byte offsets of the item's pixels 0 / 2 (1 / 3: + 64); bit e of lok: pixel e is a window pixel
+#pragma unroll
+  for (int s = 0; s < SI; ++s) {
+    const int it = LPP * (NSL * s + hsel) + lane;
+    const bool mine = lane < LPP && it < NITEM;
+    const int r = it / IPR, j = it - r * IPR;
+    const int iy = I0 - 2 + r, ix = J0 - 4 + 4 * j;                // the item lies inside the row or outside it as a whole
+    const bool ok = mine && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
+    xoff[s] = ok ? (iy * p.w + ix) * 4 : 0x7ffffff0;
+    const int cc0 = 4 * j - 2;                                      // window column of pixel 0
+    lofa[s] = (r * TC_WC + cc0) * 64 + ((g ^ tc_swz(cc0 & 0x7ffffffe)) << 4);          // pixels 0, 1 share a swizzle ((cc >> 1) & 3) ...
+    lofb[s] = (r * TC_WC + cc0 + 2) * 64 + ((g ^ tc_swz(cc0 + 2)) << 4);               // ... pixels 2, 3 the next one
+    int m = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) m |= (mine && cc0 + e >= 0 && cc0 + e < TC_WC) ? (1 << e) : 0;
+    lok[s] = m;
+  }
+  constexpr bool FA = TC_FULLAHEAD != 0;            // both pieces in their own registers; 1 / 2: requested at the top of a chunk, into their own registers
+  constexpr int RS = FA ? SI : SH;
+  tc_f32x4 raw[RS][4];                              // [piece][channel]: four pixels
+  auto stage_load = [&](int c, auto half_tag) __attribute__((always_inline)) {
+    constexpr int S0 = decltype(half_tag)::value ? SH : 0, S1 = decltype(half_tag)::value ? SI : SH;
+    constexpr int R0 = FA ? 0 : S0;
+    const int s0 = (16 * c + 4 * g) * hw4;
+#pragma unroll
+    for (int s = S0; s < S1; ++s) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (TC_ABL & 1) raw[s - R0][k] = tc_f32x4{1.f, 1.f, 1.f, 1.f};
+        else raw[s - R0][k] = __builtin_bit_cast(tc_f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, xoff[s], s0 + k * hw4, 0));
+      }
+    }
+  };
+  auto stage_store = [&](int c, int buf, auto half_tag) __attribute__((always_inline)) {
+    constexpr int S0 = decltype(half_tag)::value ? SH : 0, S1 = decltype(half_tag)::value ? SI : SH;
+    constexpr int R0 = FA ? 0 : S0;
+    const tc_f32x4 sv = *reinterpret_cast<const tc_f32x4*>(&St[16 * c + 4 * g]);
+    unsigned char* dst = Ls + buf * BUFB;
+#pragma unroll
+    for (int s = S0; s < S1; ++s) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v0 = tc_mul(raw[s - R0][0][e], sv[0]), v1 = tc_mul(raw[s - R0][1][e], sv[1]),
+                    v2 = tc_mul(raw[s - R0][2][e], sv[2]), v3 = tc_mul(raw[s - R0][3][e], sv[3]);
+        const tc_f16x2 h01 = __builtin_convertvector(tc_f32x2{v0, v1}, tc_f16x2);
+        const tc_f16x2 h23 = __builtin_convertvector(tc_f32x2{v2, v3}, tc_f16x2);
+        float r0, r1, r2, r3;                      // v - (float)h, exact
+        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h01), "v"(v0));
+        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h01), "v"(v1));
+        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r2) : "v"(h23), "v"(v2));
+        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r3) : "v"(h23), "v"(v3));
+        const tc_f16x2 l01 = __builtin_convertvector(tc_f32x2{r0, r1}, tc_f16x2);
+        const tc_f16x2 l23 = __builtin_convertvector(tc_f32x2{r2, r3}, tc_f16x2);
+        const tc_f16x8 word = {h01[0], h01[1], h23[0], h23[1], l01[0], l01[1], l23[0], l23[1]};
+        if (lok[s] & (1 << e)) *reinterpret_cast<tc_f16x8*>(dst + (e < 2 ? lofa[s] : lofb[s]) + (e & 1) * 64) = word;
+      }
+    }
+  };
+  // (TC_FULLAHEAD == 3) the same in parts, for the software pipeline of `chunk`: channels K0 .. K1 - 1 of a piece requested,
+  // pixels E0 .. E1 - 1 of a piece converted and written
+  auto stage_load_part = [&](int c, auto s_tag, auto k0_tag, auto k1_tag) __attribute__((always_inline)) {
+    constexpr int s = decltype(s_tag)::value, K0 = decltype(k0_tag)::value, K1 = decltype(k1_tag)::value;
+    const int s0 = (16 * c + 4 * g) * hw4;
+#pragma unroll
+    for (int k = K0; k < K1; ++k) {
+      if (TC_ABL & 1) raw[s % RS][k] = tc_f32x4{1.f, 1.f, 1.f, 1.f};
+      else raw[s % RS][k] = __builtin_bit_cast(tc_f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, xoff[s], s0 + k * hw4, 0));
+    }
+  };
+  auto stage_store_part = [&](int c, int buf, auto s_tag, auto e0_tag, auto e1_tag) __attribute__((always_inline)) {
+    constexpr int s = decltype(s_tag)::value, E0 = decltype(e0_tag)::value, E1 = decltype(e1_tag)::value;
+    const tc_f32x4 sv = *reinterpret_cast<const tc_f32x4*>(&St[16 * c + 4 * g]);
+    unsigned char* dst = Ls + buf * BUFB;
+#pragma unroll
+    for (int e = E0; e < E1; ++e) {
+      const float v0 = tc_mul(raw[s % RS][0][e], sv[0]), v1 = tc_mul(raw[s % RS][1][e], sv[1]),
+                  v2 = tc_mul(raw[s % RS][2][e], sv[2]), v3 = tc_mul(raw[s % RS][3][e], sv[3]);
+      const tc_f16x2 h01 = __builtin_convertvector(tc_f32x2{v0, v1}, tc_f16x2);
+      const tc_f16x2 h23 = __builtin_convertvector(tc_f32x2{v2, v3}, tc_f16x2);
+      float r0, r1, r2, r3;                        // v - (float)h, exact
+      asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h01), "v"(v0));
+      asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h01), "v"(v1));
+      asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r2) : "v"(h23), "v"(v2));
+      asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r3) : "v"(h23), "v"(v3));
+      const tc_f16x2 l01 = __builtin_convertvector(tc_f32x2{r0, r1}, tc_f16x2);
+      const tc_f16x2 l23 = __builtin_convertvector(tc_f32x2{r2, r3}, tc_f16x2);
+      const tc_f16x8 word = {h01[0], h01[1], h23[0], h23[1], l01[0], l01[1], l23[0], l23[1]};
+      if (lok[s] & (1 << e)) *reinterpret_cast<tc_f16x8*>(dst + (e < 2 ? lofa[s] : lofb[s]) + (e & 1) * 64) = word;
+    }
+  };
+  constexpr bool PIPE = TC_FULLAHEAD == 3;
+#else
+  // (the one-pixel form of round 5: a lane stages the four channels of ONE pixel 64 (NSL s + (v >> 2)) + lane of the flattened
+  // window -- 4-byte loads)
   constexpr int SI = (NPIX + 64 * NSL - 1) / (64 * NSL), SH = (SI + 1) / 2;
   int xoff[SI], loff[SI];
 #pragma unroll
@@ -187,6 +324,9 @@ __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
     xoff[s] = ok ? (iy * p.w + ix) * 4 : 0x7fffffff;
     loff[s] = pi < NPIX ? pi * 64 + ((g ^ tc_swz(cc)) << 4) : -1;
   }
+  constexpr bool FA = false, PIPE = false;
+  auto stage_load_part = [&](int, auto, auto, auto) {};
+  auto stage_store_part = [&](int, int, auto, auto, auto) {};
   float raw[SH][4];
   auto stage_load = [&](int c, auto half_tag) __attribute__((always_inline)) {
     constexpr int S0 = decltype(half_tag)::value ? SH : 0, S1 = decltype(half_tag)::value ? SI : SH;
@@ -218,6 +358,7 @@ __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
       if (loff[s] >= 0) *reinterpret_cast<tc_f16x8*>(dst + loff[s]) = word;
     }
   };
+#endif
   // the chunk's weights of this workgroup's 16 out-channels: 9216 contiguous bytes of the packed array -> LDS
   const unsigned char* wsrc = p.wp + (int64_t)ot * T * 1024;
   constexpr int NWP = (TC_WCH / 16 + THREADS - 1) / THREADS;       // 16-byte pieces per thread
@@ -225,9 +366,10 @@ __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
   auto wstage_load = [&](int c) __attribute__((always_inline)) {
     const unsigned char* src = wsrc + (int64_t)c * TC_WCH;
 #pragma unroll
-    for (int k = 0; k < NWP; ++k)
-      if ((k + 1) * THREADS <= TC_WCH / 16 || tid + k * THREADS < TC_WCH / 16)
-        wraw[k] = *reinterpret_cast<const tc_f32x4*>(src + (tid + k * THREADS) * 16);
+    for (int k = 0; k < NWP; ++k) {                 // (no branch around a request: the threads past the end read the last piece again)
+      const int pc = tid + k * THREADS < TC_WCH / 16 ? tid + k * THREADS : TC_WCH / 16 - 1;
+      wraw[k] = *reinterpret_cast<const tc_f32x4*>(src + pc * 16);
+    }
   };
   auto wstage_store = [&](int buf) __attribute__((always_inline)) {
     unsigned char* dst = Wl + buf * TC_WCH;
@@ -239,14 +381,16 @@ __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
 
   // ---- this wave's position blocks: operand addresses of the lane's position q = 16 blk + lt (clamped), pixel offsets
   // (a, b) = x[i - a][j - b] at window pixel (r + 1 - a, c + 1 - b)
-  unsigned pb0[BPW], pb1[BPW];                     // column offset b = 0 / 1 at row offset a = 0 (a = 1: - TC_WC * 64)
+  // (the ROW ABOVE, a = 1; the position's own row is + TC_WC * 64: an immediate.  They include the window buffer's offset and
+  // move by +- BUFB at the end of a chunk -- ten additions per chunk where `buffer base + offset` cost one per operand read: 33)
+  unsigned pb0[BPW], pb1[BPW];                     // column offset b = 0 / 1 at row offset a = 1
 #pragma unroll
   for (int b = 0; b < BPW; ++b) {
     int q = 16 * (wave + WAVES * b) + lt;
     q = q < NPOS ? q : NPOS - 1;
     const int r = q / TC_PC, c = q - r * TC_PC;
-    pb0[b] = (unsigned)(((r + 1) * TC_WC + c + 1) * 64 + ((lk ^ tc_swz(c + 1)) << 4));
-    pb1[b] = (unsigned)(((r + 1) * TC_WC + c) * 64 + ((lk ^ tc_swz(c)) << 4));
+    pb0[b] = (unsigned)((r * TC_WC + c + 1) * 64 + ((lk ^ tc_swz(c + 1)) << 4));
+    pb1[b] = (unsigned)((r * TC_WC + c) * 64 + ((lk ^ tc_swz(c)) << 4));
   }
 
   tc_f32x4 acc[BPW][4];
@@ -265,23 +409,57 @@ __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
 #define TC_UL(T_) (*reinterpret_cast<const tc_f32x2*>(wb + (T_) * 1024 + 512))
 #define TC_PIX(OFF) (*reinterpret_cast<const tc_f16x8*>(lb + (OFF)))
 #define TC_VH(OFF) (*reinterpret_cast<const tc_f32x2*>(lb + (OFF)))
+  TP_DECL(tp = 0, tp_all = 0, tp_g0 = 0, tp_s0 = 0, tp_g1 = 0, tp_g2 = 0, tp_s1 = 0, tp_bar = 0, tp_pro = 0);
   auto chunk = [&](int c, auto last_tag) __attribute__((always_inline)) {
     constexpr bool LAST = decltype(last_tag)::value != 0;
     const int buf = c & 1;
-    const unsigned char* lb = Ls + buf * BUFB;
+    const unsigned char* lb = Ls;                   // (pb0 / pb1 carry the buffer's offset: they move by +- BUFB at the end of a chunk)
     const unsigned char* wb = Wl + buf * TC_WCH + lane * 8;
-    if (!LAST) { stage_load(c + 1, tc_int<0>()); wstage_load(c + 1); }
+    TP_NOW(tp);
+    // TC_FULLAHEAD == 3, the software pipeline: what is requested during chunk c (piece 0 behind the first tap group's blocks 2, 3,
+    // piece 1 behind the second group's, the weights behind the third's) belongs to chunk c + 2 and is converted / written
+    // during chunk c + 1 (behind blocks 0, 1 of the same groups, just before the registers are requested again): every load has
+    // a whole chunk to arrive, the requests are spread (eight waves requesting a window at once stall at the issue of their loads:
+    // the MFMAs behind them wait, profiles/r06s), the conversion sits between MFMAs.  The chunk barrier waits for LDS only.
+    // (No branches around the requests: past the end they read the last chunk again, into registers nobody converts -- with
+    // them inside conditionals hipcc waits for vmcnt(0) at the first conversion of every chunk.)
+    constexpr bool st = !LAST, ld = true;
+    const int c2 = c + 2 < NC ? c + 2 : NC - 1;
+    auto hook = [&](auto grp_tag, int b) __attribute__((always_inline)) {
+      constexpr int grp = decltype(grp_tag)::value;
+      if (!PIPE) return;
+#if TC_PROF
+      if (b < 4) { if (grp == 0) { TP_ADD(tp_g0, tp); } else if (grp == 1) { TP_ADD(tp_g1, tp); } else { TP_ADD(tp_g2, tp); } }
+#endif
+      if constexpr (grp < 2) {
+        if (b == 0 && st) stage_store_part(c + 1, buf ^ 1, tc_int<grp>(), tc_int<0>(), tc_int<2>());
+        if (b == 1 && st) stage_store_part(c + 1, buf ^ 1, tc_int<grp>(), tc_int<2>(), tc_int<4>());
+        if (b == 2 && ld) stage_load_part(c2, tc_int<grp>(), tc_int<0>(), tc_int<2>());
+        if (b == 3 && ld) stage_load_part(c2, tc_int<grp>(), tc_int<2>(), tc_int<4>());
+      } else {
+        if (b == 0 && st) wstage_store(buf ^ 1);
+        if (b == 1 && ld) wstage_load(c2);
+      }
+#if TC_PROF
+      if (b < 2) { TP_ADD(tp_s0, tp); } else if (b < 4) { TP_ADD(tp_s1, tp); }
+#endif
+    };
+    if (!LAST && !PIPE) {
+      wstage_load(c + 1);
+      stage_load(c + 1, tc_int<0>());
+      if (FA) stage_load(c + 1, tc_int<1>());
+    }
     // (operands one block ahead, the order pinned: left to itself the scheduler hoists every block's LDS reads to the top
     // of a group and spills; only the last block of a wave can be missing: NBLK > WAVES (BPW - 1))
     constexpr int LB = BPW - 1;
     const bool last_ok = wave + WAVES * LB < NBLK;  // wave-uniform
     {
       const tc_f16x8 u0 = TC_UH(0), u1 = TC_UH(1), u3 = TC_UH(3), u4 = TC_UH(4), l4 = tc_expand(TC_UL(4));
-      tc_f16x8 pc = TC_PIX(pb0[0]);
+      tc_f16x8 pc = TC_PIX(pb0[0] + TC_WC * 64);
 #pragma unroll
       for (int b = 0; b < BPW; ++b) {
         tc_f16x8 pn = pc;
-        if (b + 1 < BPW) pn = TC_PIX(pb0[b + 1]);
+        if (b + 1 < BPW) pn = TC_PIX(pb0[b + 1] + TC_WC * 64);
         if (b < LB || last_ok) {
           if (TC_ABL & 2) { asm volatile("" :: "v"(pc), "v"(u0), "v"(u1), "v"(u3), "v"(u4), "v"(l4)); }
           else {
@@ -289,24 +467,27 @@ __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
             TC_MFMA(3, pc, l4);                     // (never two dependent MFMAs back to back)
           }
         }
+        hook(tc_int<0>(), b);
         __builtin_amdgcn_sched_barrier(0);
         pc = pn;
       }
     }
-    if (!LAST) {                                    // the first half of the next window: converted behind a group's MFMAs
+    TP_ADD(tp_g0, tp);
+    if (!LAST && !FA) {                             // the first half of the next window: converted behind a group's MFMAs
       stage_store(c + 1, buf ^ 1, tc_int<0>());
       stage_load(c + 1, tc_int<1>());
     }
     __builtin_amdgcn_sched_barrier(0);
+    TP_ADD(tp_s0, tp);
     {
       const tc_f16x8 u2 = TC_UH(2), u5 = TC_UH(5), m02 = tc_pair(TC_UL(0), TC_UL(2)), m35 = tc_pair(TC_UL(3), TC_UL(5));
-      tc_f32x2 hc = TC_VH(pb0[0]);                  // Vh of x[i][j]: the first half of its word
-      tc_f16x8 qc = TC_PIX(pb1[0]);
+      tc_f32x2 hc = TC_VH(pb0[0] + TC_WC * 64);     // Vh of x[i][j]: the first half of its word
+      tc_f16x8 qc = TC_PIX(pb1[0] + TC_WC * 64);
 #pragma unroll
       for (int b = 0; b < BPW; ++b) {
         tc_f32x2 hn = hc;
         tc_f16x8 qn = qc;
-        if (b + 1 < BPW) { hn = TC_VH(pb0[b + 1]); qn = TC_PIX(pb1[b + 1]); }
+        if (b + 1 < BPW) { hn = TC_VH(pb0[b + 1] + TC_WC * 64); qn = TC_PIX(pb1[b + 1] + TC_WC * 64); }
         if (b < LB || last_ok) {
           if (TC_ABL & 2) { asm volatile("" :: "v"(hc), "v"(qc), "v"(u2), "v"(u5), "v"(m02), "v"(m35)); }
           else {
@@ -315,20 +496,27 @@ __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
             TC_MFMA(0, M, m02); TC_MFMA(2, M, m35);                               // Vh Ul of (0, 0) + (0, 2); (1, 0) + (1, 2)
           }
         }
+        hook(tc_int<1>(), b);
         __builtin_amdgcn_sched_barrier(0);
         hc = hn; qc = qn;
       }
     }
+    TP_ADD(tp_g1, tp);
+    if (!LAST && FA && TC_FULLAHEAD == 1) {         // (both pieces in flight since the top: the first one behind two groups; 2: behind all three)
+      stage_store(c + 1, buf ^ 1, tc_int<0>());
+      __builtin_amdgcn_sched_barrier(0);
+      TP_ADD(tp_s0, tp);
+    }
     {
       const tc_f16x8 u6 = TC_UH(6), u7 = TC_UH(7), u8 = TC_UH(8), m17 = tc_pair(TC_UL(1), TC_UL(7)),
                      m68 = tc_pair(TC_UL(6), TC_UL(8));
-      tc_f32x2 hc = TC_VH(pb0[0]);
-      tc_f16x8 qc = TC_PIX(pb0[0] - TC_WC * 64), rc = TC_PIX(pb1[0] - TC_WC * 64);
+      tc_f32x2 hc = TC_VH(pb0[0] + TC_WC * 64);
+      tc_f16x8 qc = TC_PIX(pb0[0]), rc = TC_PIX(pb1[0]);
 #pragma unroll
       for (int b = 0; b < BPW; ++b) {
         tc_f32x2 hn = hc;
         tc_f16x8 qn = qc, rn = rc;
-        if (b + 1 < BPW) { hn = TC_VH(pb0[b + 1]); qn = TC_PIX(pb0[b + 1] - TC_WC * 64); rn = TC_PIX(pb1[b + 1] - TC_WC * 64); }
+        if (b + 1 < BPW) { hn = TC_VH(pb0[b + 1] + TC_WC * 64); qn = TC_PIX(pb0[b + 1]); rn = TC_PIX(pb1[b + 1]); }
         if (b < LB || last_ok) {
           if (TC_ABL & 2) { asm volatile("" :: "v"(hc), "v"(qc), "v"(rc), "v"(u6), "v"(u7), "v"(u8), "v"(m17), "v"(m68)); }
           else {
@@ -338,18 +526,35 @@ __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
             TC_MFMA(0, M23, m68);                                                 // Vh Ul of (2, 0) + (2, 2)
           }
         }
+        hook(tc_int<2>(), b);
         __builtin_amdgcn_sched_barrier(0);
         hc = hn; qc = qn; rc = rn;
       }
     }
+    TP_ADD(tp_g2, tp);
     if (!LAST) {
+      const unsigned delta = buf ? (unsigned)-BUFB : (unsigned)BUFB;
+#pragma unroll
+      for (int b = 0; b < BPW; ++b) { pb0[b] += delta; pb1[b] += delta; }
+    }
+    if (!LAST && PIPE) {
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_waitcnt(0xC07F);           // lgkmcnt(0): the requests of chunk c + 2 stay in flight across the barrier
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      TP_ADD(tp_bar, tp);
+    } else if (!LAST) {
+      if (FA && TC_FULLAHEAD == 2) stage_store(c + 1, buf ^ 1, tc_int<0>());
       stage_store(c + 1, buf ^ 1, tc_int<1>());
       wstage_store(buf ^ 1);
+      TP_ADD(tp_s1, tp);
       __syncthreads();
+      TP_ADD(tp_bar, tp);
     }
   };
 
   // ---- prologue
+  TP_NOW(tp_all);
   wstage_load(0);
   stage_load(0, tc_int<0>());
   stage_store(0, 0, tc_int<0>());
@@ -357,9 +562,26 @@ __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
   stage_store(0, 0, tc_int<1>());
   wstage_store(0);
   __syncthreads();
+  if (PIPE) {                                       // chunk 1 (in_ch == 16: chunk 0 again, never converted): in flight through chunk 0
+    const int c1 = NC > 1 ? 1 : 0;
+    // (in the order of a chunk's requests, pinned: the waits of the loop count the requests behind the one they need)
+    __builtin_amdgcn_sched_barrier(0);
+    stage_load_part(c1, tc_int<0>(), tc_int<0>(), tc_int<4>());
+    __builtin_amdgcn_sched_barrier(0);
+    stage_load_part(c1, tc_int<1>(), tc_int<0>(), tc_int<4>());
+    __builtin_amdgcn_sched_barrier(0);
+    wstage_load(c1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
 
+#if TC_PROF
+  TP_NOW(tp); tp_pro = tp - tp_all;
+#endif
   for (int c = 0; c + 1 < NC; ++c) chunk(c, tc_int<0>());
   chunk(NC - 1, tc_int<1>());
+#if TC_PROF
+  const unsigned long long tp_loop_end = (unsigned long long)clock64();
+#endif
   if (TC_ABL & 8) { if (acc[0][0][0] != 12345.f) return; }
   __syncthreads();                                  // every wave has read its last operands: the windows become the z tile
 
@@ -492,6 +714,14 @@ __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
     }
     __syncthreads();
   }
+#if TC_PROF
+  if (lane == 0 && (wave == 0 || wave == 7) && (blockIdx.x == gridDim.x / 2 || blockIdx.x == gridDim.x / 2 + 777)) {
+    unsigned long long* o = tc_prof + (blockIdx.x == gridDim.x / 2 ? 0 : 32) + (wave == 0 ? 0 : 16);
+    const unsigned long long now = (unsigned long long)clock64();
+    o[0] = now - tp_all; o[1] = tp_pro; o[2] = tp_g0; o[3] = tp_s0; o[4] = tp_g1; o[5] = tp_g2; o[6] = tp_s1; o[7] = tp_bar;
+    o[8] = now - tp_loop_end; o[9] = NC;
+  }
+#endif
   if (p.y_amax) rw_bound_store_wave(p.y_amax, rw_wave_max(ymax));
 }
 
@@ -523,22 +753,6 @@ __global__ void __launch_bounds__(512, 1) tconv_blur_t16_kernel(const TconvProbl
 #endif
 #ifndef TC_PP_MQ
 #define TC_PP_MQ 2        // pipelined form: of a tile's four blur passes, how many the multiplying waves take (0 .. 4)
-#endif
-#ifndef TC_PROF
-#define TC_PROF 0         // 1: workgroups 0 and 100 leave cycle counts of wave 0 (multiplying) and wave 4 (staging) in tc_prof
-#endif
-#if TC_PROF
-__device__ unsigned long long tc_prof[64];
-extern "C" int rw_tconv_prof(unsigned long long* out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tc_prof), sizeof(unsigned long long) * 64);
-}
-#define TP_DECL(...) unsigned long long __VA_ARGS__
-#define TP_NOW(t) t = (unsigned long long)clock64()
-#define TP_ADD(var, t) { const unsigned long long tp_n = (unsigned long long)clock64(); var += tp_n - t; t = tp_n; }
-#else
-#define TP_DECL(...)
-#define TP_NOW(t)
-#define TP_ADD(var, t)
 #endif
 
 __global__ void __launch_bounds__(512, 2) tconv_blur_ws_kernel(const TconvProblem p) {
