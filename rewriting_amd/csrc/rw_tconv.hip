@@ -40,6 +40,7 @@
 // output where the direct 16-tap form spends 16, and a third of its LDS reads; any other FIR takes the 16-tap form.
 #include "rw_common.h"
 #include <stdlib.h>
+#include <stdio.h>
 typedef float tc_f32x4 __attribute__((ext_vector_type(4)));
 typedef float tc_f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 tc_f16x2 __attribute__((ext_vector_type(2)));
@@ -63,13 +64,6 @@ struct TconvProblem {
 
 #ifndef TC_LDS_PAD
 #define TC_LDS_PAD 0
-#endif
-#ifndef TC_FULLAHEAD
-#define TC_FULLAHEAD 3    // tconv_body, 16-byte loads: 3 = the software pipeline of `chunk` (default); 1 / 2 = both pieces of the next window
-                          // requested at the top of a chunk, written behind two / three tap groups; 0 = one piece at a time (round 5)
-#endif
-#ifndef TC_STAGE_B128
-#define TC_STAGE_B128 1   // tconv_body: 1 = the window arrives in 16-byte loads (four pixels of a channel), 0 = round 5's 4-byte loads
 #endif
 #ifndef TC_ABL
 #define TC_ABL 0          // timing ablations (results WRONG): 1 = no staging loads, 2 = no MFMAs, 8 = no epilogue,
@@ -127,15 +121,11 @@ __device__ __forceinline__ float tc_mul(float a, float b) {
   return r;
 }
 
-template <int TY, int WAVES>
+template <int TY, int WAVES, int NT>
 __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
   constexpr int THREADS = 64 * WAVES;
   constexpr int PR = TY + 2;                        // position rows
-#if TC_ABL & 128
-  constexpr int NPOS = PR * TC_PC, NBLK = 3 * WAVES, BPW = 3;       // (ablation: three blocks per wave -> fewer registers; results wrong)
-#else
   constexpr int NPOS = PR * TC_PC, NBLK = (NPOS + 15) / 16, BPW = (NBLK + WAVES - 1) / WAVES;
-#endif
   constexpr int WR = TY + 3, NPIX = WR * TC_WC;    // window rows: input rows I0 - 2 .. I0 + TY
   constexpr int BUFB = NPIX * 64;                   // bytes of a window buffer: 16 channels x (2 + 2) bytes per pixel
   constexpr int ZR = 2 * PR, CHS = ZR * TC_ZP + 4;  // z rows of the tile; z channel stride (floats)
@@ -143,14 +133,17 @@ __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
   constexpr int SR = 2 * TY * 128 / THREADS;        // output rows of a thread's strip in the epilogue
   static_assert(WAVES % 4 == 0 && THREADS % 128 == 0 && SR * (THREADS / 128) == 2 * TY && (SR == 4 || SR == 8),
                 "four or eight output rows per strip segment");
+  // NT blocks of 16 out-channels per workgroup (p.o_tiles = out_ch / OC): a pixel operand read from LDS multiplies into NT
+  // accumulator blocks, the window is staged (requested, converted, written) once per OC out-channels
+  constexpr int OC = 16 * NT, WCH = NT * TC_WCH;
   __shared__ __attribute__((aligned(16))) unsigned char Ls[2 * BUFB];
-  __shared__ __attribute__((aligned(16))) unsigned char Wl[2 * TC_WCH];
+  __shared__ __attribute__((aligned(16))) unsigned char Wl[2 * WCH];
   __shared__ __attribute__((aligned(16))) float St[512];
-  __shared__ float Sc[16], Bs[16], Po[16], Kf[16], Red[WAVES];
+  __shared__ float Sc[OC], Bs[OC], Po[OC], Kf[16], Red[WAVES];
 #if TC_LDS_PAD
   // (experiment / workaround, TY == 16 only: claim the rest of the CU's 160 KB of LDS so that no workgroup that uses LDS --
   // to_rgb_kernel -- can share the CU: profiles/r05i)
-  constexpr int PADB = TY == 16 ? 163840 - 2 * BUFB - 2 * TC_WCH - 2048 - 4 * 64 - 4 * WAVES - 64 : 16;
+  constexpr int PADB = TY == 16 ? 163840 - 2 * BUFB - 2 * WCH - 2048 - 4 * 64 - 4 * WAVES - 64 : 16;
   __shared__ unsigned char Pad[PADB];
   if (p.batch < 0) Pad[threadIdx.x] = 1;           // never true: keeps the array allocated
 #endif
@@ -189,11 +182,13 @@ __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
   }
   const float gain = p.act ? 1.4142135623730951f : 1.f, slope = p.act ? 0.2f : 1.f;
   for (int i = tid; i < p.in_ch; i += THREADS) St[i] = (p.style ? p.style[(int64_t)ib * p.in_ch + i] : 1.0f) * in_scale;
-  if (tid < 16) {
-    const int o = 16 * ot + tid;
+  if (tid < OC) {
+    const int o = OC * ot + tid;
     Sc[tid] = (p.demod ? p.demod[(int64_t)ib * p.out_ch + o] * p.w_scale : p.w_scale) * out_scale * gain;
     Bs[tid] = p.act ? p.bias[o] * gain : 0.f;
     Po[tid] = p.post ? p.post[(int64_t)ib * p.out_ch + o] : 1.f;
+  }
+  if (tid < 16) {
     const int a = tid >> 2, c = tid & 3;
     Kf[tid] = p.k4[(3 - a) * 4 + (3 - c)];        // flipped, as upfirdn2d applies it
   }
@@ -201,24 +196,23 @@ __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
   __syncthreads();                                  // the tables are read by other threads than their writers
 
   // ---- staging: wave v stages channel quad g = v & 3
+  // A lane's ITEM is a 16-byte aligned run of four window columns (4 j - 2 .. 4 j + 1 of the window: input columns
+  // J0 - 4 + 4 j ..) of one row: four 16-byte loads -- one per channel of the quad -- bring 4 pixels x 4 channels, i.e. four
+  // LDS words.  (Round 5 staged one pixel per lane with 4-byte loads: the 24 loads a thread issued per chunk took ~20 cycles
+  // EACH to issue -- cycle counters, profiles/r06q: the vector-memory address path, not latency or bandwidth, paced the
+  // window; requesting both halves a whole chunk ahead made it slower.)  Items outside the image read 0 through the
+  // descriptor's range check; the two columns left of the window (j = 0) and the three right of it (j = IPR - 1) are loaded
+  // and dropped.  Piece s of wave v: item LPP (NSL s + (v >> 2)) + lane of the WR x IPR items, lanes < LPP -- every wave has
+  // every piece (48 of 64 lanes each at TY = 16): no wave-dependent branch around a request, which would make hipcc's vmcnt
+  // waits for the OLDER requests assume it absent (the software pipeline below keeps up to eleven in flight).
   constexpr int NSL = WAVES / 4;
   const int g = wave & 3, hsel = wave >> 2;
   const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(p.x + (int64_t)ib * p.in_ch * hw), 0, (int)((int64_t)p.in_ch * hw * 4), 0x00020000);
   const int hw4 = (int)hw * 4;
-#if TC_STAGE_B128
-  // A lane's ITEM is a 16-byte aligned run of four window columns (4 j - 2 .. 4 j + 1 of the window: input columns
-  // J0 - 4 + 4 j ..) of one row: four 16-byte loads -- one per channel of the quad -- bring 4 pixels x 4 channels, i.e. four
-  // LDS words.  A quarter of the load instructions of the one-pixel form below for the same bytes: there the 24 dword loads a
-  // thread issues per chunk took ~20 cycles EACH to issue (cycle counters, profiles/r06q: the vector-memory address path, not
-  // latency or bandwidth, paced the window -- requesting both halves a whole chunk ahead made it slower).  Items outside the
-  // image read 0 through the descriptor's range check; the two columns left of the window (j = 0) and the three right of it
-  // (j = IPR - 1) are loaded and dropped.  Piece s of wave v: item LPP (NSL s + (v >> 2)) + lane of the WR x IPR items, lanes
-  // < LPP -- every wave has BOTH pieces (48 of 64 lanes each at TY = 16): no wave-dependent branch around a request, which
-  // would make hipcc's vmcnt waits for the OLDER requests assume it absent (the software pipeline below keeps ten in flight).
   constexpr int IPR = TC_TX / 4 + 2, NITEM = WR * IPR;
-  constexpr int SI = 2, SH = 1, LPP = ((NITEM + SI * NSL - 1) / (SI * NSL) + 3) & ~3;
-  static_assert(LPP <= 64 && LPP * SI * NSL >= NITEM, "two pieces per wave cover the window");
+  constexpr int SI = (NITEM + 64 * NSL - 1) / (64 * NSL), LPP = ((NITEM + SI * NSL - 1) / (SI * NSL) + 3) & ~3;
+  static_assert(SI <= 2 && LPP <= 64 && LPP * SI * NSL >= NITEM, "one or two pieces per wave cover the window");
   int xoff[SI], lofa[SI], lofb[SI], lok[SI];        // LDS byte offsets of the item's pixels 0 / 2 (1 / 3: + 64); bit e of lok: pixel e is a window pixel
 #pragma unroll
   for (int s = 0; s < SI; ++s) {
@@ -236,66 +230,26 @@ __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
     for (int e = 0; e < 4; ++e) m |= (mine && cc0 + e >= 0 && cc0 + e < TC_WC) ? (1 << e) : 0;
     lok[s] = m;
   }
-  constexpr bool FA = TC_FULLAHEAD != 0;            // both pieces in their own registers; 1 / 2: requested at the top of a chunk, into their own registers
-  constexpr int RS = FA ? SI : SH;
-  tc_f32x4 raw[RS][4];                              // [piece][channel]: four pixels
-  auto stage_load = [&](int c, auto half_tag) __attribute__((always_inline)) {
-    constexpr int S0 = decltype(half_tag)::value ? SH : 0, S1 = decltype(half_tag)::value ? SI : SH;
-    constexpr int R0 = FA ? 0 : S0;
-    const int s0 = (16 * c + 4 * g) * hw4;
-#pragma unroll
-    for (int s = S0; s < S1; ++s) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (TC_ABL & 1) raw[s - R0][k] = tc_f32x4{1.f, 1.f, 1.f, 1.f};
-        else raw[s - R0][k] = __builtin_bit_cast(tc_f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, xoff[s], s0 + k * hw4, 0));
-      }
-    }
-  };
-  auto stage_store = [&](int c, int buf, auto half_tag) __attribute__((always_inline)) {
-    constexpr int S0 = decltype(half_tag)::value ? SH : 0, S1 = decltype(half_tag)::value ? SI : SH;
-    constexpr int R0 = FA ? 0 : S0;
-    const tc_f32x4 sv = *reinterpret_cast<const tc_f32x4*>(&St[16 * c + 4 * g]);
-    unsigned char* dst = Ls + buf * BUFB;
-#pragma unroll
-    for (int s = S0; s < S1; ++s) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float v0 = tc_mul(raw[s - R0][0][e], sv[0]), v1 = tc_mul(raw[s - R0][1][e], sv[1]),
-                    v2 = tc_mul(raw[s - R0][2][e], sv[2]), v3 = tc_mul(raw[s - R0][3][e], sv[3]);
-        const tc_f16x2 h01 = __builtin_convertvector(tc_f32x2{v0, v1}, tc_f16x2);
-        const tc_f16x2 h23 = __builtin_convertvector(tc_f32x2{v2, v3}, tc_f16x2);
-        float r0, r1, r2, r3;                      // v - (float)h, exact
-        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h01), "v"(v0));
-        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h01), "v"(v1));
-        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r2) : "v"(h23), "v"(v2));
-        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r3) : "v"(h23), "v"(v3));
-        const tc_f16x2 l01 = __builtin_convertvector(tc_f32x2{r0, r1}, tc_f16x2);
-        const tc_f16x2 l23 = __builtin_convertvector(tc_f32x2{r2, r3}, tc_f16x2);
-        const tc_f16x8 word = {h01[0], h01[1], h23[0], h23[1], l01[0], l01[1], l23[0], l23[1]};
-        if (lok[s] & (1 << e)) *reinterpret_cast<tc_f16x8*>(dst + (e < 2 ? lofa[s] : lofb[s]) + (e & 1) * 64) = word;
-      }
-    }
-  };
-  // (TC_FULLAHEAD == 3) the same in parts, for the software pipeline of `chunk`: channels K0 .. K1 - 1 of a piece requested,
-  // pixels E0 .. E1 - 1 of a piece converted and written
+  tc_f32x4 raw[SI][4];                              // [piece][channel]: four pixels
+  // channels K0 .. K1 - 1 of piece s of chunk c requested
   auto stage_load_part = [&](int c, auto s_tag, auto k0_tag, auto k1_tag) __attribute__((always_inline)) {
     constexpr int s = decltype(s_tag)::value, K0 = decltype(k0_tag)::value, K1 = decltype(k1_tag)::value;
     const int s0 = (16 * c + 4 * g) * hw4;
 #pragma unroll
     for (int k = K0; k < K1; ++k) {
-      if (TC_ABL & 1) raw[s % RS][k] = tc_f32x4{1.f, 1.f, 1.f, 1.f};
-      else raw[s % RS][k] = __builtin_bit_cast(tc_f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, xoff[s], s0 + k * hw4, 0));
+      if (TC_ABL & 1) raw[s][k] = tc_f32x4{1.f, 1.f, 1.f, 1.f};
+      else raw[s][k] = __builtin_bit_cast(tc_f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, xoff[s], s0 + k * hw4, 0));
     }
   };
+  // pixels E0 .. E1 - 1 of piece s converted (style, exact f16 pair split) and written
   auto stage_store_part = [&](int c, int buf, auto s_tag, auto e0_tag, auto e1_tag) __attribute__((always_inline)) {
     constexpr int s = decltype(s_tag)::value, E0 = decltype(e0_tag)::value, E1 = decltype(e1_tag)::value;
     const tc_f32x4 sv = *reinterpret_cast<const tc_f32x4*>(&St[16 * c + 4 * g]);
     unsigned char* dst = Ls + buf * BUFB;
 #pragma unroll
     for (int e = E0; e < E1; ++e) {
-      const float v0 = tc_mul(raw[s % RS][0][e], sv[0]), v1 = tc_mul(raw[s % RS][1][e], sv[1]),
-                  v2 = tc_mul(raw[s % RS][2][e], sv[2]), v3 = tc_mul(raw[s % RS][3][e], sv[3]);
+      const float v0 = tc_mul(raw[s][0][e], sv[0]), v1 = tc_mul(raw[s][1][e], sv[1]), v2 = tc_mul(raw[s][2][e], sv[2]),
+                  v3 = tc_mul(raw[s][3][e], sv[3]);
       const tc_f16x2 h01 = __builtin_convertvector(tc_f32x2{v0, v1}, tc_f16x2);
       const tc_f16x2 h23 = __builtin_convertvector(tc_f32x2{v2, v3}, tc_f16x2);
       float r0, r1, r2, r3;                        // v - (float)h, exact
@@ -305,84 +259,37 @@ __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
       asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r3) : "v"(h23), "v"(v3));
       const tc_f16x2 l01 = __builtin_convertvector(tc_f32x2{r0, r1}, tc_f16x2);
       const tc_f16x2 l23 = __builtin_convertvector(tc_f32x2{r2, r3}, tc_f16x2);
-      const tc_f16x8 word = {h01[0], h01[1], h23[0], h23[1], l01[0], l01[1], l23[0], l23[1]};
-      if (lok[s] & (1 << e)) *reinterpret_cast<tc_f16x8*>(dst + (e < 2 ? lofa[s] : lofb[s]) + (e & 1) * 64) = word;
+      tc_f16x8 word = {h01[0], h01[1], h23[0], h23[1], l01[0], l01[1], l23[0], l23[1]};
+      if (TC_ABL & 256)                            // (timing ablation: no conversion arithmetic; results wrong)
+        word = __builtin_bit_cast(tc_f16x8, tc_f32x4{raw[s][0][e], raw[s][1][e], raw[s][2][e], raw[s][3][e]});
+      if (TC_ABL & 512) { asm volatile("" :: "v"(word)); }            // (timing ablation: no LDS store of the window)
+      else if (lok[s] & (1 << e)) *reinterpret_cast<tc_f16x8*>(dst + (e < 2 ? lofa[s] : lofb[s]) + (e & 1) * 64) = word;
     }
   };
-  constexpr bool PIPE = TC_FULLAHEAD == 3;
-#else
-  // (the one-pixel form of round 5: a lane stages the four channels of ONE pixel 64 (NSL s + (v >> 2)) + lane of the flattened
-  // window -- 4-byte loads)
-  constexpr int SI = (NPIX + 64 * NSL - 1) / (64 * NSL), SH = (SI + 1) / 2;
-  int xoff[SI], loff[SI];
-#pragma unroll
-  for (int s = 0; s < SI; ++s) {
-    const int pi = 64 * (NSL * s + hsel) + lane;
-    const int r = pi / TC_WC, cc = pi - r * TC_WC;
-    const int iy = I0 - 2 + r, ix = J0 - 2 + cc;
-    const bool ok = pi < NPIX && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
-    xoff[s] = ok ? (iy * p.w + ix) * 4 : 0x7fffffff;
-    loff[s] = pi < NPIX ? pi * 64 + ((g ^ tc_swz(cc)) << 4) : -1;
-  }
-  constexpr bool FA = false, PIPE = false;
-  auto stage_load_part = [&](int, auto, auto, auto) {};
-  auto stage_store_part = [&](int, int, auto, auto, auto) {};
-  float raw[SH][4];
-  auto stage_load = [&](int c, auto half_tag) __attribute__((always_inline)) {
-    constexpr int S0 = decltype(half_tag)::value ? SH : 0, S1 = decltype(half_tag)::value ? SI : SH;
-    const int s0 = (16 * c + 4 * g) * hw4;
-#pragma unroll
-    for (int s = S0; s < S1; ++s)
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        raw[s - S0][k] = (TC_ABL & 1) ? 1.f : __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xsrc, xoff[s], s0 + k * hw4, 0));
-  };
-  auto stage_store = [&](int c, int buf, auto half_tag) __attribute__((always_inline)) {
-    constexpr int S0 = decltype(half_tag)::value ? SH : 0, S1 = decltype(half_tag)::value ? SI : SH;
-    const tc_f32x4 sv = *reinterpret_cast<const tc_f32x4*>(&St[16 * c + 4 * g]);
-    unsigned char* dst = Ls + buf * BUFB;
-#pragma unroll
-    for (int s = S0; s < S1; ++s) {
-      const float (&rw)[4] = raw[s - S0];
-      const float v0 = rw[0] * sv[0], v1 = rw[1] * sv[1], v2 = rw[2] * sv[2], v3 = rw[3] * sv[3];
-      const tc_f16x2 h01 = __builtin_convertvector(tc_f32x2{v0, v1}, tc_f16x2);
-      const tc_f16x2 h23 = __builtin_convertvector(tc_f32x2{v2, v3}, tc_f16x2);
-      float r0, r1, r2, r3;                        // v - (float)h, exact
-      asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h01), "v"(v0));
-      asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h01), "v"(v1));
-      asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r2) : "v"(h23), "v"(v2));
-      asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r3) : "v"(h23), "v"(v3));
-      const tc_f16x2 l01 = __builtin_convertvector(tc_f32x2{r0, r1}, tc_f16x2);
-      const tc_f16x2 l23 = __builtin_convertvector(tc_f32x2{r2, r3}, tc_f16x2);
-      const tc_f16x8 word = {h01[0], h01[1], h23[0], h23[1], l01[0], l01[1], l23[0], l23[1]};
-      if (loff[s] >= 0) *reinterpret_cast<tc_f16x8*>(dst + loff[s]) = word;
-    }
-  };
-#endif
-  // the chunk's weights of this workgroup's 16 out-channels: 9216 contiguous bytes of the packed array -> LDS
-  const unsigned char* wsrc = p.wp + (int64_t)ot * T * 1024;
-  constexpr int NWP = (TC_WCH / 16 + THREADS - 1) / THREADS;       // 16-byte pieces per thread
+  // the chunk's weights of this workgroup's NT out-channel blocks: NT x 9216 contiguous bytes of the packed array -> LDS
+  const unsigned char* wsrc = p.wp + (int64_t)(NT * ot) * T * 1024;
+  constexpr int NPC = NT * (TC_WCH / 16), NWP = (NPC + THREADS - 1) / THREADS;      // 16-byte pieces, per thread
   tc_f32x4 wraw[NWP];
   auto wstage_load = [&](int c) __attribute__((always_inline)) {
-    const unsigned char* src = wsrc + (int64_t)c * TC_WCH;
 #pragma unroll
     for (int k = 0; k < NWP; ++k) {                 // (no branch around a request: the threads past the end read the last piece again)
-      const int pc = tid + k * THREADS < TC_WCH / 16 ? tid + k * THREADS : TC_WCH / 16 - 1;
-      wraw[k] = *reinterpret_cast<const tc_f32x4*>(src + pc * 16);
+      const int pc = tid + k * THREADS < NPC ? tid + k * THREADS : NPC - 1;
+      const int n = pc / (TC_WCH / 16), r = pc - n * (TC_WCH / 16);
+      wraw[k] = *reinterpret_cast<const tc_f32x4*>(wsrc + ((int64_t)n * T + 9 * c) * 1024 + r * 16);
     }
   };
   auto wstage_store = [&](int buf) __attribute__((always_inline)) {
-    unsigned char* dst = Wl + buf * TC_WCH;
+    unsigned char* dst = Wl + buf * WCH;
 #pragma unroll
     for (int k = 0; k < NWP; ++k)
-      if ((k + 1) * THREADS <= TC_WCH / 16 || tid + k * THREADS < TC_WCH / 16)
+      if ((k + 1) * THREADS <= NPC || tid + k * THREADS < NPC)
         *reinterpret_cast<tc_f32x4*>(dst + (tid + k * THREADS) * 16) = wraw[k];
   };
 
   // ---- this wave's position blocks: operand addresses of the lane's position q = 16 blk + lt (clamped), pixel offsets
   // (a, b) = x[i - a][j - b] at window pixel (r + 1 - a, c + 1 - b)
   // (the ROW ABOVE, a = 1; the position's own row is + TC_WC * 64: an immediate.  They include the window buffer's offset and
-  // move by +- BUFB at the end of a chunk -- ten additions per chunk where `buffer base + offset` cost one per operand read: 33)
+  // move by +- BUFB at the end of a chunk -- 2 BPW additions per chunk where `buffer base + offset` cost one per operand read)
   unsigned pb0[BPW], pb1[BPW];                     // column offset b = 0 / 1 at row offset a = 1
 #pragma unroll
   for (int b = 0; b < BPW; ++b) {
@@ -393,78 +300,87 @@ __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
     pb1[b] = (unsigned)((r * TC_WC + c) * 64 + ((lk ^ tc_swz(c)) << 4));
   }
 
-  tc_f32x4 acc[BPW][4];
+  tc_f32x4 acc[BPW][NT][4];
 #pragma unroll
   for (int b = 0; b < BPW; ++b)
 #pragma unroll
-    for (int ph = 0; ph < 4; ++ph) acc[b][ph] = tc_f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int ph = 0; ph < 4; ++ph) acc[b][n][ph] = tc_f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // One chunk in THREE tap groups, so that at most five weight operands (20 registers) are live beside the 80 - 96
-  // accumulators: G0 = the taps on x[i][j] alone, G1 = those that also need x[i][j-1], G2 = those on the row above.
+  // One chunk in THREE tap groups, so that at most five weight operands per out-channel block (20 NT registers) are live
+  // beside the accumulators: G0 = the taps on x[i][j] alone, G1 = those that also need x[i][j-1], G2 = those on the row above.
   // Tap t = 3 ky + kx of phase ph = 2 py + px sits on the operand (a, b) = x[i-a][j-b] with ky = py + 2a, kx = px + 2b.
   // Three piece products (rw_dconv.hip): Vh Uh + Vl Uh by [Vh | Vl] x [Uh | Uh]; the Vh Ul of two taps of one phase share an
   // instruction, [Vh(P) | Vh(Q)] x [Ul(tP) | Ul(tQ)]; tap (1, 1), alone in its phase, keeps all four ([Ul | Ul]).
+#define TB_MFMA(PH, A, B) acc[b][n][PH] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, acc[b][n][PH], 0, 0, 0)
+#define TB_UH(T_) tc_expand(*reinterpret_cast<const tc_f32x2*>(wb + n * TC_WCH + (T_) * 1024))
+#define TB_UL(T_) (*reinterpret_cast<const tc_f32x2*>(wb + n * TC_WCH + (T_) * 1024 + 512))
+#define TC_PIX(OFF) (*reinterpret_cast<const tc_f16x8*>(lb + (OFF)))
+#define TC_VH(OFF) (*reinterpret_cast<const tc_f32x2*>(lb + (OFF)))
+// (the persistent kernels below: one out-channel block per workgroup)
 #define TC_MFMA(PH, A, B) acc[b][PH] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, acc[b][PH], 0, 0, 0)
 #define TC_UH(T_) tc_expand(*reinterpret_cast<const tc_f32x2*>(wb + (T_) * 1024))
 #define TC_UL(T_) (*reinterpret_cast<const tc_f32x2*>(wb + (T_) * 1024 + 512))
-#define TC_PIX(OFF) (*reinterpret_cast<const tc_f16x8*>(lb + (OFF)))
-#define TC_VH(OFF) (*reinterpret_cast<const tc_f32x2*>(lb + (OFF)))
   TP_DECL(tp = 0, tp_all = 0, tp_g0 = 0, tp_s0 = 0, tp_g1 = 0, tp_g2 = 0, tp_s1 = 0, tp_bar = 0, tp_pro = 0);
   auto chunk = [&](int c, auto last_tag) __attribute__((always_inline)) {
     constexpr bool LAST = decltype(last_tag)::value != 0;
     const int buf = c & 1;
-    const unsigned char* lb = Ls;                   // (pb0 / pb1 carry the buffer's offset: they move by +- BUFB at the end of a chunk)
-    const unsigned char* wb = Wl + buf * TC_WCH + lane * 8;
+    const unsigned char* lb = Ls;                   // (pb0 / pb1 carry the buffer's offset)
+    const unsigned char* wb = Wl + buf * WCH + lane * 8;
     TP_NOW(tp);
-    // TC_FULLAHEAD == 3, the software pipeline: what is requested during chunk c (piece 0 behind the first tap group's blocks 2, 3,
-    // piece 1 behind the second group's, the weights behind the third's) belongs to chunk c + 2 and is converted / written
-    // during chunk c + 1 (behind blocks 0, 1 of the same groups, just before the registers are requested again): every load has
-    // a whole chunk to arrive, the requests are spread (eight waves requesting a window at once stall at the issue of their loads:
-    // the MFMAs behind them wait, profiles/r06s), the conversion sits between MFMAs.  The chunk barrier waits for LDS only.
-    // (No branches around the requests: past the end they read the last chunk again, into registers nobody converts -- with
-    // them inside conditionals hipcc waits for vmcnt(0) at the first conversion of every chunk.)
-    constexpr bool st = !LAST, ld = true;
+    // The software pipeline: what is requested during chunk c (piece 0 behind the first tap group's blocks, piece 1 behind the
+    // second group's, the weights behind the third's) belongs to chunk c + 2 and is converted / written during chunk c + 1
+    // (behind the first blocks of the same groups, just before the registers are requested again): every load has a whole
+    // chunk to arrive, the requests are spread (eight waves requesting a window at once stall at the issue of their loads and
+    // the MFMAs behind them wait: profiles/r06s), the conversion sits between MFMAs.  The chunk barrier waits for LDS only.
+    // No branches around the requests: past the end they read the last chunk again, into registers nobody converts -- with
+    // them inside conditionals hipcc waits for vmcnt(0) at the first conversion of every chunk.
+    constexpr bool st = !LAST;
     const int c2 = c + 2 < NC ? c + 2 : NC - 1;
     auto hook = [&](auto grp_tag, int b) __attribute__((always_inline)) {
       constexpr int grp = decltype(grp_tag)::value;
-      if (!PIPE) return;
 #if TC_PROF
       if (b < 4) { if (grp == 0) { TP_ADD(tp_g0, tp); } else if (grp == 1) { TP_ADD(tp_g1, tp); } else { TP_ADD(tp_g2, tp); } }
 #endif
-      if constexpr (grp < 2) {
+      if constexpr (grp < SI) {
         if (b == 0 && st) stage_store_part(c + 1, buf ^ 1, tc_int<grp>(), tc_int<0>(), tc_int<2>());
         if (b == 1 && st) stage_store_part(c + 1, buf ^ 1, tc_int<grp>(), tc_int<2>(), tc_int<4>());
-        if (b == 2 && ld) stage_load_part(c2, tc_int<grp>(), tc_int<0>(), tc_int<2>());
-        if (b == 3 && ld) stage_load_part(c2, tc_int<grp>(), tc_int<2>(), tc_int<4>());
-      } else {
+        if constexpr (BPW >= 4) {
+          if (b == 2) stage_load_part(c2, tc_int<grp>(), tc_int<0>(), tc_int<2>());
+          if (b == 3) stage_load_part(c2, tc_int<grp>(), tc_int<2>(), tc_int<4>());
+        } else {
+          if (b == 2) stage_load_part(c2, tc_int<grp>(), tc_int<0>(), tc_int<4>());
+        }
+      } else if constexpr (grp == 2) {
         if (b == 0 && st) wstage_store(buf ^ 1);
-        if (b == 1 && ld) wstage_load(c2);
+        if (b == 1) wstage_load(c2);
       }
 #if TC_PROF
       if (b < 2) { TP_ADD(tp_s0, tp); } else if (b < 4) { TP_ADD(tp_s1, tp); }
 #endif
     };
-    if (!LAST && !PIPE) {
-      wstage_load(c + 1);
-      stage_load(c + 1, tc_int<0>());
-      if (FA) stage_load(c + 1, tc_int<1>());
-    }
     // (operands one block ahead, the order pinned: left to itself the scheduler hoists every block's LDS reads to the top
     // of a group and spills; only the last block of a wave can be missing: NBLK > WAVES (BPW - 1))
     constexpr int LB = BPW - 1;
     const bool last_ok = wave + WAVES * LB < NBLK;  // wave-uniform
     {
-      const tc_f16x8 u0 = TC_UH(0), u1 = TC_UH(1), u3 = TC_UH(3), u4 = TC_UH(4), l4 = tc_expand(TC_UL(4));
+      tc_f16x8 u0[NT], u1[NT], u3[NT], u4[NT], l4[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) { u0[n] = TB_UH(0); u1[n] = TB_UH(1); u3[n] = TB_UH(3); u4[n] = TB_UH(4); l4[n] = tc_expand(TB_UL(4)); }
       tc_f16x8 pc = TC_PIX(pb0[0] + TC_WC * 64);
 #pragma unroll
       for (int b = 0; b < BPW; ++b) {
         tc_f16x8 pn = pc;
         if (b + 1 < BPW) pn = TC_PIX(pb0[b + 1] + TC_WC * 64);
         if (b < LB || last_ok) {
-          if (TC_ABL & 2) { asm volatile("" :: "v"(pc), "v"(u0), "v"(u1), "v"(u3), "v"(u4), "v"(l4)); }
-          else {
-            TC_MFMA(3, pc, u4); TC_MFMA(0, pc, u0); TC_MFMA(1, pc, u1); TC_MFMA(2, pc, u3);
-            TC_MFMA(3, pc, l4);                     // (never two dependent MFMAs back to back)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            if (TC_ABL & 2) { asm volatile("" :: "v"(pc), "v"(u0[n]), "v"(u1[n]), "v"(u3[n]), "v"(u4[n]), "v"(l4[n])); }
+            else {
+              TB_MFMA(3, pc, u4[n]); TB_MFMA(0, pc, u0[n]); TB_MFMA(1, pc, u1[n]); TB_MFMA(2, pc, u3[n]);
+              TB_MFMA(3, pc, l4[n]);                // (never two dependent MFMAs back to back)
+            }
           }
         }
         hook(tc_int<0>(), b);
@@ -473,14 +389,11 @@ __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
       }
     }
     TP_ADD(tp_g0, tp);
-    if (!LAST && !FA) {                             // the first half of the next window: converted behind a group's MFMAs
-      stage_store(c + 1, buf ^ 1, tc_int<0>());
-      stage_load(c + 1, tc_int<1>());
-    }
     __builtin_amdgcn_sched_barrier(0);
-    TP_ADD(tp_s0, tp);
     {
-      const tc_f16x8 u2 = TC_UH(2), u5 = TC_UH(5), m02 = tc_pair(TC_UL(0), TC_UL(2)), m35 = tc_pair(TC_UL(3), TC_UL(5));
+      tc_f16x8 u2[NT], u5[NT], m02[NT], m35[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) { u2[n] = TB_UH(2); u5[n] = TB_UH(5); m02[n] = tc_pair(TB_UL(0), TB_UL(2)); m35[n] = tc_pair(TB_UL(3), TB_UL(5)); }
       tc_f32x2 hc = TC_VH(pb0[0] + TC_WC * 64);     // Vh of x[i][j]: the first half of its word
       tc_f16x8 qc = TC_PIX(pb1[0] + TC_WC * 64);
 #pragma unroll
@@ -489,11 +402,14 @@ __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
         tc_f16x8 qn = qc;
         if (b + 1 < BPW) { hn = TC_VH(pb0[b + 1] + TC_WC * 64); qn = TC_PIX(pb1[b + 1] + TC_WC * 64); }
         if (b < LB || last_ok) {
-          if (TC_ABL & 2) { asm volatile("" :: "v"(hc), "v"(qc), "v"(u2), "v"(u5), "v"(m02), "v"(m35)); }
-          else {
-            const tc_f16x8 M = tc_pair_hq(hc, qc);
-            TC_MFMA(0, qc, u2); TC_MFMA(2, qc, u5);                               // taps (0, 2), (1, 2)
-            TC_MFMA(0, M, m02); TC_MFMA(2, M, m35);                               // Vh Ul of (0, 0) + (0, 2); (1, 0) + (1, 2)
+          const tc_f16x8 M = tc_pair_hq(hc, qc);
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            if (TC_ABL & 2) { asm volatile("" :: "v"(hc), "v"(qc), "v"(u2[n]), "v"(u5[n]), "v"(m02[n]), "v"(m35[n])); }
+            else {
+              TB_MFMA(0, qc, u2[n]); TB_MFMA(2, qc, u5[n]);                       // taps (0, 2), (1, 2)
+              TB_MFMA(0, M, m02[n]); TB_MFMA(2, M, m35[n]);                       // Vh Ul of (0, 0) + (0, 2); (1, 0) + (1, 2)
+            }
           }
         }
         hook(tc_int<1>(), b);
@@ -502,14 +418,13 @@ __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
       }
     }
     TP_ADD(tp_g1, tp);
-    if (!LAST && FA && TC_FULLAHEAD == 1) {         // (both pieces in flight since the top: the first one behind two groups; 2: behind all three)
-      stage_store(c + 1, buf ^ 1, tc_int<0>());
-      __builtin_amdgcn_sched_barrier(0);
-      TP_ADD(tp_s0, tp);
-    }
     {
-      const tc_f16x8 u6 = TC_UH(6), u7 = TC_UH(7), u8 = TC_UH(8), m17 = tc_pair(TC_UL(1), TC_UL(7)),
-                     m68 = tc_pair(TC_UL(6), TC_UL(8));
+      tc_f16x8 u6[NT], u7[NT], u8[NT], m17[NT], m68[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        u6[n] = TB_UH(6); u7[n] = TB_UH(7); u8[n] = TB_UH(8);
+        m17[n] = tc_pair(TB_UL(1), TB_UL(7)); m68[n] = tc_pair(TB_UL(6), TB_UL(8));
+      }
       tc_f32x2 hc = TC_VH(pb0[0] + TC_WC * 64);
       tc_f16x8 qc = TC_PIX(pb0[0]), rc = TC_PIX(pb1[0]);
 #pragma unroll
@@ -518,12 +433,15 @@ __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
         tc_f16x8 qn = qc, rn = rc;
         if (b + 1 < BPW) { hn = TC_VH(pb0[b + 1] + TC_WC * 64); qn = TC_PIX(pb0[b + 1]); rn = TC_PIX(pb1[b + 1]); }
         if (b < LB || last_ok) {
-          if (TC_ABL & 2) { asm volatile("" :: "v"(hc), "v"(qc), "v"(rc), "v"(u6), "v"(u7), "v"(u8), "v"(m17), "v"(m68)); }
-          else {
-            const tc_f16x8 M02 = tc_pair_hq(hc, qc), M23 = tc_pair(qc, rc);
-            TC_MFMA(0, qc, u6); TC_MFMA(1, qc, u7);                               // taps (2, 0), (2, 1)
-            TC_MFMA(0, rc, u8); TC_MFMA(1, M02, m17);                             // tap (2, 2); Vh Ul of (0, 1) + (2, 1)
-            TC_MFMA(0, M23, m68);                                                 // Vh Ul of (2, 0) + (2, 2)
+          const tc_f16x8 M02 = tc_pair_hq(hc, qc), M23 = tc_pair(qc, rc);
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            if (TC_ABL & 2) { asm volatile("" :: "v"(hc), "v"(qc), "v"(rc), "v"(u6[n]), "v"(u7[n]), "v"(u8[n]), "v"(m17[n]), "v"(m68[n])); }
+            else {
+              TB_MFMA(0, qc, u6[n]); TB_MFMA(1, qc, u7[n]);                       // taps (2, 0), (2, 1)
+              TB_MFMA(0, rc, u8[n]); TB_MFMA(1, M02, m17[n]);                     // tap (2, 2); Vh Ul of (0, 1) + (2, 1)
+              TB_MFMA(0, M23, m68[n]);                                            // Vh Ul of (2, 0) + (2, 2)
+            }
           }
         }
         hook(tc_int<2>(), b);
@@ -536,39 +454,33 @@ __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
       const unsigned delta = buf ? (unsigned)-BUFB : (unsigned)BUFB;
 #pragma unroll
       for (int b = 0; b < BPW; ++b) { pb0[b] += delta; pb1[b] += delta; }
-    }
-    if (!LAST && PIPE) {
       asm volatile("" ::: "memory");
       __builtin_amdgcn_s_waitcnt(0xC07F);           // lgkmcnt(0): the requests of chunk c + 2 stay in flight across the barrier
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       TP_ADD(tp_bar, tp);
-    } else if (!LAST) {
-      if (FA && TC_FULLAHEAD == 2) stage_store(c + 1, buf ^ 1, tc_int<0>());
-      stage_store(c + 1, buf ^ 1, tc_int<1>());
-      wstage_store(buf ^ 1);
-      TP_ADD(tp_s1, tp);
-      __syncthreads();
-      TP_ADD(tp_bar, tp);
     }
   };
 
-  // ---- prologue
+  // ---- prologue: chunk 0 requested, converted, written; chunk 1 (in_ch == 16: chunk 0 again, never converted) requested, in
+  // the order of a chunk's requests, pinned -- the waits of the loop count the requests behind the one they need
   TP_NOW(tp_all);
   wstage_load(0);
-  stage_load(0, tc_int<0>());
-  stage_store(0, 0, tc_int<0>());
-  stage_load(0, tc_int<1>());
-  stage_store(0, 0, tc_int<1>());
+#pragma unroll
+  for (int s = 0; s < SI; ++s) {
+    if (s == 0) stage_load_part(0, tc_int<0>(), tc_int<0>(), tc_int<4>());
+    else stage_load_part(0, tc_int<SI - 1>(), tc_int<0>(), tc_int<4>());
+  }
+  stage_store_part(0, 0, tc_int<0>(), tc_int<0>(), tc_int<4>());
+  if constexpr (SI > 1) stage_store_part(0, 0, tc_int<SI - 1>(), tc_int<0>(), tc_int<4>());
   wstage_store(0);
   __syncthreads();
-  if (PIPE) {                                       // chunk 1 (in_ch == 16: chunk 0 again, never converted): in flight through chunk 0
+  {
     const int c1 = NC > 1 ? 1 : 0;
-    // (in the order of a chunk's requests, pinned: the waits of the loop count the requests behind the one they need)
     __builtin_amdgcn_sched_barrier(0);
     stage_load_part(c1, tc_int<0>(), tc_int<0>(), tc_int<4>());
     __builtin_amdgcn_sched_barrier(0);
-    stage_load_part(c1, tc_int<1>(), tc_int<0>(), tc_int<4>());
+    if constexpr (SI > 1) stage_load_part(c1, tc_int<SI - 1>(), tc_int<0>(), tc_int<4>());
     __builtin_amdgcn_sched_barrier(0);
     wstage_load(c1);
     __builtin_amdgcn_sched_barrier(0);
@@ -582,7 +494,7 @@ __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
 #if TC_PROF
   const unsigned long long tp_loop_end = (unsigned long long)clock64();
 #endif
-  if (TC_ABL & 8) { if (acc[0][0][0] != 12345.f) return; }
+  if (TC_ABL & 8) { if (acc[0][0][0][0] != 12345.f) return; }
   __syncthreads();                                  // every wave has read its last operands: the windows become the z tile
 
   // ---- epilogue, eight channels at a time
@@ -603,7 +515,7 @@ __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
   const int W2 = 2 * p.w;
   const int64_t hw2 = 4 * hw;
   // strip of this thread (separable FIR): four output columns, SR output rows, one channel per pass.  Its SR noise
-  // vectors are the same in both passes: requested here, ahead of the z writes and their barrier (one L2 round trip
+  // vectors are the same in every pass: requested here, ahead of the z writes and their barrier (one L2 round trip
   // instead of one per output row)
   const int strip = tid & 127, seg = tid >> 7;
   const int s_og = strip & 15, s_ch = strip >> 4, s_oy0 = SR * seg;
@@ -615,6 +527,8 @@ __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
     if (sep && p.noise && !(TC_ABL & 32))
       nzr[oy] = *reinterpret_cast<const tc_f32x4*>(p.noise + (int64_t)ib * hw2 + s_pix + (int64_t)oy * W2);
   }
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
 #pragma unroll 1
   for (int pass = 0; pass < 2; ++pass) {
     if ((lt >> 3) == pass) {
@@ -628,10 +542,10 @@ __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
           if (q < NPOS) {
             const int r = q / TC_PC, c = q - r * TC_PC;
             float* zp = zc + (2 * r) * TC_ZP + 2 * c + 3;
-            zp[0] = acc[b][0][j];
-            zp[1] = acc[b][1][j];
-            zp[TC_ZP] = acc[b][2][j];
-            zp[TC_ZP + 1] = acc[b][3][j];
+            zp[0] = acc[b][n][0][j];
+            zp[1] = acc[b][n][1][j];
+            zp[TC_ZP] = acc[b][n][2][j];
+            zp[TC_ZP + 1] = acc[b][n][3][j];
           }
         }
       }
@@ -640,9 +554,9 @@ __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
     if (sep) {
       // strip of four output columns, SR output rows: z rows oy0 + 1 .. oy0 + SR + 3, each read once
       const float* zb = Z + s_ch * CHS + (s_oy0 + 1) * TC_ZP + 4 * s_og + 4;
-      const int cl = 8 * pass + s_ch;               // channel within the workgroup's 16
+      const int cl = 16 * n + 8 * pass + s_ch;      // channel within the workgroup's OC
       const float sc = Sc[cl], bs = Bs[cl], post = Po[cl];
-      float* yb = p.y + ((int64_t)ib * p.out_ch + 16 * ot + cl) * hw2 + s_pix;
+      float* yb = p.y + ((int64_t)ib * p.out_ch + OC * ot + cl) * hw2 + s_pix;
       tc_f32x4 hrow[4];                             // the last four horizontally filtered rows
       tc_f32x4 lo = *reinterpret_cast<const tc_f32x4*>(zb), hi = *reinterpret_cast<const tc_f32x4*>(zb + 4);
 #pragma unroll
@@ -697,7 +611,7 @@ __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) res[q] += rowv[q + cc] * kf[a * 4 + cc];
         }
-        const int cl = 8 * pass + ch;
+        const int cl = 16 * n + 8 * pass + ch;
         const int64_t pix = (int64_t)(2 * I0 + oy) * W2 + 2 * J0 + 4 * og;
         tc_f32x4 nz = {0.f, 0.f, 0.f, 0.f};
         if (p.noise) nz = *reinterpret_cast<const tc_f32x4*>(p.noise + (int64_t)ib * hw2 + pix) * noise_wg;
@@ -709,10 +623,11 @@ __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
           v[q] = fmaxf(u, u * slope) * post;
           ymax = fmaxf(ymax, fabsf(v[q]));
         }
-        *reinterpret_cast<tc_f32x4*>(p.y + ((int64_t)ib * p.out_ch + 16 * ot + cl) * hw2 + pix) = v;
+        *reinterpret_cast<tc_f32x4*>(p.y + ((int64_t)ib * p.out_ch + OC * ot + cl) * hw2 + pix) = v;
       }
     }
     __syncthreads();
+  }
   }
 #if TC_PROF
   if (lane == 0 && (wave == 0 || wave == 7) && (blockIdx.x == gridDim.x / 2 || blockIdx.x == gridDim.x / 2 + 777)) {
@@ -725,8 +640,10 @@ __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
   if (p.y_amax) rw_bound_store_wave(p.y_amax, rw_wave_max(ymax));
 }
 
-__global__ void __launch_bounds__(256, 2) tconv_blur_t8_kernel(const TconvProblem p) { tconv_body<8, 4>(p); }
-__global__ void __launch_bounds__(512, 1) tconv_blur_t16_kernel(const TconvProblem p) { tconv_body<16, 8>(p); }
+__global__ void __launch_bounds__(256, 2) tconv_blur_t8_kernel(const TconvProblem p) { tconv_body<8, 4, 1>(p); }
+__global__ void __launch_bounds__(512, 1) tconv_blur_t16_kernel(const TconvProblem p) { tconv_body<16, 8, 1>(p); }
+// 32 out-channels per workgroup (round 6): an 8 x 32 tile, eight waves of three position blocks x two out-channel blocks
+__global__ void __launch_bounds__(512, 1) tconv_blur_n32_kernel(const TconvProblem p) { tconv_body<8, 8, 2>(p); }
 // (four waves per SIMD -- <8, 8> twice per CU, <16, 16> once -- do not fit: 128 registers against 48 accumulators + ~125
 // for the operands and the epilogue, 120 - 150 spilled)
 
@@ -1845,7 +1762,12 @@ extern "C" int rw_tconv_blur_f32(const float* x, const float* wp, const float* k
   const char* e = getenv("RW_TCONV_TY");
   // (RW_TCONV_PERSISTENT = 0 / 2: which of the two persistent kernels the automatic choice means)
   const char* pe = getenv("RW_TCONV_PERSISTENT");
-  const int sel = e ? atoi(e) : (in_ch >= 32 && in_ch <= 128 ? (pe && atoi(pe) == 2 ? 2 : 0) : 16);
+  // (RW_TCONV_N32 = "lo:hi": the input-channel range the automatic choice gives to the 32-out-channel form)
+  int n32_lo = 128, n32_hi = 128;
+  if (const char* ne = getenv("RW_TCONV_N32")) { if (sscanf(ne, "%d:%d", &n32_lo, &n32_hi) != 2) { n32_lo = 1; n32_hi = 0; } }
+  const int sel = e ? atoi(e)
+                    : (out_ch % 32 == 0 && in_ch >= n32_lo && in_ch <= n32_hi ? 32
+                       : (in_ch >= 32 && in_ch <= 128 ? (pe && atoi(pe) == 2 ? 2 : 0) : 16));
   if ((sel == 0 || sel == 2) && in_ch >= 32) {      // 0: the specialised persistent kernel (one workgroup of eight waves per CU); 2: its pipelined form
     p.tiles_x = w / TC_TX; p.tiles_y = h / 8; p.o_tiles = out_ch / 16;
     const int64_t tiles = (int64_t)batch * p.tiles_y * p.tiles_x * p.o_tiles;
@@ -1860,13 +1782,15 @@ extern "C" int rw_tconv_blur_f32(const float* x, const float* wp, const float* k
     if (rc || !y_amax) return rc;
     return rw_bound_finish(y_amax, 8 * grid, rw_s(stream));
   }
+  const bool n32 = sel == 32 && out_ch % 32 == 0;   // 32 out-channels per workgroup (8 x 32 tile, eight waves)
   const int ty = sel == 16 ? 16 : 8;
-  const int waves = ty == 16 ? 8 : 4;
-  p.tiles_x = w / TC_TX; p.tiles_y = h / ty; p.o_tiles = out_ch / 16;
+  const int waves = ty == 16 || n32 ? 8 : 4;
+  p.tiles_x = w / TC_TX; p.tiles_y = h / ty; p.o_tiles = out_ch / (n32 ? 32 : 16);
   const int64_t work = (int64_t)batch * p.tiles_y * p.tiles_x * p.o_tiles;
   if (work <= 0 || work > 0x7fffffff) return RW_ERR_UNSUPPORTED;
   if (y_amax && waves * work > rw_bound_slot_capacity((int64_t)batch * out_ch * 4 * h * w)) return RW_ERR_UNSUPPORTED;
-  if (ty == 16) hipLaunchKernelGGL(tconv_blur_t16_kernel, dim3((unsigned)work), dim3(512), 0, rw_s(stream), p);
+  if (n32) hipLaunchKernelGGL(tconv_blur_n32_kernel, dim3((unsigned)work), dim3(512), 0, rw_s(stream), p);
+  else if (ty == 16) hipLaunchKernelGGL(tconv_blur_t16_kernel, dim3((unsigned)work), dim3(512), 0, rw_s(stream), p);
   else hipLaunchKernelGGL(tconv_blur_t8_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
   const int rc = RW_LAUNCH_RESULT();
   if (rc || !y_amax) return rc;

@@ -1065,7 +1065,7 @@ TCONV_CASES = [(1, 16, 16, 16, 32), (2, 64, 32, 16, 64), (1, 32, 16, 32, 32), (1
 
 
 TCONV_FORMS = {'two-workgroups-per-cu': '8', 'one-workgroup-per-cu': '16', 'specialised-persistent': '0',
-               'pipelined-persistent': '2', 'automatic': None}
+               'pipelined-persistent': '2', 'thirty-two-out-channels': '32', 'automatic': None}
 
 
 @pytest.mark.parametrize('form', sorted(TCONV_FORMS))
