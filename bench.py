@@ -90,6 +90,24 @@ def conv_kernel_name(out_ch, in_ch, width, upsample):
     return 'conv_mfma(+ksplit)_kernel'
 
 
+def tconv_auto_form(in_ch, out_ch):
+    """The form rw_tconv_blur_f32 picks when RW_TCONV_TY is unset (csrc/rw_tconv.hip, the launcher): the 32-out-channel
+    kernel for the input-channel range RW_TCONV_N32 = "lo:hi" (default 128:128), a persistent kernel for 32 .. 128 input
+    channels otherwise, one eight-wave workgroup per CU above."""
+    lo, hi = 128, 128
+    spec = os.environ.get('RW_TCONV_N32')
+    if spec:
+        try:
+            lo, hi = (int(v) for v in spec.split(':'))
+        except ValueError:
+            lo, hi = 1, 0
+    if out_ch % 32 == 0 and lo <= in_ch <= hi:
+        return '32'
+    if 32 <= in_ch <= 128:
+        return '2' if os.environ.get('RW_TCONV_PERSISTENT') == '2' else '0'
+    return '16'
+
+
 class ConvTimer:
     """HIP events around every implicit-GEMM conv call, on the stream the kernels are launched on
     (torch's current stream), attributed to the kernel the call dispatches to.  Installed for
@@ -105,6 +123,7 @@ class ConvTimer:
                       hip.conv_transpose3x3s2_blur_wino4, hip.conv3x3_wino4_to_rgb,
                       hip.conv3x3_direct16, hip.conv_transpose3x3s2_blur_direct16, hip.conv3x3_direct16_to_rgb)
         self._orig_fused = hip.conv_transpose3x3s2_blur_fused
+        self._orig_rgbp = hip.conv3x3_direct16_rgb_partial
         timer = self
 
         def fused(x, wp, k4, out_ch, w_scale, *a, **k):
@@ -114,9 +133,10 @@ class ConvTimer:
             y = timer._orig_fused(x, wp, k4, out_ch, w_scale, *a, **k)
             e.record()
             b, i, h, w = x.shape
-            form = os.environ.get('RW_TCONV_TY') or ('0' if 32 <= i <= 128 else '16')
-            name = {'0': 'tconv_blur_ws_kernel' if i >= 32 else 'tconv_blur_t8_kernel',
-                    '16': 'tconv_blur_t16_kernel'}.get(form, 'tconv_blur_t8_kernel')
+            form = os.environ.get('RW_TCONV_TY') or tconv_auto_form(i, out_ch)
+            name = {'0': 'tconv_blur_ws_kernel' if i >= 32 else 'tconv_blur_t8_kernel', '2': 'tconv_blur_pp_kernel',
+                    '16': 'tconv_blur_t16_kernel',
+                    '32': 'tconv_blur_n32_kernel' if out_ch % 32 == 0 else 'tconv_blur_t8_kernel'}.get(form, 'tconv_blur_t8_kernel')
             timer.calls.append((name, s, e, 2.0 * 9 * i * out_ch * h * w * b, 4.0 * (b * i * h * w + b * out_ch * 4 * h * w)))
             return y
         hip.conv_transpose3x3s2_blur_fused = fused
@@ -131,7 +151,9 @@ class ConvTimer:
                 e.record()
                 b, i, h, w = x.shape
                 lib = hip.lib()
-                if wino in ('d16', 'd16up', 'd16rgb'):
+                if wino == 'd16p':            # the direct sum that also leaves the ToRGB's channel sums (one-role kernels only)
+                    name = 'dconv_w%d_rgbp_kernel' % (4 if out_ch % 128 == 0 else 2 if out_ch % 64 == 0 else 1)
+                elif wino in ('d16', 'd16up', 'd16rgb'):
                     # rw_dconv.hip: the specialised kernels take a style on load, >= 32 channels, maps 64 columns wide
                     ws = k.get('style') is not None and i >= 32 and w % 64 == 0 and os.environ.get('RW_DCONV_V') != '1'
                     if wino == 'd16up':
@@ -181,6 +203,8 @@ class ConvTimer:
                     out_elems = b * 3 * h * w * 2                  # running image read and written; no feature map
                 elif upsample:
                     out_elems = b * out_ch * (2 * h + 1) * (2 * w + 1)
+                elif wino == 'd16p':
+                    out_elems = b * out_ch * h * w + (out_ch // 32) * b * 3 * h * w      # + the partial images
                 else:
                     out_elems = b * out_ch * h * w
                 timer.calls.append((name, s, e, 2.0 * 9 * i * out_ch * h * w * b, 4.0 * (b * i * h * w + out_elems)))
@@ -199,6 +223,7 @@ class ConvTimer:
         hip.conv3x3_direct16 = wrap(self._orig[10], False, wino='d16')
         hip.conv_transpose3x3s2_blur_direct16 = wrap(self._orig[11], True, wino='d16up')
         hip.conv3x3_direct16_to_rgb = wrap(self._orig[12], False, wino='d16rgb')
+        hip.conv3x3_direct16_rgb_partial = wrap(self._orig_rgbp, False, wino='d16p')
 
     def remove(self):
         from rewriting_amd import hip
@@ -207,6 +232,7 @@ class ConvTimer:
          hip.conv_transpose3x3s2_blur_wino4, hip.conv3x3_wino4_to_rgb, hip.conv3x3_direct16,
          hip.conv_transpose3x3s2_blur_direct16, hip.conv3x3_direct16_to_rgb) = self._orig
         hip.conv_transpose3x3s2_blur_fused = self._orig_fused
+        hip.conv3x3_direct16_rgb_partial = self._orig_rgbp
 
     def result(self):
         per = {}
@@ -292,7 +318,7 @@ def issued_fraction(kernel):
     if kernel.startswith('dconv'):
         return (4.0 * 5 / 6, 'direct sum, 3.33 f16 piece products issued per multiply') + f16d
     if kernel.startswith('tconv_blur'):
-        halo = 18.0 * 34 / (16 * 32) if 't16' in kernel else 10.0 * 34 / (8 * 32)     # positions computed / positions kept
+        halo = 18.0 * 34 / (16 * 32) if 't16' in kernel else 10.0 * 34 / (8 * 32)     # positions computed / positions kept (t16 | 8-row tiles)
         return (14.0 / 18.0 * 4 * halo, 'transposed conv as a direct sum at its own multiply count (14 MFMAs per block and '
                 'chunk where four piece products take 18; x %.2f halo positions), its (2H+1)^2 map in LDS, blur from there'
                 % halo) + f16d

@@ -73,7 +73,7 @@ class DemodConv(Function):
 
     @staticmethod
     def forward(ctx, fmap, weight, style, module):
-        y = module.run(fmap, style, style_on_load=False)
+        y = module.run(fmap, style, style_on_load=False, weight_changes=bool(weight.requires_grad))
         ctx.module = module
         ctx.save_for_backward(fmap, weight, style, y)
         return y

@@ -199,7 +199,10 @@ def conv_algo():
         tolerance is 1e-3) -- and F(2x2,3x3) elsewhere;
       * every other way -- a hooked model, a nethook.subsequence slice (key statistics, goal maps, the solve's
         context and its rendering), RW_FUSE=0: 'winograd' = F(2x2,3x3) (hip.conv3x3_wino: 2.25x fewer matrix FLOPs,
-        the fp32 error class of the direct sum).
+        the fp32 error class of the direct sum) -- which since round 5 is what runs BELOW 32^2 only: from 32^2 up these
+        models' stride-1 layers are direct sums on the 16-bit pipe (DemodulatedConv2dF.hooked_direct16: exact f16
+        operand pairs, 4e-7 from the fp32 direct sum; not a layer whose weight is being optimised) and their upsampling layers
+        the fused split kernel (fused_upsample); the statistics goldens hold at 4e-6 - 5e-6 from the reference's.
     Consequence: model(z) and the same weights run through rewriter.sample_image_from_latent differ by 1e-5 .. 1e-4
     on the image.  RW_CONV_ALGO=direct|winograd|winograd4 forces one algorithm everywhere; shapes an algorithm
     does not take always run the next one down ('direct' = the implicit GEMM takes everything)."""
@@ -573,7 +576,12 @@ class DemodulatedConv2dF(nn.Module):
         32^2 up as DIRECT sums on the 16-bit matrix pipe (exact f16 operand pairs, fp32 accumulation: 4e-7 from the fp32
         direct sum, the error class these models are held to) in place of the fp32 F(2x2,3x3) kernel -- where their F(2,2)
         transposed convolutions run in the split form too (matrix_mode('up')).  The kernel measures its input itself: nobody
-        hands a bound over outside the un-hooked forward.  RW_DIRECT16_HOOKED=0: off."""
+        hands a bound over outside the un-hooked forward.  RW_DIRECT16_HOOKED=0: off.  Not where the weight itself is being
+        optimised (run(weight_changes=True), from grad.DemodConv: an autograd `insert` changes it every step, and each
+        re-packing reads the weights' maximum back to the host -- hip._split_scale -- two launches and a sync per layer and
+        iteration that the fp32 kernel does not have) and not while the stream is being captured (the read-back would fail)."""
+        if self.weight.is_cuda and torch.cuda.is_current_stream_capturing():
+            return False
         return (not self.upsample and not _rgb_branch.image_path and os.environ.get('RW_DIRECT16_HOOKED', '1') == '1'
                 and os.environ.get('RW_CONV_ALGO') is None and matrix_mode('up') == 'split' and conv_impl() == 0
                 and conv_precision() == 'f32' and _direct16(self, h, w, 'conv'))
@@ -593,11 +601,12 @@ class DemodulatedConv2dF(nn.Module):
                 and self.out_channel % 32 == 0
                 and hip.wino4_supported(self.out_channel, self.in_channel, h, w) and _direct16(self, h, w, 'conv'))
 
-    def run(self, fmap, style, style_on_load, demod=None, x_amax=None, y_amax=None, rgb=None, **epilogue):
+    def run(self, fmap, style, style_on_load, demod=None, x_amax=None, y_amax=None, rgb=None, weight_changes=False,
+            **epilogue):
         """x_amax: the bound of |fmap| if the producer of fmap left one (hip.new_bound; split-operand kernels -- they
         measure the map themselves otherwise); y_amax: a hip.new_bound buffer that receives the bound of the result
         where the split-operand F(4x4,3x3) kernel runs (`runs_split_wino4` says whether it will); rgb: only where
-        `leaves_rgb_partials` says so."""
+        `leaves_rgb_partials` says so; weight_changes: the caller differentiates with respect to the weight (see hooked_direct16)."""
         if rgb is not None and not self.leaves_rgb_partials(fmap.shape[-2], fmap.shape[-1]):
             raise RuntimeError('run(rgb=...) on a layer that does not leave ToRGB partial sums')
         if demod is None:
@@ -666,7 +675,7 @@ class DemodulatedConv2dF(nn.Module):
                                          demod=demod, x_amax=x_amax, y_amax=y_amax, **epilogue)
             return hip.conv3x3_wino4(fmap, self.wino4_weight(), self.out_channel, self.scale, style=load_style,
                                      demod=demod, **epilogue)
-        if self.hooked_direct16(fmap.shape[-2], fmap.shape[-1]):
+        if not weight_changes and self.hooked_direct16(fmap.shape[-2], fmap.shape[-1]):
             return hip.conv3x3_direct16(fmap, self.direct16_weight(), self.out_channel, self.scale, style=load_style,
                                         demod=demod, x_amax=x_amax, **epilogue)
         if (conv_algo() in ('winograd', 'winograd4') and conv_impl() == 0 and conv_precision() == 'f32'

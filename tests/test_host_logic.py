@@ -516,3 +516,42 @@ def test_running_quantile_keeps_streaming_after_a_save_and_after_a_cache_load():
     assert abs(sum(lv.shape[1] * 2 ** l for l, lv in enumerate(again._levels)) - 6000) == 0
     loaded.compress_()
     assert torch.equal(loaded.quantiles(qs), again.quantiles(qs))
+
+
+def test_hooked_models_leave_a_layer_whose_weight_requires_grad_on_the_fp32_kernel(emulated_hip, monkeypatch):
+    """A hooked / sliced model runs its stride-1 layers of maps from 32^2 up as direct sums on the 16-bit pipe
+    (DemodulatedConv2dF.hooked_direct16; tests/test_emulated_path.py holds which layers and the statistics bar) -- but not
+    a layer whose weight requires grad (an autograd `insert`): every re-packing of a changing weight would read its maximum
+    back to the host, two launches and a sync per layer and optimiser step."""
+    import torch
+    from rewriting_amd import hip
+    from rewriting_amd.utils import nethook
+    from tests.conftest import build_stylegan
+    model = build_stylegan(64, 0.5, device='cpu')
+    z = torch.randn(2, 512)
+    seen = []
+    orig = hip.conv3x3_direct16
+
+    def spy(x, wp, out_ch, *a, **k):
+        seen.append((x.shape[1], out_ch, x.shape[-1]))
+        return orig(x, wp, out_ch, *a, **k)
+    monkeypatch.setattr(hip, 'conv3x3_direct16', spy)
+
+    def hooked_run():
+        del seen[:]
+        with nethook.InstrumentedModel(model) as inst:
+            inst.retain_layer('layer7', detach=False)
+            return inst(z)
+    with torch.no_grad():
+        want = hooked_run()
+    assert sorted(w for _, _, w in seen) == [32, 64], seen         # layers 8 and 10 of the 64^2 generator
+    layer = [m for n, m in model.named_modules() if n.startswith('layer10') and hasattr(m, 'hooked_direct16')][0]
+    nethook.set_requires_grad(False, model)
+    assert layer.hooked_direct16(64, 64)
+    layer.weight.requires_grad_(True)
+    try:
+        got = hooked_run()
+        assert sorted(w for _, _, w in seen) == [32], seen          # layer 8 only: layer 10's weight is being optimised
+        assert (got.detach() - want).abs().max().item() < 1e-4     # the fp32 kernel's result: the image barely moves
+    finally:
+        layer.weight.requires_grad_(False)
