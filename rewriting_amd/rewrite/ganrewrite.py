@@ -447,79 +447,82 @@ class ProgressiveGanRewriter(object):
         return renormalize.from_url(mask, target='pt')[0].sum() == 0.0
 
     # ---- goals ----------------------------------------------------------------------------
+    # Host-side glue around three renderings (rewrite/ganrewrite.py:442-520 of the reference: same names, same return
+    # tuples).  Nothing here is differentiated -- `insert` detaches key and value (:265) -- so every rendering runs under
+    # no_grad and the sub-models keep their fused kernels (under grad mode a styled convolution runs module by module,
+    # utils/stylegan2/grad.py).
+    def _mask_on(self, mask, shape):
+        """The mask (a data URL from the UI) as a 0/1 map at a layer's resolution."""
+        return renormalize.from_url(mask, target='pt', size=shape[2:])[0]
+
+    def _render_to_target(self, imgnum):
+        """(bag in front of the edited layer, bag behind it) of image `imgnum`, unedited."""
+        with torch.no_grad():
+            before = self.context_model(self.get_z(imgnum))
+            return before, self.target_model(before)
+
+    def _goal_pair(self, before, keys, key_box, behind, values, value_box):
+        """(goal_in, goal_out): the two bags with their key / value maps swapped in, cropped to the boxes (None: whole map)."""
+        return (self.merge_target_output(before, keys, key_box), self.merge_target_output(behind, values, value_box))
+
     def object_from_selection(self, imgnum, mask):
         """The value patch to copy: activations of the target layer under the mask's bounding box."""
-        area = renormalize.from_url(mask, target='pt', size=self.v_shape[2:])[0]
-        with torch.no_grad():
-            v_output = self.target_model(self.context_model(self.get_z(imgnum)))
-            v_acts = self.target_acts(v_output)
-        t, l, b, r = positive_bounding_box(area)
-        return v_acts[:, :, t:b, l:r], v_output, area[t:b, l:r], (t, l, b, r)
+        where = self._mask_on(mask, self.v_shape)
+        _, behind = self._render_to_target(imgnum)
+        top, left, bottom, right = box = positive_bounding_box(where)
+        patch = self.target_acts(behind)[:, :, top:bottom, left:right]
+        return patch, behind, where[top:bottom, left:right], box
 
     def paste_from_selection(self, imgnum, mask, obj_acts, obj_area):
-        area = renormalize.from_url(mask, target='pt', size=self.v_shape[2:])[0]
-        # goal construction is not differentiated (insert detaches key and value, :265): no graph, and the sub-models
-        # keep their fused kernels (under grad mode a styled convolution runs module by module, utils/stylegan2/grad.py)
-        with torch.no_grad():
-            source_outputs = self.context_model(self.get_z(imgnum))
-            source_acts = self.context_acts(source_outputs)
-            unchanged_outputs = self.target_model(source_outputs)
-            unchanged_acts = self.target_acts(unchanged_outputs)
-        target_acts, bounds = paste_clip_at_center(
-            unchanged_acts, obj_acts, centered_location(area), obj_area if self.alpha_area else None)
-        full_target_acts = target_acts
-        source_bounds = target_bounds = None
+        before, behind = self._render_to_target(imgnum)
+        keys = self.context_acts(before)
+        pasted, bounds = paste_clip_at_center(self.target_acts(behind), obj_acts,
+                                              centered_location(self._mask_on(mask, self.v_shape)),
+                                              obj_area if self.alpha_area else None)
+        viz_out = self.merge_target_output(behind, pasted, None)        # the whole pasted map, for the UI
+        key_box = value_box = None
+        values = pasted
         if self.tight_paste:
-            source_acts, target_acts, source_bounds, target_bounds = crop_clip_to_bounds(
-                source_acts, target_acts, bounds)
-        goal_in = self.merge_target_output(source_outputs, source_acts, source_bounds)
-        goal_out = self.merge_target_output(unchanged_outputs, target_acts, target_bounds)
-        viz_out = self.merge_target_output(unchanged_outputs, full_target_acts, None)
+            keys, values, key_box, value_box = crop_clip_to_bounds(keys, pasted, bounds)
+        goal_in, goal_out = self._goal_pair(before, keys, key_box, behind, values, value_box)
         return goal_in, goal_out, viz_out, bounds
 
     def normdissect_units(self, imgnum_mask_pairs, rank):
         """Units whose squared activation, relative to its sweep mean, is largest under the masks."""
         with torch.no_grad():
-            observed = self._key_observations(imgnum_mask_pairs)
-            obs = torch.cat([o for o, _, _ in observed])
-            wts = torch.cat([w for _, _, w in observed])
-            scale = self.square_scales_for_units().to(obs.device)
-            score = ((obs.pow(2) / scale[None, :]) * wts).sum(0) / wts.sum()
+            seen = self._key_observations(imgnum_mask_pairs)
+            acts = torch.cat([o for o, _, _ in seen])
+            weight = torch.cat([w for _, _, w in seen])
+            per_unit = self.square_scales_for_units().to(acts.device)
+            score = ((acts.pow(2) / per_unit[None, :]) * weight).sum(0) / weight.sum()
             return score.sort(descending=True)[1][:rank]
 
     def erase_from_selection(self, imgnum, mask, context_mask_pairs, rank):
-        k_area = renormalize.from_url(mask, target='pt', size=self.k_shape[2:])[0]
-        area = renormalize.from_url(mask, target='pt', size=self.v_shape[2:])[0]
-        with torch.no_grad():               # see paste_from_selection
-            source_outputs = self.context_model(self.get_z(imgnum))
-            source_acts = self.context_acts(source_outputs)
-            unchanged_outputs = self.target_model(source_outputs)
-            without = source_acts.clone()
-            without[:, self.normdissect_units(context_mask_pairs, rank)] = 0.0
-            erased_out = self.target_model(self.merge_target_output(source_outputs, without, None))
-            target_acts = self.target_acts(erased_out)
-        source_bounds = target_bounds = None
+        before, behind = self._render_to_target(imgnum)
+        keys = self.context_acts(before)
+        with torch.no_grad():
+            silenced = keys.clone()
+            silenced[:, self.normdissect_units(context_mask_pairs, rank)] = 0.0
+            values = self.target_acts(self.target_model(self.merge_target_output(before, silenced, None)))
+        key_box = value_box = None
         if self.tight_paste:
-            source_bounds = positive_bounding_box(k_area)
-            target_bounds = positive_bounding_box(area)
-        goal_in = self.merge_target_output(source_outputs, source_acts, source_bounds)
-        goal_out = self.merge_target_output(unchanged_outputs, target_acts, target_bounds)
-        return goal_in, goal_out
+            key_box = positive_bounding_box(self._mask_on(mask, self.k_shape))
+            value_box = positive_bounding_box(self._mask_on(mask, self.v_shape))
+        return self._goal_pair(before, keys, key_box, behind, values, value_box)
 
     def rgb_from_selection(self, imgnum, mask):
-        area = renormalize.from_url(mask, target='pt', size=self.x_shape[2:])[0]
+        where = self._mask_on(mask, self.x_shape)
         with torch.no_grad():
-            x_output = self.model(self.get_z(imgnum))
-        t, l, b, r = positive_bounding_box(area)
-        return x_output[:, :, t:b, l:r], x_output, area[t:b, l:r], (t, l, b, r)
+            image = self.model(self.get_z(imgnum))
+        top, left, bottom, right = box = positive_bounding_box(where)
+        return image[:, :, top:bottom, left:right], image, where[top:bottom, left:right], box
 
     def rgbpaste_from_selection(self, imgnum, mask, obj_rgb, obj_area):
+        z = self.get_z(imgnum)
         with torch.no_grad():
-            area = renormalize.from_url(mask, target='pt', size=self.x_shape[2:])[0]
-            source_z = self.get_z(imgnum)
-            changed, bounds = paste_clip_at_center(
-                self.model(source_z), obj_rgb, centered_location(area), obj_area)
-        return source_z, changed, bounds
+            changed, bounds = paste_clip_at_center(self.model(z), obj_rgb,
+                                                   centered_location(self._mask_on(mask, self.x_shape)), obj_area)
+        return z, changed, bounds
 
     # ---- UI conveniences ------------------------------------------------------------------
     def _flat_units(self, zbatch):
