@@ -1,3 +1,9 @@
+// hipcc-keep-packed-fp32
+// (csrc/build.sh compiles every other file without packed fp32 instructions.  This one keeps the code generation its multi-step
+// goldens were established with: the solve is an Adam trajectory -- a re-ordered rounding moves the 11-step low-rank erase golden from
+// 5.0e-5 to 1.02e-4 of the reference's update, against a bar of 1e-4 (profiles/r06ah) -- and it gains nothing from the change: 27.3 ms
+// per 2001-step solve either way.  Its packed FMAs run beside its OWN MFMA waves only; tests/test_gpu_overlap.py holds the
+// one-launch solver bit-exact beside the upsampling kernels.)
 // The rank-constrained projected-gradient solve of ProgressiveGanRewriter.insert
 // (rewrite/ganrewrite.py:254-298) for a stride-1 SeqStyleGAN2 layer, as four kernels per
 // iteration (arithmetic: SURVEY.md section 10):

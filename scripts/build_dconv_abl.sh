@@ -5,7 +5,7 @@ set -e
 R=$PWD; C=$R/rewriting_amd/csrc; mkdir -p scripts/probe/abl /tmp/dcabl
 (cd $C && bash build.sh > /dev/null)
 for a in "$@"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -DDC_ABL=$a $DC_FLAGS -c $C/rw_dconv.hip -o /tmp/dcabl/rw_dconv_$a.o &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Xclang -target-feature -Xclang -packed-fp32-ops -DDC_ABL=$a $DC_FLAGS -c $C/rw_dconv.hip -o /tmp/dcabl/rw_dconv_$a.o &
 done
 wait
 for a in "$@"; do

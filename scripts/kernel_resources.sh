@@ -2,7 +2,7 @@
 # registers / spills / LDS of every kernel of one source file: bash scripts/kernel_resources.sh rewriting_amd/csrc/rw_tconv.hip [extra flags]
 src=$1; shift
 extra="$(sed -n 's|^// hipcc-flags: ||p' "$src" | head -1)"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result $extra "$@" -Rpass-analysis=kernel-resource-usage -c "$src" -o /tmp/kr_$$.o 2>&1 | \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Xclang -target-feature -Xclang -packed-fp32-ops $extra "$@" -Rpass-analysis=kernel-resource-usage -c "$src" -o /tmp/kr_$$.o 2>&1 | \
   python3 -c "
 import re,sys
 cur=None; rows={}

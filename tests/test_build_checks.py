@@ -106,3 +106,31 @@ def test_side_stream_kernels_are_compiled_without_packed_fp32_fma():
         for insn in ('v_pk_fma_f32', 'v_pk_mul_f32', 'v_pk_add_f32'):
             lines = [l for l in text.splitlines() if insn in l and not l.lstrip().startswith(';')]
             assert not lines, (name, insn, len(lines))
+
+
+@pytest.mark.skipif(not os.path.exists('/opt/rocm/lib/llvm/bin/llvm-objdump'), reason='no llvm-objdump')
+def test_the_shipped_library_contains_no_packed_fp32_instruction():
+    """csrc/build.sh compiles every kernel but the solver's (rw_solve.hip) with the device feature -packed-fp32-ops (round 6): beside another wave's MFMAs a
+    packed fp32 instruction costs more issue time than the two scalar ones it replaces (the forward is 4 - 5 % faster without
+    them, profiles/r06af / r06ag), and a v_pk_fma_f32 with op_sel modifiers can return a wrong low half while another wave
+    interleaves MFMAs with memory instructions (profiles/r06_interference_probe.md).  Checked on the code objects of the
+    library that ships (rewriting_amd/librewriting_hip.so), not on a recompilation."""
+    import tempfile
+    from rewriting_amd import _lib
+    objdump = '/opt/rocm/lib/llvm/bin/llvm-objdump'
+    assert os.path.isfile(_lib.LIB_PATH), 'build the library first (rewriting_amd/csrc/build.sh)'
+    with tempfile.TemporaryDirectory() as d:
+        shutil.copy(_lib.LIB_PATH, os.path.join(d, 'lib.so'))
+        r = subprocess.run([objdump, '--offloading', 'lib.so'], cwd=d, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        objs = sorted(f for f in os.listdir(d) if 'hipv4-amdgcn' in f)
+        assert len(objs) >= 10, objs                     # one code object per source file
+        kernels = 0
+        for f in objs:
+            text = subprocess.run([objdump, '-d', '--mcpu=gfx950', f], cwd=d, capture_output=True, text=True).stdout
+            kernels += text.count('v_mfma_f32') > 0
+            if 'solve_persistent_kernel' in text:        # rw_solve.hip keeps them ("// hipcc-keep-packed-fp32": its header says why)
+                continue
+            for insn in ('v_pk_fma_f32', 'v_pk_mul_f32', 'v_pk_add_f32'):
+                assert insn not in text, (f, insn, text.count(insn))
+        assert kernels >= 6                              # (the disassembly is real: the MFMA kernels are in it)
