@@ -92,9 +92,9 @@ def conv_kernel_name(out_ch, in_ch, width, upsample):
 
 def tconv_auto_form(in_ch, out_ch):
     """The form rw_tconv_blur_f32 picks when RW_TCONV_TY is unset (csrc/rw_tconv.hip, the launcher): the 32-out-channel
-    kernel for the input-channel range RW_TCONV_N32 = "lo:hi" (default 128:128), a persistent kernel for 32 .. 128 input
+    kernel for the input-channel range RW_TCONV_N32 = "lo:hi" (default: none), a persistent kernel for 32 .. 128 input
     channels otherwise, one eight-wave workgroup per CU above."""
-    lo, hi = 128, 128
+    lo, hi = 1, 0
     spec = os.environ.get('RW_TCONV_N32')
     if spec:
         try:

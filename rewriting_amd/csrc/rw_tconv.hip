@@ -65,6 +65,9 @@ struct TconvProblem {
 #ifndef TC_LDS_PAD
 #define TC_LDS_PAD 0
 #endif
+#ifndef TC_STAGE_PRIO
+#define TC_STAGE_PRIO 0   // persistent forms: s_setprio of the staging waves (0: none)
+#endif
 #ifndef TC_ABL
 #define TC_ABL 0          // timing ablations (results WRONG): 1 = no staging loads, 2 = no MFMAs, 8 = no epilogue,
                           // 16 = the epilogue without its global stores, 32 = without its noise loads, 64 = without the blur
@@ -849,6 +852,9 @@ __global__ void __launch_bounds__(512, 2) tconv_blur_ws_kernel(const TconvProble
 
   if (wave >= MW) {
     // =========================== staging waves: channel quad g of every chunk ===========================
+#if TC_STAGE_PRIO
+    __builtin_amdgcn_s_setprio(TC_STAGE_PRIO);      // (static: the second-dispatched half loses the VALU arbitration by age otherwise)
+#endif
     const int g = wave - MW, lid = g * 64 + lane;
     const float xam = rw_bound_load(p.x_amax);
     const int hw4 = (int)hw * 4;
@@ -1388,6 +1394,9 @@ __global__ void __launch_bounds__(512, 2) tconv_blur_pp_kernel(const TconvProble
 
   if (wave >= MW) {
     // =========================== staging + blurring waves ===========================
+#if TC_STAGE_PRIO
+    __builtin_amdgcn_s_setprio(TC_STAGE_PRIO);
+#endif
     const int g = wave - MW;
     const float xam = rw_bound_load(p.x_amax);
     const int hw4 = (int)hw * 4;
@@ -1762,8 +1771,10 @@ extern "C" int rw_tconv_blur_f32(const float* x, const float* wp, const float* k
   const char* e = getenv("RW_TCONV_TY");
   // (RW_TCONV_PERSISTENT = 0 / 2: which of the two persistent kernels the automatic choice means)
   const char* pe = getenv("RW_TCONV_PERSISTENT");
-  // (RW_TCONV_N32 = "lo:hi": the input-channel range the automatic choice gives to the 32-out-channel form)
-  int n32_lo = 128, n32_hi = 128;
+  // (RW_TCONV_N32 = "lo:hi": the input-channel range the automatic choice gives to the 32-out-channel form.  Default: none --
+  // stand-alone it ties the persistent form on layer 15 (4.2 against 4.3 ms), inside the forward the persistent form is ahead:
+  // 1526 - 1528 against 1507 - 1518 img/s, same box, interleaved, profiles/r06ak)
+  int n32_lo = 1, n32_hi = 0;
   if (const char* ne = getenv("RW_TCONV_N32")) { if (sscanf(ne, "%d:%d", &n32_lo, &n32_hi) != 2) { n32_lo = 1; n32_hi = 0; } }
   const int sel = e ? atoi(e)
                     : (out_ch % 32 == 0 && in_ch >= n32_lo && in_ch <= n32_hi ? 32
