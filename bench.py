@@ -151,8 +151,11 @@ class ConvTimer:
                 e.record()
                 b, i, h, w = x.shape
                 lib = hip.lib()
-                if wino == 'd16p':            # the direct sum that also leaves the ToRGB's channel sums (one-role kernels only)
-                    name = 'dconv_w%d_rgbp_kernel' % (4 if out_ch % 128 == 0 else 2 if out_ch % 64 == 0 else 1)
+                if wino == 'd16p':            # the direct sum that also leaves the ToRGB's channel sums
+                    ws = (k.get('style') is not None and i >= 32 and w % 64 == 0 and out_ch % 64 == 0 and h % 8 == 0
+                          and os.environ.get('RW_DCONV_V') != '1')
+                    name = 'dconv_ws_w2_rgbp_kernel' if ws else \
+                        'dconv_w%d_rgbp_kernel' % (4 if out_ch % 128 == 0 else 2 if out_ch % 64 == 0 else 1)
                 elif wino in ('d16', 'd16up', 'd16rgb'):
                     # rw_dconv.hip: the specialised kernels take a style on load, >= 32 channels, maps 64 columns wide
                     ws = k.get('style') is not None and i >= 32 and w % 64 == 0 and os.environ.get('RW_DCONV_V') != '1'

@@ -488,7 +488,7 @@ __device__ __forceinline__ void dconv_body(const DconvProblem& p) {
 // pixel -- a 34-float row is three lines, a 66-float row is three lines too); NL staging waves (4 / NL channel quads each)
 template <int MODE, int WM, int MW, int NL, int WC>
 __device__ __forceinline__ void dconv_ws_body(const DconvProblem& p) {
-  constexpr bool UP = MODE == 1, RGB = MODE == 2;
+  constexpr bool UP = MODE == 1, RGB = MODE == 2, RGBP = MODE == 3, PLAIN = MODE == 0 || MODE == 3;      // RGBP: dconv_body's
   static_assert(!RGB || WM == 1, "ToRGB: one wave holds all out-channels of its pixels");
   static_assert(!UP || WM == 2, "UP: the wave pairs are the two row phases");
   constexpr int WN = MW / WM, WR = WN / WC, TR = 4 * WR, PR = TR + 2, TC = 32 * WC, PW = TC + 2;
@@ -503,7 +503,7 @@ __device__ __forceinline__ void dconv_ws_body(const DconvProblem& p) {
   __shared__ __attribute__((aligned(16))) unsigned char Ls[2 * BUFB];
   __shared__ __attribute__((aligned(16))) unsigned char Wl[2 * WBUF];
   __shared__ float Ct[2][2][VCH];
-  __shared__ float Cr[2][3][32];
+  __shared__ float Cr[2][3][VCH];
   __shared__ float Po[2][16];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -565,6 +565,7 @@ __device__ __forceinline__ void dconv_ws_body(const DconvProblem& p) {
     dc_f32x4 raw[QW][SI][4];                         // [channel k]: four pixels
     float psv[QW][4];
     float a_demod = 1.f, a_bias = 0.f, a_rgb = 0.f, a_post = 1.f, a_oscale = 1.f, a_iscale = 1.f;
+    float a_crw[3] = {0.f, 0.f, 0.f};                // RGBP: the ToRGB weights of the tile's out-channel block
     bool a_first = false;
     int a_par = 0;
     float crw[3] = {0.f, 0.f, 0.f};
@@ -615,7 +616,11 @@ __device__ __forceinline__ void dconv_ws_body(const DconvProblem& p) {
           const int o = UP ? 16 * l_ot + (lid & 15) : l_ot * VCH + lid;
           a_demod = p.demod ? p.demod[(int64_t)l_ib * real_ch + o] : 1.f;
           a_bias = p.act ? p.bias[o] : 0.f;
-          if (RGB) a_rgb = p.rgb_style[(int64_t)l_ib * p.out_ch + o];
+          if (RGB || RGBP) a_rgb = p.rgb_style[(int64_t)l_ib * p.out_ch + o];
+          if (RGBP) {
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) a_crw[cc] = p.rgb_weight[cc * p.out_ch + o] * p.rgb_scale;
+          }
           if (UP && lid < 16 && p.post) a_post = p.post[(int64_t)l_ib * real_ch + o];
         }
       }
@@ -658,9 +663,9 @@ __device__ __forceinline__ void dconv_ws_body(const DconvProblem& p) {
         if (lid < VCH) {
           Ct[a_par][0][lid] = a_demod * p.w_scale * a_oscale * gain;
           Ct[a_par][1][lid] = a_bias * gain;
-          if (RGB) {
+          if (RGB || RGBP) {
 #pragma unroll
-            for (int cc = 0; cc < 3; ++cc) Cr[a_par][cc][lid] = a_rgb * crw[cc];
+            for (int cc = 0; cc < 3; ++cc) Cr[a_par][cc][lid] = a_rgb * (RGBP ? a_crw[cc] : crw[cc]);
           }
           if (UP && lid < 16) Po[a_par][lid] = a_post;
         }
@@ -769,7 +774,7 @@ __device__ __forceinline__ void dconv_ws_body(const DconvProblem& p) {
       }
   };
   const float noise_wg = p.noise ? p.noise_w[0] * gain : 0.f;
-  dc_f32x4 nzp[MODE == 0 ? 8 : 1];
+  dc_f32x4 nzp[PLAIN ? 8 : 1];
   dc_f32x4 acc[2][8];
 #pragma unroll
   for (int ob = 0; ob < 2; ++ob)
@@ -793,7 +798,7 @@ __device__ __forceinline__ void dconv_ws_body(const DconvProblem& p) {
 #endif
     const unsigned char* lb = Ls + (n & 1) * BUFB;
     const unsigned char* wb = Wl + (n & 1) * WBUF;
-    if (MODE == 0 && c == NC - 1 && p.noise) {      // the tile's noise, requested a chunk of MFMAs before its epilogue
+    if (PLAIN && c == NC - 1 && p.noise) {          // the tile's noise, requested a chunk of MFMAs before its epilogue
       const float* np = p.noise + (int64_t)ib * hw + (int64_t)(ty * TR + 4 * wr) * p.w + tx * TC + 32 * wc + 4 * lk;
 #pragma unroll
       for (int pb = 0; pb < 8; ++pb) nzp[pb] = *reinterpret_cast<const dc_f32x4*>(np + (int64_t)(pb >> 1) * p.w + 16 * (pb & 1));
@@ -871,25 +876,45 @@ __device__ __forceinline__ void dconv_ws_body(const DconvProblem& p) {
     const int par = (tile - t0) & 1;
     const int y0 = ty * TR, x0 = tx * TC;
     if (!(DC_ABL & 8)) {
-      if (MODE == 0) {
+      if (PLAIN) {
         const int oc = 16 * (2 * wm) + lt;          // + 16 ob
         const float sc[2] = {Ct[par][0][oc], Ct[par][0][oc + 16]}, bs[2] = {Ct[par][1][oc], Ct[par][1][oc + 16]};
         float* yb = p.y + ((int64_t)ib * p.out_ch + ot * VCH + oc) * hw;
+        // RGBP: this wave's share of the ToRGB that reads the result (dconv_body): the sum over ITS 32 channels, per colour --
+        // partial (ot WM + wm) of out_ch / 32, planes [partial][image][colour]
+        float cr[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+        float* rb = nullptr;
+        if (RGBP) {
+#pragma unroll
+          for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) cr[ob][cc] = Cr[par][cc][oc + 16 * ob];
+          rb = p.rgb_out + (((int64_t)(ot * WM + wm) * p.batch + ib) * 3 + (lt < 3 ? lt : 0)) * hw;
+        }
 #pragma unroll
         for (int pb = 0; pb < 8; ++pb) {
           const int64_t pix = (int64_t)(y0 + 4 * wr + (pb >> 1)) * p.w + x0 + 32 * wc + 16 * (pb & 1) + 4 * lk;
           dc_f32x4 nz = {0.f, 0.f, 0.f, 0.f};
           if (p.noise) nz = nzp[pb] * noise_wg;
+          dc_f32x4 v[2];
 #pragma unroll
           for (int ob = 0; ob < 2; ++ob) {
-            dc_f32x4 v;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const float u = acc[ob][pb][j] * sc[ob] + nz[j] + bs[ob];
-              v[j] = fmaxf(u, u * slope);
-              ymax = fmaxf(ymax, fabsf(v[j]));
+              v[ob][j] = fmaxf(u, u * slope);
+              ymax = fmaxf(ymax, fabsf(v[ob][j]));
             }
-            if (!(DC_ABL & 16)) *reinterpret_cast<dc_f32x4*>(yb + (int64_t)(16 * ob) * hw + pix) = v;
+            if (!(DC_ABL & 16)) *reinterpret_cast<dc_f32x4*>(yb + (int64_t)(16 * ob) * hw + pix) = v[ob];
+          }
+          if (RGBP) {
+            dc_f32x4 sum[3];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int cc = 0; cc < 3; ++cc) sum[cc][j] = dc_row_sum(v[0][j] * cr[0][cc] + v[1][j] * cr[1][cc]);
+            // every lane of the row holds the sums: lane lt == cc stores colour cc
+            if (lt < 3 && !(DC_ABL & 16)) *reinterpret_cast<dc_f32x4*>(rb + pix) = lt == 0 ? sum[0] : (lt == 1 ? sum[1] : sum[2]);
           }
         }
       } else if (UP) {
@@ -973,6 +998,8 @@ __device__ __forceinline__ void dconv_ws_body(const DconvProblem& p) {
 // tiles 64 columns wide: 16 rows (32 out-channels), 8 rows (64), 4 rows (128)
 __global__ void __launch_bounds__(768, 3) dconv_ws_w2_kernel(const DconvProblem p) { dconv_ws_body<0, 2, 8, 4, 2>(p); }
 __global__ void __launch_bounds__(768, 3) dconv_ws_up_kernel(const DconvProblem p) { dconv_ws_body<1, 2, 8, 4, 2>(p); }
+// (round 6) the same + the ToRGB channel sums of its result: one partial image per multiplying wave's 32 out-channels
+__global__ void __launch_bounds__(768, 3) dconv_ws_w2_rgbp_kernel(const DconvProblem p) { dconv_ws_body<3, 2, 8, 4, 2>(p); }
 // ToRGB in the epilogue (out_ch == 32: a wave holds every out-channel of its pixels): four multiplying waves (one per SIMD,
 // 8 rows x 64 columns per tile) + two staging waves (two channel quads and one weight block each); 120 KB of LDS
 __global__ void __launch_bounds__(384, 2) dconv_ws_rgb_kernel(const DconvProblem p) { dconv_ws_body<2, 1, 4, 2, 2>(p); }
@@ -1189,6 +1216,13 @@ extern "C" int rw_dconv3x3_rgb_partial_f32(const float* x, const float* wp, floa
   p.tiles_y = h / (16 / wm);
   const int64_t work = (int64_t)batch * p.tiles_y * p.tiles_x * p.o_tiles;
   if (work <= 0 || work > 0x7fffffff) return RW_ERR_UNSUPPORTED;
+  if (dconv_specialised(in_ch, ep) && out_ch % 64 == 0 && h % 8 == 0 && w % 64 == 0) {      // as rw_dconv3x3_f32: a style on load
+    p.o_tiles = out_ch / 64; p.tiles_y = h / 8; p.tiles_x = w / 64;
+    const unsigned grid = dconv_ws_grid((int64_t)batch * p.tiles_y * p.tiles_x * p.o_tiles);
+    if (y_amax && 12LL * grid > cap) return RW_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(dconv_ws_w2_rgbp_kernel, dim3(grid), dim3(768), 0, rw_s(stream), p);
+    return dconv_finish(y_amax, 12LL * grid, stream);
+  }
   if (y_amax && 4 * work > cap) return RW_ERR_UNSUPPORTED;
   if (wm == 4) hipLaunchKernelGGL(dconv_w4_rgbp_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);
   else if (wm == 2) hipLaunchKernelGGL(dconv_w2_rgbp_kernel, dim3((unsigned)work), dim3(256), 0, rw_s(stream), p);

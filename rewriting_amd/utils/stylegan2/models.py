@@ -592,6 +592,17 @@ class DemodulatedConv2dF(nn.Module):
     def demod_factors(self, style):
         return hip.demod(self.squared_sums(), style) if self.demodulate else None
 
+    def specialised_direct16(self, h, w):
+        """Inside the un-hooked forward: will this stride-1 layer run the direct sum with SPECIALISED waves (rw_dconv.hip's
+        dconv_ws_w2 kernels: one persistent twelve-wave workgroup per CU; 64 out-channels and 64 columns per tile, a style
+        on load)?  Then the layer in front does not pre-scale its result for it.  RW_DCONV_WS_FWD=0: the one-role kernels
+        on a pre-scaled map, as in round 5."""
+        return (not self.upsample and _rgb_branch.image_path and os.environ.get('RW_DCONV_WS_FWD', '1') != '0'
+                and os.environ.get('RW_DCONV_V') != '1' and _split_part('w4') and conv_algo() == 'winograd4'
+                and conv_impl() == 0 and conv_precision() == 'f32'
+                and self.in_channel >= 32 and self.out_channel % 64 == 0 and h % 8 == 0 and w % 64 == 0
+                and hip.wino4_supported(self.out_channel, self.in_channel, h, w) and _direct16(self, h, w, 'conv'))
+
     def leaves_rgb_partials(self, h, w):
         """Will run(..., rgb=...) on a map of h x w execute the direct-sum kernel that also leaves the channel sums of the
         ToRGB reading its result (hip.conv3x3_direct16_rgb_partial)?  Inside the un-hooked forward only; RW_RGB_PARTIAL=0:
@@ -974,6 +985,8 @@ class StyledConvSeq(nn.Sequential):
                 or act.negative_slope != 0.2 or abs(act.scale - 2 ** 0.5) > 1e-12):
             return False
         dconv = mconv.dconv
+        if dconv.specialised_direct16(h, w):
+            return False            # that kernel's staging waves apply the style themselves (it needs one on load)
         return (conv_algo() == 'winograd4' and conv_impl() == 0 and conv_precision() == 'f32'
                 and hip.wino4_supported(dconv.out_channel, dconv.in_channel, h, w))
 
