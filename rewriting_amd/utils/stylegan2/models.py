@@ -571,6 +571,16 @@ class DemodulatedConv2dF(nn.Module):
         return (not self.upsample and _split_part('w4') and conv_algo() == 'winograd4' and conv_impl() == 0
                 and conv_precision() == 'f32' and hip.wino4_supported(self.out_channel, self.in_channel, h, w))
 
+    def runs_small_direct16(self, h, w):
+        """Inside the un-hooked forward: the 32^2 stride-1 layer -- too narrow for F(4x4,3x3); the fp32 F(2x2,3x3) kernel until
+        round 6 -- as a direct sum on the 16-bit pipe (0.8 against 1.4 ms at batch 64; the forward +1.7 %, same box,
+        interleaved: profiles/r06aq).  It measures its input itself (the layer in front runs an fp32 kernel that reports
+        nothing) and reports the bound of its result like the other split-operand kernels.  RW_DIRECT16_SMALL=0: off."""
+        return (not self.upsample and _rgb_branch.image_path and _split_part('w4')
+                and os.environ.get('RW_DIRECT16_SMALL', '1') != '0' and conv_algo() == 'winograd4' and conv_impl() == 0
+                and conv_precision() == 'f32' and min(h, w) >= 32
+                and not hip.wino4_supported(self.out_channel, self.in_channel, h, w) and _direct16(self, h, w, 'conv'))
+
     def hooked_direct16(self, h, w):
         """A hooked / sliced model (statistics sweeps, goal maps, the solve's context): the stride-1 convolutions of maps from
         32^2 up as DIRECT sums on the 16-bit matrix pipe (exact f16 operand pairs, fp32 accumulation: 4e-7 from the fp32
@@ -686,6 +696,9 @@ class DemodulatedConv2dF(nn.Module):
                                          demod=demod, x_amax=x_amax, y_amax=y_amax, **epilogue)
             return hip.conv3x3_wino4(fmap, self.wino4_weight(), self.out_channel, self.scale, style=load_style,
                                      demod=demod, **epilogue)
+        if self.runs_small_direct16(fmap.shape[-2], fmap.shape[-1]):
+            return hip.conv3x3_direct16(fmap, self.direct16_weight(), self.out_channel, self.scale, style=load_style,
+                                        demod=demod, x_amax=x_amax, y_amax=y_amax, **epilogue)
         if not weight_changes and self.hooked_direct16(fmap.shape[-2], fmap.shape[-1]):
             return hip.conv3x3_direct16(fmap, self.direct16_weight(), self.out_channel, self.scale, style=load_style,
                                         demod=demod, x_amax=x_amax, **epilogue)
@@ -967,7 +980,7 @@ class StyledConvSeq(nn.Sequential):
             return False
         dconv = self.mconv.dconv
         if not self.mconv.upsample:
-            return dconv.runs_split_wino4(h, w)
+            return dconv.runs_split_wino4(h, w) or dconv.runs_small_direct16(h, w)
         probe = torch.empty(0, dconv.in_channel, h, w, device='meta')
         if dconv.fused_upsample(probe, self.mconv.blur):
             return True
@@ -1109,7 +1122,7 @@ class StyledConvSeq(nn.Sequential):
                     demod=demod if demod is not None else dconv.demod_factors(style), noise=noise,
                     noise_w=self.noise.weight, bias=act.bias, act=True, **mm)
                 return DataBag(d, style=style, fmap=None, fused_rgb=rgb)
-            y_amax = y_bound(h, w) if want_amax and dconv.runs_split_wino4(h, w) else None
+            y_amax = y_bound(h, w) if want_amax and (dconv.runs_split_wino4(h, w) or dconv.runs_small_direct16(h, w)) else None
             y_amax_set = y_amax is not None
             # the ToRGB that reads this layer's result (to_rgbK follows layer 2K): its channel sums are left by the
             # convolution itself where the direct-sum kernel runs -- the RGB stream then adds a few small images instead

@@ -469,10 +469,23 @@ def test_bounds_are_produced_only_where_the_next_layer_reads_them(emulated_hip, 
     hook.remove()
     b = z.shape[0]
     # 64-model: layer 10 (64^2, F(4x4,3x3) + ToRGB) reads the bound of layer 9's result (the blur pass reports it); layer 9
-    # (32^2 -> 64^2, F(2,2) split) measures its input itself, because layer 8 runs an fp32 kernel that reports nothing; the
-    # layers in front ask for none; the last layer has no reader
-    assert made == [b * model.channels[64] * 64 * 64], made
-    assert measured == [(b, model.channels[32], 32, 32)], measured
+    # (32^2 -> 64^2, F(2,2) split) reads layer 8's -- since round 6 the 32^2 stride-1 layer is a direct sum on the 16-bit
+    # pipe (runs_small_direct16), which reports its result's bound and reads the one layer 7's blur pass leaves; the
+    # layers in front ask for none; the last layer has no reader; nobody measures a map
+    n32 = b * model.channels[32] * 32 * 32
+    assert made == [n32, n32, b * model.channels[64] * 64 * 64], made
+    assert measured == [], measured
+    monkeypatch.setenv('RW_DIRECT16_SMALL', '0')      # round 5's route: layer 8 on the fp32 F(2x2,3x3) kernel, which reports nothing
+    del made[:]
+    with torch.no_grad():
+        model(z)
+    assert made == [b * model.channels[64] * 64 * 64] and measured == [(b, model.channels[32], 32, 32)], (made, measured)
+    monkeypatch.delenv('RW_DIRECT16_SMALL')
+    del made[:], measured[:], bags[:]
+    hook = model.layer9.register_forward_hook(lambda m, i, o: bags.append(o))
+    with torch.no_grad():
+        img = model(z)
+    hook.remove()
     assert all('amax' not in bag for bag in bags)
     fm = bags[0].fmap
     assert isinstance(getattr(fm, 'rw_amax', None), tuple) and fm.rw_amax[0].numel() >= hip.bound_floats(fm.numel())
