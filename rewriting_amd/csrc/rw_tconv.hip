@@ -675,8 +675,11 @@ __global__ void __launch_bounds__(512, 1) tconv_blur_n32_kernel(const TconvProbl
 #define TC_PP_MQ 2        // pipelined form: of a tile's four blur passes, how many the multiplying waves take (0 .. 4)
 #endif
 
-__global__ void __launch_bounds__(512, 2) tconv_blur_ws_kernel(const TconvProblem p) {
-  constexpr int TY = 8, MW = 4;
+// MW multiplying waves (4: the form of round 5, one per SIMD beside a staging wave; 8: two per SIMD beside a staging wave --
+// twelve waves of at most 168 registers, which the kernel fits since the library is compiled without packed fp32 math: round 6)
+template <int MW>
+__device__ __forceinline__ void tconv_ws_body(const TconvProblem& p) {
+  constexpr int TY = 8;
   constexpr int PR = TY + 2, NPOS = PR * TC_PC, NBLK = (NPOS + 15) / 16, BPW = (NBLK + MW - 1) / MW;
   constexpr int WR = TY + 3, NPIX = WR * TC_WC, BUFB = NPIX * 64;
   constexpr int IPR = TC_TX / 4 + 2, NITEM = WR * IPR, SI = (NITEM + 63) / 64;   // items: window columns 4 j - 2 .. 4 j + 1
@@ -685,7 +688,8 @@ __global__ void __launch_bounds__(512, 2) tconv_blur_ws_kernel(const TconvProble
   // pairs; the blur reads the aligned 16-byte pieces 4 og + 4 .. 4 og + 11 and uses seven of them)
   constexpr int ZR = 2 * PR + 2, CHS = ZR * TC_ZP + 4;
   constexpr int SR = 4, CT = 512;                   // output rows of a strip; threads of the blur (all)
-  static_assert(SI == 2 && BPW == 6 && SR * (CT / 128) == 2 * TY, "piece / block / strip counts the code below is written for");
+  static_assert(SI == 2 && BPW == 24 / MW && (MW == 4 || MW == 8) && SR * (CT / 128) == 2 * TY, "piece / block / strip counts the code below is written for");
+  constexpr bool STAGERS_BLUR = MW == 4;            // (MW == 8: the 512 threads of the multiplying waves are the blur's)
   __shared__ __attribute__((aligned(16))) unsigned char Ls[2 * BUFB];
   __shared__ __attribute__((aligned(16))) unsigned char Wl[2 * TC_WCH];
   __shared__ __attribute__((aligned(16))) float Zs[8 * CHS];
@@ -1017,7 +1021,7 @@ __global__ void __launch_bounds__(512, 2) tconv_blur_ws_kernel(const TconvProble
       __builtin_amdgcn_sched_barrier(0);
       // (the strip's noise BEFORE this interval's window requests: loads return in order, and the wait for the noise at the
       // blur must leave the younger window loads in flight)
-      if (cn == NC - 1) noise_request(e_ty, e_tx, e_ib);
+      if (STAGERS_BLUR && cn == NC - 1) noise_request(e_ty, e_tx, e_ib);
       __builtin_amdgcn_sched_barrier(0);
       setup(tag);
       TP_ADD(tp_setup, tp);
@@ -1032,12 +1036,12 @@ __global__ void __launch_bounds__(512, 2) tconv_blur_ws_kernel(const TconvProble
       if (++cn == NC) {                             // the tile's epilogue (the loads stay in flight)
         cn = 0;
         const int par = e_pos & 1;
-        blur(0, par, e_ot, e_tx, e_ty, e_ib);
+        if (STAGERS_BLUR) blur(0, par, e_ot, e_tx, e_ty, e_ib);
         TP_ADD(tp_blur, tp);
         lds_barrier();                              // z is free: the multiplying waves write the other eight channels
         lds_barrier();
         TP_ADD(tp_ebar, tp);
-        blur(1, par, e_ot, e_tx, e_ty, e_ib);
+        if (STAGERS_BLUR) blur(1, par, e_ot, e_tx, e_ty, e_ib);
         TP_ADD(tp_blur, tp);
         ++e_pos;
         advance(e_ot, e_tx, e_ty, e_ib);
@@ -1211,6 +1215,8 @@ __global__ void __launch_bounds__(512, 2) tconv_blur_ws_kernel(const TconvProble
 #endif
   if (p.y_amax) rw_bound_store_wave(p.y_amax, rw_wave_max(ymax));
 }
+__global__ void __launch_bounds__(512, 2) tconv_blur_ws_kernel(const TconvProblem p) { tconv_ws_body<4>(p); }
+__global__ void __launch_bounds__(768, 1) tconv_blur_ws12_kernel(const TconvProblem p) { tconv_ws_body<8>(p); }
 
 // ---------------------------------------------------------------------------------------
 // Fourth form (round 6): the persistent kernel above with its two halves PIPELINED across tiles.  There the phases of a
@@ -1779,19 +1785,21 @@ extern "C" int rw_tconv_blur_f32(const float* x, const float* wp, const float* k
   const int sel = e ? atoi(e)
                     : (out_ch % 32 == 0 && in_ch >= n32_lo && in_ch <= n32_hi ? 32
                        : (in_ch >= 32 && in_ch <= 128 ? (pe && atoi(pe) == 2 ? 2 : 0) : 16));
-  if ((sel == 0 || sel == 2) && in_ch >= 32) {      // 0: the specialised persistent kernel (one workgroup of eight waves per CU); 2: its pipelined form
+  if ((sel == 0 || sel == 2 || sel == 12) && in_ch >= 32) {      // 0: the specialised persistent kernel (one workgroup of eight waves per CU); 2: its pipelined form; 12: twelve waves
     p.tiles_x = w / TC_TX; p.tiles_y = h / 8; p.o_tiles = out_ch / 16;
     const int64_t tiles = (int64_t)batch * p.tiles_y * p.tiles_x * p.o_tiles;
     if (tiles <= 0 || tiles > 0x7fffffff) return RW_ERR_UNSUPPORTED;
     const char* ge = getenv("RW_TCONV_GRID");
     int64_t grid = ge ? atoi(ge) : rw_cu_count();       // one persistent workgroup per compute unit
     grid = grid < 1 ? 1 : (grid > tiles ? tiles : grid);
-    if (y_amax && 8 * grid > rw_bound_slot_capacity((int64_t)batch * out_ch * 4 * h * w)) return RW_ERR_UNSUPPORTED;
+    const int wv = sel == 12 ? 12 : 8;
+    if (y_amax && wv * grid > rw_bound_slot_capacity((int64_t)batch * out_ch * 4 * h * w)) return RW_ERR_UNSUPPORTED;
     if (sel == 2) hipLaunchKernelGGL(tconv_blur_pp_kernel, dim3((unsigned)grid), dim3(512), 0, rw_s(stream), p);
+    else if (sel == 12) hipLaunchKernelGGL(tconv_blur_ws12_kernel, dim3((unsigned)grid), dim3(768), 0, rw_s(stream), p);
     else hipLaunchKernelGGL(tconv_blur_ws_kernel, dim3((unsigned)grid), dim3(512), 0, rw_s(stream), p);
     const int rc = RW_LAUNCH_RESULT();
     if (rc || !y_amax) return rc;
-    return rw_bound_finish(y_amax, 8 * grid, rw_s(stream));
+    return rw_bound_finish(y_amax, wv * grid, rw_s(stream));
   }
   const bool n32 = sel == 32 && out_ch % 32 == 0;   // 32 out-channels per workgroup (8 x 32 tile, eight waves)
   const int ty = sel == 16 ? 16 : 8;

@@ -1065,7 +1065,8 @@ TCONV_CASES = [(1, 16, 16, 16, 32), (2, 64, 32, 16, 64), (1, 32, 16, 32, 32), (1
 
 
 TCONV_FORMS = {'two-workgroups-per-cu': '8', 'one-workgroup-per-cu': '16', 'specialised-persistent': '0',
-               'pipelined-persistent': '2', 'thirty-two-out-channels': '32', 'automatic': None}
+               'pipelined-persistent': '2', 'thirty-two-out-channels': '32', 'twelve-wave-persistent': '12',
+               'automatic': None}
 
 
 @pytest.mark.parametrize('form', sorted(TCONV_FORMS))
@@ -1113,7 +1114,7 @@ def test_fused_transposed_conv_and_blur_matches_conv_then_blur(case, form, monke
         scale = want.abs().max().item()
         assert (got - want).abs().max().item() < 2e-5 * scale, (got - want).abs().max().item() / scale
         assert rel(got, want) < 3e-6, rel(got, want)
-        if form in ('specialised-persistent', 'pipelined-persistent'):
+        if form in ('specialised-persistent', 'pipelined-persistent', 'twelve-wave-persistent'):
             monkeypatch.setenv('RW_TCONV_GRID', '5')
             again = hip.conv_transpose3x3s2_blur_fused(x.to(DEV), pk, k4, o, s, style=style.to(DEV), demod=dm, **kw)
             monkeypatch.delenv('RW_TCONV_GRID')
