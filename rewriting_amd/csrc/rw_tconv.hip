@@ -65,6 +65,9 @@ struct TconvProblem {
 #ifndef TC_LDS_PAD
 #define TC_LDS_PAD 0
 #endif
+#ifndef TC_AHEAD
+#define TC_AHEAD 1        // tconv_body: how many position blocks ahead the pixel operands are requested (1 or 2)
+#endif
 #ifndef TC_STAGE_PRIO
 #define TC_STAGE_PRIO 0   // persistent forms: s_setprio of the staging waves (0: none)
 #endif
@@ -371,11 +374,13 @@ __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
       tc_f16x8 u0[NT], u1[NT], u3[NT], u4[NT], l4[NT];
 #pragma unroll
       for (int n = 0; n < NT; ++n) { u0[n] = TB_UH(0); u1[n] = TB_UH(1); u3[n] = TB_UH(3); u4[n] = TB_UH(4); l4[n] = tc_expand(TB_UL(4)); }
-      tc_f16x8 pc = TC_PIX(pb0[0] + TC_WC * 64);
+      // (TC_AHEAD blocks ahead: 1 = round 5; 2 = the pixel operands of block b + 2 requested before block b's MFMAs)
+      tc_f16x8 pc = TC_PIX(pb0[0] + TC_WC * 64), pd = pc;
+      if (TC_AHEAD == 2 && BPW > 1) pd = TC_PIX(pb0[1] + TC_WC * 64);
 #pragma unroll
       for (int b = 0; b < BPW; ++b) {
-        tc_f16x8 pn = pc;
-        if (b + 1 < BPW) pn = TC_PIX(pb0[b + 1] + TC_WC * 64);
+        tc_f16x8 pn = TC_AHEAD == 2 ? pd : pc;
+        if (b + TC_AHEAD < BPW) pn = TC_PIX(pb0[b + TC_AHEAD] + TC_WC * 64);
         if (b < LB || last_ok) {
 #pragma unroll
           for (int n = 0; n < NT; ++n) {
@@ -388,7 +393,7 @@ __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
         }
         hook(tc_int<0>(), b);
         __builtin_amdgcn_sched_barrier(0);
-        pc = pn;
+        if (TC_AHEAD == 2) { pc = pd; pd = pn; } else pc = pn;
       }
     }
     TP_ADD(tp_g0, tp);
@@ -397,13 +402,14 @@ __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
       tc_f16x8 u2[NT], u5[NT], m02[NT], m35[NT];
 #pragma unroll
       for (int n = 0; n < NT; ++n) { u2[n] = TB_UH(2); u5[n] = TB_UH(5); m02[n] = tc_pair(TB_UL(0), TB_UL(2)); m35[n] = tc_pair(TB_UL(3), TB_UL(5)); }
-      tc_f32x2 hc = TC_VH(pb0[0] + TC_WC * 64);     // Vh of x[i][j]: the first half of its word
-      tc_f16x8 qc = TC_PIX(pb1[0] + TC_WC * 64);
+      tc_f32x2 hc = TC_VH(pb0[0] + TC_WC * 64), hd = hc;    // Vh of x[i][j]: the first half of its word
+      tc_f16x8 qc = TC_PIX(pb1[0] + TC_WC * 64), qd = qc;
+      if (TC_AHEAD == 2 && BPW > 1) { hd = TC_VH(pb0[1] + TC_WC * 64); qd = TC_PIX(pb1[1] + TC_WC * 64); }
 #pragma unroll
       for (int b = 0; b < BPW; ++b) {
-        tc_f32x2 hn = hc;
-        tc_f16x8 qn = qc;
-        if (b + 1 < BPW) { hn = TC_VH(pb0[b + 1] + TC_WC * 64); qn = TC_PIX(pb1[b + 1] + TC_WC * 64); }
+        tc_f32x2 hn = TC_AHEAD == 2 ? hd : hc;
+        tc_f16x8 qn = TC_AHEAD == 2 ? qd : qc;
+        if (b + TC_AHEAD < BPW) { hn = TC_VH(pb0[b + TC_AHEAD] + TC_WC * 64); qn = TC_PIX(pb1[b + TC_AHEAD] + TC_WC * 64); }
         if (b < LB || last_ok) {
           const tc_f16x8 M = tc_pair_hq(hc, qc);
 #pragma unroll
@@ -417,7 +423,7 @@ __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
         }
         hook(tc_int<1>(), b);
         __builtin_amdgcn_sched_barrier(0);
-        hc = hn; qc = qn;
+        if (TC_AHEAD == 2) { hc = hd; qc = qd; hd = hn; qd = qn; } else { hc = hn; qc = qn; }
       }
     }
     TP_ADD(tp_g1, tp);
@@ -428,13 +434,14 @@ __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
         u6[n] = TB_UH(6); u7[n] = TB_UH(7); u8[n] = TB_UH(8);
         m17[n] = tc_pair(TB_UL(1), TB_UL(7)); m68[n] = tc_pair(TB_UL(6), TB_UL(8));
       }
-      tc_f32x2 hc = TC_VH(pb0[0] + TC_WC * 64);
-      tc_f16x8 qc = TC_PIX(pb0[0]), rc = TC_PIX(pb1[0]);
+      tc_f32x2 hc = TC_VH(pb0[0] + TC_WC * 64), hd = hc;
+      tc_f16x8 qc = TC_PIX(pb0[0]), rc = TC_PIX(pb1[0]), qd = qc, rd = rc;
+      if (TC_AHEAD == 2 && BPW > 1) { hd = TC_VH(pb0[1] + TC_WC * 64); qd = TC_PIX(pb0[1]); rd = TC_PIX(pb1[1]); }
 #pragma unroll
       for (int b = 0; b < BPW; ++b) {
-        tc_f32x2 hn = hc;
-        tc_f16x8 qn = qc, rn = rc;
-        if (b + 1 < BPW) { hn = TC_VH(pb0[b + 1] + TC_WC * 64); qn = TC_PIX(pb0[b + 1]); rn = TC_PIX(pb1[b + 1]); }
+        tc_f32x2 hn = TC_AHEAD == 2 ? hd : hc;
+        tc_f16x8 qn = TC_AHEAD == 2 ? qd : qc, rn = TC_AHEAD == 2 ? rd : rc;
+        if (b + TC_AHEAD < BPW) { hn = TC_VH(pb0[b + TC_AHEAD] + TC_WC * 64); qn = TC_PIX(pb0[b + TC_AHEAD]); rn = TC_PIX(pb1[b + TC_AHEAD]); }
         if (b < LB || last_ok) {
           const tc_f16x8 M02 = tc_pair_hq(hc, qc), M23 = tc_pair(qc, rc);
 #pragma unroll
@@ -449,7 +456,7 @@ __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
         }
         hook(tc_int<2>(), b);
         __builtin_amdgcn_sched_barrier(0);
-        hc = hn; qc = qn; rc = rn;
+        if (TC_AHEAD == 2) { hc = hd; qc = qd; rc = rd; hd = hn; qd = qn; rd = rn; } else { hc = hn; qc = qn; rc = rn; }
       }
     }
     TP_ADD(tp_g2, tp);
