@@ -65,6 +65,9 @@ struct TconvProblem {
 #ifndef TC_LDS_PAD
 #define TC_LDS_PAD 0
 #endif
+#ifndef TC_ITEM_G
+#define TC_ITEM_G 1       // tconv_body: lane -> item order within a piece (1: consecutive; 4: see there)
+#endif
 #ifndef TC_AHEAD
 #define TC_AHEAD 1        // tconv_body: how many position blocks ahead the pixel operands are requested (1 or 2)
 #endif
@@ -222,7 +225,10 @@ __device__ __forceinline__ void tconv_body(const TconvProblem& p) {
   int xoff[SI], lofa[SI], lofb[SI], lok[SI];        // LDS byte offsets of the item's pixels 0 / 2 (1 / 3: + 64); bit e of lok: pixel e is a window pixel
 #pragma unroll
   for (int s = 0; s < SI; ++s) {
-    const int it = LPP * (NSL * s + hsel) + lane;
+    // (TC_ITEM_G == 4: lane l takes item (l & 3) LPP / 4 + (l >> 2) of the piece -- the eight lanes of a ds_write_b128 group then
+    // write to two rows and both item parities: the four 16-byte slots the operand swizzle can give pixels 4 columns apart)
+    const int li = TC_ITEM_G == 4 ? (lane & 3) * (LPP / 4) + (lane >> 2) : lane;
+    const int it = LPP * (NSL * s + hsel) + li;
     const bool mine = lane < LPP && it < NITEM;
     const int r = it / IPR, j = it - r * IPR;
     const int iy = I0 - 2 + r, ix = J0 - 4 + 4 * j;                // the item lies inside the row or outside it as a whole
