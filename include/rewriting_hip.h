@@ -369,7 +369,9 @@ int rw_dconv3x3_f32(const float* x, const float* wp, float* y, int batch, int in
  * rgb->scale as in rw_rgb_epilogue, rgb->bias / rgb->skip are NOT used here.  rw_rgb_combine_f32 finishes the ToRGB:
  *   out[b][c][p] = sum_k partial[k][b][c][p] + bias[c] + skip[b][c][p]      (bias, skip nullable; hw % 4 == 0).
  * The feature map y is written as by rw_dconv3x3_f32 (the next layer reads it); the second pass over it (rw_to_rgb_f32)
- * disappears.  Same shapes as rw_dconv3x3_f32. */
+ * disappears.  Same shapes as rw_dconv3x3_f32, and the same choice of kernel: with a style on load (ep->style), in_ch >= 32,
+ * 64 | out_ch, 8 | h, 64 | w the specialised persistent kernel (twelve waves per compute unit), the one-role kernels otherwise
+ * (RW_DCONV_V=1: always) -- y and the partial images are bit-identical to rw_dconv3x3_f32's y + a float32 channel sum. */
 int rw_dconv3x3_rgb_partials(int out_ch);
 int rw_dconv3x3_rgb_partial_f32(const float* x, const float* wp, float* y, int batch, int in_ch, int out_ch, int h, int w,
                                 float w_scale, const rw_conv_epilogue* ep, const rw_rgb_epilogue* rgb, float u_inv,
